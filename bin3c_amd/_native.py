@@ -1,0 +1,248 @@
+"""
+ctypes binding of libb3c.so (include/b3c.h).  This is the ONLY route from the Python host code to the
+device: there is no CPU fallback.  Import fails loudly when the library has not been built, and every
+compute call fails loudly when no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libb3c.so')
+
+OK, E_ARG, E_HIP, E_NAN, E_NOCONV, E_NOMEM = 0, -1, -2, -3, -4, -5
+F64, U32 = 0, 1
+
+
+class B3CError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, message)
+        self.code = code
+
+
+class KRInfo(C.Structure):
+    _fields_ = [('n_iter', C.c_int64), ('n_outer', C.c_int64), ('n_zero_diag', C.c_int64),
+                ('is_symmetric', C.c_int32), ('hit_max_iter', C.c_int32), ('hit_delta', C.c_int64),
+                ('hit_Delta', C.c_int64), ('rout', C.c_double), ('spmv_ms', C.c_double), ('n_spmv', C.c_int64)]
+
+
+class LouvainInfo(C.Structure):
+    _fields_ = [('n_comm', C.c_int32), ('n_levels', C.c_int32), ('n_sweeps', C.c_int64), ('n_moves', C.c_int64),
+                ('quant_shift', C.c_int32), ('reserved', C.c_int32), ('modularity', C.c_double),
+                ('move_ms', C.c_double), ('n_move_launch', C.c_int64), ('move_nnz', C.c_int64)]
+
+
+# every symbol include/b3c.h declares: (name, restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = [
+    ('b3c_ctx_create', C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
+    ('b3c_ctx_destroy', C.c_int, [_VP]),
+    ('b3c_last_error', C.c_char_p, [_VP]),
+    ('b3c_ctx_sync', C.c_int, [_VP]),
+    ('b3c_ctx_bytes', C.c_int64, [_VP]),
+    ('b3c_mat_upload', C.c_int, [_VP, C.c_int64, C.c_int64, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
+    ('b3c_mat_free', C.c_int, [_VP, _VP]),
+    ('b3c_mat_info', C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ('b3c_mat_download', C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    ('b3c_mat_device_ptrs', C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
+    ('b3c_max_offdiag_u32', C.c_int, [_VP, _VP, C.c_int, _VP]),
+    ('b3c_site_norm', C.c_int, [_VP, _VP, _VP, C.POINTER(_VP)]),
+    ('b3c_scale_sym', C.c_int, [_VP, _VP, _VP]),
+    ('b3c_compress', C.c_int, [_VP, _VP, _VP, C.POINTER(_VP)]),
+    ('b3c_max_value', C.c_int, [_VP, _VP, C.POINTER(C.c_double)]),
+    ('b3c_kr_balance', C.c_int, [_VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, _VP, C.POINTER(KRInfo)]),
+    ('b3c_louvain', C.c_int, [_VP, _VP, C.c_double, C.c_int, C.c_int, _VP, C.POINTER(LouvainInfo)]),
+    ('b3c_graph_quantise', C.c_int, [_VP, _VP, C.c_double, _VP, C.POINTER(C.c_int32)]),
+    ('b3c_version', C.c_char_p, []),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen libb3c.so and type every entry point.  Raises ImportError if it was never built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('{} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(hipcc --offload-arch=gfx950); there is no CPU fallback'.format(LIB_PATH))
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    """host numpy array, raw integer device pointer, or None -> c_void_p"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, 'data_ptr'):  # torch tensor (device or host)
+        return C.c_void_p(a.data_ptr())
+    raise TypeError('cannot pass {} to libb3c'.format(type(a)))
+
+
+class Mat(object):
+    """Device-resident CSR matrix handle (b3c_mat*)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+        n, nnz, kind = C.c_int64(), C.c_int64(), C.c_int()
+        ctx.lib.b3c_mat_info(handle, C.byref(n), C.byref(nnz), C.byref(kind))
+        self.n, self.nnz, self.kind = n.value, nnz.value, kind.value
+
+    def download(self, structure=True):
+        """-> (indptr int64, indices int32, data) as numpy arrays"""
+        ip = np.empty(self.n + 1, dtype=np.int64) if structure else None
+        ix = np.empty(self.nnz, dtype=np.int32) if structure else None
+        data = np.empty(self.nnz, dtype=np.uint32 if self.kind == U32 else np.float64)
+        self.ctx._check(self.ctx.lib.b3c_mat_download(self.ctx.h, self.h, _ptr(ip), _ptr(ix), _ptr(data)))
+        return ip, ix, data
+
+    def device_ptrs(self):
+        a, b, c = _VP(), _VP(), _VP()
+        self.ctx.lib.b3c_mat_device_ptrs(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def free(self):
+        if self.h is not None:
+            self.ctx.lib.b3c_mat_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h is not None:
+                self.free()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """b3c_ctx*: one device, one stream, one caching HBM pool."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = _VP()
+        rc = self.lib.b3c_ctx_create(int(device), _VP(stream) if stream else None, C.byref(h))
+        if rc != OK:
+            raise B3CError(rc, 'b3c_ctx_create(device={}) failed with code {}: no usable MI355X/HIP device; '
+                               'libb3c has no CPU fallback'.format(device, rc))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h is not None:
+            self.lib.b3c_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            msg = self.lib.b3c_last_error(self.h)
+            raise B3CError(rc, msg.decode() if msg else 'libb3c error {}'.format(rc))
+
+    def sync(self):
+        self._check(self.lib.b3c_ctx_sync(self.h))
+
+    def bytes_in_use(self):
+        return int(self.lib.b3c_ctx_bytes(self.h))
+
+    # ---- matrices ----
+    def upload(self, indptr, indices, data, n=None, nnz=None):
+        """CSR -> HBM.  numpy arrays are converted to the ABI dtypes; device pointers need n/nnz."""
+        if isinstance(indptr, np.ndarray):
+            indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+            indices = np.ascontiguousarray(indices, dtype=np.int32)
+            if data.dtype == np.uint32:
+                kind = U32
+                data = np.ascontiguousarray(data)
+            else:
+                kind = F64
+                data = np.ascontiguousarray(data, dtype=np.float64)
+            n = indptr.shape[0] - 1
+            nnz = int(indptr[-1])
+            assert indices.shape[0] >= nnz and data.shape[0] >= nnz
+        else:
+            kind = U32 if getattr(data, 'element_size', lambda: 8)() == 4 else F64
+        h = _VP()
+        self._check(self.lib.b3c_mat_upload(self.h, n, nnz, _ptr(indptr), _ptr(indices), _ptr(data), kind, C.byref(h)))
+        return Mat(self, h)
+
+    # ---- helpers ----
+    def max_offdiag_u32(self, mat, assume_symmetric=False, out=None):
+        res = np.empty(mat.n, dtype=np.uint32) if out is None else out
+        self._check(self.lib.b3c_max_offdiag_u32(self.h, mat.h, int(bool(assume_symmetric)), _ptr(res)))
+        return res
+
+    def site_norm(self, counts, sites):
+        if isinstance(sites, np.ndarray):
+            sites = np.ascontiguousarray(sites, dtype=np.float64)
+        h = _VP()
+        self._check(self.lib.b3c_site_norm(self.h, counts.h, _ptr(sites), C.byref(h)))
+        return Mat(self, h)
+
+    def scale_sym(self, mat, x):
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, dtype=np.float64)
+        self._check(self.lib.b3c_scale_sym(self.h, mat.h, _ptr(x)))
+
+    def compress(self, mat, mask):
+        if isinstance(mask, np.ndarray):
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        h = _VP()
+        self._check(self.lib.b3c_compress(self.h, mat.h, _ptr(mask), C.byref(h)))
+        return Mat(self, h)
+
+    def max_value(self, mat):
+        out = C.c_double()
+        self._check(self.lib.b3c_max_value(self.h, mat.h, C.byref(out)))
+        return out.value
+
+    # ---- KR ----
+    def kr_balance(self, mat, tol=1e-6, delta=0.1, Delta=3.0, max_iter=1000, x_out=None, check=True):
+        """-> (rc, x, KRInfo); raises B3CError for rc != OK when check"""
+        x = np.empty(mat.n, dtype=np.float64) if x_out is None else x_out
+        info = KRInfo()
+        rc = self.lib.b3c_kr_balance(self.h, mat.h, tol, delta, Delta, int(max_iter), _ptr(x), C.byref(info))
+        if check:
+            self._check(rc)
+        return rc, x, info
+
+    # ---- Louvain ----
+    def louvain(self, mat, scl=1.0, n_sub=0, max_sweeps=0, labels_out=None):
+        labels = np.empty(mat.n, dtype=np.int32) if labels_out is None else labels_out
+        info = LouvainInfo()
+        self._check(self.lib.b3c_louvain(self.h, mat.h, float(scl), int(n_sub), int(max_sweeps), _ptr(labels),
+                                         C.byref(info)))
+        return labels, info
+
+    def graph_quantise(self, mat, scl=1.0):
+        q = np.empty(mat.nnz, dtype=np.int64)
+        shift = C.c_int32()
+        self._check(self.lib.b3c_graph_quantise(self.h, mat.h, float(scl), _ptr(q), C.byref(shift)))
+        return q, shift.value
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use)."""
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx.h is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,155 @@
+// Context and matrix management for libb3c (see include/b3c.h).
+#include "common.hpp"
+
+extern "C" const char *b3c_version(void) { return "b3c 0.1 (gfx950)"; }
+
+extern "C" int b3c_ctx_create(int device, void *stream, b3c_ctx **out)
+{
+    if (!out) return B3C_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return B3C_E_HIP;
+    if (device < 0 || device >= count) return B3C_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return B3C_E_HIP;
+    b3c_ctx *ctx = new b3c_ctx();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return B3C_E_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return B3C_OK;
+}
+
+extern "C" int b3c_ctx_destroy(b3c_ctx *ctx)
+{
+    if (!ctx) return B3C_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->trim();
+    for (auto &kv : ctx->live) (void)hipFree(kv.first);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return B3C_OK;
+}
+
+extern "C" const char *b3c_last_error(const b3c_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int b3c_ctx_sync(b3c_ctx *ctx)
+{
+    if (!ctx) return B3C_E_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return B3C_OK;
+}
+
+extern "C" int64_t b3c_ctx_bytes(const b3c_ctx *ctx) { return ctx ? ctx->bytes : 0; }
+
+int b3c_copy_in(b3c_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return B3C_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
+    return B3C_OK;
+}
+
+int b3c_copy_out(b3c_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return B3C_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return B3C_OK;
+}
+
+int b3c_mat_alloc(b3c_ctx *ctx, int64_t n, int64_t nnz, int kind, b3c_mat **out)
+{
+    b3c_mat *m = new b3c_mat();
+    m->n = n;
+    m->nnz = nnz;
+    m->kind = kind;
+    size_t esz = kind == B3C_U32 ? 4 : 8;
+    m->indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(n + 1));
+    m->indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)nnz);
+    m->data = ctx->alloc(esz * (size_t)nnz);
+    if (!m->indptr || !m->indices || !m->data) {
+        ctx->release(m->indptr);
+        ctx->release(m->indices);
+        ctx->release(m->data);
+        delete m;
+        return ctx->fail(B3C_E_NOMEM, "out of device memory allocating %lld x %lld matrix", (long long)n, (long long)nnz);
+    }
+    *out = m;
+    return B3C_OK;
+}
+
+extern "C" int b3c_mat_upload(b3c_ctx *ctx, int64_t n, int64_t nnz, const int64_t *indptr, const int32_t *indices,
+                              const void *data, int kind, b3c_mat **out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!out || n < 0 || nnz < 0 || !indptr || (nnz > 0 && (!indices || !data)) || (kind != B3C_F64 && kind != B3C_U32))
+        return ctx->fail(B3C_E_ARG, "b3c_mat_upload: bad argument");
+    if (n >= (int64_t)INT32_MAX) return ctx->fail(B3C_E_ARG, "b3c_mat_upload: n must fit int32 column ids");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    b3c_mat *m = nullptr;
+    int rc = b3c_mat_alloc(ctx, n, nnz, kind, &m);
+    if (rc) return rc;
+    size_t esz = kind == B3C_U32 ? 4 : 8;
+    if ((rc = b3c_copy_in(ctx, m->indptr, indptr, sizeof(int64_t) * (size_t)(n + 1))) ||
+        (rc = b3c_copy_in(ctx, m->indices, indices, sizeof(int32_t) * (size_t)nnz)) ||
+        (rc = b3c_copy_in(ctx, m->data, data, esz * (size_t)nnz))) {
+        b3c_mat_free(ctx, m);
+        return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out = m;
+    return B3C_OK;
+}
+
+extern "C" int b3c_mat_free(b3c_ctx *ctx, b3c_mat *m)
+{
+    if (!ctx || !m) return B3C_OK;
+    ctx->release(m->indptr);
+    ctx->release(m->indices);
+    ctx->release(m->data);
+    delete m;
+    return B3C_OK;
+}
+
+extern "C" int b3c_mat_info(const b3c_mat *m, int64_t *n, int64_t *nnz, int *kind)
+{
+    if (!m) return B3C_E_ARG;
+    if (n) *n = m->n;
+    if (nnz) *nnz = m->nnz;
+    if (kind) *kind = m->kind;
+    return B3C_OK;
+}
+
+extern "C" int b3c_mat_download(b3c_ctx *ctx, const b3c_mat *m, int64_t *indptr, int32_t *indices, void *data)
+{
+    if (!ctx || !m) return B3C_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t esz = m->kind == B3C_U32 ? 4 : 8;
+    if (indptr) HIP_TRY(ctx, hipMemcpyAsync(indptr, m->indptr, sizeof(int64_t) * (size_t)(m->n + 1), hipMemcpyDefault, ctx->stream));
+    if (indices && m->nnz) HIP_TRY(ctx, hipMemcpyAsync(indices, m->indices, sizeof(int32_t) * (size_t)m->nnz, hipMemcpyDefault, ctx->stream));
+    if (data && m->nnz) HIP_TRY(ctx, hipMemcpyAsync(data, m->data, esz * (size_t)m->nnz, hipMemcpyDefault, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return B3C_OK;
+}
+
+extern "C" int b3c_mat_device_ptrs(const b3c_mat *m, void **indptr, void **indices, void **data)
+{
+    if (!m) return B3C_E_ARG;
+    if (indptr) *indptr = m->indptr;
+    if (indices) *indices = m->indices;
+    if (data) *data = m->data;
+    return B3C_OK;
+}

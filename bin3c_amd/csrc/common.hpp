@@ -1,0 +1,147 @@
+// libb3c internals shared by the .hip translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "b3c.h"
+
+// ---------------------------------------------------------------------------------------------
+// context: device, stream, caching HBM pool, error text
+// ---------------------------------------------------------------------------------------------
+struct b3c_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::multimap<size_t, void *> pool;   // free blocks by size
+    std::map<void *, size_t> live;        // every block handed out or pooled -> size
+    int64_t bytes = 0;
+    int n_cu = 256;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int fail(int code, const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+
+    // Pooled allocation: HBM blocks are recycled between calls so that the timed path issues no
+    // hipMalloc once warm.
+    void *alloc(size_t nbytes)
+    {
+        if (nbytes == 0) nbytes = 16;
+        nbytes = (nbytes + 255) & ~size_t(255);
+        auto it = pool.lower_bound(nbytes);
+        if (it != pool.end() && it->first <= nbytes + nbytes / 4 + 4096) {
+            void *p = it->second;
+            pool.erase(it);
+            return p;
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, nbytes) != hipSuccess) {
+            // release the pool and retry once
+            trim();
+            if (hipMalloc(&p, nbytes) != hipSuccess) return nullptr;
+        }
+        live[p] = nbytes;
+        bytes += (int64_t)nbytes;
+        return p;
+    }
+    void release(void *p)
+    {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        pool.insert({it->second, p});
+    }
+    void trim()
+    {
+        for (auto &kv : pool) {
+            (void)hipFree(kv.second);
+            bytes -= (int64_t)kv.first;
+            live.erase(kv.second);
+        }
+        pool.clear();
+    }
+};
+
+struct b3c_mat {
+    int64_t n = 0, nnz = 0;
+    int kind = B3C_F64;
+    int64_t *indptr = nullptr;
+    int32_t *indices = nullptr;
+    void *data = nullptr;
+};
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return (ctx)->fail(B3C_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// scoped pooled buffer
+template <typename T>
+struct DevBuf {
+    b3c_ctx *ctx;
+    T *p;
+    DevBuf(b3c_ctx *c, size_t count) : ctx(c), p((T *)c->alloc(count * sizeof(T))) {}
+    ~DevBuf() { ctx->release(p); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    operator T *() const { return p; }
+};
+
+static inline int grid_for(int64_t work_items, int block, int max_blocks)
+{
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers: wave64 reductions with a fixed shuffle tree (deterministic)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// internal cross-file entry points
+int b3c_mat_alloc(b3c_ctx *ctx, int64_t n, int64_t nnz, int kind, b3c_mat **out);
+int b3c_copy_in(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
+int b3c_copy_out(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);

@@ -1,0 +1,339 @@
+// CSR helper kernels around the KR iteration (gfx950): site normalisation, symmetric scaling,
+// off-diagonal maximum, mask compaction, global maximum.  All are single streaming passes over the
+// stored entries (HBM-bound integer/fp64 work; no MFMA).
+#include "common.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+constexpr int BLK = 256;
+
+// Iterate the stored entries of a CSR matrix with LPR lanes per row; f(row, k, lane_in_row).
+template <int LPR, typename F>
+__device__ __forceinline__ void for_rows(int64_t n, const int64_t *__restrict__ indptr, F f)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x / 64);
+    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        for (int64_t k = s + sl; k < e; k += LPR) f(row, k);
+    }
+}
+
+// fast_norm_fullseq_bysite (contact_map.py:100-113) on astype(float) counts (:929); sites 0 -> 1 (:1107)
+template <int LPR>
+__global__ void __launch_bounds__(BLK) k_site_norm(int64_t n, const int64_t *__restrict__ indptr,
+                                                    const int32_t *__restrict__ indices,
+                                                    const uint32_t *__restrict__ counts,
+                                                    const double *__restrict__ sites, double *__restrict__ out)
+{
+    for_rows<LPR>(n, indptr, [&](int64_t row, int64_t k) {
+        double si = sites[row];
+        double sj = sites[indices[k]];
+        si = si == 0.0 ? 1.0 : si;
+        sj = sj == 0.0 ? 1.0 : sj;
+        out[k] = (double)counts[k] * (1.0 / (si * sj));
+    });
+}
+
+// X.T.dot(_orig.dot(X)) (sparse_utils.py:223-224): x_i * (a_ij * x_j)
+template <int LPR>
+__global__ void __launch_bounds__(BLK) k_scale_sym(int64_t n, const int64_t *__restrict__ indptr,
+                                                    const int32_t *__restrict__ indices, double *__restrict__ a,
+                                                    const double *__restrict__ x)
+{
+    for_rows<LPR>(n, indptr, [&](int64_t row, int64_t k) {
+        double t = a[k] * x[indices[k]];
+        a[k] = x[row] * t;
+    });
+}
+
+// max_offdiag (sparse_utils.py:269-281), symmetric input: row maximum with the diagonal skipped
+template <int LPR>
+__global__ void __launch_bounds__(BLK) k_max_offdiag_rows(int64_t n, const int64_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices,
+                                                           const uint32_t *__restrict__ a, uint32_t *__restrict__ out)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        uint32_t m = 0;
+        for (int64_t k = s + sl; k < e; k += LPR) {
+            uint32_t val = a[k];
+            if (indices[k] != (int32_t)row && val > m) m = val;
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            uint32_t other = (uint32_t)__shfl_down((int)m, o, LPR);
+            m = other > m ? other : m;
+        }
+        if (sl == 0) out[row] = m;
+    }
+}
+
+// general input: column maximum by integer atomics (exact, order independent)
+template <int LPR>
+__global__ void __launch_bounds__(BLK) k_max_offdiag_cols(int64_t n, const int64_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices,
+                                                           const uint32_t *__restrict__ a, uint32_t *__restrict__ out)
+{
+    for_rows<LPR>(n, indptr, [&](int64_t row, int64_t k) {
+        const int32_t j = indices[k];
+        const uint32_t val = a[k];
+        if (j != (int32_t)row && val != 0) atomicMax(&out[j], val);
+    });
+}
+
+// compress (sparse_utils.py:284-314), pass 1: kept entries per kept row
+template <int LPR>
+__global__ void __launch_bounds__(BLK) k_compress_count(int64_t n, const int64_t *__restrict__ indptr,
+                                                         const int32_t *__restrict__ indices,
+                                                         const uint8_t *__restrict__ mask,
+                                                         const int64_t *__restrict__ newid, int64_t *__restrict__ cnt)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
+        if (!mask[row]) continue;
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        int c = 0;
+        for (int64_t k = s + sl; k < e; k += LPR) c += mask[indices[k]] != 0;
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) c += __shfl_down(c, o, LPR);
+        if (sl == 0) cnt[newid[row]] = c;
+    }
+}
+
+// pass 2: order-preserving fill, one wave per kept row (ballot compaction keeps column order)
+template <typename T>
+__global__ void __launch_bounds__(BLK) k_compress_fill(int64_t n, const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices, const T *__restrict__ a,
+                                                        const uint8_t *__restrict__ mask,
+                                                        const int64_t *__restrict__ newid,
+                                                        const int64_t *__restrict__ out_indptr,
+                                                        int32_t *__restrict__ out_indices, T *__restrict__ out_a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t row = wave; row < n; row += nwave) {
+        if (!mask[row]) continue;
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        int64_t o = out_indptr[newid[row]];
+        for (int64_t base = s; base < e; base += 64) {
+            const int64_t k = base + lane;
+            int32_t j = 0;
+            bool keep = false;
+            if (k < e) {
+                j = indices[k];
+                keep = mask[j] != 0;
+            }
+            const unsigned long long b = __ballot(keep);
+            if (keep) {
+                const int pos = __popcll(b & ((1ull << lane) - 1ull));
+                out_indices[o + pos] = (int32_t)newid[j];
+                out_a[o + pos] = a[k];
+            }
+            o += __popcll(b);
+        }
+    }
+}
+
+__global__ void k_mask_to_i64(int64_t n, const uint8_t *__restrict__ mask, int64_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mask[i] != 0;
+}
+
+// _map.max() (cluster.py:316): per-block partial maxima
+__global__ void __launch_bounds__(BLK) k_max_value(int64_t nnz, const double *__restrict__ a, double *__restrict__ part)
+{
+    __shared__ double lds[BLK / 64];
+    double m = -INFINITY;
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    for (int64_t k = (int64_t)blockIdx.x * BLK + threadIdx.x; k < nnz; k += stride) m = fmax(m, a[k]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = lds[0];
+        for (int w = 1; w < BLK / 64; w++) r = fmax(r, lds[w]);
+        part[blockIdx.x] = r;
+    }
+}
+
+int pick_lpr(const b3c_mat *m)
+{
+    const double avg = m->n ? (double)m->nnz / (double)m->n : 0.0;
+    return avg >= 96 ? 64 : avg >= 40 ? 32 : avg >= 18 ? 16 : avg >= 8 ? 8 : 4;
+}
+
+#define DISPATCH_LPR(lpr, KERNEL, grid, stream, ...)                                                  \
+    switch (lpr) {                                                                                    \
+    case 64: hipLaunchKernelGGL(KERNEL<64>, dim3(grid), dim3(BLK), 0, stream, __VA_ARGS__); break;    \
+    case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(BLK), 0, stream, __VA_ARGS__); break;    \
+    case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(BLK), 0, stream, __VA_ARGS__); break;    \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(BLK), 0, stream, __VA_ARGS__); break;      \
+    default: hipLaunchKernelGGL(KERNEL<4>, dim3(grid), dim3(BLK), 0, stream, __VA_ARGS__); break;     \
+    }
+
+int row_grid(const b3c_ctx *ctx, int64_t n, int lpr)
+{
+    return grid_for(n, (BLK / 64) * (64 / lpr), 16 * ctx->n_cu);
+}
+
+}  // namespace
+
+// exclusive prefix sum of int64 (device), used by compress and by the Louvain aggregation
+int b3c_exclusive_scan_i64(b3c_ctx *ctx, const int64_t *in, int64_t *out, int64_t count)
+{
+    size_t tmp_bytes = 0;
+    HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, out, (int)count, ctx->stream));
+    DevBuf<char> tmp(ctx, tmp_bytes);
+    if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "scan workspace");
+    HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, in, out, (int)count, ctx->stream));
+    return B3C_OK;
+}
+
+extern "C" int b3c_max_offdiag_u32(b3c_ctx *ctx, const b3c_mat *counts, int assume_symmetric, uint32_t *out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!counts || counts->kind != B3C_U32 || !out) return ctx->fail(B3C_E_ARG, "b3c_max_offdiag_u32: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = counts->n;
+    if (n == 0) return B3C_OK;
+    DevBuf<uint32_t> d(ctx, n);
+    if (!d.p) return ctx->fail(B3C_E_NOMEM, "b3c_max_offdiag_u32");
+    const int lpr = pick_lpr(counts);
+    const int g = row_grid(ctx, n, lpr);
+    if (assume_symmetric) {
+        DISPATCH_LPR(lpr, k_max_offdiag_rows, g, ctx->stream, n, counts->indptr, counts->indices,
+                     (const uint32_t *)counts->data, d.p);
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(d.p, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
+        DISPATCH_LPR(lpr, k_max_offdiag_cols, g, ctx->stream, n, counts->indptr, counts->indices,
+                     (const uint32_t *)counts->data, d.p);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return b3c_copy_out(ctx, out, d.p, sizeof(uint32_t) * (size_t)n);
+}
+
+extern "C" int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *sites, b3c_mat **out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!counts || counts->kind != B3C_U32 || !sites || !out) return ctx->fail(B3C_E_ARG, "b3c_site_norm: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = counts->n;
+    b3c_mat *m = nullptr;
+    int rc = b3c_mat_alloc(ctx, n, counts->nnz, B3C_F64, &m);
+    if (rc) return rc;
+    DevBuf<double> ds(ctx, n);
+    if (!ds.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_site_norm"); }
+    if ((rc = b3c_copy_in(ctx, ds.p, sites, sizeof(double) * (size_t)n))) { b3c_mat_free(ctx, m); return rc; }
+    HIP_TRY(ctx, hipMemcpyAsync(m->indptr, counts->indptr, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(m->indices, counts->indices, sizeof(int32_t) * (size_t)counts->nnz, hipMemcpyDeviceToDevice, ctx->stream));
+    if (n) {
+        const int lpr = pick_lpr(counts);
+        DISPATCH_LPR(lpr, k_site_norm, row_grid(ctx, n, lpr), ctx->stream, n, counts->indptr, counts->indices,
+                     (const uint32_t *)counts->data, ds.p, (double *)m->data);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out = m;
+    return B3C_OK;
+}
+
+extern "C" int b3c_scale_sym(b3c_ctx *ctx, b3c_mat *a, const double *x)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a || a->kind != B3C_F64 || !x) return ctx->fail(B3C_E_ARG, "b3c_scale_sym: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = a->n;
+    if (n == 0) return B3C_OK;
+    DevBuf<double> dx(ctx, n);
+    if (!dx.p) return ctx->fail(B3C_E_NOMEM, "b3c_scale_sym");
+    int rc = b3c_copy_in(ctx, dx.p, x, sizeof(double) * (size_t)n);
+    if (rc) return rc;
+    const int lpr = pick_lpr(a);
+    DISPATCH_LPR(lpr, k_scale_sym, row_grid(ctx, n, lpr), ctx->stream, n, a->indptr, a->indices, (double *)a->data, dx.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return B3C_OK;
+}
+
+extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, b3c_mat **out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a || !mask || !out) return ctx->fail(B3C_E_ARG, "b3c_compress: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = a->n;
+    hipStream_t s = ctx->stream;
+    DevBuf<uint8_t> dm(ctx, n + 1);
+    DevBuf<int64_t> keep(ctx, n + 1), newid(ctx, n + 1), cnt(ctx, n + 1), optr(ctx, n + 2);
+    if (!dm.p || !keep.p || !newid.p || !cnt.p || !optr.p) return ctx->fail(B3C_E_NOMEM, "b3c_compress");
+    int rc = b3c_copy_in(ctx, dm.p, mask, (size_t)n);
+    if (rc) return rc;
+    // newid = i - cumsum(~mask)[i] for kept i  ==  exclusive scan of the keep flags (sparse_utils.py:307-312)
+    HIP_TRY(ctx, hipMemsetAsync(keep.p, 0, sizeof(int64_t) * (size_t)(n + 1), s));
+    if (n) hipLaunchKernelGGL(k_mask_to_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, keep.p);
+    if ((rc = b3c_exclusive_scan_i64(ctx, keep.p, newid.p, n + 1))) return rc;
+    int64_t m = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&m, newid.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, sizeof(int64_t) * (size_t)(m + 1), s));
+    const int lpr = pick_lpr(a);
+    if (n) {
+        DISPATCH_LPR(lpr, k_compress_count, row_grid(ctx, n, lpr), s, n, a->indptr, a->indices, dm.p, newid.p, cnt.p);
+    }
+    if ((rc = b3c_exclusive_scan_i64(ctx, cnt.p, optr.p, m + 1))) return rc;
+    int64_t nnz = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nnz, optr.p + m, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    b3c_mat *o = nullptr;
+    if ((rc = b3c_mat_alloc(ctx, m, nnz, a->kind, &o))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(o->indptr, optr.p, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToDevice, s));
+    if (n) {
+        const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
+        if (a->kind == B3C_F64)
+            hipLaunchKernelGGL(k_compress_fill<double>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
+                               (const double *)a->data, dm.p, newid.p, optr.p, o->indices, (double *)o->data);
+        else
+            hipLaunchKernelGGL(k_compress_fill<uint32_t>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
+                               (const uint32_t *)a->data, dm.p, newid.p, optr.p, o->indices, (uint32_t *)o->data);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    *out = o;
+    return B3C_OK;
+}
+
+extern "C" int b3c_max_value(b3c_ctx *ctx, const b3c_mat *a, double *out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a || a->kind != B3C_F64 || !out) return ctx->fail(B3C_E_ARG, "b3c_max_value: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int g = grid_for(a->nnz, BLK * 4, 4 * ctx->n_cu);
+    DevBuf<double> part(ctx, g);
+    if (!part.p) return ctx->fail(B3C_E_NOMEM, "b3c_max_value");
+    hipLaunchKernelGGL(k_max_value, dim3(g), dim3(BLK), 0, ctx->stream, a->nnz, (const double *)a->data, part.p);
+    std::vector<double> h(g);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double m = -INFINITY;
+    for (int i = 0; i < g; i++) m = h[i] > m ? h[i] : m;
+    // implicit zeros take part in scipy's max unless the matrix is completely dense
+    if ((double)a->nnz < (double)a->n * (double)a->n && m < 0.0) m = 0.0;
+    *out = m;
+    return B3C_OK;
+}

@@ -1,0 +1,119 @@
+"""
+Host-side mirror of the reference's ``mzd/sparse_utils.py`` for the hot path: same function names,
+arguments, return types, log lines and exceptions, with the arithmetic done by libb3c on the MI355X.
+
+    kr_biostochastic   mzd/sparse_utils.py:90-224
+    max_offdiag        mzd/sparse_utils.py:269-281
+    compress           mzd/sparse_utils.py:284-314
+
+There is no CPU fallback: without libb3c.so and a GPU these functions raise.
+"""
+import logging
+
+import numpy as np
+import scipy.sparse as scisp
+
+from .. import _native
+
+logger = logging.getLogger(__name__)
+
+
+def _canonical_csr(m, dtype=None):
+    """scipy matrix -> CSR with sorted indices and summed duplicates (what tolil()/tocsr() at
+    sparse_utils.py:110-118 produce), never modifying the caller's object."""
+    c = m.tocsr()
+    if c is m:
+        c = c.copy()
+    if dtype is not None and c.dtype != dtype:
+        c = c.astype(dtype)
+    c.sum_duplicates()
+    c.sort_indices()
+    return c
+
+
+def kr_biostochastic(m, tol=1e-6, x0=None, delta=0.1, Delta=3, max_iter=1000, ctx=None):
+    """
+    Normalise a matrix to be bistochastic using the Knight-Ruiz algorithm (sparse_utils.py:90-224).
+
+    :param m: the input matrix (fully symmetric), any scipy.sparse type
+    :param tol: precision tolerance
+    :param x0: an initial guess -- only None is supported, as in the reference (``if not x0`` on an
+               ndarray raises at sparse_utils.py:126)
+    :param delta: how close balancing vector can get
+    :param Delta: how far balancing vector can get
+    :param max_iter: maximum number of iterations before abandoning.
+    :return: tuple containing the bistochastic matrix (CSR) and the scale factors
+    """
+    assert scisp.isspmatrix(m), 'input matrix must be sparse matrix from scipy.spmatrix'
+    assert m.shape[0] == m.shape[1], 'input matrix must be square'
+    if x0 is not None:
+        raise ValueError('x0 is not supported (the reference cannot evaluate `not x0` on an array either)')
+
+    ctx = ctx or _native.default_context()
+    c = _canonical_csr(m, np.float64)
+    mat = ctx.upload(c.indptr, c.indices, c.data)
+    try:
+        rc, x, info = ctx.kr_balance(mat, tol, delta, Delta, max_iter, check=False)
+        # re-emit the reference's log lines in its order (:113, :121)
+        if info.n_zero_diag > 0:
+            logger.warning('treating {} zeros on diagonal as ones'.format(info.n_zero_diag))
+        if not info.is_symmetric:
+            logger.warning('input matrix is expected to be fully symmetric')
+        if rc == _native.E_NAN:
+            raise RuntimeError('scale vector has developed invalid values (NANs)!')
+        if rc == _native.E_NOCONV:
+            raise RuntimeError('matrix balancing failed to converge in {} iterations'.format(info.n_iter))
+        ctx._check(rc)
+        logger.debug('It took {} iterations to achieve bistochasticity'.format(info.n_iter))
+        if info.hit_max_iter:
+            logger.warning('Warning: maximum number of iterations ({}) reached without convergence'.format(max_iter))
+        ctx.scale_sym(mat, x)
+        _, _, data = mat.download(structure=False)
+    finally:
+        mat.free()
+    return scisp.csr_matrix((data, c.indices, c.indptr), shape=c.shape), x
+
+
+def max_offdiag(_m, ctx=None):
+    """
+    Determine the maximum off-diagonal values of a given symmetric matrix (sparse_utils.py:269-281):
+    the diagonal is zeroed, then the per-column maximum is returned (implicit zeros included).
+
+    :param _m: a scipy.sparse matrix
+    :return: the off-diagonal maximum values
+    """
+    assert scisp.isspmatrix(_m), 'Input matrix is not a scipy.sparse object'
+    ctx = ctx or _native.default_context()
+    if _m.dtype == np.uint32:
+        c = _canonical_csr(_m)
+        mat = ctx.upload(c.indptr, c.indices, c.data)
+        try:
+            return ctx.max_offdiag_u32(mat, assume_symmetric=False)
+        finally:
+            mat.free()
+    # other dtypes are not on the hot path (seq_map is uint32, sparse_utils.py:237): same semantics via scipy
+    c = _m.tolil(True)
+    c.setdiag(0)
+    return np.asarray(c.tocsr().max(axis=0).todense()).ravel()
+
+
+def compress(_m, _mask, ctx=None):
+    """
+    Remove rows and columns using a 1d boolean mask (sparse_utils.py:284-314).
+
+    :param _mask: True (keep), False (drop)
+    :return: a coo_matrix of only the accepted rows/columns
+    """
+    assert scisp.isspmatrix(_m), 'Input matrix is not a scipy sparse matrix type'
+    ctx = ctx or _native.default_context()
+    _mask = np.asarray(_mask, dtype=bool)
+    c = _canonical_csr(_m, None if _m.dtype == np.uint32 else np.float64)
+    mat = ctx.upload(c.indptr, c.indices, c.data)
+    try:
+        out = ctx.compress(mat, _mask)
+        ip, ix, data = out.download()
+        out.free()
+    finally:
+        mat.free()
+    n = ip.shape[0] - 1
+    return scisp.csr_matrix((data.astype(_m.dtype, copy=False), ix, ip), shape=(n, n)).tocoo()

@@ -1,0 +1,139 @@
+/*
+ * libb3c -- MI355X (gfx950) native hot path of bin3C: contact-map normalisation, Knight-Ruiz
+ * balancing, mask compaction and Louvain clustering.  C ABI, plain pointers and sizes only.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to cerebis/bin3C).
+ * The reference is pure Python, so its "FFI" for this path is a ctypes binding: see INTEGRATION.md
+ * for the stub a maintainer adds to mzd/sparse_utils.py, mzd/contact_map.py and mzd/cluster.py.
+ *
+ * Conventions
+ *  - Matrices are canonical CSR: int64 indptr[n+1], int32 indices[nnz] sorted within a row and free
+ *    of duplicates, values double (B3C_F64) or uint32 (B3C_U32).
+ *  - Array arguments marked "host|dev" may be host or device pointers (resolved with
+ *    hipMemcpyDefault); the library never retains or frees caller memory.
+ *  - Every call returns B3C_OK or a negative error code; b3c_last_error() gives the text.  Calls are
+ *    synchronous with respect to their outputs unless the name ends in _async.
+ *  - One b3c_ctx per host thread and device; a ctx is not re-entrant.
+ */
+#ifndef B3C_H
+#define B3C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B3C_OK 0
+#define B3C_E_ARG (-1)    /* bad argument (AssertionError in the reference: sparse_utils.py:103-104) */
+#define B3C_E_HIP (-2)    /* HIP runtime failure */
+#define B3C_E_NAN (-3)    /* RuntimeError('scale vector has developed invalid values (NANs)!') sparse_utils.py:193 */
+#define B3C_E_NOCONV (-4) /* RuntimeError('matrix balancing failed to converge in {} iterations') sparse_utils.py:214 */
+#define B3C_E_NOMEM (-5)
+
+#define B3C_F64 0
+#define B3C_U32 1
+
+typedef struct b3c_ctx b3c_ctx;
+typedef struct b3c_mat b3c_mat;
+
+/* Outcome of b3c_kr_balance; the warn-only conditions let the caller re-emit the reference's log lines. */
+typedef struct {
+    int64_t n_iter;       /* sparse_utils.py:201,218 -- number of SpMVs minus one */
+    int64_t n_outer;      /* outer (Newton) iterations */
+    int64_t n_zero_diag;  /* 'treating {} zeros on diagonal as ones' sparse_utils.py:113 */
+    int32_t is_symmetric; /* 0 -> 'input matrix is expected to be fully symmetric' sparse_utils.py:121 */
+    int32_t hit_max_iter; /* 1 -> 'maximum number of iterations ({}) reached' sparse_utils.py:220-221 */
+    int64_t hit_delta;    /* times the delta bound cut the inner loop (sparse_utils.py:171) */
+    int64_t hit_Delta;    /* times the Delta bound cut the inner loop (sparse_utils.py:179) */
+    double rout;          /* final squared residual */
+    double spmv_ms;       /* device time spent in the SpMV kernel (HIP events), 0 if not measured */
+    int64_t n_spmv;       /* SpMV launches that did work */
+} b3c_kr_info;
+
+typedef struct {
+    int32_t n_comm;
+    int32_t n_levels;
+    int64_t n_sweeps;
+    int64_t n_moves;
+    int32_t quant_shift;  /* fixed-point scale 2^shift applied to the edge weights */
+    int32_t reserved;
+    double modularity;    /* exact-integer modularity of the returned partition, as double */
+    double move_ms;       /* device time in the delta-Q neighbour-scan kernel */
+    int64_t n_move_launch;
+    int64_t move_nnz;     /* stored entries scanned by those launches (for the roofline) */
+} b3c_louvain_info;
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* Create a context on `device`.  `stream` is a hipStream_t to launch on (NULL: the library creates
+ * its own non-blocking stream). */
+int b3c_ctx_create(int device, void *stream, b3c_ctx **out);
+int b3c_ctx_destroy(b3c_ctx *ctx);
+const char *b3c_last_error(const b3c_ctx *ctx);
+int b3c_ctx_sync(b3c_ctx *ctx);
+/* HBM bytes currently held by the context's matrices and workspaces. */
+int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
+
+/* ---- matrices ------------------------------------------------------------------------------ */
+
+/* Copy a CSR matrix into HBM.  Replaces the scipy objects handed between contact_map.py:929-945. */
+int b3c_mat_upload(b3c_ctx *ctx, int64_t n, int64_t nnz, const int64_t *indptr /*host|dev*/,
+                   const int32_t *indices /*host|dev*/, const void *data /*host|dev*/, int kind, b3c_mat **out);
+int b3c_mat_free(b3c_ctx *ctx, b3c_mat *m);
+int b3c_mat_info(const b3c_mat *m, int64_t *n, int64_t *nnz, int *kind);
+/* Copy back; any of the three output pointers may be NULL. */
+int b3c_mat_download(b3c_ctx *ctx, const b3c_mat *m, int64_t *indptr, int32_t *indices, void *data);
+/* Raw device pointers of a matrix (for zero-copy consumers such as torch tensors). */
+int b3c_mat_device_ptrs(const b3c_mat *m, void **indptr, void **indices, void **data);
+
+/* ---- CSR helpers --------------------------------------------------------------------------- */
+
+/* max_offdiag (sparse_utils.py:269-281): per-column maximum with the diagonal zeroed; out is
+ * uint32[n].  `assume_symmetric` != 0 lets the kernel reduce rows instead (seq_map is symmetric by
+ * construction, sparse_utils.py:261-266). */
+int b3c_max_offdiag_u32(b3c_ctx *ctx, const b3c_mat *counts, int assume_symmetric, uint32_t *out /*host|dev*/);
+
+/* _norm_seq(use_sites=True) (contact_map.py:1110-1129) + fast_norm_fullseq_bysite (:100-113) after
+ * the astype(float) of :929: out_ij = counts_ij * (1.0 / (s_i * s_j)), zero sites -> 1 (:1103-1108).
+ * Creates a new B3C_F64 matrix that shares no storage with `counts`. */
+int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *sites /*host|dev*/, b3c_mat **out);
+
+/* X.T * (orig * X) (sparse_utils.py:223-224): a_ij <- x_i * (a_ij * x_j), in place. */
+int b3c_scale_sym(b3c_ctx *ctx, b3c_mat *a, const double *x /*host|dev*/);
+
+/* compress (sparse_utils.py:284-314): keep rows/columns with mask != 0, ids re-indexed by
+ * i - cumsum(~mask)[i]. */
+int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask /*host|dev*/, b3c_mat **out);
+
+/* _map.max() (cluster.py:316). */
+int b3c_max_value(b3c_ctx *ctx, const b3c_mat *a, double *out);
+
+/* ---- Knight-Ruiz --------------------------------------------------------------------------- */
+
+/* kr_biostochastic (sparse_utils.py:90-224) minus the final scaling (use b3c_scale_sym):
+ * x (double[n], host|dev) such that diag(x) A diag(x) is doubly stochastic.  `a` is not modified;
+ * zero diagonals are treated as one on an internal working term (sparse_utils.py:110-115).
+ * Returns B3C_E_NOCONV / B3C_E_NAN like the reference raises; `info` is filled in either case. */
+int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double delta, double Delta, int64_t max_iter,
+                   double *x /*host|dev*/, b3c_kr_info *info);
+
+/* ---- Louvain ------------------------------------------------------------------------------- */
+
+/* to_graph's weight scaling (cluster.py:316-321) + louvain.cluster / community.best_partition
+ * (louvain.py:70) on a structurally symmetric B3C_F64 matrix: labels[i] in [0, n_comm) or -1 for a
+ * node whose row is empty (never added to the graph by cluster.py:321).  scl multiplies every
+ * weight (pass 1/max for scale=True).  n_sub = sub-rounds per sweep (0 -> default 4). */
+int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub, int max_sweeps,
+                int32_t *labels /*host|dev*/, b3c_louvain_info *info);
+
+/* Fixed-point edge weights the Louvain kernels work on (int64[nnz], host|dev) and their shift. */
+int b3c_graph_quantise(b3c_ctx *ctx, const b3c_mat *a, double scl, int64_t *q /*host|dev*/, int32_t *shift);
+
+/* ---- build info ---------------------------------------------------------------------------- */
+const char *b3c_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
