@@ -1,10 +1,726 @@
-// placeholder until the Louvain kernels land
+// Louvain community detection on gfx950 -- replaces to_graph's weight scaling (mzd/cluster.py:316-321)
+// and louvain.cluster -> community.best_partition (mzd/louvain.py:70).
+//
+// Schedule and arithmetic are specified by oracle/louvain_bsp.c (the scalar restatement the tests
+// compare against, bit for bit): fixed-point edge weights, exact integer gains, a sweep of n_sub
+// bulk-synchronous sub-rounds, ties to the lowest community id, singleton guard, python-louvain's
+// 1e-7 stopping rules.  Because every sum is an integer sum, no result depends on the order in which
+// lanes, waves or atomics happen to run.
+//
+// Kernels (all HBM/L2-bound integer work; no MFMA):
+//   lv_decide   one wave per node: neighbour-community weights accumulated in an LDS hash table
+//               (open addressing, ds_cmpst + ds_add_u64), own-community weight in registers, exact
+//               128-bit gain per candidate, wave arg-max by shuffles.  Hubs whose table does not fit
+//               LDS use a global-memory table.
+//   lv_apply    moves of one sub-round: integer atomics on the community totals
+//   lv_modularity / lv_tot2   exact modularity numerator
+//   aggregation: (community pair, weight) keys -> radix sort + reduce-by-key (hipcub) -> next level CSR
 #include "common.hpp"
-extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *, double, int, int, int32_t *, b3c_louvain_info *)
+
+#include <cstdlib>
+#include <hipcub/hipcub.hpp>
+
+int b3c_exclusive_scan_i64(b3c_ctx *ctx, const int64_t *in, int64_t *out, int64_t count);
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int WPB = BLK / 64;
+typedef __int128 i128;
+typedef unsigned long long u64;
+
+__host__ __device__ __forceinline__ uint32_t bucket_of(int64_t i, int n_sub)
 {
-    return ctx ? ctx->fail(B3C_E_ARG, "b3c_louvain: not built yet") : B3C_E_ARG;
+    uint32_t h = (uint32_t)i * 2654435761u;
+    return (h >> 16) % (uint32_t)n_sub;
 }
-extern "C" int b3c_graph_quantise(b3c_ctx *ctx, const b3c_mat *, double, int64_t *, int32_t *)
+
+struct LvGraph {
+    int64_t n = 0, nnz = 0;
+    int64_t *indptr = nullptr;
+    int32_t *indices = nullptr;
+    int64_t *q = nullptr;
+    bool owned = false;
+};
+
+// ---------------------------------------------------------------------------------------------
+// graph weights + quantisation
+// ---------------------------------------------------------------------------------------------
+// w = a * scl with the value of the LOWER triangle entry on both sides (cluster.py:319-321: a later
+// add_edge(v,u) overwrites the earlier (u,v)).  Rows must have sorted columns.
+__global__ void __launch_bounds__(BLK) k_graph_w(int64_t n, const int64_t *__restrict__ indptr,
+                                                  const int32_t *__restrict__ indices,
+                                                  const double *__restrict__ a, double scl, double *__restrict__ w,
+                                                  double *__restrict__ part_max)
 {
-    return ctx ? ctx->fail(B3C_E_ARG, "b3c_graph_quantise: not built yet") : B3C_E_ARG;
+    __shared__ double lds[WPB];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    double mx = 0.0;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        for (int64_t k = s + lane; k < e; k += 64) {
+            const int32_t j = indices[k];
+            double val = a[k];
+            if (j > row) {
+                int64_t lo = indptr[j], hi = indptr[j + 1];
+                const int64_t je = hi;
+                while (lo < hi) {
+                    int64_t mid = (lo + hi) >> 1;
+                    if (indices[mid] < (int32_t)row) lo = mid + 1; else hi = mid;
+                }
+                if (lo < je && indices[lo] == (int32_t)row) val = a[lo];
+            }
+            const double ww = val * scl;
+            w[k] = ww;
+            mx = fmax(mx, ww);
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) lds[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = lds[0];
+        for (int i = 1; i < WPB; i++) r = fmax(r, lds[i]);
+        part_max[blockIdx.x] = r;
+    }
+}
+
+// sum of ceil(w * 2^(20-e)), diagonal twice: exact integer bound on 2m (oracle: orc_quant_shift)
+__global__ void __launch_bounds__(BLK) k_quant_total(int64_t n, const int64_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ indices,
+                                                      const double *__restrict__ w, int ex, u64 *__restrict__ total)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    u64 acc = 0;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        for (int64_t k = s + lane; k < e; k += 64) {
+            u64 c = (u64)ceil(ldexp(w[k], ex));
+            acc += indices[k] == (int32_t)row ? 2 * c : c;
+        }
+    }
+    acc = (u64)wave_sum_ll((long long)acc);
+    if (lane == 0 && acc) atomicAdd(total, acc);
+}
+
+__global__ void k_quantise(int64_t nnz, const double *__restrict__ w, int shift, int64_t *__restrict__ q)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride)
+        q[k] = __double2ll_rn(ldexp(w[k], shift));
+}
+
+// ---------------------------------------------------------------------------------------------
+// level set-up
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__restrict__ indptr,
+                                                  const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
+                                                  int64_t *__restrict__ kdeg, int64_t *__restrict__ tot,
+                                                  int32_t *__restrict__ com, int32_t *__restrict__ nxt,
+                                                  int32_t *__restrict__ csize, u64 *__restrict__ m2)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    long long total = 0;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        long long d = 0;
+        for (int64_t k = s + lane; k < e; k += 64) d += indices[k] == (int32_t)row ? 2 * q[k] : q[k];
+        d = wave_sum_ll(d);
+        if (lane == 0) {
+            kdeg[row] = d;
+            tot[row] = d;
+            com[row] = (int32_t)row;
+            nxt[row] = (int32_t)row;
+            csize[row] = e > s ? 1 : 0;   // empty rows are not graph nodes (cluster.py:321 never adds them)
+            total += d;
+        }
+    }
+    if (lane == 0 && total) atomicAdd(m2, (u64)total);
+}
+
+// ---------------------------------------------------------------------------------------------
+// delta-Q neighbour scan
+// ---------------------------------------------------------------------------------------------
+constexpr int32_t EMPTY = -1;
+
+__device__ __forceinline__ uint32_t hash_slot(int32_t c, int lg) { return ((uint32_t)c * 0x9E3779B1u) >> (32 - lg); }
+
+struct Best {
+    i128 gain;
+    int32_t com;
+    int32_t have;
+};
+
+__device__ __forceinline__ void best_take(Best &b, i128 g, int32_t c)
+{
+    if (g > 0 && (!b.have || g > b.gain || (g == b.gain && c < b.com))) {
+        b.gain = g;
+        b.com = c;
+        b.have = 1;
+    }
+}
+
+__device__ __forceinline__ Best best_wave_reduce(Best b)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        long long hi = __shfl_down((long long)(b.gain >> 64), o, 64);
+        u64 lo = (u64)__shfl_down((long long)(u64)b.gain, o, 64);
+        int32_t c = __shfl_down(b.com, o, 64);
+        int32_t hv = __shfl_down(b.have, o, 64);
+        i128 g = ((i128)hi << 64) | (i128)lo;
+        if (hv && (!b.have || g > b.gain || (g == b.gain && c < b.com))) {
+            b.gain = g;
+            b.com = c;
+            b.have = 1;
+        }
+    }
+    return b;
+}
+
+// CAP = LDS table entries per wave.  Nodes with 2*deg > CAP use the global table at gkeys/gvals + goff[i].
+template <int CAP>
+__global__ void __launch_bounds__(BLK) k_lv_decide(int64_t n, int n_sub, int round, u64 m2,
+                                                    const int64_t *__restrict__ indptr,
+                                                    const int32_t *__restrict__ indices,
+                                                    const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
+                                                    const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
+                                                    const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
+                                                    const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
+                                                    u64 *__restrict__ gvals)
+{
+    __shared__ int32_t skeys[WPB][CAP];
+    __shared__ u64 svals[WPB][CAP];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + wib;
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    int32_t *lk = skeys[wib];
+    u64 *lv = svals[wib];
+    for (int t = lane; t < CAP; t += 64) { lk[t] = EMPTY; lv[t] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+    for (int64_t i = wave; i < n; i += nwave) {
+        if (bucket_of(i, n_sub) != (uint32_t)round) continue;
+        const long long ki = kdeg[i];
+        if (ki == 0) continue;
+        const int64_t s = indptr[i], e = indptr[i + 1];
+        const int64_t deg = e - s;
+        const int32_t a = com[i];
+        const bool use_lds = 2 * deg <= CAP;
+        int lg = 6;
+        while ((1ll << lg) < 2 * deg) lg++;
+        const uint32_t mask = (1u << lg) - 1u;
+        int32_t *keys = use_lds ? lk : gkeys + goff[i];
+        u64 *vals = use_lds ? lv : gvals + goff[i];
+
+        long long own = 0;
+        for (int64_t k = s + lane; k < e; k += 64) {
+            const int32_t j = indices[k];
+            if (j == (int32_t)i) continue;
+            const int32_t c = com[j];
+            const u64 qv = (u64)q[k];
+            if (c == a) { own += (long long)qv; continue; }
+            uint32_t slot = hash_slot(c, lg);
+            for (;;) {
+                int32_t prev = atomicCAS(&keys[slot], EMPTY, c);
+                if (prev == EMPTY || prev == c) { atomicAdd(&vals[slot], qv); break; }
+                slot = (slot + 1) & mask;
+            }
+        }
+        own = wave_sum_ll(own);
+        if (use_lds) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+
+        Best b;
+        b.gain = 0; b.com = a; b.have = 0;
+        for (uint32_t t = lane; t <= mask; t += 64) {
+            const int32_t c = keys[t];
+            if (c != EMPTY) {
+                const u64 d = vals[t];
+                keys[t] = EMPTY;
+                vals[t] = 0;
+                const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
+                best_take(b, g, c);
+            }
+        }
+        if (lane == 0) {
+            // staying: i removed from its own community first (python-louvain __remove)
+            const i128 g = (i128)own * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            best_take(b, g, a);
+        }
+        b = best_wave_reduce(b);
+        if (lane == 0) {
+            int32_t best = b.have ? b.com : a;
+            if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
+            nxt[i] = best;
+        }
+        if (use_lds) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    }
+}
+
+__global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int round, const int64_t *__restrict__ kdeg,
+                                                   int64_t *__restrict__ tot, int32_t *__restrict__ com,
+                                                   const int32_t *__restrict__ nxt, int32_t *__restrict__ csize,
+                                                   u64 *__restrict__ moved)
+{
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    int cnt = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+        if (bucket_of(i, n_sub) != (uint32_t)round) continue;
+        const int32_t a = com[i], b = nxt[i];
+        if (a == b) continue;
+        const long long ki = kdeg[i];
+        atomicAdd((u64 *)&tot[a], (u64)(-ki));
+        atomicAdd((u64 *)&tot[b], (u64)ki);
+        atomicSub(&csize[a], 1);
+        atomicAdd(&csize[b], 1);
+        com[i] = b;
+        cnt++;
+    }
+    u64 bal = __ballot(cnt != 0);
+    if (bal) {
+        long long c = wave_sum_ll(cnt);
+        if ((threadIdx.x & 63) == 0) atomicAdd(moved, (u64)c);
+    }
+}
+
+// I2 = sum_i ( sum_{j != i, com j == com i} q_ij + 2 q_ii )
+__global__ void __launch_bounds__(BLK) k_lv_internal(int64_t n, const int64_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ indices,
+                                                      const int64_t *__restrict__ q, const int32_t *__restrict__ com,
+                                                      u64 *__restrict__ i2)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    long long acc = 0;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        const int32_t a = com[row];
+        for (int64_t k = s + lane; k < e; k += 64) {
+            const int32_t j = indices[k];
+            if (j == (int32_t)row) acc += 2 * q[k];
+            else if (com[j] == a) acc += q[k];
+        }
+    }
+    acc = wave_sum_ll(acc);
+    if (lane == 0 && acc) atomicAdd(i2, (u64)acc);
+}
+
+// T2 = sum_c tot_c^2 as four 32-bit limbs, each accumulated in a u64
+__global__ void __launch_bounds__(BLK) k_lv_tot2(int64_t n, const int64_t *__restrict__ tot, u64 *__restrict__ limbs)
+{
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    u64 l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    for (int64_t c = (int64_t)blockIdx.x * BLK + threadIdx.x; c < n; c += stride) {
+        const unsigned __int128 t = (unsigned __int128)(u64)tot[c] * (u64)tot[c];
+        l0 += (u64)(t & 0xFFFFFFFFu);
+        l1 += (u64)((t >> 32) & 0xFFFFFFFFu);
+        l2 += (u64)((t >> 64) & 0xFFFFFFFFu);
+        l3 += (u64)(t >> 96);
+    }
+    l0 = (u64)wave_sum_ll((long long)l0);
+    l1 = (u64)wave_sum_ll((long long)l1);
+    l2 = (u64)wave_sum_ll((long long)l2);
+    l3 = (u64)wave_sum_ll((long long)l3);
+    if ((threadIdx.x & 63) == 0) {
+        if (l0) atomicAdd(&limbs[0], l0);
+        if (l1) atomicAdd(&limbs[1], l1);
+        if (l2) atomicAdd(&limbs[2], l2);
+        if (l3) atomicAdd(&limbs[3], l3);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// aggregation
+// ---------------------------------------------------------------------------------------------
+__global__ void k_flag_used(int64_t n, const int32_t *__restrict__ csize, int64_t *__restrict__ used)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) used[i] = csize[i] > 0;
+    if (i == n) used[i] = 0;
+}
+
+__global__ void k_node_newcom(int64_t n, const int32_t *__restrict__ com, const int64_t *__restrict__ newid,
+                              const int32_t *__restrict__ csize, int32_t *__restrict__ cn)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int32_t c = com[i];
+        cn[i] = csize[c] > 0 ? (int32_t)newid[c] : -1;   // -1 only for empty-row nodes of level 0
+    }
+}
+
+__global__ void k_update_labels(int64_t n0, int32_t *__restrict__ labels, const int32_t *__restrict__ cn)
+{
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n0) {
+        const int32_t l = labels[v];
+        labels[v] = l >= 0 ? cn[l] : -1;
+    }
+}
+
+__global__ void __launch_bounds__(BLK) k_make_pairs(int64_t n, int64_t kc, const int64_t *__restrict__ indptr,
+                                                     const int32_t *__restrict__ indices,
+                                                     const int64_t *__restrict__ q, const int32_t *__restrict__ cn,
+                                                     int64_t *__restrict__ keys, int64_t *__restrict__ vals)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        const int64_t c1 = cn[row];
+        for (int64_t k = s + lane; k < e; k += 64) {
+            const int32_t j = indices[k];
+            keys[k] = c1 * kc + cn[j];
+            vals[k] = j == (int32_t)row ? 2 * q[k] : q[k];   // loops doubled so the internal total halves exactly
+        }
+    }
+}
+
+__global__ void k_rows_from_keys(int64_t kc, int64_t nu, const int64_t *__restrict__ ukeys,
+                                 int64_t *__restrict__ indptr)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > kc) return;
+    const int64_t target = r * kc;   // first key of row r
+    int64_t lo = 0, hi = nu;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (ukeys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    indptr[r] = lo;
+}
+
+__global__ void k_fill_from_keys(int64_t kc, int64_t nu, const int64_t *__restrict__ ukeys,
+                                 const int64_t *__restrict__ usums, int32_t *__restrict__ indices,
+                                 int64_t *__restrict__ q)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nu; e += stride) {
+        const int64_t key = ukeys[e];
+        const int64_t r = key / kc, c = key - r * kc;
+        indices[e] = (int32_t)c;
+        q[e] = r == c ? usums[e] / 2 : usums[e];
+    }
+}
+
+__global__ void k_init_labels(int64_t n, const int64_t *__restrict__ indptr, int32_t *__restrict__ labels)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) labels[i] = indptr[i + 1] > indptr[i] ? (int32_t)i : -1;
+}
+
+__global__ void k_big_table_sizes(int64_t n, int cap, const int64_t *__restrict__ indptr, int64_t *__restrict__ sz)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int64_t deg = indptr[i + 1] - indptr[i];
+        int64_t t = 0;
+        if (2 * deg > cap) {
+            int lg = 6;
+            while ((1ll << lg) < 2 * deg) lg++;
+            t = 1ll << lg;
+        }
+        sz[i] = t;
+    }
+    if (i == n) sz[i] = 0;
+}
+
+__global__ void k_max_degree(int64_t n, const int64_t *__restrict__ indptr, u64 *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long d = i < n ? indptr[i + 1] - indptr[i] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        long long t = __shfl_down(d, o, 64);
+        d = t > d ? t : d;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (u64)d);
+}
+
+struct Events {
+    std::vector<hipEvent_t> ev;
+    bool on = false;
+    hipStream_t s;
+    void rec()
+    {
+        if (!on) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); ev.push_back(e); }
+    }
+    double total_ms()
+    {
+        double ms = 0;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float f = 0;
+            if (hipEventElapsedTime(&f, ev[i], ev[i + 1]) == hipSuccess) ms += f;
+        }
+        for (auto e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        return ms;
+    }
+};
+
+int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, double scl, int64_t *q, int32_t *shift_out)
+{
+    hipStream_t s = ctx->stream;
+    const int64_t n = a->n, nnz = a->nnz;
+    *shift_out = 0;
+    if (nnz == 0) return B3C_OK;
+    DevBuf<double> w(ctx, nnz);
+    const int g = grid_for(n, WPB, 16 * ctx->n_cu);
+    DevBuf<double> part(ctx, g);
+    DevBuf<u64> total(ctx, 1);
+    if (!w.p || !part.p || !total.p) return ctx->fail(B3C_E_NOMEM, "quantise_graph");
+    hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, scl,
+                       w.p, part.p);
+    std::vector<double> hp(g);
+    HIP_TRY(ctx, hipMemcpyAsync(hp.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    double wmax = 0.0;
+    for (int i = 0; i < g; i++) wmax = hp[i] > wmax ? hp[i] : wmax;
+    int shift = 0;
+    if (wmax > 0.0) {
+        int e;
+        frexp(wmax, &e);   // wmax < 2^e
+        HIP_TRY(ctx, hipMemsetAsync(total.p, 0, sizeof(u64), s));
+        hipLaunchKernelGGL(k_quant_total, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, w.p, 20 - e, total.p);
+        u64 tot = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&tot, total.p, sizeof(u64), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        int bits = 0;
+        while (bits < 64 && (tot >> bits)) bits++;
+        shift = 61 - (bits - 20 + e);
+    }
+    hipLaunchKernelGGL(k_quantise, dim3(grid_for(nnz, BLK * 4, 8 * ctx->n_cu)), dim3(BLK), 0, s, nnz, w.p, shift, q);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    *shift_out = shift;
+    return B3C_OK;
+}
+
+void free_graph(b3c_ctx *ctx, LvGraph &g)
+{
+    if (g.owned) {
+        ctx->release(g.indptr);
+        ctx->release(g.indices);
+        ctx->release(g.q);
+    }
+    g = LvGraph();
+}
+
+}  // namespace
+
+extern "C" int b3c_graph_quantise(b3c_ctx *ctx, const b3c_mat *a, double scl, int64_t *q, int32_t *shift)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a || a->kind != B3C_F64 || !q || !shift) return ctx->fail(B3C_E_ARG, "b3c_graph_quantise: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<int64_t> dq(ctx, a->nnz);
+    if (!dq.p) return ctx->fail(B3C_E_NOMEM, "b3c_graph_quantise");
+    int rc = quantise_graph(ctx, a, scl, dq.p, shift);
+    if (rc) return rc;
+    return b3c_copy_out(ctx, q, dq.p, sizeof(int64_t) * (size_t)a->nnz);
+}
+
+extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub, int max_sweeps, int32_t *labels_out,
+                           b3c_louvain_info *info)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a || a->kind != B3C_F64 || !labels_out || !info) return ctx->fail(B3C_E_ARG, "b3c_louvain: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    memset(info, 0, sizeof(*info));
+    if (n_sub <= 0) n_sub = 4;
+    hipStream_t s = ctx->stream;
+    const int64_t n0 = a->n;
+    if (n0 == 0) return B3C_OK;
+    const double PL_MIN = 0.0000001;   // community_louvain.__MIN
+
+    Events evs;
+    evs.on = getenv("B3C_PROFILE") != nullptr;
+    evs.s = s;
+
+    DevBuf<int32_t> labels(ctx, n0);
+    DevBuf<int64_t> q0(ctx, a->nnz);
+    if (!labels.p || !q0.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
+    int32_t shift = 0;
+    int rc = quantise_graph(ctx, a, scl, q0.p, &shift);
+    if (rc) return rc;
+    info->quant_shift = shift;
+    hipLaunchKernelGGL(k_init_labels, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, n0, a->indptr, labels.p);
+
+    LvGraph g;
+    g.n = n0; g.nnz = a->nnz; g.indptr = a->indptr; g.indices = a->indices; g.q = q0.p; g.owned = false;
+
+    double mod = 0.0;
+    bool first = true;
+    DevBuf<u64> ctr(ctx, 8);   // [0] m2, [1] moved, [2] i2, [3..6] tot2 limbs, [7] max degree
+    if (!ctr.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
+
+    for (;;) {
+        const int64_t n = g.n;
+        DevBuf<int64_t> kdeg(ctx, n), tot(ctx, n), goff(ctx, n + 1), gsz(ctx, n + 1);
+        DevBuf<int32_t> com(ctx, n), nxt(ctx, n), csize(ctx, n);
+        if (!kdeg.p || !tot.p || !goff.p || !gsz.p || !com.p || !nxt.p || !csize.p) {
+            free_graph(ctx, g);
+            return ctx->fail(B3C_E_NOMEM, "b3c_louvain: level buffers");
+        }
+        const int gw = grid_for(n, WPB, 16 * ctx->n_cu);     // wave-per-row kernels
+        const int gv = grid_for(n, BLK, 8 * ctx->n_cu);      // thread-per-node kernels
+        HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 8, s));
+        hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, kdeg.p, tot.p, com.p,
+                           nxt.p, csize.p, ctr.p);
+        hipLaunchKernelGGL(k_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
+        u64 hc[8];
+        HIP_TRY(ctx, hipMemcpyAsync(hc, ctr.p, sizeof(hc), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        const u64 m2 = hc[0];
+        const int64_t maxdeg = (int64_t)hc[7];
+        if (m2 == 0) break;   // no links: every node alone (generate_dendrogram special case)
+
+        // LDS table capacity per wave for this level; nodes beyond it use the global table
+        const int cap = 2 * maxdeg <= 128 ? 128 : 2 * maxdeg <= 512 ? 512 : 2048;
+        hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap, g.indptr, gsz.p);
+        if ((rc = b3c_exclusive_scan_i64(ctx, gsz.p, goff.p, n + 1))) { free_graph(ctx, g); return rc; }
+        int64_t gtab = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&gtab, goff.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        DevBuf<int32_t> gkeys(ctx, gtab + 1);
+        DevBuf<u64> gvals(ctx, gtab + 1);
+        if (!gkeys.p || !gvals.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hub tables"); }
+        if (gtab) {
+            HIP_TRY(ctx, hipMemsetAsync(gkeys.p, 0xFF, sizeof(int32_t) * (size_t)gtab, s));
+            HIP_TRY(ctx, hipMemsetAsync(gvals.p, 0, sizeof(u64) * (size_t)gtab, s));
+        }
+
+        auto modularity = [&](double *out) -> int {
+            HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64) * 5, s));
+            hipLaunchKernelGGL(k_lv_internal, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, com.p, ctr.p + 2);
+            hipLaunchKernelGGL(k_lv_tot2, dim3(gv), dim3(BLK), 0, s, n, tot.p, ctr.p + 3);
+            u64 h[8];
+            HIP_TRY(ctx, hipMemcpyAsync(h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            unsigned __int128 t2 = (unsigned __int128)h[3] + ((unsigned __int128)h[4] << 32) +
+                                   ((unsigned __int128)h[5] << 64) + ((unsigned __int128)h[6] << 96);
+            i128 num = (i128)m2 * (i128)h[2] - (i128)t2;
+            *out = (double)num / ((double)m2 * (double)m2);
+            return B3C_OK;
+        };
+
+        double cur_mod, new_mod;
+        if ((rc = modularity(&new_mod))) { free_graph(ctx, g); return rc; }
+        int sweep = 0;
+        for (;;) {
+            cur_mod = new_mod;
+            sweep++;
+            info->n_sweeps++;
+            HIP_TRY(ctx, hipMemsetAsync(ctr.p + 1, 0, sizeof(u64), s));
+            for (int r = 0; r < n_sub; r++) {
+                evs.rec();
+                if (cap == 128)
+                    hipLaunchKernelGGL(k_lv_decide<128>, dim3(gw), dim3(BLK), 0, s, n, n_sub, r, m2, g.indptr, g.indices,
+                                       g.q, kdeg.p, tot.p, com.p, csize.p, nxt.p, goff.p, gkeys.p, gvals.p);
+                else if (cap == 512)
+                    hipLaunchKernelGGL(k_lv_decide<512>, dim3(gw), dim3(BLK), 0, s, n, n_sub, r, m2, g.indptr, g.indices,
+                                       g.q, kdeg.p, tot.p, com.p, csize.p, nxt.p, goff.p, gkeys.p, gvals.p);
+                else
+                    hipLaunchKernelGGL(k_lv_decide<2048>, dim3(gw), dim3(BLK), 0, s, n, n_sub, r, m2, g.indptr, g.indices,
+                                       g.q, kdeg.p, tot.p, com.p, csize.p, nxt.p, goff.p, gkeys.p, gvals.p);
+                evs.rec();
+                info->n_move_launch++;
+                hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, kdeg.p, tot.p, com.p, nxt.p,
+                                   csize.p, ctr.p + 1);
+            }
+            info->move_nnz += g.nnz;
+            u64 moved = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&moved, ctr.p + 1, sizeof(u64), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            info->n_moves += (int64_t)moved;
+            if (moved == 0) break;
+            if ((rc = modularity(&new_mod))) { free_graph(ctx, g); return rc; }
+            if (new_mod - cur_mod < PL_MIN) break;
+            if (max_sweeps > 0 && sweep >= max_sweeps) break;
+        }
+        if (!first && new_mod - mod < PL_MIN) break;
+        first = false;
+        mod = new_mod;
+        info->n_levels++;
+
+        // ---- renumber by ascending community id, relabel the original nodes ----
+        DevBuf<int64_t> used(ctx, n + 1), newid(ctx, n + 1);
+        DevBuf<int32_t> cn(ctx, n);
+        if (!used.p || !newid.p || !cn.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: renumber"); }
+        hipLaunchKernelGGL(k_flag_used, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, csize.p, used.p);
+        if ((rc = b3c_exclusive_scan_i64(ctx, used.p, newid.p, n + 1))) { free_graph(ctx, g); return rc; }
+        int64_t kc = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&kc, newid.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_node_newcom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, com.p, newid.p, csize.p, cn.p);
+        hipLaunchKernelGGL(k_update_labels, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, n0, labels.p, cn.p);
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        info->n_comm = (int32_t)kc;
+
+        // ---- induced graph: sort (community pair) keys, sum weights ----
+        const int64_t m = g.nnz;
+        DevBuf<int64_t> k_in(ctx, m), k_out(ctx, m), v_in(ctx, m), v_out(ctx, m), nruns(ctx, 1);
+        if (!k_in.p || !k_out.p || !v_in.p || !v_out.p || !nruns.p) {
+            free_graph(ctx, g);
+            return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation buffers");
+        }
+        hipLaunchKernelGGL(k_make_pairs, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, k_in.p, v_in.p);
+        int end_bit = 1;
+        while (end_bit < 63 && ((unsigned __int128)1 << end_bit) < (unsigned __int128)kc * (unsigned __int128)kc) end_bit++;
+        size_t tb = 0;
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)m, 0, end_bit, s));
+        {
+            DevBuf<char> tmp(ctx, tb);
+            if (!tmp.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "sort workspace"); }
+            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)m, 0, end_bit, s));
+        }
+        tb = 0;
+        HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tb, k_out.p, k_in.p, v_out.p, v_in.p, nruns.p,
+                                                       hipcub::Sum(), (int)m, s));
+        {
+            DevBuf<char> tmp(ctx, tb);
+            if (!tmp.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "reduce workspace"); }
+            HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(tmp.p, tb, k_out.p, k_in.p, v_out.p, v_in.p, nruns.p,
+                                                           hipcub::Sum(), (int)m, s));
+        }
+        int64_t nu = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&nu, nruns.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+
+        LvGraph h;
+        h.n = kc; h.nnz = nu; h.owned = true;
+        h.indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(kc + 1));
+        h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu > 0 ? nu : 1));
+        h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu > 0 ? nu : 1));
+        if (!h.indptr || !h.indices || !h.q) {
+            free_graph(ctx, h);
+            free_graph(ctx, g);
+            return ctx->fail(B3C_E_NOMEM, "b3c_louvain: next level");
+        }
+        hipLaunchKernelGGL(k_rows_from_keys, dim3((unsigned)((kc + 256) / 256)), dim3(256), 0, s, kc, nu, k_in.p, h.indptr);
+        if (nu)
+            hipLaunchKernelGGL(k_fill_from_keys, dim3(grid_for(nu, 256, 8 * ctx->n_cu)), dim3(256), 0, s, kc, nu, k_in.p,
+                               v_in.p, h.indices, h.q);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        free_graph(ctx, g);
+        g = h;
+    }
+    free_graph(ctx, g);
+    info->modularity = mod;
+    info->move_ms = evs.total_ms();
+    HIP_TRY(ctx, hipGetLastError());
+    return b3c_copy_out(ctx, labels_out, labels.p, sizeof(int32_t) * (size_t)n0);
 }

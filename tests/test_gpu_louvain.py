@@ -1,0 +1,104 @@
+"""
+GPU suite: HIP Louvain (delta-Q neighbour scan, apply, exact modularity, sort/reduce aggregation)
+through the C ABI against the scalar restatement of the same schedule (oracle/louvain_bsp.c).
+Integer label work: identical labels, identical level/sweep counts, identical exact modularity.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import graphs
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(ctx, oracle, ip, ix, a, scl, n_sub=4):
+    mat = ctx.upload(ip, ix, a)
+    q_dev, shift = ctx.graph_quantise(mat, scl)
+    w = oracle.graph_weights(ip, ix, a, scl)
+    S = oracle.quant_shift(ip, ix, w)
+    q = oracle.quantise(w, S)
+    assert shift == S
+    assert np.array_equal(q_dev, q)
+    ref = oracle.louvain_bsp(ip, ix, q, n_sub=n_sub)
+    labels, info = ctx.louvain(mat, scl, n_sub=n_sub)
+    mat.free()
+    return ref, labels, info
+
+
+def _assert_same(ref, labels, info):
+    assert info.n_levels == ref['n_levels']
+    assert info.n_sweeps == ref['n_sweeps']
+    assert info.modularity == ref['Q']
+    assert np.array_equal(labels, ref['labels'])
+    if ref['n_levels'] > 0:
+        assert info.n_comm == ref['n_comm']
+
+
+@pytest.mark.parametrize('maker', [graphs.two_cliques, graphs.ring_of_cliques, graphs.karate])
+def test_small_graphs(ctx, oracle_lib, maker):
+    n, edges = maker()
+    ip, ix, w = graphs.csr_from_edges(n, edges)
+    ref, labels, info = _run_both(ctx, oracle_lib, ip, ix, w, 1.0 / w.max())
+    _assert_same(ref, labels, info)
+
+
+def test_multilevel_ring(ctx, oracle_lib):
+    n, edges = graphs.ring_of_cliques(30, 5, 1.0, 1.0)
+    ip, ix, w = graphs.csr_from_edges(n, edges)
+    ref, labels, info = _run_both(ctx, oracle_lib, ip, ix, w, 1.0)
+    assert ref['n_levels'] >= 2
+    _assert_same(ref, labels, info)
+
+
+def test_loops_empty_rows_and_no_edges(ctx, oracle_lib):
+    n, edges = graphs.two_cliques(4, 0.05)
+    ip, ix, w = graphs.csr_from_edges(n + 2, edges, loops={0: 2.0, 8: 1.0})
+    ref, labels, info = _run_both(ctx, oracle_lib, ip, ix, w, 0.5)
+    _assert_same(ref, labels, info)
+    assert labels[9] == -1
+    ip = np.zeros(6, dtype=np.int64)
+    mat = ctx.upload(ip, np.zeros(0, np.int32), np.zeros(0))
+    labels, info = ctx.louvain(mat, 1.0)
+    assert (labels == -1).all() and info.n_levels == 0
+
+
+@pytest.mark.parametrize('n_sub', [1, 2, 4, 8])
+def test_pipeline_golden_graph(ctx, oracle_lib, n_sub):
+    """The compressed, balanced map of the reference pipeline fixture (cluster.py:310-321)."""
+    g = np.load(os.path.join(GOLDEN, 'pipeline.npz'))
+    ref, labels, info = _run_both(ctx, oracle_lib, g['sub_indptr'], g['sub_indices'], g['sub_data'], float(g['scl']),
+                                  n_sub=n_sub)
+    _assert_same(ref, labels, info)
+
+
+@pytest.mark.parametrize('n,e,seed', [(1000, 50000, 1), (5000, 100000, 2), (30000, 900000, 3)])
+def test_synthetic_maps(ctx, oracle_lib, n, e, seed):
+    gr = graphs.synth_graph(oracle_lib, n, e, seed)
+    ref, labels, info = _run_both(ctx, oracle_lib, gr['indptr'], gr['indices'], gr['data'], gr['scl'])
+    _assert_same(ref, labels, info)
+    assert graphs.same_partition(labels, gr['sm'].genome[gr['mask']])
+
+
+def test_hub_rows_use_global_table(ctx, oracle_lib):
+    """A star hub of degree 3000 (> LDS table capacity) on top of a clustered graph."""
+    rs = np.random.RandomState(8)
+    n, edges = graphs.ring_of_cliques(500, 6, 1.0, 0.2)
+    hub = n
+    edges += [(hub, int(v), float(rs.uniform(0.01, 0.5))) for v in rs.choice(n, 2999, replace=False)]
+    edges.append((hub, hub + 1, 5.0))
+    ip, ix, w = graphs.csr_from_edges(n + 2, edges)
+    assert np.diff(ip).max() == 3000
+    ref, labels, info = _run_both(ctx, oracle_lib, ip, ix, w, 1.0 / w.max())
+    _assert_same(ref, labels, info)
+
+
+def test_powerlaw_map_and_determinism(ctx, oracle_lib):
+    gr = graphs.synth_graph(oracle_lib, 20000, 400000, 9, degree_law='powerlaw')
+    ref, labels, info = _run_both(ctx, oracle_lib, gr['indptr'], gr['indices'], gr['data'], gr['scl'])
+    _assert_same(ref, labels, info)
+    mat = ctx.upload(gr['indptr'], gr['indices'], gr['data'])
+    l2, i2 = ctx.louvain(mat, gr['scl'])
+    assert np.array_equal(l2, labels) and i2.modularity == info.modularity

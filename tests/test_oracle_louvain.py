@@ -1,0 +1,109 @@
+"""
+CPU suite: the two Louvain oracles on hand-checkable graphs.  python-louvain itself is absent
+(PARITY UNPINNED, see oracle/louvain_seq.c), so these pin what CAN be pinned: the obvious partitions,
+modularity against networkx's independent `modularity` implementation, exactness of the fixed-point
+schedule, and agreement between the sequential and the bulk-synchronous schedule on easy graphs.
+"""
+import numpy as np
+import pytest
+
+import graphs
+
+
+def _nx_modularity(n, edges, labels, loops=None):
+    import networkx as nx
+    g = nx.Graph()
+    g.add_nodes_from(range(n))
+    for u, v, w in edges:
+        g.add_edge(u, v, weight=w)
+    for u, w in (loops or {}).items():
+        g.add_edge(u, u, weight=w)
+    comms = {}
+    for i, l in enumerate(labels):
+        comms.setdefault(int(l), set()).add(i)
+    return nx.algorithms.community.modularity(g, list(comms.values()), weight='weight')
+
+
+def test_two_cliques_sequential(oracle_lib):
+    n, edges = graphs.two_cliques()
+    ip, ix, w = graphs.csr_from_edges(n, edges)
+    r = oracle_lib.louvain_seq(ip, ix, w)
+    assert r['n_comm'] == 2
+    assert graphs.same_partition(r['labels'], [0] * 5 + [1] * 5)
+    assert abs(r['Q'] - _nx_modularity(n, edges, r['labels'])) < 1e-12
+    assert abs(oracle_lib.modularity(ip, ix, w, r['labels']) - r['Q']) < 1e-12
+
+
+@pytest.mark.parametrize('maker', [graphs.ring_of_cliques, graphs.karate])
+def test_sequential_modularity_matches_networkx(oracle_lib, maker):
+    n, edges = maker()
+    ip, ix, w = graphs.csr_from_edges(n, edges)
+    r = oracle_lib.louvain_seq(ip, ix, w)
+    assert abs(r['Q'] - _nx_modularity(n, edges, r['labels'])) < 1e-12
+    assert r['Q'] > 0.35
+    assert r['labels'].min() == 0 and r['labels'].max() == r['n_comm'] - 1
+
+
+def test_ring_of_cliques_multilevel(oracle_lib):
+    """30 cliques of 5 on a ring: level 0 finds the cliques, a second level merges neighbours (resolution limit)."""
+    n, edges = graphs.ring_of_cliques(30, 5, 1.0, 1.0)
+    ip, ix, w = graphs.csr_from_edges(n, edges)
+    r = oracle_lib.louvain_seq(ip, ix, w)
+    assert r['n_levels'] >= 2 and r['n_comm'] < 30
+    # cliques are never split
+    lab = r['labels'].reshape(30, 5)
+    assert (lab == lab[:, :1]).all()
+    S = oracle_lib.quant_shift(ip, ix, w)
+    b = oracle_lib.louvain_bsp(ip, ix, oracle_lib.quantise(w, S), n_sub=4)
+    lab = b['labels'].reshape(30, 5)
+    assert (lab == lab[:, :1]).all() and b['n_levels'] >= 2
+
+
+def test_self_loops_and_isolated_rows(oracle_lib):
+    n, edges = graphs.two_cliques(4, 0.05)
+    n += 2                                   # node 8: only a self-loop; node 9: empty row
+    ip, ix, w = graphs.csr_from_edges(n, edges, loops={0: 2.0, 8: 1.0})
+    r = oracle_lib.louvain_seq(ip, ix, w)
+    assert r['labels'][9] == -1              # never added to the graph (cluster.py:321)
+    assert r['labels'][8] >= 0 and (r['labels'] == r['labels'][8]).sum() == 1
+    assert abs(r['Q'] - _nx_modularity(9, edges, r['labels'][:9], loops={0: 2.0, 8: 1.0})) < 1e-12
+    S = oracle_lib.quant_shift(ip, ix, w)
+    b = oracle_lib.louvain_bsp(ip, ix, oracle_lib.quantise(w, S))
+    assert graphs.same_partition(b['labels'], r['labels'])
+
+
+def test_no_edges(oracle_lib):
+    ip = np.zeros(6, dtype=np.int64)
+    r = oracle_lib.louvain_seq(ip, np.zeros(0, np.int32), np.zeros(0))
+    assert (r['labels'] == -1).all() and r['n_comm'] == 0
+    b = oracle_lib.louvain_bsp(ip, np.zeros(0, np.int32), np.zeros(0, np.int64))
+    assert (b['labels'] == -1).all()
+
+
+def test_quantisation_is_exact_and_bounded(oracle_lib):
+    rs = np.random.RandomState(3)
+    n, edges = graphs.ring_of_cliques(20, 8)
+    edges = [(u, v, w * rs.uniform(1e-6, 1.0)) for u, v, w in edges]
+    ip, ix, w = graphs.csr_from_edges(n, edges, loops={3: 0.7})
+    S = oracle_lib.quant_shift(ip, ix, w)
+    q = oracle_lib.quantise(w, S)
+    rows = np.repeat(np.arange(n), np.diff(ip))
+    total = int(q.sum()) + int(q[rows == ix].sum())          # 2m with loops counted twice
+    assert 2 ** 59 <= total < 2 ** 61                         # uses the headroom, never overflows
+    np.testing.assert_allclose(q / 2.0 ** S, w, rtol=0, atol=2.0 ** -S)
+    assert np.array_equal(q, np.rint(np.ldexp(w, S)).astype(np.int64))
+
+
+@pytest.mark.parametrize('n_sub', [1, 2, 4, 8])
+def test_bsp_close_to_sequential_on_synthetic_map(oracle_lib, n_sub):
+    gr = graphs.synth_graph(oracle_lib, 3000, 90000, 5)
+    seq = oracle_lib.louvain_seq(gr['indptr'], gr['indices'], gr['w'])
+    S = oracle_lib.quant_shift(gr['indptr'], gr['indices'], gr['w'])
+    bsp = oracle_lib.louvain_bsp(gr['indptr'], gr['indices'], oracle_lib.quantise(gr['w'], S), n_sub=n_sub)
+    qb = oracle_lib.modularity(gr['indptr'], gr['indices'], gr['w'], bsp['labels'])
+    assert abs(qb - bsp['Q']) < 1e-9           # exact-integer Q equals the fp64 Q of the same partition
+    assert qb > seq['Q'] - 0.01                # schedule changes the optimum found only marginally
+    # planted genomes are recovered by both
+    gen = gr['sm'].genome[gr['mask']]
+    assert graphs.same_partition(seq['labels'], gen)
+    assert graphs.same_partition(bsp['labels'], gen)
