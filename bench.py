@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""
+bench.py -- contact-graph edges/s through KR-normalise + Louvain (BASELINE.json metric).
+
+One "step" = one pass of the cluster hot path over one synthetic contact map that is already
+resident in HBM: acceptance mask -> site normalisation -> Knight-Ruiz balancing -> X A X ->
+mask compaction -> weight scaling -> Louvain labels on the host (bin3c_amd/pipeline.py).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3]
+
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL); ranks
+process independent maps of the same shape (weak scaling) until the row-sharded KR lands.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault('B3C_PROFILE', '1')      # HIP events around the SpMV / delta-Q launches
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(sample_n, sample_e, seed):
+    """Oracle (scalar C port of the reference path) on a bounded sample of the same workload, 1 thread."""
+    import oracle
+    from bin3c_amd.synth import make_synth
+    oracle.build()
+    sm = make_synth(sample_n, sample_e, seed)
+    e_true = sm.n_edges
+    t0 = time.perf_counter()
+    sig = oracle.max_offdiag_u32(sm.indptr, sm.indices, sm.counts)
+    mask = (sm.lengths >= 1000) & (sig >= 5)
+    nd = oracle.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
+    rc, x, st = oracle.kr_balance(sm.indptr, sm.indices, nd)
+    proc = oracle.scale_sym(sm.indptr, sm.indices, nd, x)
+    m, ip, ix, a = oracle.compress(sm.indptr, sm.indices, proc, mask)
+    scl = 1.0 / oracle.max_value(ip, a)
+    w = oracle.graph_weights(ip, ix, a, scl)
+    r = oracle.louvain_seq(ip, ix, w)
+    dt = time.perf_counter() - t0
+    return {'value': e_true / dt, 'unit': 'edges/s', 'cores': 1, 'kind': 'port',
+            'sample': 'hic-synth-v1 n={} E={} seed={}: full mask+norm+KR({} SpMV)+compress+sequential Louvain '
+                      '({} sweeps) in {:.1f}s on 1 host thread'.format(sample_n, e_true, seed, st.n_iter + 1,
+                                                                       r['n_sweeps'], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='C3', choices=['C1', 'C2', 'C3'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False and libb3c has no CPU path')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+
+    from bin3c_amd import _native
+    from bin3c_amd.pipeline import run_hot_path
+    from bin3c_amd.synth import CONFIGS, make_synth
+
+    n, n_edges, seed, law = CONFIGS[args.config]
+    sm = make_synth(n, n_edges, seed + rank, law)      # each rank: an independent map of the same shape
+    e_true = sm.n_edges
+    ctx = _native.Context(local_rank)
+    counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    sites = sm.sites
+    lengths = sm.lengths
+    nnz = sm.nnz
+    min_len, min_sig = 1000, 5
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    last = None
+    for _ in range(args.warmup):
+        last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig)
+    barrier()
+    t0 = time.perf_counter()
+    stage = {}
+    spmv_ms = spmv_n = move_ms = move_n = move_nnz = move_rows = 0
+    for _ in range(args.steps):
+        last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig)
+        for k, v in last.timings.items():
+            stage[k] = stage.get(k, 0.0) + v
+        spmv_ms += last.kr_info.spmv_ms
+        spmv_n += last.kr_info.n_spmv
+        move_ms += last.lv_info.move_ms
+        move_n += last.lv_info.n_move_launch
+        move_nnz += last.lv_info.move_nnz
+        move_rows += last.lv_info.move_rows
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ee = torch.tensor([float(e_true)], dtype=torch.float64, device='cuda')
+        dist.all_reduce(ee, op=dist.ReduceOp.SUM)
+        e_total = float(ee.item())
+    else:
+        e_total = float(e_true)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = e_total * args.steps / dt
+        # dominant kernel by accumulated device time
+        n_acc = int(last.mask.sum())
+        if spmv_ms >= move_ms:
+            per_launch = 12.0 * nnz + 20.0 * n             # one KR SpMV
+            avg_ms = spmv_ms / max(spmv_n, 1)
+            kname = 'kr_kb (CSR SpMV + fused KR epilogue)'
+        else:
+            per_launch = (16.0 * move_nnz + 28.0 * move_rows) / max(move_n, 1)   # Louvain sweep / n_sub
+            avg_ms = move_ms / max(move_n, 1)
+            kname = 'k_lv_decide (Louvain delta-Q neighbour scan)'
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'contact-graph edges/s through KR-normalise + Louvain',
+            'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '{}: hic-synth-v1 n={} contigs, E={} undirected edges (nnz={}), seed={}'.format(
+                           args.config, n, e_true, nnz, seed),
+                       'parallelism': 'single GPU' if world == 1 else 'replicas x{} (one map per GPU)'.format(world),
+                       'accepted_contigs': n_acc, 'kr_spmv_per_step': int(spmv_n // args.steps),
+                       'louvain_sweeps_per_step': int(last.lv_info.n_sweeps), 'louvain_levels': int(last.lv_info.n_levels),
+                       'communities': int(last.lv_info.n_comm), 'modularity': last.lv_info.modularity,
+                       'stage_ms': {k: v / args.steps * 1e3 for k, v in stage.items()},
+                       'kernel_ms': {'kr_spmv_total': spmv_ms / args.steps, 'louvain_decide_total': move_ms / args.steps}},
+            'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'bytes_per_launch': per_launch, 'avg_launch_ms': avg_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = {'C1': (1000, 50000), 'C2': (100000, 5000000), 'C3': (200000, 10000000)}[args.config]
+            out['cpu_baseline'] = cpu_baseline(sample[0], sample[1], seed)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()

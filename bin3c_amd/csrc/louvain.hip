@@ -642,6 +642,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                                    csize.p, ctr.p + 1);
             }
             info->move_nnz += g.nnz;
+            info->move_rows += g.n;
             u64 moved = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&moved, ctr.p + 1, sizeof(u64), hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));

@@ -9,7 +9,7 @@ per-contig ``length`` and ``sites`` (contact_map.py:19 ``SeqInfo``).
 
 Model (SURVEY.md section 8(d), with the deviations listed in DESIGN.md): ``G = max(4, n // 500)`` genomes
 whose contig counts follow rank**-0.5, contig ids randomly permuted (no id locality), contig length
-~ lognormal(ln 8000, 1) clipped >= 1000, sites = max(1, Poisson(length / 256)); ~90 % of edges join
+~ lognormal(ln 8000, 1) clipped >= 500 (about 2 % fall under the default min_len of 1000), sites = max(1, Poisson(length / 256)); ~90 % of edges join
 two contigs of one genome, ~10 % are uniform noise; pair counts Geometric(0.2) x 5 (intra) or x 1
 (noise), duplicates summed; diagonal Geometric(0.02) with 5 % forced zeros (exercises the
 zero-diagonal substitution of sparse_utils.py:110-115).
@@ -93,7 +93,7 @@ def make_edges(n, n_edges, seed, degree_law='flat'):
     genome = np.empty(n, dtype=np.int32)
     genome[perm] = np.repeat(np.arange(n_genomes, dtype=np.int32), sizes)
 
-    lengths = np.maximum(1000, rs.lognormal(np.log(8000.0), 1.0, n)).astype(np.int32)
+    lengths = np.maximum(500, rs.lognormal(np.log(8000.0), 1.0, n)).astype(np.int32)
     sites = np.maximum(1, rs.poisson(lengths / 256.0)).astype(np.float64)
 
     n_intra = int(round(0.9 * n_edges))

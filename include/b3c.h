@@ -62,6 +62,7 @@ typedef struct {
     double move_ms;       /* device time in the delta-Q neighbour-scan kernel */
     int64_t n_move_launch;
     int64_t move_nnz;     /* stored entries scanned by those launches (for the roofline) */
+    int64_t move_rows;    /* rows visited by those launches */
 } b3c_louvain_info;
 
 /* ---- context ------------------------------------------------------------------------------- */
