@@ -17,6 +17,9 @@
 
 #include <cstdlib>
 
+int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new);
+int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out);
+
 namespace {
 
 constexpr int BLK = 256;
@@ -253,6 +256,130 @@ __global__ void __launch_bounds__(BLK) kr_kb(int64_t n, const KRState *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// KB, streaming form (the one that runs unless a row is too long for LDS): "CSR-stream".
+// A block owns the rows whose first entry falls in a window of T stored entries, so its entries are
+// one contiguous run.  Phase 1 streams that run with every thread keeping 8 independent (index,
+// value, gather) triples in flight and parks the products a_ij*u_j in LDS; phase 2 reduces each row
+// out of LDS with LPR lanes and runs the fused epilogue.  The wave-per-row kernel above keeps only
+// ~0.8 KB per wave in flight and is latency bound (measured 0.99 TB/s at C3); this one keeps
+// ~24 KB per block in flight.
+// ---------------------------------------------------------------------------------------------
+constexpr int KB_T = 2048;      // window of stored entries per row block
+constexpr int KB_UNROLL = 8;
+
+__global__ void kr_row_blocks(int64_t n, int64_t nblk, const int64_t *__restrict__ indptr, int64_t *__restrict__ rb)
+{
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nblk) return;
+    if (b == nblk) { rb[b] = n; return; }
+    const int64_t target = b * KB_T;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    rb[b] = lo;
+}
+
+__global__ void kr_max_degree(int64_t n, const int64_t *__restrict__ indptr, unsigned long long *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long d = i < n ? indptr[i + 1] - indptr[i] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        long long t = __shfl_down(d, o, 64);
+        d = t > d ? t : d;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)d);
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(BLK) kr_kb_stream(int64_t n, int64_t nblk, int lds_cap,
+                                                     const KRState *__restrict__ sin, KRState *__restrict__ sout,
+                                                     const double *__restrict__ partA, int PA,
+                                                     const int64_t *__restrict__ rb,
+                                                     const int64_t *__restrict__ indptr,
+                                                     const int32_t *__restrict__ indices, const double *__restrict__ a,
+                                                     const double *__restrict__ dfix, const double *__restrict__ u,
+                                                     const double *__restrict__ x, const double *__restrict__ p,
+                                                     double *__restrict__ v, double *__restrict__ rk,
+                                                     double *__restrict__ w, double *__restrict__ part_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *prod = smem;               // lds_cap doubles
+    double *lds = smem + lds_cap;      // BLK doubles for the reductions
+    KRState st = *sin;
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, lds);  // :160
+    const bool inner = st.phase == A_INNER;
+    if (st.phase == A_INNER) st.phase = B_INNER;
+    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if (st.phase == P_DONE) return;
+
+    const int tid = threadIdx.x;
+    const int grp = tid / LPR, sl = tid % LPR;
+    constexpr int NGRP = BLK / LPR;
+    double contrib = 0.0;
+    for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int64_t r0 = rb[b], r1 = rb[b + 1];
+        const int64_t k0 = indptr[r0], k1 = indptr[r1];
+        const int cnt = (int)(k1 - k0);
+        // phase 1: products into LDS, KB_UNROLL independent loads per thread
+        for (int base = 0; base < cnt; base += BLK * KB_UNROLL) {
+            int32_t c[KB_UNROLL];
+            double m[KB_UNROLL];
+#pragma unroll
+            for (int q = 0; q < KB_UNROLL; q++) {
+                const int i = base + q * BLK + tid;
+                const bool ok = i < cnt;
+                c[q] = ok ? indices[k0 + i] : 0;
+                m[q] = ok ? a[k0 + i] : 0.0;
+            }
+            double g[KB_UNROLL];
+#pragma unroll
+            for (int q = 0; q < KB_UNROLL; q++) g[q] = u[c[q]];
+#pragma unroll
+            for (int q = 0; q < KB_UNROLL; q++) {
+                const int i = base + q * BLK + tid;
+                if (i < cnt) prod[i] = m[q] * g[q];
+            }
+        }
+        __syncthreads();
+        // phase 2: row sums out of LDS + fused epilogue
+        const int nrows = (int)(r1 - r0);
+        for (int rr = grp; rr < nrows; rr += NGRP) {
+            const int64_t row = r0 + rr;
+            const int s = (int)(indptr[row] - k0), e = (int)(indptr[row + 1] - k0);
+            double t0 = 0.0, t1 = 0.0;
+            int k = s + sl;
+            for (; k + LPR < e; k += 2 * LPR) { t0 += prod[k]; t1 += prod[k + LPR]; }
+            if (k < e) t0 += prod[k];
+            double t = t0 + t1;
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, LPR);
+            if (sl == 0) {
+                t += dfix[row] * u[row];
+                const double xi = x[row];
+                if (inner) {
+                    const double pi = p[row];
+                    const double wi = xi * t + v[row] * pi;
+                    w[row] = wi;
+                    contrib += pi * wi;
+                } else {
+                    const double vi = xi * t;
+                    const double r = 1.0 - vi;
+                    v[row] = vi;
+                    rk[row] = r;
+                    contrib += r * r;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    block_partial<0>(contrib, part_out, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
 // KC: inner -> alpha, min/max of ynew = y + alpha p   (sparse_utils.py:166-171,179)
 //     outer -> end-of-outer-iteration control         (:199-211, loop tests :146,:154)
 // ---------------------------------------------------------------------------------------------
@@ -430,6 +557,19 @@ __global__ void kr_asym_count(int64_t n, const int64_t *__restrict__ indptr, con
     if (lane == 0 && bad) atomicAdd(n_bad, bad);
 }
 
+__global__ void kr_gather_f64(int64_t n, const double *__restrict__ src, const int32_t *__restrict__ idx,
+                              double *__restrict__ dst)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+struct MatGuard {   // frees the permuted working copy on every exit path
+    b3c_ctx *ctx;
+    b3c_mat *m = nullptr;
+    ~MatGuard() { if (m) b3c_mat_free(ctx, m); }
+};
+
 template <int LPR>
 void launch_kb(hipStream_t s, int grid, int64_t n, const KRState *sin, KRState *sout, const double *partA, int PA,
                const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
@@ -437,6 +577,16 @@ void launch_kb(hipStream_t s, int grid, int64_t n, const KRState *sin, KRState *
 {
     hipLaunchKernelGGL(kr_kb<LPR>, dim3(grid), dim3(BLK), 0, s, n, sin, sout, partA, PA, m->indptr, m->indices,
                        (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
+}
+
+template <int LPR>
+void launch_kb_stream(hipStream_t s, int grid, size_t shmem, int64_t n, int64_t nblk, int lds_cap, const KRState *sin,
+                      KRState *sout, const double *partA, int PA, const int64_t *rb, const b3c_mat *m,
+                      const double *dfix, const double *u, const double *x, const double *p, double *v, double *rk,
+                      double *w, double *part_out)
+{
+    hipLaunchKernelGGL(kr_kb_stream<LPR>, dim3(grid), dim3(BLK), shmem, s, n, nblk, lds_cap, sin, sout, partA, PA, rb,
+                       m->indptr, m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
 }
 
 }  // namespace
@@ -460,8 +610,26 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     const double avg = (double)a->nnz / (double)n;
     const int lpr = avg >= 96 ? 64 : avg >= 40 ? 32 : avg >= 18 ? 16 : avg >= 8 ? 8 : 4;
     const int rows_per_block = (BLK / 64) * (64 / lpr);
-    const int GS = grid_for(n, rows_per_block, 8 * ctx->n_cu);
+    // streaming SpMV unless some row is too long to park in LDS (then: wave-per-row kernel)
+    unsigned long long maxdeg = 0;
+    {
+        DevBuf<unsigned long long> md(ctx, 1);
+        if (!md.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
+        HIP_TRY(ctx, hipMemsetAsync(md.p, 0, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(kr_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, md.p);
+        HIP_TRY(ctx, hipMemcpyAsync(&maxdeg, md.p, sizeof(maxdeg), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    const bool stream_kb = maxdeg <= 4096 && getenv("B3C_KR_ROWWAVE") == nullptr;
+    const int64_t nblk = a->nnz > 0 ? (a->nnz + KB_T - 1) / KB_T : 1;
+    const int lds_cap = (int)((KB_T + maxdeg + 15) & ~15ull);
+    const size_t kb_shmem = sizeof(double) * (size_t)(lds_cap + BLK);
+    // phase-2 group width: about two LDS reads per lane for an average row
+    const int lpr2 = avg >= 64 ? 32 : avg >= 24 ? 16 : avg >= 10 ? 8 : 4;
+    const int GS = stream_kb ? grid_for(nblk, 1, 8 * ctx->n_cu) : grid_for(n, rows_per_block, 8 * ctx->n_cu);
     const int P = G > GS ? G : GS;
+    DevBuf<int64_t> rb(ctx, nblk + 1);
+    if (!rb.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
 
     DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z(ctx, n), rk(ctx, n), v(ctx, n), w(ctx, n), u(ctx, n), dfix(ctx, n);
     DevBuf<double> part0(ctx, P), part1(ctx, P), part2(ctx, P);
@@ -477,6 +645,23 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
                        (const double *)a->data, dfix.p, counters.p);
     hipLaunchKernelGGL(kr_asym_count, dim3(grid_for(n, 4, 8 * ctx->n_cu)), dim3(256), 0, s, n, a->indptr, a->indices,
                        (const double *)a->data, tol, counters.p + 1);
+
+    // locality-ordered working copy (see reorder.hip): the iteration runs in the new numbering,
+    // x is returned in the caller's
+    const bool reorder = n >= 32768 && a->nnz >= (1 << 21) && getenv("B3C_NO_REORDER") == nullptr;
+    DevBuf<int32_t> new2old(ctx, reorder ? n : 1), old2new(ctx, reorder ? n : 1);
+    MatGuard perm{ctx};
+    if (reorder) {
+        if (!new2old.p || !old2new.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
+        int rc = b3c_locality_order(ctx, a, new2old.p, old2new.p);
+        if (rc) return rc;
+        if ((rc = b3c_permute_csr(ctx, a, new2old.p, old2new.p, &perm.m))) return rc;
+        hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dfix.p, new2old.p, w.p);
+        HIP_TRY(ctx, hipMemcpyAsync(dfix.p, w.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        a = perm.m;
+    }
+    if (stream_kb)
+        hipLaunchKernelGGL(kr_row_blocks, dim3((unsigned)((nblk + 256) / 256)), dim3(256), 0, s, n, nblk, a->indptr, rb.p);
 
     KRParams prm;
     prm.tol = tol; prm.delta = delta; prm.Delta = Delta; prm.rt = tol * tol; prm.stop_tol = tol * 0.5;
@@ -511,6 +696,14 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
                 HIP_TRY(ctx, hipEventRecord(e0, s));
             }
             // KB consumes part1 (from KA, G partials), produces part0 (GS partials)
+            if (stream_kb) {
+                switch (lpr2) {
+                case 32: launch_kb_stream<32>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                case 16: launch_kb_stream<16>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                case 8: launch_kb_stream<8>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                default: launch_kb_stream<4>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                }
+            } else
             switch (lpr) {
             case 64: launch_kb<64>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
             case 32: launch_kb<32>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
@@ -541,7 +734,12 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
 
     unsigned long long hc[4];
     HIP_TRY(ctx, hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(x_out, x.p, sizeof(double) * (size_t)n, hipMemcpyDefault, s));
+    if (reorder) {
+        hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x.p, old2new.p, w.p);
+        HIP_TRY(ctx, hipMemcpyAsync(x_out, w.p, sizeof(double) * (size_t)n, hipMemcpyDefault, s));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(x_out, x.p, sizeof(double) * (size_t)n, hipMemcpyDefault, s));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(s));
 
     info->n_iter = h.n_iter;

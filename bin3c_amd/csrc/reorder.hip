@@ -1,0 +1,343 @@
+// Locality ordering of a symmetric contact matrix (gfx950).
+//
+// Why: the KR SpMV and the Louvain neighbour scan gather one 8-byte (4-byte) vector element per
+// stored entry.  With contig ids in assembly order those gathers are random over the whole vector:
+// every one costs an L2->L1 line fill for 8 useful bytes and the kernels run at the L2 fill rate
+// (measured 0.99 TB/s algorithmic at 1M contigs / 201M entries), not at the HBM rate.  Contacts are
+// overwhelmingly intra-genome, so relabelling contigs such that strongly linked ones sit next to each
+// other turns the gathers into L1 hits.
+//
+// How (one streaming pass + O(n) work, no clustering needed): every contig points at its heaviest
+// off-diagonal neighbour; mutual pairs become roots; pointer jumping labels each tree of that forest;
+// contigs are ordered by (tree, id).  Inside a genome this is a random mapping, whose largest
+// component holds most of the nodes.  The order only affects speed: all results are returned in the
+// caller's numbering.
+#include "common.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+int b3c_exclusive_scan_i64(b3c_ctx *ctx, const int64_t *in, int64_t *out, int64_t count);
+
+namespace {
+
+constexpr int BLK = 256;
+
+// heaviest off-diagonal neighbour of every row (ties -> lowest column); rows without one point at themselves
+template <typename T, int LPR>
+__global__ void __launch_bounds__(BLK) k_heaviest(int64_t n, const int64_t *__restrict__ indptr,
+                                                   const int32_t *__restrict__ indices, const T *__restrict__ a,
+                                                   int32_t *__restrict__ parent)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        double best = -1.0;
+        int32_t bj = (int32_t)row;
+        int64_t k = s + sl;
+        for (; k + 3 * LPR < e; k += 4 * LPR) {
+            int32_t j0 = indices[k], j1 = indices[k + LPR], j2 = indices[k + 2 * LPR], j3 = indices[k + 3 * LPR];
+            double v0 = (double)a[k], v1 = (double)a[k + LPR], v2 = (double)a[k + 2 * LPR], v3 = (double)a[k + 3 * LPR];
+            if (j0 != (int32_t)row && v0 > best) { best = v0; bj = j0; }
+            if (j1 != (int32_t)row && v1 > best) { best = v1; bj = j1; }
+            if (j2 != (int32_t)row && v2 > best) { best = v2; bj = j2; }
+            if (j3 != (int32_t)row && v3 > best) { best = v3; bj = j3; }
+        }
+        for (; k < e; k += LPR) {
+            int32_t j = indices[k];
+            double v = (double)a[k];
+            if (j != (int32_t)row && v > best) { best = v; bj = j; }
+        }
+        // columns ascend along k, so within a lane the first maximum has the lowest column; across lanes
+        // prefer the larger value, then the lower column
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            double ob = __shfl_down(best, o, LPR);
+            int32_t oj = __shfl_down(bj, o, LPR);
+            if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        }
+        if (sl == 0) parent[row] = best >= 0.0 ? bj : (int32_t)row;
+    }
+}
+
+// mutual pairs: the smaller id becomes the root
+__global__ void k_break_pairs(int64_t n, const int32_t *__restrict__ parent, int32_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t j = parent[i];
+    out[i] = (parent[j] == (int32_t)i && (int32_t)i < j) ? (int32_t)i : j;
+}
+
+__global__ void k_jump(int64_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out, int *__restrict__ changed)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (i < n) {
+        const int32_t p = in[i];
+        const int32_t g = in[p];
+        out[i] = g;
+        c = g != p;
+    }
+    if (__ballot(c) && (threadIdx.x & 63) == 0) atomicOr(changed, 1);
+}
+
+// Boruvka round: heaviest edge leaving the cluster of every node, folded per cluster with a 64-bit
+// atomicMax on (float bits of the weight, ~target cluster) -- order independent, ties to the lowest target.
+template <typename T, int LPR>
+__global__ void __launch_bounds__(BLK) k_best_external(int64_t n, const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices, const T *__restrict__ a,
+                                                        const int32_t *__restrict__ label,
+                                                        unsigned long long *__restrict__ cbest)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        const int32_t li = label[row];
+        unsigned long long best = 0;
+        int64_t k = s + sl;
+        for (; k + 3 * LPR < e; k += 4 * LPR) {
+            int32_t j0 = indices[k], j1 = indices[k + LPR], j2 = indices[k + 2 * LPR], j3 = indices[k + 3 * LPR];
+            float v0 = (float)a[k], v1 = (float)a[k + LPR], v2 = (float)a[k + 2 * LPR], v3 = (float)a[k + 3 * LPR];
+            int32_t l0 = label[j0], l1 = label[j1], l2 = label[j2], l3 = label[j3];
+            unsigned long long c0 = ((unsigned long long)__float_as_uint(v0) << 32) | (0xFFFFFFFFu - (uint32_t)l0);
+            unsigned long long c1 = ((unsigned long long)__float_as_uint(v1) << 32) | (0xFFFFFFFFu - (uint32_t)l1);
+            unsigned long long c2 = ((unsigned long long)__float_as_uint(v2) << 32) | (0xFFFFFFFFu - (uint32_t)l2);
+            unsigned long long c3 = ((unsigned long long)__float_as_uint(v3) << 32) | (0xFFFFFFFFu - (uint32_t)l3);
+            if (l0 != li && v0 > 0.f && c0 > best) best = c0;
+            if (l1 != li && v1 > 0.f && c1 > best) best = c1;
+            if (l2 != li && v2 > 0.f && c2 > best) best = c2;
+            if (l3 != li && v3 > 0.f && c3 > best) best = c3;
+        }
+        for (; k < e; k += LPR) {
+            int32_t j = indices[k];
+            float v = (float)a[k];
+            int32_t l = label[j];
+            unsigned long long c = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (uint32_t)l);
+            if (l != li && v > 0.f && c > best) best = c;
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            unsigned long long ob = (unsigned long long)__shfl_down((long long)best, o, LPR);
+            best = ob > best ? ob : best;
+        }
+        if (sl == 0 && best) atomicMax(&cbest[li], best);
+    }
+}
+
+__global__ void k_cluster_ptr(int64_t n, const unsigned long long *__restrict__ cbest, int32_t *__restrict__ cptr)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) {
+        const unsigned long long key = cbest[c];
+        cptr[c] = key ? (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu)) : (int32_t)c;
+    }
+}
+
+__global__ void k_relabel(int64_t n, int32_t *__restrict__ label, const int32_t *__restrict__ root)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) label[i] = root[label[i]];
+}
+
+__global__ void k_iota(int64_t n, int32_t *__restrict__ v)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
+__global__ void k_gather_i32(int64_t n, const int32_t *__restrict__ src, const int32_t *__restrict__ idx,
+                             int32_t *__restrict__ dst)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+__global__ void k_invert_perm(int64_t n, const int32_t *__restrict__ new2old, int32_t *__restrict__ old2new)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) old2new[new2old[k]] = (int32_t)k;
+}
+
+__global__ void k_order_keys(int64_t n, const int32_t *__restrict__ root, int64_t *__restrict__ keys)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = (int64_t)root[i] * n + i;
+}
+
+__global__ void k_perm_from_keys(int64_t n, const int64_t *__restrict__ keys, int32_t *__restrict__ new2old,
+                                 int32_t *__restrict__ old2new)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        const int32_t o = (int32_t)(keys[k] % n);
+        new2old[k] = o;
+        old2new[o] = (int32_t)k;
+    }
+}
+
+__global__ void k_new_degrees(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ new2old,
+                              int64_t *__restrict__ deg)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        const int32_t o = new2old[k];
+        deg[k] = indptr[o + 1] - indptr[o];
+    }
+    if (k == n) deg[k] = 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLK) k_perm_keys(int64_t n, const int64_t *__restrict__ indptr,
+                                                    const int32_t *__restrict__ indices,
+                                                    const int32_t *__restrict__ old2new, int64_t *__restrict__ keys)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        const int64_t nr = (int64_t)old2new[row] * n;
+        for (int64_t k = s + lane; k < e; k += 64) keys[k] = nr + old2new[indices[k]];
+    }
+}
+
+__global__ void k_cols_from_keys(int64_t nnz, int64_t n, const int64_t *__restrict__ keys, int32_t *__restrict__ indices)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) indices[k] = (int32_t)(keys[k] % n);
+}
+
+}  // namespace
+
+// pointer jumping to the roots of a forest given as parent pointers (mutual pairs broken first)
+static int forest_roots(b3c_ctx *ctx, int64_t n, int32_t *p0, int32_t *p1, int *changed, int32_t **roots)
+{
+    hipStream_t s = ctx->stream;
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_break_pairs, dim3(gn), dim3(256), 0, s, n, p0, p1);
+    int32_t *cur = p1, *nxt = p0;
+    for (int round = 0; round < 64; round++) {
+        HIP_TRY(ctx, hipMemsetAsync(changed, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_jump, dim3(gn), dim3(256), 0, s, n, cur, nxt, changed);
+        int h = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        int32_t *t = cur; cur = nxt; nxt = t;
+        if (!h) break;
+    }
+    *roots = cur;
+    return B3C_OK;
+}
+
+// new2old / old2new: DEVICE int32[n].  Works for B3C_F64 and B3C_U32 matrices.
+// Three Boruvka rounds (heaviest neighbour, then twice heaviest edge leaving the cluster); contigs are
+// ordered by (cluster_3, cluster_2, cluster_1, id) so that every level of the merge tree is contiguous.
+int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new)
+{
+    hipStream_t s = ctx->stream;
+    const int64_t n = a->n;
+    if (n == 0) return B3C_OK;
+    constexpr int ROUNDS = 3;
+    DevBuf<int32_t> p0(ctx, n), p1(ctx, n), lab(ctx, (size_t)n * ROUNDS), kin(ctx, n), kout(ctx, n), vout(ctx, n);
+    DevBuf<unsigned long long> cbest(ctx, n);
+    DevBuf<int> changed(ctx, 1);
+    if (!p0.p || !p1.p || !lab.p || !kin.p || !kout.p || !vout.p || !cbest.p || !changed.p)
+        return ctx->fail(B3C_E_NOMEM, "b3c_locality_order");
+    const double avg = (double)a->nnz / (double)n;
+    const int g16 = grid_for(n, (BLK / 64) * 4, 16 * ctx->n_cu), g64 = grid_for(n, BLK / 64, 16 * ctx->n_cu);
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    const bool wide = avg >= 48;
+    int32_t *roots = nullptr;
+    int rc;
+    for (int r = 0; r < ROUNDS; r++) {
+        int32_t *cur = lab.p + (size_t)r * n;
+        if (r == 0) {
+            if (a->kind == B3C_F64) {
+                if (wide) hipLaunchKernelGGL((k_heaviest<double, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, p0.p);
+                else hipLaunchKernelGGL((k_heaviest<double, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, p0.p);
+            } else {
+                if (wide) hipLaunchKernelGGL((k_heaviest<uint32_t, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, p0.p);
+                else hipLaunchKernelGGL((k_heaviest<uint32_t, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, p0.p);
+            }
+            if ((rc = forest_roots(ctx, n, p0.p, p1.p, changed.p, &roots))) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(cur, roots, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        } else {
+            const int32_t *prev = lab.p + (size_t)(r - 1) * n;
+            HIP_TRY(ctx, hipMemsetAsync(cbest.p, 0, sizeof(unsigned long long) * (size_t)n, s));
+            if (a->kind == B3C_F64) {
+                if (wide) hipLaunchKernelGGL((k_best_external<double, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, prev, cbest.p);
+                else hipLaunchKernelGGL((k_best_external<double, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, prev, cbest.p);
+            } else {
+                if (wide) hipLaunchKernelGGL((k_best_external<uint32_t, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p);
+                else hipLaunchKernelGGL((k_best_external<uint32_t, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p);
+            }
+            hipLaunchKernelGGL(k_cluster_ptr, dim3(gn), dim3(256), 0, s, n, cbest.p, p0.p);
+            if ((rc = forest_roots(ctx, n, p0.p, p1.p, changed.p, &roots))) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(cur, prev, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(k_relabel, dim3(gn), dim3(256), 0, s, n, cur, roots);
+        }
+    }
+    // LSD: stable sorts by cluster_1, cluster_2, cluster_3 starting from the identity
+    int bits = 1;
+    while ((1ll << bits) < n) bits++;
+    hipLaunchKernelGGL(k_iota, dim3(gn), dim3(256), 0, s, n, new2old);
+    size_t tb = 0;
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin.p, kout.p, new2old, vout.p, (int)n, 0, bits, s));
+    DevBuf<char> tmp(ctx, tb);
+    if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_locality_order: sort workspace");
+    for (int r = 0; r < ROUNDS; r++) {
+        hipLaunchKernelGGL(k_gather_i32, dim3(gn), dim3(256), 0, s, n, lab.p + (size_t)r * n, new2old, kin.p);
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kin.p, kout.p, new2old, vout.p, (int)n, 0, bits, s));
+        HIP_TRY(ctx, hipMemcpyAsync(new2old, vout.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    }
+    hipLaunchKernelGGL(k_invert_perm, dim3(gn), dim3(256), 0, s, n, new2old, old2new);
+    HIP_TRY(ctx, hipGetLastError());
+    return B3C_OK;
+}
+
+// Symmetric permutation P A P^T into a new canonical CSR (columns sorted in the new numbering).
+int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out)
+{
+    hipStream_t s = ctx->stream;
+    const int64_t n = a->n, nnz = a->nnz;
+    b3c_mat *m = nullptr;
+    int rc = b3c_mat_alloc(ctx, n, nnz, a->kind, &m);
+    if (rc) return rc;
+    DevBuf<int64_t> deg(ctx, n + 1), k_in(ctx, nnz), k_out(ctx, nnz);
+    if (!deg.p || !k_in.p || !k_out.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr"); }
+    hipLaunchKernelGGL(k_new_degrees, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, a->indptr, new2old, deg.p);
+    if ((rc = b3c_exclusive_scan_i64(ctx, deg.p, m->indptr, n + 1))) { b3c_mat_free(ctx, m); return rc; }
+    if (nnz) {
+        hipLaunchKernelGGL(k_perm_keys<double>, dim3(grid_for(n, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr,
+                           a->indices, old2new, k_in.p);
+        int end_bit = 1;
+        while (end_bit < 63 && ((unsigned __int128)1 << end_bit) < (unsigned __int128)n * (unsigned __int128)n) end_bit++;
+        size_t tb = 0;
+        hipError_t e;
+        if (a->kind == B3C_F64)
+            e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, (const double *)a->data, (double *)m->data, (int)nnz, 0, end_bit, s);
+        else
+            e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, (const uint32_t *)a->data, (uint32_t *)m->data, (int)nnz, 0, end_bit, s);
+        if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort sizing failed"); }
+        DevBuf<char> tmp(ctx, tb);
+        if (!tmp.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort workspace"); }
+        if (a->kind == B3C_F64)
+            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, (const double *)a->data, (double *)m->data, (int)nnz, 0, end_bit, s);
+        else
+            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, (const uint32_t *)a->data, (uint32_t *)m->data, (int)nnz, 0, end_bit, s);
+        if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort failed"); }
+        hipLaunchKernelGGL(k_cols_from_keys, dim3(grid_for(nnz, 1024, 16 * ctx->n_cu)), dim3(256), 0, s, nnz, n, k_out.p, m->indices);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    *out = m;
+    return B3C_OK;
+}

@@ -96,3 +96,23 @@ def test_kr_vs_oracle_synthetic_and_deterministic(ctx, oracle_lib):
     d = (a.diagonal() == 0).astype(np.float64)
     rows = x1 * (a @ x1) + d * x1 * x1
     assert np.abs(rows - 1.0).max() < 1e-5
+
+
+def test_kr_locality_reordered_path_matches_oracle(ctx, oracle_lib, monkeypatch):
+    """Large enough for the internal locality ordering (reorder.hip) to kick in: x must not depend on it."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(40000, 1300000, 21)
+    assert sm.nnz >= (1 << 21)
+    nd = oracle_lib.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
+    rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
+    mat = ctx.upload(sm.indptr, sm.indices, nd)
+    _, x1, info = ctx.kr_balance(mat)
+    assert info.n_iter == st.n_iter and info.n_zero_diag == st.n_zero_diag
+    np.testing.assert_allclose(x1, xo, rtol=1e-9)
+    monkeypatch.setenv('B3C_NO_REORDER', '1')
+    _, x2, info2 = ctx.kr_balance(mat)
+    assert info2.n_iter == info.n_iter
+    np.testing.assert_allclose(x2, x1, rtol=1e-11)
+    monkeypatch.setenv('B3C_KR_ROWWAVE', '1')
+    _, x3, _ = ctx.kr_balance(mat)
+    np.testing.assert_allclose(x3, x1, rtol=1e-11)
