@@ -55,6 +55,9 @@ SYMBOLS = [
     ('b3c_kr_balance', C.c_int, [_VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, _VP, C.POINTER(KRInfo)]),
     ('b3c_louvain', C.c_int, [_VP, _VP, C.c_double, C.c_int, C.c_int, _VP, C.POINTER(LouvainInfo)]),
     ('b3c_graph_quantise', C.c_int, [_VP, _VP, C.c_double, _VP, C.POINTER(C.c_int32)]),
+    ('b3c_locality_order', C.c_int, [_VP, _VP, _VP, _VP]),
+    ('b3c_mat_permute', C.c_int, [_VP, _VP, _VP, C.POINTER(_VP)]),
+    ('b3c_mat_ids', C.c_int, [_VP, _VP, _VP]),
     ('b3c_version', C.c_char_p, []),
 ]
 
@@ -181,6 +184,30 @@ class Context(object):
         h = _VP()
         self._check(self.lib.b3c_mat_upload(self.h, n, nnz, _ptr(indptr), _ptr(indices), _ptr(data), kind, C.byref(h)))
         return Mat(self, h)
+
+    # ---- locality ordering ----
+    def locality_order(self, mat):
+        """-> (new2old, old2new) int32[n]"""
+        n2o = np.empty(mat.n, dtype=np.int32)
+        o2n = np.empty(mat.n, dtype=np.int32)
+        self._check(self.lib.b3c_locality_order(self.h, mat.h, _ptr(n2o), _ptr(o2n)))
+        return n2o, o2n
+
+    def permute(self, mat, new2old):
+        if isinstance(new2old, np.ndarray):
+            new2old = np.ascontiguousarray(new2old, dtype=np.int32)
+        h = _VP()
+        self._check(self.lib.b3c_mat_permute(self.h, mat.h, _ptr(new2old), C.byref(h)))
+        return Mat(self, h)
+
+    def mat_ids(self, mat):
+        """caller-side row ids of a permuted matrix, or None for identity"""
+        out = np.empty(mat.n, dtype=np.int32)
+        rc = self.lib.b3c_mat_ids(self.h, mat.h, _ptr(out))
+        if rc == 1:
+            return None
+        self._check(rc)
+        return out
 
     # ---- helpers ----
     def max_offdiag_u32(self, mat, assume_symmetric=False, out=None):

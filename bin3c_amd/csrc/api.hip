@@ -120,8 +120,17 @@ extern "C" int b3c_mat_free(b3c_ctx *ctx, b3c_mat *m)
     ctx->release(m->indptr);
     ctx->release(m->indices);
     ctx->release(m->data);
+    ctx->release(m->ids);
     delete m;
     return B3C_OK;
+}
+
+extern "C" int b3c_mat_ids(b3c_ctx *ctx, const b3c_mat *m, int32_t *out)
+{
+    if (!ctx || !m || !out) return B3C_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!m->ids) return 1;   // identity: nothing written
+    return b3c_copy_out(ctx, out, m->ids, sizeof(int32_t) * (size_t)m->n);
 }
 
 extern "C" int b3c_mat_info(const b3c_mat *m, int64_t *n, int64_t *nnz, int *kind)

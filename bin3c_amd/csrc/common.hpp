@@ -84,6 +84,10 @@ struct b3c_mat {
     int64_t *indptr = nullptr;
     int32_t *indices = nullptr;
     void *data = nullptr;
+    // locality-ordered matrices (b3c_mat_permute) remember the caller-side id of every row: Louvain
+    // hashes / tie-breaks on these so that its result does not depend on the storage order
+    int32_t *ids = nullptr;
+    bool ordered = false;
 };
 
 #define HIP_TRY(ctx, expr)                                                                          \

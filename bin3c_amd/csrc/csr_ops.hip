@@ -150,6 +150,22 @@ __global__ void __launch_bounds__(BLK) k_compress_fill(int64_t n, const int64_t 
     }
 }
 
+// ids of a compressed, locality-ordered matrix: rank of the caller-side id among the kept caller-side ids
+__global__ void k_scatter_keep(int64_t n, const uint8_t *__restrict__ mask, const int32_t *__restrict__ ids,
+                               int64_t *__restrict__ keep_orig)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep_orig[ids[i]] = mask[i] != 0;
+}
+
+__global__ void k_sub_ids(int64_t n, const uint8_t *__restrict__ mask, const int32_t *__restrict__ ids,
+                          const int64_t *__restrict__ newid, const int64_t *__restrict__ rank_orig,
+                          int32_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && mask[i]) out[newid[i]] = (int32_t)rank_orig[ids[i]];
+}
+
 __global__ void k_mask_to_i64(int64_t n, const uint8_t *__restrict__ mask, int64_t *__restrict__ out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,6 +264,12 @@ extern "C" int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *
         DISPATCH_LPR(lpr, k_site_norm, row_grid(ctx, n, lpr), ctx->stream, n, counts->indptr, counts->indices,
                      (const uint32_t *)counts->data, ds.p, (double *)m->data);
     }
+    m->ordered = counts->ordered;
+    if (counts->ids) {
+        m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+        if (!m->ids) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_site_norm"); }
+        HIP_TRY(ctx, hipMemcpyAsync(m->ids, counts->ids, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *out = m;
@@ -311,6 +333,16 @@ extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask,
         else
             hipLaunchKernelGGL(k_compress_fill<uint32_t>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
                                (const uint32_t *)a->data, dm.p, newid.p, optr.p, o->indices, (uint32_t *)o->data);
+    }
+    o->ordered = a->ordered;
+    if (a->ids && n) {
+        DevBuf<int64_t> keep_o(ctx, n + 1), rank_o(ctx, n + 1);
+        o->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1));
+        if (!keep_o.p || !rank_o.p || !o->ids) { b3c_mat_free(ctx, o); return ctx->fail(B3C_E_NOMEM, "b3c_compress"); }
+        HIP_TRY(ctx, hipMemsetAsync(keep_o.p, 0, sizeof(int64_t) * (size_t)(n + 1), s));
+        hipLaunchKernelGGL(k_scatter_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, a->ids, keep_o.p);
+        if ((rc = b3c_exclusive_scan_i64(ctx, keep_o.p, rank_o.p, n + 1))) { b3c_mat_free(ctx, o); return rc; }
+        hipLaunchKernelGGL(k_sub_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, a->ids, newid.p, rank_o.p, o->ids);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));

@@ -17,7 +17,7 @@
 
 #include <cstdlib>
 
-int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new);
+int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new);
 int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out);
 
 namespace {
@@ -648,12 +648,12 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
 
     // locality-ordered working copy (see reorder.hip): the iteration runs in the new numbering,
     // x is returned in the caller's
-    const bool reorder = n >= 32768 && a->nnz >= (1 << 21) && getenv("B3C_NO_REORDER") == nullptr;
+    const bool reorder = !a->ordered && n >= 32768 && a->nnz >= (1 << 21) && getenv("B3C_NO_REORDER") == nullptr;
     DevBuf<int32_t> new2old(ctx, reorder ? n : 1), old2new(ctx, reorder ? n : 1);
     MatGuard perm{ctx};
     if (reorder) {
         if (!new2old.p || !old2new.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
-        int rc = b3c_locality_order(ctx, a, new2old.p, old2new.p);
+        int rc = b3c_locality_order_dev(ctx, a, new2old.p, old2new.p);
         if (rc) return rc;
         if ((rc = b3c_permute_csr(ctx, a, new2old.p, old2new.p, &perm.m))) return rc;
         hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dfix.p, new2old.p, w.p);

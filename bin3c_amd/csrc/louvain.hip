@@ -21,6 +21,8 @@
 #include <hipcub/hipcub.hpp>
 
 int b3c_exclusive_scan_i64(b3c_ctx *ctx, const int64_t *in, int64_t *out, int64_t count);
+int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new);
+int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out);
 
 namespace {
 
@@ -50,7 +52,8 @@ struct LvGraph {
 // add_edge(v,u) overwrites the earlier (u,v)).  Rows must have sorted columns.
 __global__ void __launch_bounds__(BLK) k_graph_w(int64_t n, const int64_t *__restrict__ indptr,
                                                   const int32_t *__restrict__ indices,
-                                                  const double *__restrict__ a, double scl, double *__restrict__ w,
+                                                  const double *__restrict__ a, const int32_t *__restrict__ ids,
+                                                  double scl, double *__restrict__ w,
                                                   double *__restrict__ part_max)
 {
     __shared__ double lds[WPB];
@@ -60,10 +63,12 @@ __global__ void __launch_bounds__(BLK) k_graph_w(int64_t n, const int64_t *__res
     double mx = 0.0;
     for (int64_t row = wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
+        const int32_t idr = ids ? ids[row] : (int32_t)row;
         for (int64_t k = s + lane; k < e; k += 64) {
             const int32_t j = indices[k];
             double val = a[k];
-            if (j > row) {
+            // "lower triangle" is meant in the caller's numbering, whatever the storage order
+            if ((ids ? ids[j] : j) > idr) {
                 int64_t lo = indptr[j], hi = indptr[j + 1];
                 const int64_t je = hi;
                 while (lo < hi) {
@@ -119,9 +124,10 @@ __global__ void k_quantise(int64_t nnz, const double *__restrict__ w, int shift,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__restrict__ indptr,
                                                   const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
-                                                  int64_t *__restrict__ kdeg, int64_t *__restrict__ tot,
-                                                  int32_t *__restrict__ com, int32_t *__restrict__ nxt,
-                                                  int32_t *__restrict__ csize, u64 *__restrict__ m2)
+                                                  const int32_t *__restrict__ ids, int64_t *__restrict__ kdeg,
+                                                  int64_t *__restrict__ tot, int32_t *__restrict__ com,
+                                                  int32_t *__restrict__ nxt, int32_t *__restrict__ csize,
+                                                  u64 *__restrict__ m2)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -133,11 +139,12 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
         for (int64_t k = s + lane; k < e; k += 64) d += indices[k] == (int32_t)row ? 2 * q[k] : q[k];
         d = wave_sum_ll(d);
         if (lane == 0) {
+            const int32_t id = ids ? ids[row] : (int32_t)row;   // community ids live in the caller's numbering
             kdeg[row] = d;
-            tot[row] = d;
-            com[row] = (int32_t)row;
-            nxt[row] = (int32_t)row;
-            csize[row] = e > s ? 1 : 0;   // empty rows are not graph nodes (cluster.py:321 never adds them)
+            tot[id] = d;
+            com[row] = id;
+            nxt[row] = id;
+            csize[id] = e > s ? 1 : 0;   // empty rows are not graph nodes (cluster.py:321 never adds them)
             total += d;
         }
     }
@@ -184,12 +191,23 @@ __device__ __forceinline__ Best best_wave_reduce(Best b)
     return b;
 }
 
-// CAP = LDS table entries per wave.  Nodes with 2*deg > CAP use the global table at gkeys/gvals + goff[i].
+// table entries needed for a node of degree deg (worst case: every neighbour in its own community)
+__host__ __device__ __forceinline__ int table_lg(int64_t deg)
+{
+    int lg = 6;
+    while ((1ll << lg) < deg + deg / 4 + 1) lg++;
+    return lg;
+}
+
+// CAP = LDS table entries per wave.  Nodes whose table does not fit use the global table at gkeys/gvals + goff[i].
+// Loads first: every lane pulls four (index, weight) pairs, then the four community gathers, then inserts, so
+// that a wave keeps ~3 KB of independent loads in flight instead of one dependent chain per 64 entries.
 template <int CAP>
 __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t n, int n_sub, int round, u64 m2,
                                                     const int64_t *__restrict__ indptr,
                                                     const int32_t *__restrict__ indices,
-                                                    const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
+                                                    const int64_t *__restrict__ q, const int32_t *__restrict__ ids,
+                                                    const int64_t *__restrict__ kdeg,
                                                     const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
                                                     const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
                                                     const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
@@ -207,31 +225,43 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t n, int n_sub, int rou
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
     for (int64_t i = wave; i < n; i += nwave) {
-        if (bucket_of(i, n_sub) != (uint32_t)round) continue;
+        const int32_t id = ids ? ids[i] : (int32_t)i;
+        if (bucket_of(id, n_sub) != (uint32_t)round) continue;
         const long long ki = kdeg[i];
         if (ki == 0) continue;
         const int64_t s = indptr[i], e = indptr[i + 1];
         const int64_t deg = e - s;
         const int32_t a = com[i];
-        const bool use_lds = 2 * deg <= CAP;
-        int lg = 6;
-        while ((1ll << lg) < 2 * deg) lg++;
+        const int lg = table_lg(deg);
+        const bool use_lds = (1ll << lg) <= CAP;
         const uint32_t mask = (1u << lg) - 1u;
         int32_t *keys = use_lds ? lk : gkeys + goff[i];
         u64 *vals = use_lds ? lv : gvals + goff[i];
 
         long long own = 0;
-        for (int64_t k = s + lane; k < e; k += 64) {
-            const int32_t j = indices[k];
-            if (j == (int32_t)i) continue;
-            const int32_t c = com[j];
-            const u64 qv = (u64)q[k];
-            if (c == a) { own += (long long)qv; continue; }
-            uint32_t slot = hash_slot(c, lg);
-            for (;;) {
-                int32_t prev = atomicCAS(&keys[slot], EMPTY, c);
-                if (prev == EMPTY || prev == c) { atomicAdd(&vals[slot], qv); break; }
-                slot = (slot + 1) & mask;
+        for (int64_t base = s; base < e; base += 256) {
+            int32_t j[4];
+            u64 qv[4];
+            int32_t c[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                const bool ok = k < e;
+                j[t] = ok ? indices[k] : (int32_t)i;
+                qv[t] = ok ? (u64)q[k] : 0;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) c[t] = j[t] != (int32_t)i ? com[j[t]] : EMPTY;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (c[t] == EMPTY) continue;
+                if (c[t] == a) { own += (long long)qv[t]; continue; }
+                uint32_t slot = hash_slot(c[t], lg);
+                for (;;) {
+                    int32_t prev = atomicCAS(&keys[slot], EMPTY, c[t]);
+                    if (prev == EMPTY || prev == c[t]) { atomicAdd(&vals[slot], qv[t]); break; }
+                    slot = (slot + 1) & mask;
+                }
             }
         }
         own = wave_sum_ll(own);
@@ -266,7 +296,8 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t n, int n_sub, int rou
     }
 }
 
-__global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int round, const int64_t *__restrict__ kdeg,
+__global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int round, const int32_t *__restrict__ ids,
+                                                   const int64_t *__restrict__ kdeg,
                                                    int64_t *__restrict__ tot, int32_t *__restrict__ com,
                                                    const int32_t *__restrict__ nxt, int32_t *__restrict__ csize,
                                                    u64 *__restrict__ moved)
@@ -274,7 +305,7 @@ __global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int roun
     const int64_t stride = (int64_t)gridDim.x * BLK;
     int cnt = 0;
     for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
-        if (bucket_of(i, n_sub) != (uint32_t)round) continue;
+        if (bucket_of(ids ? ids[i] : (int32_t)i, n_sub) != (uint32_t)round) continue;
         const int32_t a = com[i], b = nxt[i];
         if (a == b) continue;
         const long long ki = kdeg[i];
@@ -414,6 +445,13 @@ __global__ void k_fill_from_keys(int64_t kc, int64_t nu, const int64_t *__restri
     }
 }
 
+__global__ void k_gather_labels(int64_t n, const int32_t *__restrict__ src, const int32_t *__restrict__ idx,
+                                int32_t *__restrict__ dst)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
 __global__ void k_init_labels(int64_t n, const int64_t *__restrict__ indptr, int32_t *__restrict__ labels)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -425,13 +463,8 @@ __global__ void k_big_table_sizes(int64_t n, int cap, const int64_t *__restrict_
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const int64_t deg = indptr[i + 1] - indptr[i];
-        int64_t t = 0;
-        if (2 * deg > cap) {
-            int lg = 6;
-            while ((1ll << lg) < 2 * deg) lg++;
-            t = 1ll << lg;
-        }
-        sz[i] = t;
+        const int lg = table_lg(deg);
+        sz[i] = (1ll << lg) > cap ? (1ll << lg) : 0;
     }
     if (i == n) sz[i] = 0;
 }
@@ -471,7 +504,7 @@ struct Events {
     }
 };
 
-int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, double scl, int64_t *q, int32_t *shift_out)
+int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double scl, int64_t *q, int32_t *shift_out)
 {
     hipStream_t s = ctx->stream;
     const int64_t n = a->n, nnz = a->nnz;
@@ -482,7 +515,7 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, double scl, int64_t *q, int32
     DevBuf<double> part(ctx, g);
     DevBuf<u64> total(ctx, 1);
     if (!w.p || !part.p || !total.p) return ctx->fail(B3C_E_NOMEM, "quantise_graph");
-    hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, scl,
+    hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, ids, scl,
                        w.p, part.p);
     std::vector<double> hp(g);
     HIP_TRY(ctx, hipMemcpyAsync(hp.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, s));
@@ -528,7 +561,7 @@ extern "C" int b3c_graph_quantise(b3c_ctx *ctx, const b3c_mat *a, double scl, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf<int64_t> dq(ctx, a->nnz);
     if (!dq.p) return ctx->fail(B3C_E_NOMEM, "b3c_graph_quantise");
-    int rc = quantise_graph(ctx, a, scl, dq.p, shift);
+    int rc = quantise_graph(ctx, a, a->ids, scl, dq.p, shift);
     if (rc) return rc;
     return b3c_copy_out(ctx, q, dq.p, sizeof(int64_t) * (size_t)a->nnz);
 }
@@ -550,17 +583,33 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     evs.on = getenv("B3C_PROFILE") != nullptr;
     evs.s = s;
 
+    // Locality: a matrix that the caller has not ordered (b3c_mat_permute) gets an internal ordered
+    // working copy; community ids, sub-round hashing and tie-breaks stay in the caller's numbering
+    // through `ids`, so the labels are identical either way (tests/test_gpu_louvain.py).
+    struct Guard { b3c_ctx *c; b3c_mat *m = nullptr; ~Guard() { if (m) b3c_mat_free(c, m); } } perm{ctx};
+    const bool reorder = !a->ordered && n0 >= 32768 && a->nnz >= (1 << 21) && getenv("B3C_NO_REORDER") == nullptr;
+    DevBuf<int32_t> new2old(ctx, reorder ? n0 : 1), old2new(ctx, reorder ? n0 : 1);
+    int rc;
+    if (reorder) {
+        if (!new2old.p || !old2new.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
+        if ((rc = b3c_locality_order_dev(ctx, a, new2old.p, old2new.p))) return rc;
+        if ((rc = b3c_permute_csr(ctx, a, new2old.p, old2new.p, &perm.m))) return rc;
+        a = perm.m;
+    }
+    const int32_t *ids0 = reorder ? new2old.p : a->ids;
+
     DevBuf<int32_t> labels(ctx, n0);
     DevBuf<int64_t> q0(ctx, a->nnz);
     if (!labels.p || !q0.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
     int32_t shift = 0;
-    int rc = quantise_graph(ctx, a, scl, q0.p, &shift);
+    rc = quantise_graph(ctx, a, ids0, scl, q0.p, &shift);
     if (rc) return rc;
     info->quant_shift = shift;
     hipLaunchKernelGGL(k_init_labels, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, n0, a->indptr, labels.p);
 
     LvGraph g;
     g.n = n0; g.nnz = a->nnz; g.indptr = a->indptr; g.indices = a->indices; g.q = q0.p; g.owned = false;
+    const int32_t *ids = ids0;   // level 0 only; induced graphs are numbered by ascending community id
 
     double mod = 0.0;
     bool first = true;
@@ -578,7 +627,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int gw = grid_for(n, WPB, 16 * ctx->n_cu);     // wave-per-row kernels
         const int gv = grid_for(n, BLK, 8 * ctx->n_cu);      // thread-per-node kernels
         HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 8, s));
-        hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, kdeg.p, tot.p, com.p,
+        hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p,
                            nxt.p, csize.p, ctr.p);
         hipLaunchKernelGGL(k_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
         u64 hc[8];
@@ -589,7 +638,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if (m2 == 0) break;   // no links: every node alone (generate_dendrogram special case)
 
         // LDS table capacity per wave for this level; nodes beyond it use the global table
-        const int cap = 2 * maxdeg <= 128 ? 128 : 2 * maxdeg <= 512 ? 512 : 2048;
+        const int64_t need = 1ll << table_lg(maxdeg);
+        const int cap = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
         hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap, g.indptr, gsz.p);
         if ((rc = b3c_exclusive_scan_i64(ctx, gsz.p, goff.p, n + 1))) { free_graph(ctx, g); return rc; }
         int64_t gtab = 0;
@@ -627,18 +677,20 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 1, 0, sizeof(u64), s));
             for (int r = 0; r < n_sub; r++) {
                 evs.rec();
-                if (cap == 128)
-                    hipLaunchKernelGGL(k_lv_decide<128>, dim3(gw), dim3(BLK), 0, s, n, n_sub, r, m2, g.indptr, g.indices,
-                                       g.q, kdeg.p, tot.p, com.p, csize.p, nxt.p, goff.p, gkeys.p, gvals.p);
-                else if (cap == 512)
-                    hipLaunchKernelGGL(k_lv_decide<512>, dim3(gw), dim3(BLK), 0, s, n, n_sub, r, m2, g.indptr, g.indices,
-                                       g.q, kdeg.p, tot.p, com.p, csize.p, nxt.p, goff.p, gkeys.p, gvals.p);
-                else
-                    hipLaunchKernelGGL(k_lv_decide<2048>, dim3(gw), dim3(BLK), 0, s, n, n_sub, r, m2, g.indptr, g.indices,
-                                       g.q, kdeg.p, tot.p, com.p, csize.p, nxt.p, goff.p, gkeys.p, gvals.p);
+#define LV_DECIDE(C)                                                                                       \
+    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gw), dim3(BLK), 0, s, n, n_sub, r, m2, g.indptr, g.indices, g.q, ids,    \
+                       kdeg.p, tot.p, com.p, csize.p, nxt.p, goff.p, gkeys.p, gvals.p)
+                switch (cap) {
+                case 128: LV_DECIDE(128); break;
+                case 256: LV_DECIDE(256); break;
+                case 512: LV_DECIDE(512); break;
+                case 1024: LV_DECIDE(1024); break;
+                default: LV_DECIDE(2048); break;
+                }
+#undef LV_DECIDE
                 evs.rec();
                 info->n_move_launch++;
-                hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, kdeg.p, tot.p, com.p, nxt.p,
+                hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt.p,
                                    csize.p, ctr.p + 1);
             }
             info->move_nnz += g.nnz;
@@ -718,10 +770,17 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         HIP_TRY(ctx, hipStreamSynchronize(s));
         free_graph(ctx, g);
         g = h;
+        ids = nullptr;
     }
     free_graph(ctx, g);
     info->modularity = mod;
     info->move_ms = evs.total_ms();
     HIP_TRY(ctx, hipGetLastError());
+    if (reorder) {
+        DevBuf<int32_t> lo(ctx, n0);
+        if (!lo.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
+        hipLaunchKernelGGL(k_gather_labels, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, n0, labels.p, old2new.p, lo.p);
+        return b3c_copy_out(ctx, labels_out, lo.p, sizeof(int32_t) * (size_t)n0);
+    }
     return b3c_copy_out(ctx, labels_out, labels.p, sizeof(int32_t) * (size_t)n0);
 }

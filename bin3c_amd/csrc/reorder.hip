@@ -240,7 +240,7 @@ static int forest_roots(b3c_ctx *ctx, int64_t n, int32_t *p0, int32_t *p1, int *
 // new2old / old2new: DEVICE int32[n].  Works for B3C_F64 and B3C_U32 matrices.
 // Three Boruvka rounds (heaviest neighbour, then twice heaviest edge leaving the cluster); contigs are
 // ordered by (cluster_3, cluster_2, cluster_1, id) so that every level of the merge tree is contiguous.
-int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new)
+int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new)
 {
     hipStream_t s = ctx->stream;
     const int64_t n = a->n;
@@ -338,6 +338,49 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    *out = m;
+    return B3C_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// public entry points (include/b3c.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a || !new2old || !old2new) return ctx->fail(B3C_E_ARG, "b3c_locality_order: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<int32_t> n2o(ctx, a->n), o2n(ctx, a->n);
+    if (!n2o.p || !o2n.p) return ctx->fail(B3C_E_NOMEM, "b3c_locality_order");
+    int rc = b3c_locality_order_dev(ctx, a, n2o.p, o2n.p);
+    if (rc) return rc;
+    if ((rc = b3c_copy_out(ctx, new2old, n2o.p, sizeof(int32_t) * (size_t)a->n))) return rc;
+    return b3c_copy_out(ctx, old2new, o2n.p, sizeof(int32_t) * (size_t)a->n);
+}
+
+extern "C" int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, b3c_mat **out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a || !new2old || !out) return ctx->fail(B3C_E_ARG, "b3c_mat_permute: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = a->n;
+    DevBuf<int32_t> n2o(ctx, n), o2n(ctx, n);
+    if (!n2o.p || !o2n.p) return ctx->fail(B3C_E_NOMEM, "b3c_mat_permute");
+    int rc = b3c_copy_in(ctx, n2o.p, new2old, sizeof(int32_t) * (size_t)n);
+    if (rc) return rc;
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    if (n) hipLaunchKernelGGL(k_invert_perm, dim3(gn), dim3(256), 0, ctx->stream, n, n2o.p, o2n.p);
+    b3c_mat *m = nullptr;
+    if ((rc = b3c_permute_csr(ctx, a, n2o.p, o2n.p, &m))) return rc;
+    // caller-side id of every row: compose with the input's ids if it was permuted before
+    m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    if (!m->ids) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_mat_permute"); }
+    if (n) {
+        if (a->ids) hipLaunchKernelGGL(k_gather_i32, dim3(gn), dim3(256), 0, ctx->stream, n, a->ids, n2o.p, m->ids);
+        else HIP_TRY(ctx, hipMemcpyAsync(m->ids, n2o.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    m->ordered = true;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *out = m;
     return B3C_OK;
 }

@@ -31,6 +31,7 @@ class HotPathResult(object):
         self.kr_info = None
         self.lv_info = None
         self.timings = {}
+        self.perm = (None, None)    # (new2old, old2new) of the locality ordering, or (None, None)
 
     def free(self):
         for m in (self.processed, self.sub):
@@ -46,46 +47,89 @@ def acceptance_mask(ctx, counts, lengths, min_len, min_sig):
     return mask, signal
 
 
-def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=0, cluster=True, keep=False):
+def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=0, cluster=True, keep=False,
+                 reorder=True):
     """
     :param ctx: _native.Context
     :param counts: _native.Mat (B3C_U32) raw symmetric contact counts, already in HBM
     :param sites: float64[n] restriction-site counts per contig (zeros are treated as one)
     :param lengths: int[n] contig lengths
+    :param reorder: run the whole path on a locality-ordered copy of the matrix (reorder.hip); every
+                    returned vector is in the caller's numbering either way
     :return: HotPathResult (device matrices freed unless keep=True)
     """
     res = HotPathResult()
     t = res.timings
+    sites = np.asarray(sites, dtype=np.float64)
+    lengths = np.asarray(lengths)
+    n2o = o2n = None
+    work = counts
     t0 = time.perf_counter()
-    res.mask, res.signal = acceptance_mask(ctx, counts, lengths, min_len, min_sig)
-    t['mask'] = time.perf_counter() - t0
+    if reorder and counts.n >= 32768 and counts.nnz >= (1 << 21):
+        n2o, o2n = ctx.locality_order(counts)
+        work = ctx.permute(counts, n2o)
+        sites, lengths = sites[n2o], lengths[n2o]
+    res.perm = (n2o, o2n)
+    t['order'] = time.perf_counter() - t0
+
+    try:
+        t0 = time.perf_counter()
+        mask_w, signal_w = acceptance_mask(ctx, work, lengths, min_len, min_sig)
+        t['mask'] = time.perf_counter() - t0
+
+        t0 = time.perf_counter()
+        a = ctx.site_norm(work, sites)                         # contact_map.py:929-933
+        t['norm'] = time.perf_counter() - t0
+    finally:
+        if work is not counts:
+            work.free()
 
     t0 = time.perf_counter()
-    a = ctx.site_norm(counts, sites)                       # contact_map.py:929-933
-    t['norm'] = time.perf_counter() - t0
-
-    t0 = time.perf_counter()
-    rc, res.x, res.kr_info = ctx.kr_balance(a, tol=tol, check=False)     # contact_map.py:939 -> sparse_utils.py:90
+    rc, x_w, res.kr_info = ctx.kr_balance(a, tol=tol, check=False)       # contact_map.py:939 -> sparse_utils.py:90
     if rc != _native.OK:
         a.free()
         ctx._check(rc)
-    ctx.scale_sym(a, res.x)                                # sparse_utils.py:223-224
+    ctx.scale_sym(a, x_w)                                  # sparse_utils.py:223-224
     t['kr'] = time.perf_counter() - t0
     res.processed = a
 
     t0 = time.perf_counter()
-    if res.mask.all():                                     # contact_map.py:977: only compress when something is masked
+    if mask_w.all():                                       # contact_map.py:977: only compress when something is masked
         sub = a
     else:
-        sub = ctx.compress(a, res.mask)
+        sub = ctx.compress(a, mask_w)
         res.sub = sub
     res.scl = 1.0 / ctx.max_value(sub)                     # cluster.py:316
     t['compress'] = time.perf_counter() - t0
 
+    if o2n is None:
+        res.mask, res.signal, res.x = mask_w, signal_w, x_w
+    else:
+        res.mask, res.signal, res.x = mask_w[o2n], signal_w[o2n], x_w[o2n]
+
     if cluster:
         t0 = time.perf_counter()
-        res.labels, res.lv_info = ctx.louvain(sub, res.scl, n_sub=n_sub)   # cluster.py:319-321 + louvain.py:70
+        labels_w, res.lv_info = ctx.louvain(sub, res.scl, n_sub=n_sub)    # cluster.py:319-321 + louvain.py:70
+        ids = ctx.mat_ids(sub)                             # gapless caller-side id of every row of `sub`
+        if ids is None:
+            res.labels = labels_w
+        else:
+            res.labels = np.empty_like(labels_w)
+            res.labels[ids] = labels_w
         t['louvain'] = time.perf_counter() - t0
     if not keep:
         res.free()
     return res
+
+
+def processed_to_host(ctx, res):
+    """processed_map (contact_map.py:945) as host CSR arrays in the caller's numbering."""
+    m = res.processed
+    n2o, o2n = res.perm
+    if n2o is None:
+        return m.download()
+    back = ctx.permute(m, o2n)          # row k of the result = row o2n[k] of the ordered matrix = caller row k
+    try:
+        return back.download()
+    finally:
+        back.free()

@@ -88,6 +88,24 @@ int b3c_mat_download(b3c_ctx *ctx, const b3c_mat *m, int64_t *indptr, int32_t *i
 /* Raw device pointers of a matrix (for zero-copy consumers such as torch tensors). */
 int b3c_mat_device_ptrs(const b3c_mat *m, void **indptr, void **indices, void **data);
 
+/* ---- locality ordering (performance only; results never depend on it) -------------------- */
+
+/* Order the contigs of a symmetric matrix so that strongly linked ones are adjacent (three Boruvka
+ * rounds on the heaviest contacts, reorder.hip).  new2old / old2new: int32[n], host|dev.  No reference
+ * counterpart: the reference keeps assembly order and pays for it in cache misses inside scipy. */
+int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old /*host|dev*/, int32_t *old2new /*host|dev*/);
+
+/* P A P^T as a new canonical CSR whose row k is row new2old[k] of `a`.  The result remembers the
+ * caller-side id of every row (b3c_mat_ids) and is marked ordered: KR and Louvain then skip their
+ * own internal ordering, site_norm / compress carry the ids along, and b3c_louvain hashes and
+ * tie-breaks on the ids so that its labels equal those computed on `a` (returned per ROW of the
+ * permuted matrix).  Same mechanism as ContactMap._reorder_seq (contact_map.py:1066-1085). */
+int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old /*host|dev*/, b3c_mat **out);
+
+/* Caller-side row ids of a permuted (and possibly compressed) matrix, int32[n] host|dev.
+ * Returns 1 and writes nothing when the matrix carries no ids (identity). */
+int b3c_mat_ids(b3c_ctx *ctx, const b3c_mat *m, int32_t *out /*host|dev*/);
+
 /* ---- CSR helpers --------------------------------------------------------------------------- */
 
 /* max_offdiag (sparse_utils.py:269-281): per-column maximum with the diagonal zeroed; out is

@@ -102,3 +102,31 @@ def test_powerlaw_map_and_determinism(ctx, oracle_lib):
     mat = ctx.upload(gr['indptr'], gr['indices'], gr['data'])
     l2, i2 = ctx.louvain(mat, gr['scl'])
     assert np.array_equal(l2, labels) and i2.modularity == info.modularity
+
+
+def test_labels_do_not_depend_on_storage_order(ctx, oracle_lib):
+    """Permuted storage + caller-side ids (b3c_mat_permute) must give the oracle's labels exactly."""
+    gr = graphs.synth_graph(oracle_lib, 6000, 150000, 4)
+    ip, ix, a, scl = gr['indptr'], gr['indices'], gr['data'], gr['scl']
+    w = oracle_lib.graph_weights(ip, ix, a, scl)
+    q = oracle_lib.quantise(w, oracle_lib.quant_shift(ip, ix, w))
+    ref = oracle_lib.louvain_bsp(ip, ix, q, n_sub=4)
+    mat = ctx.upload(ip, ix, a)
+    for perm in (np.random.RandomState(1).permutation(gr['n']).astype(np.int32), ctx.locality_order(mat)[0]):
+        pm = ctx.permute(mat, perm)
+        ids = ctx.mat_ids(pm)
+        assert np.array_equal(ids, perm)
+        labels_p, info = ctx.louvain(pm, scl, n_sub=4)
+        labels = np.empty_like(labels_p)
+        labels[ids] = labels_p
+        assert np.array_equal(labels, ref['labels'])
+        assert info.modularity == ref['Q'] and info.n_sweeps == ref['n_sweeps']
+        pm.free()
+
+
+def test_internal_reorder_path_matches_oracle(ctx, oracle_lib):
+    """Large enough for b3c_louvain's own locality ordering to kick in."""
+    gr = graphs.synth_graph(oracle_lib, 40000, 1300000, 21)
+    assert gr['indptr'][-1] >= (1 << 21)
+    ref, labels, info = _run_both(ctx, oracle_lib, gr['indptr'], gr['indices'], gr['data'], gr['scl'])
+    _assert_same(ref, labels, info)
