@@ -74,17 +74,17 @@ def main():
     if world > 1:
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
-    from bin3c_amd import _native
-    from bin3c_amd.pipeline import run_hot_path
+    from bin3c_amd.pipeline import make_context, run_hot_path
     from bin3c_amd.synth import CONFIGS, make_synth
 
     n, n_edges, seed, law = CONFIGS[args.config]
     sm = make_synth(n, n_edges, seed + rank, law)      # each rank: an independent map of the same shape
     e_true = sm.n_edges
-    ctx = _native.Context(local_rank)
+    ctx = make_context(local_rank)
     counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
-    sites = sm.sites
-    lengths = sm.lengths
+    # inputs resident in HBM before the timed region: the count matrix and the two per-contig tables
+    sites = torch.as_tensor(sm.sites, device='cuda')
+    lengths = torch.as_tensor(sm.lengths.astype(np.int64), device='cuda')
     nnz = sm.nnz
     min_len, min_sig = 1000, 5
 

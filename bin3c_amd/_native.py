@@ -76,8 +76,31 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get('B3C_TRACE'):
+            lib = _Traced(lib)
         _lib = lib
     return _lib
+
+
+class _Traced(object):
+    """B3C_TRACE=1: print the wall time of every C-ABI call (development aid)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        import sys
+        import time
+        fn = getattr(self._lib, name)
+
+        def call(*a):
+            t0 = time.perf_counter()
+            r = fn(*a)
+            dt = (time.perf_counter() - t0) * 1e3
+            if dt > 0.05:
+                sys.stderr.write('[b3c] %-22s %9.3f ms\n' % (name, dt))
+            return r
+        return call
 
 
 def _ptr(a):

@@ -529,6 +529,63 @@ __global__ void kr_diag_fix(int64_t n, const int64_t *__restrict__ indptr, const
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_zero, (unsigned long long)__popcll(b));
 }
 
+// Fast path of the symmetry guard: two independent order-free 64-bit checksums of the strictly upper
+// entries keyed (i, j, bits) and of the strictly lower entries keyed (j, i, bits).  Equal checksums
+// (2^-128 collision odds) mean the matrix is BITWISE symmetric, which implies the reference's
+// |a_ij - a_ji| < tol; only when they differ does the exact per-entry search below run.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(BLK) kr_sym_hash(int64_t n, const int64_t *__restrict__ indptr,
+                                                    const int32_t *__restrict__ indices, const double *__restrict__ a,
+                                                    unsigned long long *__restrict__ sums)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    unsigned long long u1 = 0, u2 = 0, l1 = 0, l2 = 0;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        for (int64_t base = s; base < e; base += 256) {
+            int32_t j[4];
+            unsigned long long b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                const bool ok = k < e;
+                j[t] = ok ? indices[k] : (int32_t)row;
+                b[t] = ok ? (unsigned long long)__double_as_longlong(a[k]) : 0ull;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (j[t] == (int32_t)row) continue;
+                if (b[t] == 0x8000000000000000ull) b[t] = 0;   // -0.0 == +0.0
+                const bool up = j[t] > (int32_t)row;
+                const unsigned long long lo = up ? (unsigned long long)row : (unsigned long long)j[t];
+                const unsigned long long hi = up ? (unsigned long long)j[t] : (unsigned long long)row;
+                const unsigned long long key = lo * (unsigned long long)n + hi;
+                const unsigned long long h1 = mix64(key ^ mix64(b[t]));
+                const unsigned long long h2 = mix64(key * 0x9E3779B97F4A7C15ull + b[t]);
+                if (up) { u1 += h1; u2 += h2; } else { l1 += h1; l2 += h2; }
+            }
+        }
+    }
+    u1 = (unsigned long long)wave_sum_ll((long long)u1);
+    u2 = (unsigned long long)wave_sum_ll((long long)u2);
+    l1 = (unsigned long long)wave_sum_ll((long long)l1);
+    l2 = (unsigned long long)wave_sum_ll((long long)l2);
+    if (lane == 0) {
+        atomicAdd(&sums[0], u1);
+        atomicAdd(&sums[1], u2);
+        atomicAdd(&sums[2], l1);
+        atomicAdd(&sums[3], l2);
+    }
+}
+
 // is_hermitian restated sparsely (sparse_utils.py:10-18): count entries with |a_ij - a_ji| >= tol
 __global__ void kr_asym_count(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                               const double *__restrict__ a, double tol, unsigned long long *n_bad)
@@ -643,8 +700,19 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     HIP_TRY(ctx, hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * 4, s));
     hipLaunchKernelGGL(kr_diag_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, a->indices,
                        (const double *)a->data, dfix.p, counters.p);
-    hipLaunchKernelGGL(kr_asym_count, dim3(grid_for(n, 4, 8 * ctx->n_cu)), dim3(256), 0, s, n, a->indptr, a->indices,
-                       (const double *)a->data, tol, counters.p + 1);
+    {
+        DevBuf<unsigned long long> hs(ctx, 4);
+        if (!hs.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
+        HIP_TRY(ctx, hipMemsetAsync(hs.p, 0, sizeof(unsigned long long) * 4, s));
+        hipLaunchKernelGGL(kr_sym_hash, dim3(grid_for(n, 4, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr, a->indices,
+                           (const double *)a->data, hs.p);
+        unsigned long long hh[4];
+        HIP_TRY(ctx, hipMemcpyAsync(hh, hs.p, sizeof(hh), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (hh[0] != hh[2] || hh[1] != hh[3] || getenv("B3C_KR_EXACT_SYMCHECK"))
+            hipLaunchKernelGGL(kr_asym_count, dim3(grid_for(n, 4, 8 * ctx->n_cu)), dim3(256), 0, s, n, a->indptr,
+                               a->indices, (const double *)a->data, tol, counters.p + 1);
+    }
 
     // locality-ordered working copy (see reorder.hip): the iteration runs in the new numbering,
     // x is returned in the caller's

@@ -64,22 +64,48 @@ __global__ void __launch_bounds__(BLK) k_graph_w(int64_t n, const int64_t *__res
     for (int64_t row = wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         const int32_t idr = ids ? ids[row] : (int32_t)row;
-        for (int64_t k = s + lane; k < e; k += 64) {
-            const int32_t j = indices[k];
-            double val = a[k];
-            // "lower triangle" is meant in the caller's numbering, whatever the storage order
-            if ((ids ? ids[j] : j) > idr) {
-                int64_t lo = indptr[j], hi = indptr[j + 1];
-                const int64_t je = hi;
-                while (lo < hi) {
-                    int64_t mid = (lo + hi) >> 1;
-                    if (indices[mid] < (int32_t)row) lo = mid + 1; else hi = mid;
-                }
-                if (lo < je && indices[lo] == (int32_t)row) val = a[lo];
+        // four independent binary searches per lane keep the dependent probes of one from stalling the wave
+        for (int64_t base = s; base < e; base += 256) {
+            int32_t j[4];
+            double val[4];
+            int64_t lo[4], hi[4], je[4];
+            bool need[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                const bool ok = k < e;
+                j[t] = ok ? indices[k] : (int32_t)row;
+                val[t] = ok ? a[k] : 0.0;
             }
-            const double ww = val * scl;
-            w[k] = ww;
-            mx = fmax(mx, ww);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                // "lower triangle" is meant in the caller's numbering, whatever the storage order
+                need[t] = (ids ? ids[j[t]] : j[t]) > idr;
+                lo[t] = need[t] ? indptr[j[t]] : 0;
+                hi[t] = need[t] ? indptr[j[t] + 1] : 0;
+                je[t] = hi[t];
+            }
+            bool any = true;
+            while (any) {
+                any = false;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (lo[t] < hi[t]) {
+                        const int64_t mid = (lo[t] + hi[t]) >> 1;
+                        if (indices[mid] < (int32_t)row) lo[t] = mid + 1; else hi[t] = mid;
+                        any = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                if (k >= e) continue;
+                if (need[t] && lo[t] < je[t] && indices[lo[t]] == (int32_t)row) val[t] = a[lo[t]];
+                const double ww = val[t] * scl;
+                w[k] = ww;
+                mx = fmax(mx, ww);
+            }
         }
     }
     mx = wave_max(mx);

@@ -6,6 +6,10 @@ Stage by stage this is what ``bin3C.py cluster`` does between ``load_object`` an
 :911 prepare_seq_map -> :1110 _norm_seq -> :1087 _bisto_seq -> sparse_utils.py:90 kr_biostochastic ->
 contact_map.py:947 get_subspace -> sparse_utils.py:284 compress -> cluster.py:316 scl ->
 louvain.py:70 best_partition), with the matrix never leaving HBM.
+
+torch is used here for what it is good at -- device buffers for the n-vectors and a stream shared with
+libb3c -- so that no vector bounces through the host between stages; all arithmetic of the path is
+in libb3c's HIP kernels.
 """
 import logging
 import time
@@ -15,6 +19,21 @@ import numpy as np
 from . import _native
 
 logger = logging.getLogger(__name__)
+
+REORDER_MIN_N = 32768          # below this the gathered vectors sit in L2 anyway
+REORDER_MIN_NNZ = 1 << 21
+
+
+def make_context(device=0):
+    """A libb3c context that launches on a torch stream of `device` (so torch ops and kernels interleave in order)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise _native.B3CError(_native.E_HIP, 'no MI355X visible: torch.cuda.is_available() is False and libb3c has '
+                                              'no CPU fallback')
+    stream = torch.cuda.Stream(device=device)
+    ctx = _native.Context(device, stream=stream.cuda_stream)
+    ctx.torch_stream = stream
+    return ctx
 
 
 class HotPathResult(object):
@@ -31,7 +50,7 @@ class HotPathResult(object):
         self.kr_info = None
         self.lv_info = None
         self.timings = {}
-        self.perm = (None, None)    # (new2old, old2new) of the locality ordering, or (None, None)
+        self.perm = (None, None)    # (new2old, old2new) int32 host arrays of the locality ordering, or (None, None)
 
     def free(self):
         for m in (self.processed, self.sub):
@@ -41,7 +60,7 @@ class HotPathResult(object):
 
 
 def acceptance_mask(ctx, counts, lengths, min_len, min_sig):
-    """set_primary_acceptance_mask (contact_map.py:888-905): length and off-diagonal signal filters."""
+    """set_primary_acceptance_mask (contact_map.py:888-905) on host arrays: length and off-diagonal signal filters."""
     signal = ctx.max_offdiag_u32(counts, assume_symmetric=True)   # seq_map is symmetric: sparse_utils.py:261-266
     mask = (np.asarray(lengths) >= min_len) & (signal >= min_sig)
     return mask, signal
@@ -50,73 +69,98 @@ def acceptance_mask(ctx, counts, lengths, min_len, min_sig):
 def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=0, cluster=True, keep=False,
                  reorder=True):
     """
-    :param ctx: _native.Context
+    :param ctx: context from :func:`make_context`
     :param counts: _native.Mat (B3C_U32) raw symmetric contact counts, already in HBM
-    :param sites: float64[n] restriction-site counts per contig (zeros are treated as one)
-    :param lengths: int[n] contig lengths
+    :param sites: float64[n] restriction-site counts per contig (zeros are treated as one); numpy or device tensor
+    :param lengths: int[n] contig lengths; numpy or device tensor
     :param reorder: run the whole path on a locality-ordered copy of the matrix (reorder.hip); every
                     returned vector is in the caller's numbering either way
     :return: HotPathResult (device matrices freed unless keep=True)
     """
+    import torch
     res = HotPathResult()
     t = res.timings
-    sites = np.asarray(sites, dtype=np.float64)
-    lengths = np.asarray(lengths)
-    n2o = o2n = None
-    work = counts
-    t0 = time.perf_counter()
-    if reorder and counts.n >= 32768 and counts.nnz >= (1 << 21):
-        n2o, o2n = ctx.locality_order(counts)
-        work = ctx.permute(counts, n2o)
-        sites, lengths = sites[n2o], lengths[n2o]
-    res.perm = (n2o, o2n)
-    t['order'] = time.perf_counter() - t0
-
-    try:
-        t0 = time.perf_counter()
-        mask_w, signal_w = acceptance_mask(ctx, work, lengths, min_len, min_sig)
-        t['mask'] = time.perf_counter() - t0
+    dev = torch.device('cuda', ctx.device)
+    n = counts.n
+    with torch.cuda.stream(ctx.torch_stream):
+        sites_t = torch.as_tensor(sites, device=dev).to(torch.float64)
+        lengths_t = torch.as_tensor(lengths, device=dev).to(torch.int64)
 
         t0 = time.perf_counter()
-        a = ctx.site_norm(work, sites)                         # contact_map.py:929-933
-        t['norm'] = time.perf_counter() - t0
-    finally:
-        if work is not counts:
-            work.free()
+        work = counts
+        n2o = o2n = None
+        if reorder and n >= REORDER_MIN_N and counts.nnz >= REORDER_MIN_NNZ:
+            n2o = torch.empty(n, dtype=torch.int32, device=dev)
+            o2n = torch.empty(n, dtype=torch.int32, device=dev)
+            ctx._check(ctx.lib.b3c_locality_order(ctx.h, counts.h, _native._ptr(n2o), _native._ptr(o2n)))
+            work = ctx.permute(counts, n2o)
+            idx = n2o.long()
+            sites_t, lengths_t = sites_t[idx], lengths_t[idx]
+        t['order'] = time.perf_counter() - t0
 
-    t0 = time.perf_counter()
-    rc, x_w, res.kr_info = ctx.kr_balance(a, tol=tol, check=False)       # contact_map.py:939 -> sparse_utils.py:90
-    if rc != _native.OK:
-        a.free()
-        ctx._check(rc)
-    ctx.scale_sym(a, x_w)                                  # sparse_utils.py:223-224
-    t['kr'] = time.perf_counter() - t0
-    res.processed = a
+        try:
+            # set_primary_acceptance_mask (contact_map.py:888-905)
+            t0 = time.perf_counter()
+            signal_w = torch.empty(n, dtype=torch.int32, device=dev)          # uint32 bit pattern
+            ctx.max_offdiag_u32(work, assume_symmetric=True, out=signal_w)
+            sig64 = signal_w.long() & 0xFFFFFFFF
+            mask_w = ((lengths_t >= int(min_len)) & (sig64 >= int(min_sig))).to(torch.uint8)
+            all_kept = bool(mask_w.all().item())
+            t['mask'] = time.perf_counter() - t0
 
-    t0 = time.perf_counter()
-    if mask_w.all():                                       # contact_map.py:977: only compress when something is masked
-        sub = a
-    else:
-        sub = ctx.compress(a, mask_w)
-        res.sub = sub
-    res.scl = 1.0 / ctx.max_value(sub)                     # cluster.py:316
-    t['compress'] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            a = ctx.site_norm(work, sites_t)                               # contact_map.py:929-933
+            t['norm'] = time.perf_counter() - t0
+        finally:
+            if work is not counts:
+                work.free()
 
-    if o2n is None:
-        res.mask, res.signal, res.x = mask_w, signal_w, x_w
-    else:
-        res.mask, res.signal, res.x = mask_w[o2n], signal_w[o2n], x_w[o2n]
-
-    if cluster:
         t0 = time.perf_counter()
-        labels_w, res.lv_info = ctx.louvain(sub, res.scl, n_sub=n_sub)    # cluster.py:319-321 + louvain.py:70
-        ids = ctx.mat_ids(sub)                             # gapless caller-side id of every row of `sub`
-        if ids is None:
-            res.labels = labels_w
+        x_w = torch.empty(n, dtype=torch.float64, device=dev)
+        rc, _, res.kr_info = ctx.kr_balance(a, tol=tol, x_out=x_w, check=False)   # contact_map.py:939 -> sparse_utils.py:90
+        if rc != _native.OK:
+            a.free()
+            ctx._check(rc)
+        ctx.scale_sym(a, x_w)                                              # sparse_utils.py:223-224
+        t['kr'] = time.perf_counter() - t0
+        res.processed = a
+
+        t0 = time.perf_counter()
+        if all_kept:                                                       # contact_map.py:977: compress only if needed
+            sub = a
         else:
-            res.labels = np.empty_like(labels_w)
-            res.labels[ids] = labels_w
-        t['louvain'] = time.perf_counter() - t0
+            sub = ctx.compress(a, mask_w)
+            res.sub = sub
+        res.scl = 1.0 / ctx.max_value(sub)                                 # cluster.py:316
+        t['compress'] = time.perf_counter() - t0
+
+        labels_t = None
+        if cluster:
+            t0 = time.perf_counter()
+            labels_w = torch.empty(sub.n, dtype=torch.int32, device=dev)
+            _, res.lv_info = ctx.louvain(sub, res.scl, n_sub=n_sub, labels_out=labels_w)   # cluster.py:319-321 + louvain.py:70
+            ids = torch.empty(sub.n, dtype=torch.int32, device=dev)
+            has_ids = ctx.lib.b3c_mat_ids(ctx.h, sub.h, _native._ptr(ids))
+            if has_ids == 1:
+                labels_t = labels_w
+            else:
+                ctx._check(has_ids)
+                labels_t = torch.empty_like(labels_w)
+                labels_t[ids.long()] = labels_w                             # back to gapless caller-side ids
+            t['louvain'] = time.perf_counter() - t0
+
+        # results to the host, in the caller's numbering
+        t0 = time.perf_counter()
+        if o2n is not None:
+            back = o2n.long()
+            mask_w, signal_w, x_w = mask_w[back], signal_w[back], x_w[back]
+            res.perm = (n2o.cpu().numpy(), o2n.cpu().numpy())
+        res.mask = mask_w.cpu().numpy().astype(bool)
+        res.signal = signal_w.cpu().numpy().view(np.uint32)
+        res.x = x_w.cpu().numpy()
+        if labels_t is not None:
+            res.labels = labels_t.cpu().numpy()
+        t['download'] = time.perf_counter() - t0
     if not keep:
         res.free()
     return res

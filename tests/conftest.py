@@ -25,7 +25,7 @@ def oracle_lib():
 @pytest.fixture(scope='session')
 def ctx():
     """libb3c context on cuda:0 -- fails loudly if the HIP library is missing or there is no GPU."""
-    from bin3c_amd import _native
-    c = _native.Context(0)
+    from bin3c_amd.pipeline import make_context
+    c = make_context(0)
     yield c
     c.close()
