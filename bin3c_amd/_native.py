@@ -71,6 +71,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError('{} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                               '(hipcc --offload-arch=gfx950); there is no CPU fallback'.format(LIB_PATH))
+        # torch bundles its own HIP/HSA runtime; a process must not end up with two of them.  Loading
+        # torch first makes its copy the one libb3c binds to as well (same sonames), whatever the
+        # import order of the caller.  Without torch, libb3c uses /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)

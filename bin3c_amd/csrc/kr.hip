@@ -380,6 +380,86 @@ __global__ void __launch_bounds__(BLK) kr_kb_stream(int64_t n, int64_t nblk, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// KB, row-group form: LPR lanes own one row and pull UN entries each up front (indices and values
+// first, then all gathers), so a wave keeps 64*UN independent 12-byte triples in flight and 64/LPR
+// rows overlap their indptr -> entries -> gather -> epilogue chains.  No LDS, no barriers, 32-bit
+// offsets inside a row.  Rows longer than LPR*UN loop.  Chosen by average row length.
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int UN>
+__global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t n, const KRState *__restrict__ sin, KRState *__restrict__ sout,
+                                                   const double *__restrict__ partA, int PA,
+                                                   const int64_t *__restrict__ indptr,
+                                                   const int32_t *__restrict__ indices, const double *__restrict__ a,
+                                                   const double *__restrict__ dfix, const double *__restrict__ u,
+                                                   const double *__restrict__ x, const double *__restrict__ p,
+                                                   double *__restrict__ v, double *__restrict__ rk,
+                                                   double *__restrict__ w, double *__restrict__ part_out)
+{
+    __shared__ double lds[BLK];
+    KRState st = *sin;
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, lds);  // :160
+    const bool inner = st.phase == A_INNER;
+    if (st.phase == A_INNER) st.phase = B_INNER;
+    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if (st.phase == P_DONE) return;
+
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    double contrib = 0.0;
+    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
+        const int64_t s = indptr[row];
+        const int len = (int)(indptr[row + 1] - s);
+        const int32_t *__restrict__ ci = indices + s;
+        const double *__restrict__ av = a + s;
+        // epilogue operands do not depend on the row sum: issue them before the long loads
+        double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0;
+        if (sl == 0) {
+            xi = x[row];
+            di = dfix[row] * u[row];
+            if (inner) { pi = p[row]; vi = v[row]; }
+        }
+        double acc = 0.0;
+        for (int base = 0; base < len; base += LPR * UN) {
+            int32_t c[UN];
+            double m[UN];
+#pragma unroll
+            for (int q = 0; q < UN; q++) {
+                const int i = base + q * LPR + sl;
+                const bool ok = i < len;
+                c[q] = ok ? ci[i] : 0;
+                m[q] = ok ? av[i] : 0.0;
+            }
+            double g[UN];
+#pragma unroll
+            for (int q = 0; q < UN; q++) g[q] = u[c[q]];
+#pragma unroll
+            for (int q = 0; q < UN; q++) acc += m[q] * g[q];
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
+        if (sl == 0) {
+            const double t = acc + di;
+            if (inner) {
+                const double wi = xi * t + vi * pi;
+                w[row] = wi;
+                contrib += pi * wi;
+            } else {
+                const double vn = xi * t;
+                const double r = 1.0 - vn;
+                v[row] = vn;
+                rk[row] = r;
+                contrib += r * r;
+            }
+        }
+    }
+    block_partial<0>(contrib, part_out, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
 // KC: inner -> alpha, min/max of ynew = y + alpha p   (sparse_utils.py:166-171,179)
 //     outer -> end-of-outer-iteration control         (:199-211, loop tests :146,:154)
 // ---------------------------------------------------------------------------------------------
@@ -646,6 +726,15 @@ void launch_kb_stream(hipStream_t s, int grid, size_t shmem, int64_t n, int64_t 
                        m->indptr, m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
 }
 
+template <int LPR, int UN>
+void launch_kb_rows(hipStream_t s, int grid, int64_t n, const KRState *sin, KRState *sout, const double *partA, int PA,
+                    const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
+                    double *rk, double *w, double *part_out)
+{
+    hipLaunchKernelGGL((kr_kb_rows<LPR, UN>), dim3(grid), dim3(BLK), 0, s, n, sin, sout, partA, PA, m->indptr, m->indices,
+                       (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
+}
+
 }  // namespace
 
 extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double delta, double Delta,
@@ -677,13 +766,21 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
         HIP_TRY(ctx, hipMemcpyAsync(&maxdeg, md.p, sizeof(maxdeg), hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
     }
-    const bool stream_kb = maxdeg <= 4096 && getenv("B3C_KR_ROWWAVE") == nullptr;
+    // SpMV form: "rows" (default), "stream" (LDS-staged CSR-stream) or "wave" (plain wave-per-row)
+    const char *kform = getenv("B3C_KR_KERNEL");
+    if (getenv("B3C_KR_ROWWAVE")) kform = "wave";
+    const bool stream_kb = kform && !strcmp(kform, "stream") && maxdeg <= 4096;
+    const bool rows_kb = !stream_kb && !(kform && !strcmp(kform, "wave"));
+    // rows form: lanes per row so that LPR*8 covers an average row
+    const int lpr_r = avg > 128 ? 32 : avg > 64 ? 16 : avg > 32 ? 8 : 4;
     const int64_t nblk = a->nnz > 0 ? (a->nnz + KB_T - 1) / KB_T : 1;
     const int lds_cap = (int)((KB_T + maxdeg + 15) & ~15ull);
     const size_t kb_shmem = sizeof(double) * (size_t)(lds_cap + BLK);
     // phase-2 group width: about two LDS reads per lane for an average row
     const int lpr2 = avg >= 64 ? 32 : avg >= 24 ? 16 : avg >= 10 ? 8 : 4;
-    const int GS = stream_kb ? grid_for(nblk, 1, 8 * ctx->n_cu) : grid_for(n, rows_per_block, 8 * ctx->n_cu);
+    const int GS = stream_kb ? grid_for(nblk, 1, 8 * ctx->n_cu)
+                 : rows_kb ? grid_for(n, (BLK / 64) * (64 / lpr_r), 8 * ctx->n_cu)
+                           : grid_for(n, rows_per_block, 8 * ctx->n_cu);
     const int P = G > GS ? G : GS;
     DevBuf<int64_t> rb(ctx, nblk + 1);
     if (!rb.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
@@ -770,6 +867,13 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
                 case 16: launch_kb_stream<16>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
                 case 8: launch_kb_stream<8>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
                 default: launch_kb_stream<4>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                }
+            } else if (rows_kb) {
+                switch (lpr_r) {
+                case 32: launch_kb_rows<32, 8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                case 16: launch_kb_rows<16, 8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                case 8: launch_kb_rows<8, 8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                default: launch_kb_rows<4, 8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
                 }
             } else
             switch (lpr) {
