@@ -1,0 +1,280 @@
+"""
+Host-side mirror of the reference's ``mzd/cluster.py`` for the cluster hot path.
+
+    cluster_map        mzd/cluster.py:44-226   solver dispatch + integer standardisation of the result
+    to_graph           mzd/cluster.py:278-325  contact map -> weighted graph (here: CSR triple or networkx)
+    add_cluster_names  mzd/cluster.py:23-41
+    write_mcl          mzd/cluster.py:521-548
+    readers/writers of the solver wire format: _read_mcl :57, _read_table :76, _read_tree :111, _write_edges :139
+
+``method='louvain'`` runs mask -> normalise -> KR -> compress -> Louvain on the GPU through
+bin3c_amd.pipeline (the reference's own louvain branch is latently broken downstream of
+louvain.cluster, cluster.py:208-209; the reader contract ``{cluster_id: ndarray of gapless seq ids}`` is
+what is honoured here).  External solvers still plug in through the file formats below.
+"""
+import logging
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+
+from .contact_map import SeqOrder
+from .utils import app_path
+
+logger = logging.getLogger(__name__)
+
+
+def add_cluster_names(clustering, prefix='CL'):
+    """Name clusters CL1.. with enough zero padding for the largest id (cluster.py:23-41); in place."""
+    try:
+        num_width = max(1, int(np.ceil(np.log10(max(clustering) + 1))))
+    except OverflowError:
+        num_width = 1
+    for cl_id in clustering:
+        clustering[cl_id]['name'] = '{0}{1:0{2}d}'.format(prefix, cl_id + 1, num_width)
+
+
+# ---- solver wire formats --------------------------------------------------------------------------
+
+def read_mcl(pathname):
+    """One cluster per line, members space separated (cluster.py:57-74)."""
+    cl_map = {}
+    with open(pathname, 'r') as h_in:
+        for cl_id, line in enumerate(h_in):
+            line = line.rstrip()
+            if not line:
+                break
+            cl_map[cl_id] = np.array(sorted(int(tok) for tok in line.split()))
+    return cl_map
+
+
+def read_table(pathname, seq_col=0, cl_col=1):
+    """``seq cluster`` per line, or implicit sequence numbering with seq_col=None (cluster.py:76-109)."""
+    assert seq_col != cl_col, 'sequence and cluster columns must be different'
+    cl_map = {}
+    n = 0
+    with open(pathname, 'r') as h_in:
+        for line in h_in:
+            line = line.strip()
+            if not line:
+                break
+            if seq_col is None:
+                cl_id, seq_id = int(line), n
+                n += 1
+            else:
+                t = line.split()
+                if len(t) != 2:
+                    logger.warning('invalid line encountered when reading cluster table: {}'.format(line))
+                seq_id, cl_id = int(t[seq_col]), int(t[cl_col])
+            cl_map.setdefault(cl_id, []).append(seq_id)
+    return {k: np.array(v, dtype=np.int64) for k, v in cl_map.items()}
+
+
+def read_tree(pathname):
+    """Infomap ``.tree``: cluster = path minus the leaf, renumbered by descending size (cluster.py:111-137)."""
+    cl_map = {}
+    with open(pathname, 'r') as in_h:
+        for line in in_h:
+            line = line.strip()
+            if not line:
+                break
+            if line.startswith('#'):
+                continue
+            fields = line.split()
+            hierarchy = fields[0].split(':')
+            cl_map.setdefault(tuple(['orig'] + hierarchy[:-1]), []).append(fields[-1])
+    desc_key = sorted(cl_map, key=lambda x: len(cl_map[x]), reverse=True)
+    return {n: np.array(cl_map[k], dtype=np.int64) for n, k in enumerate(desc_key)}
+
+
+def write_edges(graph, parent_dir, base_name, sep=' '):
+    """``u v weight`` per undirected edge, the file every external solver reads (cluster.py:139-151).
+    ``graph`` is the (indptr, indices, weights) triple of :func:`to_graph`; each edge is written once
+    from its lower endpoint, self-loops included, like ``nx.write_edgelist`` on the reference's graph."""
+    edge_file = os.path.join(parent_dir, '{}.edges'.format(base_name))
+    ip, ix, w = graph
+    rows = np.repeat(np.arange(ip.shape[0] - 1), np.diff(ip))
+    keep = rows <= ix
+    with open(edge_file, 'w') as out:
+        for u, v, ww in zip(rows[keep].tolist(), ix[keep].tolist(), w[keep].tolist()):
+            out.write('{}{}{}{}{}\n'.format(u, sep, v, sep, repr(ww)))
+    return edge_file
+
+
+# ---- graph ------------------------------------------------------------------------------------------
+
+def to_graph(contact_map, norm=True, bisto=False, scale=False, extern_ids=False, min_len=None, min_sig=None,
+             as_networkx=False):
+    """
+    cluster.py:278-325: accept/refresh the mask, prepare the map if needed, take the accepted subspace and
+    scale the weights by 1/max.  Returns the graph as a symmetric CSR triple (indptr, indices, weights)
+    whose both directions hold the value nx.Graph would hold (the later, lower-triangle entry wins,
+    cluster.py:319-321) -- or a networkx.Graph with as_networkx=True for code that wants the reference's type.
+    """
+    if not min_len and not min_sig:
+        contact_map.set_primary_acceptance_mask()
+    else:
+        contact_map.set_primary_acceptance_mask(min_len, min_sig, update=True)
+    if contact_map.processed_map is None:
+        contact_map.prepare_seq_map(norm=norm, bisto=bisto)
+    _map = contact_map.get_subspace(marginalise=True, flatten=False)
+    logger.info('Graph will have {} nodes'.format(contact_map.order.count_accepted()))
+    c = sp.csr_matrix(_map)
+    c.sort_indices()
+    scl = 1.0 / c.max() if scale else 1
+    # lower triangle wins: mirror it over the upper triangle
+    low = sp.tril(c, k=0, format='csr')
+    sym = low + sp.tril(c, k=-1, format='csr').T
+    sym = sym.tocsr()
+    sym.sort_indices()
+    w = sym.data * scl
+    if not as_networkx:
+        return sym.indptr.astype(np.int64), sym.indices.astype(np.int32), w
+    import networkx as nx
+    g = nx.Graph(name='contact_graph')
+    _nn = (lambda x: contact_map.seq_info[x].name) if extern_ids else (lambda x: x)
+    coo = c.tocoo()
+    for u, v, ww in zip(coo.row.tolist(), coo.col.tolist(), coo.data.tolist()):
+        g.add_edge(_nn(u), _nn(v), weight=ww * scl)
+    return g
+
+
+# ---- clustering -------------------------------------------------------------------------------------
+
+def _louvain_device(contact_map, min_len, min_sig):
+    """mask -> normalise -> KR -> compress -> Louvain without leaving HBM; -> {cluster: gapless ids}."""
+    from ..pipeline import run_hot_path, cluster_prepared
+    if not min_len and not min_sig:
+        mask = contact_map.set_primary_acceptance_mask()
+    else:
+        mask = contact_map.set_primary_acceptance_mask(min_len, min_sig, update=True)
+    contact_map.order.set_mask_only(mask)
+    ctx = contact_map._context()
+    hot = contact_map._hot
+    if hot is not None and hot.processed is not None:
+        res = cluster_prepared(ctx, hot, mask)
+    elif contact_map.processed_map is not None:
+        # a map that was prepared in an earlier session: upload the cached balanced matrix
+        c = contact_map.processed_map.tocsr()
+        c.sort_indices()
+        from ..pipeline import HotPathResult
+        res = HotPathResult()
+        res.processed = ctx.upload(c.indptr, c.indices, c.data.astype(np.float64))
+        contact_map._hot = res
+        res = cluster_prepared(ctx, res, mask)
+    else:
+        c = contact_map._counts_csr()
+        counts = ctx.upload(c.indptr, c.indices, c.data)
+        try:
+            res = run_hot_path(ctx, counts, contact_map._get_sites(), contact_map.order.lengths(),
+                               contact_map.min_len, contact_map.min_sig, mask=mask, keep=True)
+        finally:
+            counts.free()
+        contact_map._report_kr(res.kr_info)
+        contact_map.bisto_scale = res.x
+        contact_map._processed_host = None
+        contact_map._hot = res
+    logger.info('Graph will have {} nodes'.format(contact_map.order.count_accepted()))
+    labels = res.labels
+    info = res.lv_info
+    logger.info('Louvain: {} communities, {} levels, {} sweeps, modularity {:.6f}'.format(
+        info.n_comm, info.n_levels, info.n_sweeps, info.modularity))
+    order = np.argsort(labels, kind='stable')
+    srt = labels[order]
+    first = np.flatnonzero(np.concatenate(([True], srt[1:] != srt[:-1])))
+    bounds = np.concatenate((first, [len(srt)]))
+    return {int(srt[bounds[i]]): order[bounds[i]:bounds[i + 1]] for i in range(len(first)) if srt[bounds[i]] >= 0}
+
+
+def cluster_map(contact_map, seed, method='louvain', min_len=None, min_sig=None, work_dir='.'):
+    """
+    Cluster a contact map into genome bins (cluster.py:44-226).
+
+    :param contact_map: ContactMap
+    :param seed: random seed handed to external solvers (the GPU Louvain is deterministic)
+    :param method: 'louvain' (GPU) or one of the reference's external solvers
+                   ('infomap', 'mcl', 'slm', 'simap') if its executable is present under external/
+    :return: {rank: {'seq_ids': ndarray, 'extent': int, 'name': str}} ordered by descending extent
+    """
+    assert os.path.exists(work_dir), 'supplied output path [{}] does not exist'.format(work_dir)
+    base_name = 'cm_graph'
+    method = method.lower()
+    logger.info('Clustering contact graph using method: {}'.format(method))
+
+    if method == 'louvain':
+        cl_to_ids = _louvain_device(contact_map, min_len, min_sig)
+    elif method in ('infomap', 'mcl', 'slm', 'simap'):
+        g = to_graph(contact_map, min_len=min_len, min_sig=min_sig, norm=True, bisto=True, scale=True)
+        cl_to_ids = _run_external(method, g, seed, work_dir, base_name)
+    else:
+        raise RuntimeError('unimplemented method: {}'.format(method))
+
+    logger.info('Clustering using {} resulted in {} clusters'.format(method, len(cl_to_ids)))
+    return standardise(contact_map, cl_to_ids)
+
+
+def standardise(contact_map, cl_to_ids):
+    """cluster.py:205-226: ascending member ids, gapless -> surrogate ids, extent, descending-extent order, names."""
+    lengths = contact_map.order.lengths()
+    clustering = {}
+    for cl_id, _seqs in cl_to_ids.items():
+        _ord = SeqOrder.asindex(np.sort(_seqs))
+        _seqs = contact_map.order.remap_gapless(_ord)['index']
+        clustering[cl_id] = {'seq_ids': _seqs, 'extent': lengths[_seqs].sum()}
+    sorted_keys = sorted(clustering, key=lambda k: clustering[k]['extent'], reverse=True)
+    clustering = {n: clustering[k] for n, k in enumerate(sorted_keys)}
+    add_cluster_names(clustering)
+    return clustering
+
+
+def _run_external(method, g, seed, work_dir, base_name):
+    """The reference's subprocess branches (cluster.py:163-199); needs the third-party executables."""
+    def need(path):
+        if not os.path.exists(path):
+            raise RuntimeError('external solver {} is not installed (bin3C bundles it under external/)'.format(path))
+        return path
+
+    if method == 'mcl':
+        ofile = os.path.join(work_dir, '{}.mcl'.format(base_name))
+        edge_file = write_edges(g, work_dir, base_name)
+        with open(os.path.join(work_dir, 'mcl.log'), 'w+') as stdout:
+            subprocess.check_call([need(app_path('external', 'mcl')), edge_file, '--abc', '-I', '1.2', '-o', ofile],
+                                  stdout=stdout, stderr=subprocess.STDOUT)
+        return read_mcl(ofile)
+    if method == 'infomap':
+        edge_file = write_edges(g, work_dir, base_name)
+        with open(os.path.join(work_dir, 'infomap.log'), 'w+') as stdout:
+            subprocess.check_call([need(app_path('external', 'Infomap')), '-u', '-v', '-z', '-i', 'link-list', '-s',
+                                   str(seed), '-N', '10', edge_file, work_dir], stdout=stdout, stderr=subprocess.STDOUT)
+        return read_tree(os.path.join(work_dir, '{}.tree'.format(base_name)))
+    if method == 'simap':
+        ofile = os.path.join(work_dir, '{}.simap'.format(base_name))
+        edge_file = write_edges(g, work_dir, base_name)
+        with open(os.path.join(work_dir, 'simap.log'), 'w+') as stdout:
+            subprocess.check_call(['java', '-jar', need(app_path('external', 'simap-1.0.0.jar')), 'mdl', '-s', str(seed),
+                                   '-i', '1e-5', '1e-3', '-a', '1e-5', '-g', edge_file, '-o', ofile],
+                                  stdout=stdout, stderr=subprocess.STDOUT)
+        return read_table(ofile)
+    ofile = os.path.join(work_dir, '{}.slm'.format(base_name))
+    edge_file = write_edges(g, work_dir, base_name, sep='\t')
+    with open(os.path.join(work_dir, 'slm.log'), 'w+') as stdout:
+        subprocess.check_call(['java', '-jar', need(app_path('external', 'ModularityOptimizer.jar')), edge_file, ofile,
+                               '1', '2.0', '3', '10', '10', str(seed), '1'], stdout=stdout, stderr=subprocess.STDOUT)
+    return read_table(ofile, seq_col=None, cl_col=0)
+
+
+def write_mcl(contact_map, fname, clustering):
+    """clustering.mcl (cluster.py:521-548): one line of sequence names per cluster; filtered-out sequences become singletons."""
+    seq_info = contact_map.seq_info
+    lost = np.ones(contact_map.total_seq, dtype=np.bool_)
+    cl_soln = {}
+    for k, v in clustering.items():
+        lost[v['seq_ids']] = False
+        cl_soln[k] = [seq_info[ix].name for ix in np.sort(v['seq_ids'])]
+    for n, ix in enumerate(np.flatnonzero(lost), len(cl_soln)):
+        cl_soln[n] = [seq_info[ix].name]
+    with open(fname, 'w') as outh:
+        for k in sorted(cl_soln.keys()):
+            outh.write(' '.join(cl_soln[k]))
+            outh.write('\n')

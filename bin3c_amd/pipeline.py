@@ -51,6 +51,7 @@ class HotPathResult(object):
         self.lv_info = None
         self.timings = {}
         self.perm = (None, None)    # (new2old, old2new) int32 host arrays of the locality ordering, or (None, None)
+        self._n2o = self._o2n = None  # the same on the device
 
     def free(self):
         for m in (self.processed, self.sub):
@@ -67,7 +68,7 @@ def acceptance_mask(ctx, counts, lengths, min_len, min_sig):
 
 
 def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=0, cluster=True, keep=False,
-                 reorder=True):
+                 reorder=True, mask=None):
     """
     :param ctx: context from :func:`make_context`
     :param counts: _native.Mat (B3C_U32) raw symmetric contact counts, already in HBM
@@ -75,6 +76,8 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
     :param lengths: int[n] contig lengths; numpy or device tensor
     :param reorder: run the whole path on a locality-ordered copy of the matrix (reorder.hip); every
                     returned vector is in the caller's numbering either way
+    :param mask: bool[n] acceptance mask decided by the caller (ContactMap.primary_acceptance_mask); when
+                 None it is computed here from lengths / min_len / min_sig
     :return: HotPathResult (device matrices freed unless keep=True)
     """
     import torch
@@ -84,7 +87,7 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
     n = counts.n
     with torch.cuda.stream(ctx.torch_stream):
         sites_t = torch.as_tensor(sites, device=dev).to(torch.float64)
-        lengths_t = torch.as_tensor(lengths, device=dev).to(torch.int64)
+        lengths_t = torch.as_tensor(np.asarray(lengths) if not torch.is_tensor(lengths) else lengths, device=dev).to(torch.int64)
 
         t0 = time.perf_counter()
         work = counts
@@ -96,16 +99,22 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
             work = ctx.permute(counts, n2o)
             idx = n2o.long()
             sites_t, lengths_t = sites_t[idx], lengths_t[idx]
+        res._n2o, res._o2n = n2o, o2n
         t['order'] = time.perf_counter() - t0
 
         try:
             # set_primary_acceptance_mask (contact_map.py:888-905)
             t0 = time.perf_counter()
-            signal_w = torch.empty(n, dtype=torch.int32, device=dev)          # uint32 bit pattern
-            ctx.max_offdiag_u32(work, assume_symmetric=True, out=signal_w)
-            sig64 = signal_w.long() & 0xFFFFFFFF
-            mask_w = ((lengths_t >= int(min_len)) & (sig64 >= int(min_sig))).to(torch.uint8)
-            all_kept = bool(mask_w.all().item())
+            signal_w = None
+            if mask is None:
+                signal_w = torch.empty(n, dtype=torch.int32, device=dev)          # uint32 bit pattern
+                ctx.max_offdiag_u32(work, assume_symmetric=True, out=signal_w)
+                sig64 = signal_w.long() & 0xFFFFFFFF
+                mask_w = ((lengths_t >= int(min_len)) & (sig64 >= int(min_sig))).to(torch.uint8)
+            else:
+                mask_w = torch.as_tensor(np.asarray(mask, dtype=np.uint8), device=dev)
+                if n2o is not None:
+                    mask_w = mask_w[n2o.long()]
             t['mask'] = time.perf_counter() - t0
 
             t0 = time.perf_counter()
@@ -125,44 +134,73 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
         t['kr'] = time.perf_counter() - t0
         res.processed = a
 
-        t0 = time.perf_counter()
-        if all_kept:                                                       # contact_map.py:977: compress only if needed
-            sub = a
-        else:
-            sub = ctx.compress(a, mask_w)
-            res.sub = sub
-        res.scl = 1.0 / ctx.max_value(sub)                                 # cluster.py:316
-        t['compress'] = time.perf_counter() - t0
-
         labels_t = None
         if cluster:
-            t0 = time.perf_counter()
-            labels_w = torch.empty(sub.n, dtype=torch.int32, device=dev)
-            _, res.lv_info = ctx.louvain(sub, res.scl, n_sub=n_sub, labels_out=labels_w)   # cluster.py:319-321 + louvain.py:70
-            ids = torch.empty(sub.n, dtype=torch.int32, device=dev)
-            has_ids = ctx.lib.b3c_mat_ids(ctx.h, sub.h, _native._ptr(ids))
-            if has_ids == 1:
-                labels_t = labels_w
-            else:
-                ctx._check(has_ids)
-                labels_t = torch.empty_like(labels_w)
-                labels_t[ids.long()] = labels_w                             # back to gapless caller-side ids
-            t['louvain'] = time.perf_counter() - t0
+            labels_t = _cluster_stage(ctx, res, mask_w, n_sub)
 
         # results to the host, in the caller's numbering
         t0 = time.perf_counter()
         if o2n is not None:
             back = o2n.long()
-            mask_w, signal_w, x_w = mask_w[back], signal_w[back], x_w[back]
+            mask_w, x_w = mask_w[back], x_w[back]
+            signal_w = signal_w[back] if signal_w is not None else None
             res.perm = (n2o.cpu().numpy(), o2n.cpu().numpy())
         res.mask = mask_w.cpu().numpy().astype(bool)
-        res.signal = signal_w.cpu().numpy().view(np.uint32)
+        if signal_w is not None:
+            res.signal = signal_w.cpu().numpy().view(np.uint32)
         res.x = x_w.cpu().numpy()
         if labels_t is not None:
             res.labels = labels_t.cpu().numpy()
         t['download'] = time.perf_counter() - t0
     if not keep:
         res.free()
+    return res
+
+
+def _cluster_stage(ctx, res, mask_w, n_sub=0):
+    """get_subspace + to_graph scaling + Louvain on the device-resident balanced map; mask_w in the map's row order."""
+    import torch
+    t = res.timings
+    a = res.processed
+    t0 = time.perf_counter()
+    if res.sub is not None:
+        res.sub.free()
+        res.sub = None
+    if bool(mask_w.all().item()):                                          # contact_map.py:977: compress only if needed
+        sub = a
+    else:
+        sub = ctx.compress(a, mask_w)
+        res.sub = sub
+    res.scl = 1.0 / ctx.max_value(sub)                                     # cluster.py:316
+    t['compress'] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    dev = mask_w.device
+    labels_w = torch.empty(sub.n, dtype=torch.int32, device=dev)
+    _, res.lv_info = ctx.louvain(sub, res.scl, n_sub=n_sub, labels_out=labels_w)   # cluster.py:319-321 + louvain.py:70
+    ids = torch.empty(sub.n, dtype=torch.int32, device=dev)
+    has_ids = ctx.lib.b3c_mat_ids(ctx.h, sub.h, _native._ptr(ids))
+    if has_ids == 1:
+        labels_t = labels_w
+    else:
+        ctx._check(has_ids)
+        labels_t = torch.empty_like(labels_w)
+        labels_t[ids.long()] = labels_w                                     # back to gapless caller-side ids
+    t['louvain'] = time.perf_counter() - t0
+    return labels_t
+
+
+def cluster_prepared(ctx, res, mask, n_sub=0):
+    """Cluster a map that :func:`run_hot_path` (cluster=False, keep=True) left in HBM, under a caller-side mask."""
+    import torch
+    dev = torch.device('cuda', ctx.device)
+    with torch.cuda.stream(ctx.torch_stream):
+        mask_w = torch.as_tensor(np.asarray(mask, dtype=np.uint8), device=dev)
+        if res._n2o is not None:
+            mask_w = mask_w[res._n2o.long()]
+        labels_t = _cluster_stage(ctx, res, mask_w, n_sub)
+        res.mask = np.asarray(mask, dtype=bool)
+        res.labels = labels_t.cpu().numpy()
     return res
 
 

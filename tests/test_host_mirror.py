@@ -1,0 +1,143 @@
+"""
+CPU suite: the host-side mirror of the reference's Python surface (integer / label work must be identical).
+Expected values in tests/golden/seqorder_cluster.npz were produced by the reference's own SeqOrder class,
+add_cluster_names and the standardisation block of cluster_map (tools/make_golden.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+class _SI(object):
+    def __init__(self, length):
+        self.length = length
+
+
+@pytest.fixture(scope='module')
+def g():
+    return np.load(os.path.join(GOLDEN, 'seqorder_cluster.npz'))
+
+
+def _order(g):
+    from bin3c_amd.mzd.contact_map import SeqOrder
+    o = SeqOrder([_SI(int(v)) for v in g['lengths']])
+    o.set_mask_only(g['mask'])
+    return o
+
+
+def test_seqorder_mask_positions_and_remaps(g):
+    from bin3c_amd.mzd.contact_map import SeqOrder
+    o = _order(g)
+    assert o.order.dtype == SeqOrder.STRUCT_TYPE
+    assert np.array_equal(o.order['pos'], g['pos_after_mask'])
+    assert np.array_equal(o.all_positions(), g['positions'])
+    assert np.array_equal(o.gapless_positions(), g['gapless'])
+    assert np.array_equal(o.remap_gapless(g['dense']), g['remap_plain'])
+    r = o.remap_gapless(SeqOrder.asindex(np.sort(g['dense'])))
+    assert r.dtype == SeqOrder.INDEX_TYPE
+    assert np.array_equal(r['index'], g['remap_index_index']) and np.array_equal(r['ori'], g['remap_index_ori'])
+    assert o.count_accepted() == int(g['mask'].sum()) and o.count_excluded() == int((~g['mask']).sum())
+    assert np.array_equal(o.accepted(), np.flatnonzero(g['mask']))
+    assert np.array_equal(o.lengths(exclude_masked=True), g['lengths'][g['mask']])
+
+
+def test_cluster_map_standardisation(g):
+    from bin3c_amd.mzd import cluster
+
+    class _CM(object):
+        pass
+
+    cm = _CM()
+    cm.order = _order(g)
+    lab = g['labels']
+    cl_to_ids = {int(c): np.flatnonzero(lab == c) for c in np.unique(lab)}
+    out = cluster.standardise(cm, cl_to_ids)
+    assert len(out) == int(g['n_clusters'])
+    for k in out:
+        assert np.array_equal(out[k]['seq_ids'], g['cl{}_seq_ids'.format(k)])
+        assert int(out[k]['extent']) == int(g['cl{}_extent'.format(k)])
+        assert out[k]['name'] == str(g['cl{}_name'.format(k)])
+    extents = [out[k]['extent'] for k in sorted(out)]
+    assert extents == sorted(extents, reverse=True)
+
+
+@pytest.mark.parametrize('k', [1, 9, 10, 11, 99, 100, 101, 1000])
+def test_cluster_names_width(g, k):
+    from bin3c_amd.mzd.cluster import add_cluster_names
+    d = {i: {} for i in range(k)}
+    add_cluster_names(d)
+    assert d[0]['name'] == str(g['names_{}_first'.format(k)])
+    assert d[k - 1]['name'] == str(g['names_{}_last'.format(k)])
+
+
+def test_solver_wire_formats(tmp_path):
+    from bin3c_amd.mzd import cluster
+    p = tmp_path / 'x.mcl'
+    p.write_text('3 1 2\n7 5\n\n9\n')
+    m = cluster.read_mcl(str(p))
+    assert list(m) == [0, 1] and m[0].tolist() == [1, 2, 3] and m[1].tolist() == [5, 7]
+    p = tmp_path / 'x.tab'
+    p.write_text('0 4\n1 4\n2 9\n')
+    t = cluster.read_table(str(p))
+    assert t[4].tolist() == [0, 1] and t[9].tolist() == [2]
+    p.write_text('4\n4\n9\n')
+    t = cluster.read_table(str(p), seq_col=None, cl_col=0)
+    assert t[4].tolist() == [0, 1] and t[9].tolist() == [2]
+    p = tmp_path / 'x.tree'
+    p.write_text('# comment\n1:1 0.1 "a" 5\n1:2 0.1 "b" 6\n2:1 0.1 "c" 7\n1:3 0.1 "d" 8\n')
+    tr = cluster.read_tree(str(p))
+    assert tr[0].tolist() == [5, 6, 8] and tr[1].tolist() == [7]          # renumbered by descending size
+    ip = np.array([0, 2, 4, 5], dtype=np.int64)
+    ix = np.array([0, 1, 0, 2, 1], dtype=np.int32)
+    w = np.array([0.5, 0.25, 0.25, 1.0, 1.0])
+    f = cluster.write_edges((ip, ix, w), str(tmp_path), 'cm_graph')
+    assert open(f).read().split('\n')[:3] == ['0 0 0.5', '0 1 0.25', '1 2 1.0']
+
+
+def test_object_io_roundtrip_and_suffixes(tmp_path):
+    from bin3c_amd.mzd import io_utils
+    obj = {'a': np.arange(5), 'b': 'x'}
+    io_utils.save_object(str(tmp_path / 'thing.p'), obj)
+    assert (tmp_path / 'thing.p.gz').exists()                               # .gz appended (io_utils.py:73-76)
+    back = io_utils.load_object(str(tmp_path / 'thing.p.gz'))
+    assert back['b'] == 'x' and np.array_equal(back['a'], obj['a'])
+    import bz2
+    import pickle
+    with bz2.BZ2File(str(tmp_path / 'o.bz2'), 'wb') as h:
+        pickle.dump([1, 2], h)
+    assert io_utils.load_object(str(tmp_path / 'o.bz2')) == [1, 2]
+
+
+def test_exception_family_and_utils(tmp_path):
+    from bin3c_amd.mzd import exceptions as ex, utils
+    assert issubclass(ex.NoneAcceptedException, ex.ApplicationException)
+    assert ex.NoneAcceptedException().message == 'all sequences were excluded'
+    assert ex.ZeroLengthException('c1').message == 'Sequence [c1] has zero length'
+    assert 1000000 <= utils.make_random_seed() < 10000000
+    d = tmp_path / 'o'
+    utils.make_dir(str(d))
+    with pytest.raises(IOError):
+        utils.make_dir(str(d))
+    utils.make_dir(str(d), exist_ok=True)
+
+
+def test_contact_map_surface_pickles_without_device(tmp_path):
+    """The attribute surface of contact_map.py:492-518 survives a save/load cycle (no GPU needed for that)."""
+    from bin3c_amd.mzd.contact_map import ContactMap
+    from bin3c_amd.mzd import io_utils
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(300, 6000, 3)
+    cm = ContactMap.from_arrays(sm.to_scipy(), sm.lengths, sm.sites)
+    for attr in ('strong bam_file bin_size min_mapq min_insert min_len min_sig min_extent min_size max_fold '
+                 'random_state seq_info seq_map seq_file grouping extent_map order tip_size precount total_reads '
+                 'cov_info processed_map primary_acceptance_mask bisto_scale seq_analyzer enzymes total_len '
+                 'total_seq current_mask').split():
+        assert hasattr(cm, attr), attr
+    assert cm.seq_map.dtype == np.uint32 and cm.total_seq == 300 and not cm.is_empty() and not cm.is_tipbased()
+    io_utils.save_object(str(tmp_path / 'contact_map.p'), cm)
+    back = io_utils.load_object(str(tmp_path / 'contact_map.p.gz'))
+    assert (back.seq_map != cm.seq_map).nnz == 0 and back.processed_map is None
+    assert np.array_equal(back.order.order, cm.order.order)
