@@ -86,8 +86,11 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
     dev = torch.device('cuda', ctx.device)
     n = counts.n
     with torch.cuda.stream(ctx.torch_stream):
-        sites_t = torch.as_tensor(sites, device=dev).to(torch.float64)
-        lengths_t = torch.as_tensor(np.asarray(lengths) if not torch.is_tensor(lengths) else lengths, device=dev).to(torch.int64)
+        # structured-array fields (SeqOrder.lengths()) are strided views: make them contiguous first
+        sites_t = torch.as_tensor(sites if torch.is_tensor(sites) else np.ascontiguousarray(sites, dtype=np.float64),
+                                  device=dev).to(torch.float64)
+        lengths_t = torch.as_tensor(lengths if torch.is_tensor(lengths) else np.ascontiguousarray(lengths, dtype=np.int64),
+                                    device=dev).to(torch.int64)
 
         t0 = time.perf_counter()
         work = counts
