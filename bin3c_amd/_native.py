@@ -24,7 +24,8 @@ class B3CError(RuntimeError):
 class KRInfo(C.Structure):
     _fields_ = [('n_iter', C.c_int64), ('n_outer', C.c_int64), ('n_zero_diag', C.c_int64),
                 ('is_symmetric', C.c_int32), ('hit_max_iter', C.c_int32), ('hit_delta', C.c_int64),
-                ('hit_Delta', C.c_int64), ('rout', C.c_double), ('spmv_ms', C.c_double), ('n_spmv', C.c_int64)]
+                ('hit_Delta', C.c_int64), ('rout', C.c_double), ('spmv_ms', C.c_double), ('n_spmv', C.c_int64),
+                ('bitwise_symmetric', C.c_int32), ('reserved', C.c_int32)]
 
 
 class LouvainInfo(C.Structure):
@@ -50,6 +51,7 @@ SYMBOLS = [
     ('b3c_max_offdiag_u32', C.c_int, [_VP, _VP, C.c_int, _VP]),
     ('b3c_site_norm', C.c_int, [_VP, _VP, _VP, C.POINTER(_VP)]),
     ('b3c_scale_sym', C.c_int, [_VP, _VP, _VP]),
+    ('b3c_scale_sym_graph', C.c_int, [_VP, _VP, _VP]),
     ('b3c_compress', C.c_int, [_VP, _VP, _VP, C.POINTER(_VP)]),
     ('b3c_max_value', C.c_int, [_VP, _VP, C.POINTER(C.c_double)]),
     ('b3c_kr_balance', C.c_int, [_VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, _VP, C.POINTER(KRInfo)]),
@@ -256,6 +258,11 @@ class Context(object):
         if isinstance(x, np.ndarray):
             x = np.ascontiguousarray(x, dtype=np.float64)
         self._check(self.lib.b3c_scale_sym(self.h, mat.h, _ptr(x)))
+
+    def scale_sym_graph(self, mat, x):
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, dtype=np.float64)
+        self._check(self.lib.b3c_scale_sym_graph(self.h, mat.h, _ptr(x)))
 
     def compress(self, mat, mask):
         if isinstance(mask, np.ndarray):

@@ -88,6 +88,9 @@ struct b3c_mat {
     // hashes / tie-breaks on these so that its result does not depend on the storage order
     int32_t *ids = nullptr;
     bool ordered = false;
+    // values are bitwise symmetric (a_ij == a_ji): set by b3c_scale_sym_graph, kept by compress / permute;
+    // lets Louvain take the edge weight straight from the entry instead of searching its mirror
+    bool value_symmetric = false;
 };
 
 #define HIP_TRY(ctx, expr)                                                                          \

@@ -52,6 +52,23 @@ __global__ void __launch_bounds__(BLK) k_scale_sym(int64_t n, const int64_t *__r
     });
 }
 
+// Graph form of the same scaling for a bitwise-symmetric A: both triangles get the value the LOWER
+// triangle has in scipy's result, x_hi * (a * x_lo) with hi/lo by caller-side id -- the value that
+// nx.Graph ends up holding for the edge (cluster.py:319-321: the later add_edge(v,u) overwrites (u,v)).
+template <int LPR>
+__global__ void __launch_bounds__(BLK) k_scale_sym_graph(int64_t n, const int64_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ indices, double *__restrict__ a,
+                                                          const double *__restrict__ x, const int32_t *__restrict__ ids)
+{
+    for_rows<LPR>(n, indptr, [&](int64_t row, int64_t k) {
+        const int32_t j = indices[k];
+        const int32_t idr = ids ? ids[row] : (int32_t)row, idj = ids ? ids[j] : j;
+        const double xr = x[row], xj = x[j];
+        const double xhi = idr >= idj ? xr : xj, xlo = idr >= idj ? xj : xr;
+        a[k] = xhi * (a[k] * xlo);
+    });
+}
+
 // max_offdiag (sparse_utils.py:269-281), symmetric input: row maximum with the diagonal skipped
 template <int LPR>
 __global__ void __launch_bounds__(BLK) k_max_offdiag_rows(int64_t n, const int64_t *__restrict__ indptr,
@@ -294,6 +311,26 @@ extern "C" int b3c_scale_sym(b3c_ctx *ctx, b3c_mat *a, const double *x)
     return B3C_OK;
 }
 
+extern "C" int b3c_scale_sym_graph(b3c_ctx *ctx, b3c_mat *a, const double *x)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a || a->kind != B3C_F64 || !x) return ctx->fail(B3C_E_ARG, "b3c_scale_sym_graph: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = a->n;
+    if (n == 0) return B3C_OK;
+    DevBuf<double> dx(ctx, n);
+    if (!dx.p) return ctx->fail(B3C_E_NOMEM, "b3c_scale_sym_graph");
+    int rc = b3c_copy_in(ctx, dx.p, x, sizeof(double) * (size_t)n);
+    if (rc) return rc;
+    const int lpr = pick_lpr(a);
+    DISPATCH_LPR(lpr, k_scale_sym_graph, row_grid(ctx, n, lpr), ctx->stream, n, a->indptr, a->indices, (double *)a->data,
+                 dx.p, a->ids);
+    a->value_symmetric = true;
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return B3C_OK;
+}
+
 extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, b3c_mat **out)
 {
     if (!ctx) return B3C_E_ARG;
@@ -335,6 +372,7 @@ extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask,
                                (const uint32_t *)a->data, dm.p, newid.p, optr.p, o->indices, (uint32_t *)o->data);
     }
     o->ordered = a->ordered;
+    o->value_symmetric = a->value_symmetric;
     if (a->ids && n) {
         DevBuf<int64_t> keep_o(ctx, n + 1), rank_o(ctx, n + 1);
         o->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1));

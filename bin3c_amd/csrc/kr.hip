@@ -806,7 +806,8 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
         unsigned long long hh[4];
         HIP_TRY(ctx, hipMemcpyAsync(hh, hs.p, sizeof(hh), hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
-        if (hh[0] != hh[2] || hh[1] != hh[3] || getenv("B3C_KR_EXACT_SYMCHECK"))
+        info->bitwise_symmetric = hh[0] == hh[2] && hh[1] == hh[3];
+        if (!info->bitwise_symmetric || getenv("B3C_KR_EXACT_SYMCHECK"))
             hipLaunchKernelGGL(kr_asym_count, dim3(grid_for(n, 4, 8 * ctx->n_cu)), dim3(256), 0, s, n, a->indptr,
                                a->indices, (const double *)a->data, tol, counters.p + 1);
     }

@@ -118,6 +118,28 @@ __global__ void __launch_bounds__(BLK) k_graph_w(int64_t n, const int64_t *__res
     }
 }
 
+// value-symmetric matrices: the entry already is the edge weight
+__global__ void __launch_bounds__(BLK) k_graph_w_sym(int64_t nnz, const double *__restrict__ a, double scl,
+                                                      double *__restrict__ w, double *__restrict__ part_max)
+{
+    __shared__ double lds[WPB];
+    double mx = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    for (int64_t k = (int64_t)blockIdx.x * BLK + threadIdx.x; k < nnz; k += stride) {
+        const double ww = a[k] * scl;
+        w[k] = ww;
+        mx = fmax(mx, ww);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = lds[0];
+        for (int i = 1; i < WPB; i++) r = fmax(r, lds[i]);
+        part_max[blockIdx.x] = r;
+    }
+}
+
 // sum of ceil(w * 2^(20-e)), diagonal twice: exact integer bound on 2m (oracle: orc_quant_shift)
 __global__ void __launch_bounds__(BLK) k_quant_total(int64_t n, const int64_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices,
@@ -541,8 +563,11 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
     DevBuf<double> part(ctx, g);
     DevBuf<u64> total(ctx, 1);
     if (!w.p || !part.p || !total.p) return ctx->fail(B3C_E_NOMEM, "quantise_graph");
-    hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, ids, scl,
-                       w.p, part.p);
+    if (a->value_symmetric)
+        hipLaunchKernelGGL(k_graph_w_sym, dim3(g), dim3(BLK), 0, s, nnz, (const double *)a->data, scl, w.p, part.p);
+    else
+        hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, ids, scl,
+                           w.p, part.p);
     std::vector<double> hp(g);
     HIP_TRY(ctx, hipMemcpyAsync(hp.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));

@@ -380,6 +380,7 @@ extern "C" int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ne
         else HIP_TRY(ctx, hipMemcpyAsync(m->ids, n2o.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     }
     m->ordered = true;
+    m->value_symmetric = a->value_symmetric;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *out = m;
     return B3C_OK;

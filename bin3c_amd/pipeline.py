@@ -133,7 +133,12 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
         if rc != _native.OK:
             a.free()
             ctx._check(rc)
-        ctx.scale_sym(a, x_w)                                              # sparse_utils.py:223-224
+        # sparse_utils.py:223-224.  A bitwise-symmetric A (the normal case: counts are symmetric by construction)
+        # is scaled in graph form so that Louvain needs no mirror lookups; otherwise exactly as scipy does.
+        if res.kr_info.bitwise_symmetric:
+            ctx.scale_sym_graph(a, x_w)
+        else:
+            ctx.scale_sym(a, x_w)
         t['kr'] = time.perf_counter() - t0
         res.processed = a
 

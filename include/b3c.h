@@ -49,6 +49,8 @@ typedef struct {
     double rout;          /* final squared residual */
     double spmv_ms;       /* device time spent in the SpMV kernel (HIP events), 0 if not measured */
     int64_t n_spmv;       /* SpMV launches that did work */
+    int32_t bitwise_symmetric; /* 1: a_ij == a_ji exactly (checksum path); precondition of b3c_scale_sym_graph */
+    int32_t reserved;
 } b3c_kr_info;
 
 typedef struct {
@@ -120,6 +122,13 @@ int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *sites /*hos
 
 /* X.T * (orig * X) (sparse_utils.py:223-224): a_ij <- x_i * (a_ij * x_j), in place. */
 int b3c_scale_sym(b3c_ctx *ctx, b3c_mat *a, const double *x /*host|dev*/);
+
+/* The same scaling in "graph form", for a BITWISE symmetric `a` (b3c_kr_info.is_symmetric came from
+ * the checksum path): both triangles receive x_hi * (a_ij * x_lo), hi/lo by caller-side id, i.e. the value
+ * scipy's result holds in the LOWER triangle and nx.Graph ends up holding for the edge (cluster.py:319-321,
+ * the later add_edge(v,u) overwrites (u,v)).  The upper triangle then differs from sparse_utils.py:223-224 by
+ * at most one ulp; in exchange b3c_louvain needs no mirror lookups.  Marks the matrix value-symmetric. */
+int b3c_scale_sym_graph(b3c_ctx *ctx, b3c_mat *a, const double *x /*host|dev*/);
 
 /* compress (sparse_utils.py:284-314): keep rows/columns with mask != 0, ids re-indexed by
  * i - cumsum(~mask)[i]. */

@@ -116,3 +116,35 @@ def test_kr_locality_reordered_path_matches_oracle(ctx, oracle_lib, monkeypatch)
     monkeypatch.setenv('B3C_KR_ROWWAVE', '1')
     _, x3, _ = ctx.kr_balance(mat)
     np.testing.assert_allclose(x3, x1, rtol=1e-11)
+
+
+def test_symmetry_guard_fast_and_exact_paths(ctx):
+    """Checksum path (bitwise symmetric), exact path (asymmetric beyond tol, and within tol but not bitwise)."""
+    g = np.load(os.path.join(GOLDEN, 'kr_random1000.npz'))
+    n = g['in_indptr'].shape[0] - 1
+    _, _, info = ctx.kr_balance(ctx.upload(g['in_indptr'], g['in_indices'], g['in_data']))
+    assert info.is_symmetric == 1 and info.bitwise_symmetric == 1
+    d = g['in_data'].copy()
+    rows = np.repeat(np.arange(n), np.diff(g['in_indptr']))
+    k = np.flatnonzero(rows < g['in_indices'])[5]
+    d[k] *= (1 + 1e-12)                                     # not bitwise symmetric, but |a_ij - a_ji| < tol
+    _, _, info = ctx.kr_balance(ctx.upload(g['in_indptr'], g['in_indices'], d))
+    assert info.is_symmetric == 1 and info.bitwise_symmetric == 0
+    d[k] += 0.5                                             # beyond tol
+    _, _, info = ctx.kr_balance(ctx.upload(g['in_indptr'], g['in_indices'], d))
+    assert info.is_symmetric == 0 and info.bitwise_symmetric == 0
+
+
+def test_graph_form_scaling_matches_reference_graph_weights(ctx):
+    """b3c_scale_sym_graph: lower triangle == scipy's X A X bit for bit, upper == its mirror."""
+    g = np.load(os.path.join(GOLDEN, 'kr_planted5000.npz'))
+    n = g['in_indptr'].shape[0] - 1
+    mat = ctx.upload(g['in_indptr'], g['in_indices'], g['in_data'])
+    ctx.scale_sym_graph(mat, g['x'])
+    _, _, data = mat.download(structure=False)
+    rows = np.repeat(np.arange(n), np.diff(g['in_indptr']))
+    low = rows >= g['in_indices']
+    assert np.array_equal(data[low], g['out_data'][low])
+    m = sp.csr_matrix((data, g['in_indices'], g['in_indptr']), shape=(n, n))
+    assert (m != m.T).nnz == 0
+    np.testing.assert_allclose(data, g['out_data'], rtol=3e-16)
