@@ -127,7 +127,7 @@ int b3c_scale_sym(b3c_ctx *ctx, b3c_mat *a, const double *x /*host|dev*/);
  * the checksum path): both triangles receive x_hi * (a_ij * x_lo), hi/lo by caller-side id, i.e. the value
  * scipy's result holds in the LOWER triangle and nx.Graph ends up holding for the edge (cluster.py:319-321,
  * the later add_edge(v,u) overwrites (u,v)).  The upper triangle then differs from sparse_utils.py:223-224 by
- * at most one ulp; in exchange b3c_louvain needs no mirror lookups.  Marks the matrix value-symmetric. */
+ * at most two ulps; in exchange b3c_louvain needs no mirror lookups.  Marks the matrix value-symmetric. */
 int b3c_scale_sym_graph(b3c_ctx *ctx, b3c_mat *a, const double *x /*host|dev*/);
 
 /* compress (sparse_utils.py:284-314): keep rows/columns with mask != 0, ids re-indexed by

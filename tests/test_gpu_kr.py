@@ -147,4 +147,4 @@ def test_graph_form_scaling_matches_reference_graph_weights(ctx):
     assert np.array_equal(data[low], g['out_data'][low])
     m = sp.csr_matrix((data, g['in_indices'], g['in_indptr']), shape=(n, n))
     assert (m != m.T).nnz == 0
-    np.testing.assert_allclose(data, g['out_data'], rtol=3e-16)
+    np.testing.assert_allclose(data, g["out_data"], rtol=5e-16)      # two roundings each side
