@@ -8,8 +8,9 @@ mask compaction -> weight scaling -> Louvain labels on the host (bin3c_amd/pipel
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3]
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL); ranks
-process independent maps of the same shape (weak scaling) until the row-sharded KR lands.
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL): the ranks work on
+contig-row ranges of ONE map (bin3c_amd/dist.py; strong scaling, `--mode sharded`, the default) or on one
+independent map each (`--mode replicas`, weak scaling, no data-path collective).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -60,6 +61,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='C3', choices=['C1', 'C2', 'C3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', default='sharded', choices=['sharded', 'replicas'], help='N > 1 only')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -78,9 +80,15 @@ def main():
     from bin3c_amd.synth import CONFIGS, make_synth
 
     n, n_edges, seed, law = CONFIGS[args.config]
-    sm = make_synth(n, n_edges, seed + rank, law)      # each rank: an independent map of the same shape
+    sharded = world > 1 and args.mode == 'sharded'
+    # sharded: every rank builds the same map and owns a row range of it; replicas: one map per rank
+    sm = make_synth(n, n_edges, seed if sharded else seed + rank, law)
     e_true = sm.n_edges
     ctx = make_context(local_rank)
+    sess = None
+    if sharded:
+        from bin3c_amd.dist import DistSession
+        sess = DistSession(ctx, n)
     counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
     # inputs resident in HBM before the timed region: the count matrix and the two per-contig tables
     sites = torch.as_tensor(sm.sites, device='cuda')
@@ -119,7 +127,9 @@ def main():
         dt = float(tt.item())
         ee = torch.tensor([float(e_true)], dtype=torch.float64, device='cuda')
         dist.all_reduce(ee, op=dist.ReduceOp.SUM)
-        e_total = float(ee.item())
+        e_total = float(e_true) if sharded else float(ee.item())
+        if sess is not None:
+            sess.check()
     else:
         e_total = float(e_true)
 
@@ -140,11 +150,14 @@ def main():
         out = {
             'metric': 'contact-graph edges/s through KR-normalise + Louvain',
             'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if sharded else 'weak',
+            'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '{}: hic-synth-v1 n={} contigs, E={} undirected edges (nnz={}), seed={}'.format(
                            args.config, n, e_true, nnz, seed),
-                       'parallelism': 'single GPU' if world == 1 else 'replicas x{} (one map per GPU)'.format(world),
+                       'parallelism': 'single GPU' if world == 1 else (
+                           'contig-row ranges of one map over {} GPUs, RCCL all-gather per SpMV / sub-round'.format(world)
+                           if sharded else 'replicas x{} (one map per GPU)'.format(world)),
                        'accepted_contigs': n_acc, 'kr_spmv_per_step': int(spmv_n // args.steps),
                        'louvain_sweeps_per_step': int(last.lv_info.n_sweeps), 'louvain_levels': int(last.lv_info.n_levels),
                        'communities': int(last.lv_info.n_comm), 'modularity': last.lv_info.modularity,

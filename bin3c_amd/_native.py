@@ -43,6 +43,7 @@ SYMBOLS = [
     ('b3c_last_error', C.c_char_p, [_VP]),
     ('b3c_ctx_sync', C.c_int, [_VP]),
     ('b3c_ctx_bytes', C.c_int64, [_VP]),
+    ('b3c_ctx_set_dist', C.c_int, [_VP, _VP]),
     ('b3c_mat_upload', C.c_int, [_VP, C.c_int64, C.c_int64, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
     ('b3c_mat_free', C.c_int, [_VP, _VP]),
     ('b3c_mat_info', C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),

@@ -53,6 +53,18 @@ extern "C" int b3c_ctx_sync(b3c_ctx *ctx)
     return B3C_OK;
 }
 
+extern "C" int b3c_ctx_set_dist(b3c_ctx *ctx, const b3c_dist *dist)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!dist) { ctx->has_dist = false; return B3C_OK; }
+    if (dist->world < 1 || dist->rank < 0 || dist->rank >= dist->world || dist->chunk < 1 || !dist->allgather ||
+        !dist->vec || !dist->scal || !dist->labels || !dist->isum)
+        return ctx->fail(B3C_E_ARG, "b3c_ctx_set_dist: bad argument");
+    ctx->dist = *dist;
+    ctx->has_dist = dist->world > 1;
+    return B3C_OK;
+}
+
 extern "C" int64_t b3c_ctx_bytes(const b3c_ctx *ctx) { return ctx ? ctx->bytes : 0; }
 
 int b3c_copy_in(b3c_ctx *ctx, void *dst, const void *src, size_t bytes)

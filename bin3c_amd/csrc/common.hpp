@@ -26,6 +26,8 @@ struct b3c_ctx {
     int64_t bytes = 0;
     int n_cu = 256;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    b3c_dist dist;            // row-sharded multi-GPU execution (b3c_ctx_set_dist); world <= 1: off
+    bool has_dist = false;
 
     int fail(int code, const char *fmt, ...)
     {

@@ -15,6 +15,7 @@
 // the same x, bit for bit.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new);
@@ -55,12 +56,12 @@ struct KRParams {
 // Sum / min / max of P partials, identical in every block: thread t folds t, t+256, ... then a fixed
 // LDS tree.  Returns the result to all threads.
 template <int OP>  // 0 sum, 1 min, 2 max
-__device__ double reduce_partials(const double *__restrict__ part, int P, double *lds)
+__device__ double reduce_partials(const double *__restrict__ part, int P, int stride, double *lds)
 {
     const int t = threadIdx.x;
     double v = OP == 0 ? 0.0 : (OP == 1 ? INFINITY : -INFINITY);
     for (int i = t; i < P; i += BLK) {
-        double q = part[i];
+        double q = part[(size_t)i * stride];
         v = OP == 0 ? v + q : (OP == 1 ? fmin(v, q) : fmax(v, q));
     }
     lds[t] = v;
@@ -98,8 +99,8 @@ __device__ void block_partial(double v, double *__restrict__ part, double *lds)
 // ---------------------------------------------------------------------------------------------
 // KA: control after KD, then either p/u of the next CG step or the outer update x *= y
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLK) kr_ka(int64_t n, KRParams prm, const KRState *__restrict__ sin,
-                                              KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
+__global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm, const KRState *__restrict__ sin,
+                                              KRState *__restrict__ sout, const double *__restrict__ partA, int PA, int PS,
                                               double *__restrict__ x, double *__restrict__ y, double *__restrict__ p,
                                               double *__restrict__ Z, const double *__restrict__ rk,
                                               const double *__restrict__ v, double *__restrict__ u,
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t n, KRParams prm, const KRSt
     int yone = 0;
     if (st.phase == P_INNER_PENDING) {
         // sparse_utils.py:187,190 then the loop test of :154
-        double s = reduce_partials<0>(partA, PA, lds);
+        double s = reduce_partials<0>(partA, PA, PS, lds);
         st.rho_km2 = st.rho_km1;
         st.rho_km1 = s;
         if (flags[0] & 1) {  // :192-193
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t n, KRParams prm, const KRSt
             st.phase = A_OUTER;
         }
     } else if (st.phase == P_CUT_PENDING) {
-        st.gamma = reduce_partials<1>(partA, PA, lds);  // :175 / :181
+        st.gamma = reduce_partials<1>(PS > 1 ? partA + 3 : partA, PA, PS, lds);  // :175 / :181 (sharded: slot 3)
         yone = st.k == 1;
         st.phase = A_OUTER;
     } else if (st.phase == P_CUT0) {
@@ -146,8 +147,9 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t n, KRParams prm, const KRSt
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
     if (st.phase == P_DONE) return;
 
+    // rows [r0, n) of this rank (r0 = 0 and n = all rows on a single GPU)
     const int64_t stride = (int64_t)gridDim.x * BLK;
-    int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    int64_t i = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x;
     if (entered == P_INIT) {
         for (; i < n; i += stride) { x[i] = 1.0; u[i] = 1.0; }  // :126-127,134
         return;
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t n, KRParams prm, const KRSt
 // ---------------------------------------------------------------------------------------------
 template <int LPR>
 __global__ void __launch_bounds__(BLK) kr_kb(int64_t n, const KRState *__restrict__ sin, KRState *__restrict__ sout,
-                                              const double *__restrict__ partA, int PA,
+                                              const double *__restrict__ partA, int PA, int PS,
                                               const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                               const double *__restrict__ a, const double *__restrict__ dfix,
                                               const double *__restrict__ u, const double *__restrict__ x,
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(BLK) kr_kb(int64_t n, const KRState *__restric
 {
     __shared__ double lds[BLK];
     KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, lds);  // :160
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
     const bool inner = st.phase == A_INNER;
     if (st.phase == A_INNER) st.phase = B_INNER;
     else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
@@ -296,7 +298,7 @@ __global__ void kr_max_degree(int64_t n, const int64_t *__restrict__ indptr, uns
 template <int LPR>
 __global__ void __launch_bounds__(BLK) kr_kb_stream(int64_t n, int64_t nblk, int lds_cap,
                                                      const KRState *__restrict__ sin, KRState *__restrict__ sout,
-                                                     const double *__restrict__ partA, int PA,
+                                                     const double *__restrict__ partA, int PA, int PS,
                                                      const int64_t *__restrict__ rb,
                                                      const int64_t *__restrict__ indptr,
                                                      const int32_t *__restrict__ indices, const double *__restrict__ a,
@@ -309,7 +311,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_stream(int64_t n, int64_t nblk, int
     double *prod = smem;               // lds_cap doubles
     double *lds = smem + lds_cap;      // BLK doubles for the reductions
     KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, lds);  // :160
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
     const bool inner = st.phase == A_INNER;
     if (st.phase == A_INNER) st.phase = B_INNER;
     else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
@@ -386,8 +388,8 @@ __global__ void __launch_bounds__(BLK) kr_kb_stream(int64_t n, int64_t nblk, int
 // offsets inside a row.  Rows longer than LPR*UN loop.  Chosen by average row length.
 // ---------------------------------------------------------------------------------------------
 template <int LPR, int UN>
-__global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t n, const KRState *__restrict__ sin, KRState *__restrict__ sout,
-                                                   const double *__restrict__ partA, int PA,
+__global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t r0, int64_t n, const KRState *__restrict__ sin, KRState *__restrict__ sout,
+                                                   const double *__restrict__ partA, int PA, int PS,
                                                    const int64_t *__restrict__ indptr,
                                                    const int32_t *__restrict__ indices, const double *__restrict__ a,
                                                    const double *__restrict__ dfix, const double *__restrict__ u,
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t n, const KRState *__re
 {
     __shared__ double lds[BLK];
     KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, lds);  // :160
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
     const bool inner = st.phase == A_INNER;
     if (st.phase == A_INNER) st.phase = B_INNER;
     else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
@@ -410,7 +412,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t n, const KRState *__re
     const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
     double contrib = 0.0;
-    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
+    for (int64_t row = r0 + wave * RPW + sub; row < n; row += nwave * RPW) {
         const int64_t s = indptr[row];
         const int len = (int)(indptr[row + 1] - s);
         const int32_t *__restrict__ ci = indices + s;
@@ -463,19 +465,19 @@ __global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t n, const KRState *__re
 // KC: inner -> alpha, min/max of ynew = y + alpha p   (sparse_utils.py:166-171,179)
 //     outer -> end-of-outer-iteration control         (:199-211, loop tests :146,:154)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLK) kr_kc(int64_t n, KRParams prm, const KRState *__restrict__ sin,
-                                              KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
+__global__ void __launch_bounds__(BLK) kr_kc(int64_t r0, int64_t n, KRParams prm, const KRState *__restrict__ sin,
+                                              KRState *__restrict__ sout, const double *__restrict__ partA, int PA, int PS,
                                               const double *__restrict__ y, const double *__restrict__ p,
                                               double *__restrict__ part_min, double *__restrict__ part_max)
 {
     __shared__ double lds[BLK];
     KRState st = *sin;
     if (st.phase == B_INNER) {
-        double pw = reduce_partials<0>(partA, PA, lds);
+        double pw = reduce_partials<0>(partA, PA, PS, lds);
         st.alpha = st.rho_km1 / pw;  // :166
         st.phase = C_INNER;
     } else if (st.phase == B_OUTER || st.phase == B_INIT) {
-        double s = reduce_partials<0>(partA, PA, lds);
+        double s = reduce_partials<0>(partA, PA, PS, lds);
         st.rho_km1 = s;  // :139 / :199
         st.rout = s;
         if (st.phase == B_INIT) {
@@ -510,7 +512,7 @@ __global__ void __launch_bounds__(BLK) kr_kc(int64_t n, KRParams prm, const KRSt
     const bool yone = st.k == 1;
     double mn = INFINITY, mx = -INFINITY;
     const int64_t stride = (int64_t)gridDim.x * BLK;
-    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+    for (int64_t i = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
         double yn = (yone ? 1.0 : y[i]) + alpha * p[i];  // :167,169
         mn = fmin(mn, yn);
         mx = fmax(mx, yn);
@@ -523,9 +525,9 @@ __global__ void __launch_bounds__(BLK) kr_kc(int64_t n, KRParams prm, const KRSt
 // KD: inner -> branch on min/max(ynew): bound cut (gamma partials) or the CG update
 //     (sparse_utils.py:171-190)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLK) kr_kd(int64_t n, KRParams prm, const KRState *__restrict__ sin,
+__global__ void __launch_bounds__(BLK) kr_kd(int64_t r0, int64_t n, KRParams prm, const KRState *__restrict__ sin,
                                               KRState *__restrict__ sout, const double *__restrict__ part_min,
-                                              const double *__restrict__ part_max, int PA, double *__restrict__ y,
+                                              const double *__restrict__ part_max, int PA, int PS, double *__restrict__ y,
                                               const double *__restrict__ p, double *__restrict__ rk,
                                               const double *__restrict__ w, const double *__restrict__ v,
                                               double *__restrict__ Z, double *__restrict__ part_out)
@@ -534,8 +536,8 @@ __global__ void __launch_bounds__(BLK) kr_kd(int64_t n, KRParams prm, const KRSt
     KRState st = *sin;
     int mode = 0;  // 1 normal update, 2 delta cut, 3 Delta cut
     if (st.phase == C_INNER) {
-        double mn = reduce_partials<1>(part_min, PA, lds);
-        double mx = reduce_partials<2>(part_max, PA, lds);
+        double mn = reduce_partials<1>(part_min, PA, PS, lds);
+        double mx = reduce_partials<2>(part_max, PA, PS, lds);
         if (mn <= prm.delta) {  // :171
             st.hit_delta += 1;
             if (prm.delta == 0.0) st.phase = P_CUT0;  // :172-173
@@ -557,7 +559,7 @@ __global__ void __launch_bounds__(BLK) kr_kd(int64_t n, KRParams prm, const KRSt
     const double alpha = st.alpha;
     const bool yone = st.k == 1;
     const int64_t stride = (int64_t)gridDim.x * BLK;
-    int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    int64_t i = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x;
     if (mode == 1) {
         double acc = 0.0;
         for (; i < n; i += stride) {
@@ -707,12 +709,21 @@ struct MatGuard {   // frees the permuted working copy on every exit path
     ~MatGuard() { if (m) b3c_mat_free(ctx, m); }
 };
 
+// multi-GPU: fold this rank's block partials into its slot of the packed scalar buffer
+__global__ void __launch_bounds__(BLK) kr_fold(const double *__restrict__ part, int P, int op, double *__restrict__ dst)
+{
+    __shared__ double lds[BLK];
+    double r = op == 0 ? reduce_partials<0>(part, P, 1, lds) : op == 1 ? reduce_partials<1>(part, P, 1, lds)
+                                                                       : reduce_partials<2>(part, P, 1, lds);
+    if (threadIdx.x == 0) *dst = r;
+}
+
 template <int LPR>
 void launch_kb(hipStream_t s, int grid, int64_t n, const KRState *sin, KRState *sout, const double *partA, int PA,
                const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
                double *rk, double *w, double *part_out)
 {
-    hipLaunchKernelGGL(kr_kb<LPR>, dim3(grid), dim3(BLK), 0, s, n, sin, sout, partA, PA, m->indptr, m->indices,
+    hipLaunchKernelGGL(kr_kb<LPR>, dim3(grid), dim3(BLK), 0, s, n, sin, sout, partA, PA, 1, m->indptr, m->indices,
                        (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
 }
 
@@ -722,16 +733,16 @@ void launch_kb_stream(hipStream_t s, int grid, size_t shmem, int64_t n, int64_t 
                       const double *dfix, const double *u, const double *x, const double *p, double *v, double *rk,
                       double *w, double *part_out)
 {
-    hipLaunchKernelGGL(kr_kb_stream<LPR>, dim3(grid), dim3(BLK), shmem, s, n, nblk, lds_cap, sin, sout, partA, PA, rb,
+    hipLaunchKernelGGL(kr_kb_stream<LPR>, dim3(grid), dim3(BLK), shmem, s, n, nblk, lds_cap, sin, sout, partA, PA, 1, rb,
                        m->indptr, m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
 }
 
 template <int LPR, int UN>
-void launch_kb_rows(hipStream_t s, int grid, int64_t n, const KRState *sin, KRState *sout, const double *partA, int PA,
-                    const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
+void launch_kb_rows(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
+                    int PA, int PS, const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
                     double *rk, double *w, double *part_out)
 {
-    hipLaunchKernelGGL((kr_kb_rows<LPR, UN>), dim3(grid), dim3(BLK), 0, s, n, sin, sout, partA, PA, m->indptr, m->indices,
+    hipLaunchKernelGGL((kr_kb_rows<LPR, UN>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr, m->indices,
                        (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
 }
 
@@ -751,8 +762,15 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
         return B3C_OK;
     }
 
-    // geometry: fixed for a given (n, nnz) so that reductions are reproducible
-    const int G = grid_for(n, BLK * 2, 4 * ctx->n_cu);
+    // multi-GPU: this rank's row range (single GPU: everything)
+    const bool dist = ctx->has_dist && ctx->dist.world > 1;
+    const b3c_dist &D = ctx->dist;
+    if (dist && (int64_t)D.world * D.chunk < n) return ctx->fail(B3C_E_ARG, "b3c_kr_balance: dist buffers too small for n");
+    const int64_t r0 = dist ? std::min<int64_t>(n, (int64_t)D.rank * D.chunk) : 0;
+    const int64_t r1 = dist ? std::min<int64_t>(n, r0 + D.chunk) : n;
+    const int64_t nloc = r1 - r0;
+    // geometry: fixed for a given (n, nnz, world) so that reductions are reproducible
+    const int G = grid_for(nloc, BLK * 2, 4 * ctx->n_cu);
     const double avg = (double)a->nnz / (double)n;
     const int lpr = avg >= 96 ? 64 : avg >= 40 ? 32 : avg >= 18 ? 16 : avg >= 8 ? 8 : 4;
     const int rows_per_block = (BLK / 64) * (64 / lpr);
@@ -769,8 +787,8 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     // SpMV form: "rows" (default), "stream" (LDS-staged CSR-stream) or "wave" (plain wave-per-row)
     const char *kform = getenv("B3C_KR_KERNEL");
     if (getenv("B3C_KR_ROWWAVE")) kform = "wave";
-    const bool stream_kb = kform && !strcmp(kform, "stream") && maxdeg <= 4096;
-    const bool rows_kb = !stream_kb && !(kform && !strcmp(kform, "wave"));
+    const bool stream_kb = !dist && kform && !strcmp(kform, "stream") && maxdeg <= 4096;
+    const bool rows_kb = dist || (!stream_kb && !(kform && !strcmp(kform, "wave")));
     // rows form: lanes per row so that LPR*8 covers an average row
     const int lpr_r = avg > 128 ? 32 : avg > 64 ? 16 : avg > 32 ? 8 : 4;
     const int64_t nblk = a->nnz > 0 ? (a->nnz + KB_T - 1) / KB_T : 1;
@@ -779,17 +797,18 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     // phase-2 group width: about two LDS reads per lane for an average row
     const int lpr2 = avg >= 64 ? 32 : avg >= 24 ? 16 : avg >= 10 ? 8 : 4;
     const int GS = stream_kb ? grid_for(nblk, 1, 8 * ctx->n_cu)
-                 : rows_kb ? grid_for(n, (BLK / 64) * (64 / lpr_r), 8 * ctx->n_cu)
+                 : rows_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_r), 8 * ctx->n_cu)
                            : grid_for(n, rows_per_block, 8 * ctx->n_cu);
     const int P = G > GS ? G : GS;
     DevBuf<int64_t> rb(ctx, nblk + 1);
     if (!rb.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
 
-    DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z(ctx, n), rk(ctx, n), v(ctx, n), w(ctx, n), u(ctx, n), dfix(ctx, n);
+    DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z(ctx, n), rk(ctx, n), v(ctx, n), w(ctx, n), u_own(ctx, dist ? 1 : n), dfix(ctx, n);
+    struct { double *p; } u{dist ? D.vec : u_own.p};   // the gathered operand lives in the exchange buffer when sharded
     DevBuf<double> part0(ctx, P), part1(ctx, P), part2(ctx, P);
     DevBuf<KRState> states(ctx, 2);
     DevBuf<unsigned long long> counters(ctx, 4);
-    if (!x.p || !y.p || !p.p || !Z.p || !rk.p || !v.p || !w.p || !u.p || !dfix.p || !part0.p || !part1.p || !part2.p ||
+    if (!x.p || !y.p || !p.p || !Z.p || !rk.p || !v.p || !w.p || !u_own.p || !dfix.p || !part0.p || !part1.p || !part2.p ||
         !states.p || !counters.p)
         return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: out of device memory");
     int *flags = (int *)(counters.p + 2);
@@ -846,12 +865,24 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     int t = 0;  // state ping-pong index
     const int BATCH = 8;
     long long ticks = 0;
+    // sharded: a kernel's block partials are folded into this rank's slot of the packed scalar buffer and
+    // all-gathered; the consumer then reduces `world` values (stride 4) in rank order instead of P block partials
+    double *my_scal = dist ? D.scal + 4 * D.rank : nullptr;
+    auto xchg = [&](int buf) -> int {
+        if (D.allgather(D.user, buf) != 0) return ctx->fail(B3C_E_HIP, "b3c_kr_balance: all-gather callback failed");
+        return B3C_OK;
+    };
     for (;;) {
         for (int b = 0; b < BATCH; b++) {
             KRState *s0 = states.p + (t & 1), *s1 = states.p + ((t + 1) & 1);
             // KA consumes part0 (rk.Z or gamma), may produce part1 (rk.Z for k == 1)
-            hipLaunchKernelGGL(kr_ka, dim3(G), dim3(BLK), 0, s, n, prm, s0, s1, part0.p, G, x.p, y.p, p.p, Z.p, rk.p,
-                               v.p, u.p, part1.p, flags);
+            hipLaunchKernelGGL(kr_ka, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : part0.p, dist ? D.world : G,
+                               dist ? 4 : 1, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, part1.p, flags);
+            if (dist) {
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part1.p, G, 0, my_scal);
+                int rc;
+                if ((rc = xchg(B3C_BUF_SCAL)) || (rc = xchg(B3C_BUF_VEC))) return rc;
+            }
             t++;
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
             if (prof) {
@@ -862,6 +893,8 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
                 HIP_TRY(ctx, hipEventRecord(e0, s));
             }
             // KB consumes part1 (from KA, G partials), produces part0 (GS partials)
+            const double *kbp = dist ? D.scal : part1.p;
+            const int kbP = dist ? D.world : G, kbS = dist ? 4 : 1;
             if (stream_kb) {
                 switch (lpr2) {
                 case 32: launch_kb_stream<32>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
@@ -871,10 +904,10 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
                 }
             } else if (rows_kb) {
                 switch (lpr_r) {
-                case 32: launch_kb_rows<32, 8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                case 16: launch_kb_rows<16, 8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                case 8: launch_kb_rows<8, 8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                default: launch_kb_rows<4, 8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                case 32: launch_kb_rows<32, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                case 16: launch_kb_rows<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                case 8: launch_kb_rows<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
+                default: launch_kb_rows<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
                 }
             } else
             switch (lpr) {
@@ -885,15 +918,35 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
             default: launch_kb<4>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
             }
             if (prof) HIP_TRY(ctx, hipEventRecord(evs.back(), s));
+            if (dist) {
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part0.p, GS, 0, my_scal);
+                int rc;
+                if ((rc = xchg(B3C_BUF_SCAL))) return rc;
+            }
             t++;
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
             // KC consumes part0 (GS), produces part1/part2 (min/max, G)
-            hipLaunchKernelGGL(kr_kc, dim3(G), dim3(BLK), 0, s, n, prm, s0, s1, part0.p, GS, y.p, p.p, part1.p, part2.p);
+            hipLaunchKernelGGL(kr_kc, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : part0.p, dist ? D.world : GS,
+                               dist ? 4 : 1, y.p, p.p, part1.p, part2.p);
+            if (dist) {
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part1.p, G, 1, my_scal + 1);
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part2.p, G, 2, my_scal + 2);
+                int rc;
+                if ((rc = xchg(B3C_BUF_SCAL))) return rc;
+            }
             t++;
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
-            // KD consumes part1/part2 (G), produces part0 (G)
-            hipLaunchKernelGGL(kr_kd, dim3(G), dim3(BLK), 0, s, n, prm, s0, s1, part1.p, part2.p, G, y.p, p.p, rk.p, w.p,
-                               v.p, Z.p, part0.p);
+            // KD consumes part1/part2 (G), produces part0 (G; a sum for the CG update, a minimum for a bound cut)
+            hipLaunchKernelGGL(kr_kd, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal + 1 : part1.p,
+                               dist ? D.scal + 2 : part2.p, dist ? D.world : G, dist ? 4 : 1, y.p, p.p, rk.p, w.p, v.p, Z.p,
+                               part0.p);
+            if (dist) {
+                // the consumer (KA) knows from the state whether slot 0 is a sum or slot 3 a minimum
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part0.p, G, 0, my_scal);
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part0.p, G, 1, my_scal + 3);
+                int rc;
+                if ((rc = xchg(B3C_BUF_SCAL))) return rc;
+            }
             t++;
             ticks++;
         }
@@ -907,6 +960,14 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
 
     unsigned long long hc[4];
     HIP_TRY(ctx, hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
+    if (dist) {
+        // every rank holds only its slice of x: all-gather it through the operand buffer
+        if (nloc > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(D.vec + r0, x.p + r0, sizeof(double) * (size_t)nloc, hipMemcpyDeviceToDevice, s));
+        int rc = xchg(B3C_BUF_VEC);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(x.p, D.vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    }
     if (reorder) {
         hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x.p, old2new.p, w.p);
         HIP_TRY(ctx, hipMemcpyAsync(x_out, w.p, sizeof(double) * (size_t)n, hipMemcpyDefault, s));

@@ -17,6 +17,7 @@
 //   aggregation: (community pair, weight) keys -> radix sort + reduce-by-key (hipcub) -> next level CSR
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
@@ -251,7 +252,7 @@ __host__ __device__ __forceinline__ int table_lg(int64_t deg)
 // Loads first: every lane pulls four (index, weight) pairs, then the four community gathers, then inserts, so
 // that a wave keeps ~3 KB of independent loads in flight instead of one dependent chain per 64 entries.
 template <int CAP>
-__global__ void __launch_bounds__(BLK) k_lv_decide(int64_t n, int n_sub, int round, u64 m2,
+__global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int n_sub, int round, u64 m2,
                                                     const int64_t *__restrict__ indptr,
                                                     const int32_t *__restrict__ indices,
                                                     const int64_t *__restrict__ q, const int32_t *__restrict__ ids,
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t n, int n_sub, int rou
     for (int t = lane; t < CAP; t += 64) { lk[t] = EMPTY; lv[t] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
-    for (int64_t i = wave; i < n; i += nwave) {
+    for (int64_t i = r0 + wave; i < n; i += nwave) {   // rows [r0, n) of this rank
         const int32_t id = ids ? ids[i] : (int32_t)i;
         if (bucket_of(id, n_sub) != (uint32_t)round) continue;
         const long long ki = kdeg[i];
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int roun
 }
 
 // I2 = sum_i ( sum_{j != i, com j == com i} q_ij + 2 q_ii )
-__global__ void __launch_bounds__(BLK) k_lv_internal(int64_t n, const int64_t *__restrict__ indptr,
+__global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, const int64_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices,
                                                       const int64_t *__restrict__ q, const int32_t *__restrict__ com,
                                                       u64 *__restrict__ i2)
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t n, const int64_t *_
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * WPB;
     long long acc = 0;
-    for (int64_t row = wave; row < n; row += nwave) {
+    for (int64_t row = r0 + wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         const int32_t a = com[row];
         for (int64_t k = s + lane; k < e; k += 64) {
@@ -675,11 +676,18 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             free_graph(ctx, g);
             return ctx->fail(B3C_E_NOMEM, "b3c_louvain: level buffers");
         }
+        // multi-GPU: level 0 is row-sharded (decide + internal-weight scan); induced graphs are tiny and replicated
+        const bool dist = ctx->has_dist && ctx->dist.world > 1 && first && (int64_t)ctx->dist.world * ctx->dist.chunk >= n;
+        const b3c_dist &D = ctx->dist;
+        const int64_t r0 = dist ? std::min<int64_t>(n, (int64_t)D.rank * D.chunk) : 0;
+        const int64_t r1 = dist ? std::min<int64_t>(n, r0 + D.chunk) : n;
+        int32_t *nxt_p = dist ? D.labels : nxt.p;
+        const int gwl = grid_for(r1 - r0, WPB, 16 * ctx->n_cu);   // wave-per-row kernels over this rank's rows
         const int gw = grid_for(n, WPB, 16 * ctx->n_cu);     // wave-per-row kernels
         const int gv = grid_for(n, BLK, 8 * ctx->n_cu);      // thread-per-node kernels
         HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 8, s));
         hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p,
-                           nxt.p, csize.p, ctr.p);
+                           nxt_p, csize.p, ctr.p);
         hipLaunchKernelGGL(k_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
         u64 hc[8];
         HIP_TRY(ctx, hipMemcpyAsync(hc, ctr.p, sizeof(hc), hipMemcpyDeviceToHost, s));
@@ -706,10 +714,21 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 
         auto modularity = [&](double *out) -> int {
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64) * 5, s));
-            hipLaunchKernelGGL(k_lv_internal, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, com.p, ctr.p + 2);
+            hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2);
             hipLaunchKernelGGL(k_lv_tot2, dim3(gv), dim3(BLK), 0, s, n, tot.p, ctr.p + 3);
             u64 h[8];
             HIP_TRY(ctx, hipMemcpyAsync(h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, s));
+            if (dist) {
+                // integer partial sums of the ranks: exact, so the order of the final addition is irrelevant
+                HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, ctr.p + 2, sizeof(u64), hipMemcpyDeviceToDevice, s));
+                if (D.allgather(D.user, B3C_BUF_ISUM) != 0) return ctx->fail(B3C_E_HIP, "b3c_louvain: all-gather callback failed");
+                std::vector<int64_t> parts(2 * (size_t)D.world);
+                HIP_TRY(ctx, hipMemcpyAsync(parts.data(), D.isum, sizeof(int64_t) * parts.size(), hipMemcpyDeviceToHost, s));
+                HIP_TRY(ctx, hipStreamSynchronize(s));
+                u64 tot_i2 = 0;
+                for (int r = 0; r < D.world; r++) tot_i2 += (u64)parts[2 * (size_t)r];
+                h[2] = tot_i2;
+            }
             HIP_TRY(ctx, hipStreamSynchronize(s));
             unsigned __int128 t2 = (unsigned __int128)h[3] + ((unsigned __int128)h[4] << 32) +
                                    ((unsigned __int128)h[5] << 64) + ((unsigned __int128)h[6] << 96);
@@ -729,8 +748,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             for (int r = 0; r < n_sub; r++) {
                 evs.rec();
 #define LV_DECIDE(C)                                                                                       \
-    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gw), dim3(BLK), 0, s, n, n_sub, r, m2, g.indptr, g.indices, g.q, ids,    \
-                       kdeg.p, tot.p, com.p, csize.p, nxt.p, goff.p, gkeys.p, gvals.p)
+    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gwl), dim3(BLK), 0, s, r0, r1, n_sub, r, m2, g.indptr, g.indices, g.q, ids,  \
+                       kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p)
                 switch (cap) {
                 case 128: LV_DECIDE(128); break;
                 case 256: LV_DECIDE(256); break;
@@ -740,8 +759,10 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 }
 #undef LV_DECIDE
                 evs.rec();
+                if (dist && D.allgather(D.user, B3C_BUF_LABELS) != 0)
+                    return ctx->fail(B3C_E_HIP, "b3c_louvain: all-gather callback failed");
                 info->n_move_launch++;
-                hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt.p,
+                hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt_p,
                                    csize.p, ctr.p + 1);
             }
             info->move_nnz += g.nnz;

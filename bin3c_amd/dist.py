@@ -1,0 +1,108 @@
+"""
+Row-sharded multi-GPU execution of the hot path: one process per GPU (torch.distributed, backend "nccl" =
+RCCL over xGMI), every rank holds the whole locality-ordered map and works on the contig-row range
+[rank*chunk, (rank+1)*chunk).  libb3c calls back into :class:`DistSession` whenever the other ranks' slices
+are needed (include/b3c.h "multi-GPU"):
+
+    KR, per SpMV     all-gather of the operand slice x∘p (8·n bytes in total) + up to four all-gathers of
+                     four packed partial scalars (p·w | rk·rk, min/max of ynew, rk·Z | gamma), reduced by
+                     every rank in rank order -> identical control flow everywhere
+    Louvain level 0  all-gather of the decided labels per sub-round (4·n bytes), all-gather of one integer
+                     partial sum per modularity evaluation; moves are applied by every rank
+
+The reference has no counterpart (single process); this is north_star's "sharded by
+contig-row range with RCCL all-reduce over xGMI for the KR column sums and community-weight vectors".
+xGMI is point to point (7 links per GPU), the vector exchange is 1-8 MB per rank and the scalar ones are
+latency bound, so each exchange is ONE collective and nothing is exchanged that can be recomputed.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+BUF_VEC, BUF_SCAL, BUF_LABELS, BUF_ISUM = 0, 1, 2, 3
+
+
+class B3CDist(C.Structure):
+    _fields_ = [('rank', C.c_int32), ('world', C.c_int32), ('chunk', C.c_int64), ('vec', C.c_void_p),
+                ('scal', C.c_void_p), ('labels', C.c_void_p), ('isum', C.c_void_p), ('allgather', C.c_void_p),
+                ('user', C.c_void_p)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+
+
+def shard_range(n, rank, world, align=64):
+    """Rows of `rank`: equal chunks (aligned so that slices stay 512-byte aligned); the last ranks may be short or empty."""
+    chunk = -(-n // world)
+    chunk = -(-chunk // align) * align
+    r0 = min(n, rank * chunk)
+    return r0, min(n, r0 + chunk), chunk
+
+
+def allgather_inplace(full, rank, world, group=None):
+    """All-gather `full` (world equal slices, this rank's already in place).  One collective."""
+    import torch.distributed as dist
+    cnt = full.numel() // world
+    mine = full[rank * cnt:(rank + 1) * cnt]
+    backend = dist.get_backend(group)
+    if backend == 'nccl':
+        dist.all_gather_into_tensor(full, mine, group=group)
+    elif full.is_cuda:
+        # gloo moves CUDA tensors only for all_reduce/broadcast (single-GPU CI): gather = sum with zeros
+        keep = mine.clone()
+        full.zero_()
+        full[rank * cnt:(rank + 1) * cnt] = keep
+        dist.all_reduce(full, group=group)
+    else:
+        dist.all_gather(list(full.view(world, cnt).unbind(0)), mine.clone(), group=group)
+
+
+class DistSession(object):
+    """Owns the exchange buffers of one context and installs them with b3c_ctx_set_dist."""
+
+    def __init__(self, ctx, n, group=None):
+        import torch
+        import torch.distributed as dist
+        assert dist.is_initialized(), 'torch.distributed must be initialised (torch.distributed.run launches bench.py)'
+        self.ctx = ctx
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.n = n
+        self.r0, self.r1, self.chunk = shard_range(n, self.rank, self.world)
+        dev = torch.device('cuda', ctx.device)
+        tot = self.chunk * self.world
+        self.vec = torch.zeros(tot, dtype=torch.float64, device=dev)
+        self.scal = torch.zeros(4 * self.world, dtype=torch.float64, device=dev)
+        self.labels = torch.zeros(tot, dtype=torch.int32, device=dev)
+        self.isum = torch.zeros(2 * self.world, dtype=torch.int64, device=dev)
+        self._bufs = {BUF_VEC: self.vec, BUF_SCAL: self.scal, BUF_LABELS: self.labels, BUF_ISUM: self.isum}
+        self.n_exchanges = 0
+        self._error = None
+        self._cb = ALLGATHER_FN(self._allgather)          # keep a reference: ctypes callbacks are not owned by C
+        d = B3CDist(self.rank, self.world, self.chunk, self.vec.data_ptr(), self.scal.data_ptr(),
+                    self.labels.data_ptr(), self.isum.data_ptr(), C.cast(self._cb, C.c_void_p), None)
+        self._struct = d
+        lib = ctx.lib
+        ctx._check(lib.b3c_ctx_set_dist(ctx.h, C.byref(d)))
+
+    def _allgather(self, user, buf_id):
+        import torch
+        try:
+            with torch.cuda.stream(self.ctx.torch_stream):    # the stream libb3c launches on: ordered with its kernels
+                allgather_inplace(self._bufs[buf_id], self.rank, self.world, self.group)
+            self.n_exchanges += 1
+            return 0
+        except Exception as ex:                                # never let an exception cross the C frame
+            self._error = ex
+            return 1
+
+    def close(self):
+        if self.ctx.h is not None:
+            self.ctx.lib.b3c_ctx_set_dist(self.ctx.h, None)
+
+    def check(self):
+        if self._error is not None:
+            raise self._error

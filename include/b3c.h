@@ -78,6 +78,35 @@ int b3c_ctx_sync(b3c_ctx *ctx);
 /* HBM bytes currently held by the context's matrices and workspaces. */
 int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
 
+/* ---- multi-GPU: contig-row ranges of ONE map across ranks ---------------------------------- */
+
+/* Every rank holds the whole (ordered) matrix and works on the rows [rank*chunk, (rank+1)*chunk); what
+ * the other ranks need is exchanged through the four caller-owned device buffers below, each laid out
+ * as `world` equal slices, by calling `allgather(user, buffer_id)`: "all-gather buffer_id in place, my
+ * slice is already written".  The callback must enqueue the collective on the context's stream (RCCL via
+ * torch.distributed in bin3c_amd/dist.py) and return 0.  KR exchanges the operand slice of x∘p once and
+ * four packed scalars up to four times per SpMV; Louvain exchanges the decided labels once per
+ * sub-round and one integer per modularity evaluation.  All ranks reduce the gathered partials in rank
+ * order, so every rank takes identical decisions and results do not depend on timing. */
+#define B3C_BUF_VEC 0     /* double[world*chunk]  KR operand / final x            */
+#define B3C_BUF_SCAL 1    /* double[world*4]      KR partial sums / min / max      */
+#define B3C_BUF_LABELS 2  /* int32[world*chunk]   Louvain decided communities      */
+#define B3C_BUF_ISUM 3    /* int64[world*2]       Louvain integer partial sums     */
+typedef int (*b3c_allgather_fn)(void *user, int buffer_id);
+typedef struct {
+    int32_t rank, world;
+    int64_t chunk;        /* rows per rank, world*chunk >= n */
+    double *vec;
+    double *scal;
+    int32_t *labels;
+    int64_t *isum;
+    b3c_allgather_fn allgather;
+    void *user;
+} b3c_dist;
+/* Install (or with NULL remove) the sharding description; it applies to b3c_kr_balance and b3c_louvain
+ * calls on matrices with n <= world*chunk rows.  No reference counterpart (bin3C is single process). */
+int b3c_ctx_set_dist(b3c_ctx *ctx, const b3c_dist *dist);
+
 /* ---- matrices ------------------------------------------------------------------------------ */
 
 /* Copy a CSR matrix into HBM.  Replaces the scipy objects handed between contact_map.py:929-945. */

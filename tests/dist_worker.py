@@ -1,0 +1,87 @@
+"""
+Worker for the world_size-2 tests (launched with torch.distributed.run, backend gloo).
+
+  cpu : host logic of the sharded path on CPU tensors -- row ranges, in-place all-gather of every buffer type,
+        rank-ordered reduction of the packed scalars (no GPU, no libb3c compute)
+  gpu : the real sharded hot path, two ranks sharing cuda:0 (gloo moves the CUDA buffers), against the
+        single-rank run of the same map
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def cpu_mode(rank, world):
+    from bin3c_amd.dist import allgather_inplace, shard_range
+    n = 1000
+    r0, r1, chunk = shard_range(n, rank, world)
+    assert chunk % 64 == 0 and chunk * world >= n
+    ranges = [shard_range(n, r, world)[:2] for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == n and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    for dtype in (torch.float64, torch.int32, torch.int64):
+        full = torch.full((chunk * world,), -1, dtype=dtype)
+        full[rank * chunk:(rank + 1) * chunk] = torch.arange(rank * chunk, (rank + 1) * chunk).to(dtype)
+        allgather_inplace(full, rank, world)
+        assert torch.equal(full, torch.arange(chunk * world).to(dtype)), dtype
+    # packed scalars: every rank reduces the gathered slots in rank order -> bit-identical on all ranks
+    scal = torch.zeros(4 * world, dtype=torch.float64)
+    scal[4 * rank:4 * rank + 4] = torch.tensor([0.1 * (rank + 1), 1.0 - rank, 3.0 + rank, 7.0 - rank], dtype=torch.float64)
+    allgather_inplace(scal, rank, world)
+    v = scal.view(world, 4)
+    s = 0.0
+    for r in range(world):
+        s += float(v[r, 0])
+    out = torch.tensor([s, float(v[:, 1].min()), float(v[:, 2].max())], dtype=torch.float64)
+    ref = out.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(out, ref)
+    print('rank %d cpu ok' % rank)
+
+
+def gpu_mode(rank, world):
+    import graphs
+    from bin3c_amd.dist import DistSession
+    from bin3c_amd.pipeline import make_context, run_hot_path
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(40000, 1300000, 21)
+    ctx = make_context(0)
+    counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    single = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)            # before sharding is installed
+    sess = DistSession(ctx, sm.n)
+    res = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)
+    sess.check()
+    assert sess.n_exchanges > 5 * (res.kr_info.n_iter + 1), sess.n_exchanges
+    assert res.kr_info.n_iter == single.kr_info.n_iter
+    assert np.array_equal(res.mask, single.mask) and np.array_equal(res.signal, single.signal)
+    np.testing.assert_allclose(res.x, single.x, rtol=1e-10)
+    assert graphs.same_partition(res.labels, single.labels)
+    assert res.lv_info.n_sweeps == single.lv_info.n_sweeps and res.lv_info.n_levels == single.lv_info.n_levels
+    # all ranks hold identical results
+    lab = torch.as_tensor(res.labels.astype(np.int64))
+    ref = lab.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(lab, ref)
+    xs = torch.as_tensor(res.x)
+    xr = xs.clone()
+    dist.broadcast(xr, 0)
+    assert torch.equal(xs, xr)
+    sess.close()
+    again = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)
+    assert np.array_equal(again.x, single.x) and np.array_equal(again.labels, single.labels)
+    print('rank %d gpu ok (%d exchanges)' % (rank, sess.n_exchanges))
+    ctx.close()
+
+
+if __name__ == '__main__':
+    dist.init_process_group(backend='gloo')
+    r, w = dist.get_rank(), dist.get_world_size()
+    (cpu_mode if sys.argv[1] == 'cpu' else gpu_mode)(r, w)
+    dist.barrier()
+    dist.destroy_process_group()
