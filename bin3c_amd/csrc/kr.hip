@@ -17,7 +17,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <hipcub/hipcub.hpp>
 
+int b3c_exclusive_scan_i64(b3c_ctx *ctx, const int64_t *in, int64_t *out, int64_t count);
 int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new);
 int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out);
 
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_stream(int64_t n, int64_t nblk, int
 // rows overlap their indptr -> entries -> gather -> epilogue chains.  No LDS, no barriers, 32-bit
 // offsets inside a row.  Rows longer than LPR*UN loop.  Chosen by average row length.
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int UN>
+template <int LPR, int UN, bool NOGATHER = false>
 __global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t r0, int64_t n, const KRState *__restrict__ sin, KRState *__restrict__ sout,
                                                    const double *__restrict__ partA, int PA, int PS,
                                                    const int64_t *__restrict__ indptr,
@@ -437,7 +439,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t r0, int64_t n, const K
             }
             double g[UN];
 #pragma unroll
-            for (int q = 0; q < UN; q++) g[q] = u[c[q]];
+            for (int q = 0; q < UN; q++) g[q] = NOGATHER ? u[row + (c[q] & 1)] : u[c[q]];   // NOGATHER: timing probe only
 #pragma unroll
             for (int q = 0; q < UN; q++) acc += m[q] * g[q];
         }
@@ -445,6 +447,280 @@ __global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t r0, int64_t n, const K
         for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
         if (sl == 0) {
             const double t = acc + di;
+            if (inner) {
+                const double wi = xi * t + vi * pi;
+                w[row] = wi;
+                contrib += pi * wi;
+            } else {
+                const double vn = xi * t;
+                const double r = 1.0 - vn;
+                v[row] = vn;
+                rk[row] = r;
+                contrib += r * r;
+            }
+        }
+    }
+    block_partial<0>(contrib, part_out, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// KB, row-group form with software pipelining: while the gathers of row r are in flight the row pointers and
+// the first LPR*UN (index, value) pairs of row r+stride are already being fetched, so the streaming loads never
+// wait behind the indptr -> entries -> gather chain of the row before.  Measured at C3 (ordered matrix): 0.72 ms per
+// SpMV = 3.37 TB/s algorithmic, against 0.88 ms un-pipelined; non-temporal loads of the matrix stream made it slower.
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int UN>
+__global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const KRState *__restrict__ sin,
+                                                   KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
+                                                   int PS, const int64_t *__restrict__ indptr,
+                                                   const int32_t *__restrict__ indices, const double *__restrict__ a,
+                                                   const double *__restrict__ dfix, const double *__restrict__ u,
+                                                   const double *__restrict__ x, const double *__restrict__ p,
+                                                   double *__restrict__ v, double *__restrict__ rk,
+                                                   double *__restrict__ w, double *__restrict__ part_out)
+{
+    __shared__ double lds[BLK];
+    KRState st = *sin;
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
+    const bool inner = st.phase == A_INNER;
+    if (st.phase == A_INNER) st.phase = B_INNER;
+    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if (st.phase == P_DONE) return;
+
+    constexpr int RPW = 64 / LPR;
+    constexpr int CH = LPR * UN;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t step = (int64_t)gridDim.x * (BLK / 64) * RPW;
+    double contrib = 0.0;
+
+    int64_t row = r0 + wave * RPW + sub;
+    int64_t s = 0;
+    int len = 0;
+    int32_t c[UN];
+    double m[UN];
+    if (row < n) {
+        s = indptr[row];
+        len = (int)(indptr[row + 1] - s);
+    }
+    {
+        const int32_t *__restrict__ ci = indices + s;
+        const double *__restrict__ av = a + s;
+#pragma unroll
+        for (int q = 0; q < UN; q++) {
+            const int i = q * LPR + sl;
+            const bool ok = i < len;
+            c[q] = ok ? ci[i] : 0;
+            m[q] = ok ? av[i] : 0.0;
+        }
+    }
+    while (row < n) {
+        const int64_t rown = row + step;
+        // 1. pointers of the next row (latency hidden behind this row's gathers)
+        int64_t sn = 0;
+        int lenn = 0;
+        if (rown < n) {
+            sn = indptr[rown];
+            lenn = (int)(indptr[rown + 1] - sn);
+        }
+        // 2. this row: epilogue operands and gathers
+        double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0;
+        if (sl == 0) {
+            xi = x[row];
+            di = dfix[row] * u[row];
+            if (inner) { pi = p[row]; vi = v[row]; }
+        }
+        double g[UN];
+#pragma unroll
+        for (int q = 0; q < UN; q++) g[q] = u[(uint32_t)c[q]];
+        // 3. first chunk of the next row
+        int32_t c2[UN];
+        double m2[UN];
+        {
+            const int32_t *__restrict__ ci = indices + sn;
+            const double *__restrict__ av = a + sn;
+#pragma unroll
+            for (int q = 0; q < UN; q++) {
+                const int i = q * LPR + sl;
+                const bool ok = i < lenn;
+                c2[q] = ok ? ci[i] : 0;
+                m2[q] = ok ? av[i] : 0.0;
+            }
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < UN; q++) acc += m[q] * g[q];
+        // rows longer than one chunk: plain loop over the rest
+        for (int base = CH; base < len; base += CH) {
+#pragma unroll
+            for (int q = 0; q < UN; q++) {
+                const int i = base + q * LPR + sl;
+                if (i < len) acc += a[s + i] * u[(uint32_t)indices[s + i]];
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
+        if (sl == 0) {
+            const double t = acc + di;
+            if (inner) {
+                const double wi = xi * t + vi * pi;
+                w[row] = wi;
+                contrib += pi * wi;
+            } else {
+                const double vn = xi * t;
+                const double r = 1.0 - vn;
+                v[row] = vn;
+                rk[row] = r;
+                contrib += r * r;
+            }
+        }
+        row = rown;
+        s = sn;
+        len = lenn;
+#pragma unroll
+        for (int q = 0; q < UN; q++) { c[q] = c2[q]; m[q] = m2[q]; }
+    }
+    block_partial<0>(contrib, part_out, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// KB, sliced-ELL form (SELL-64-sigma): the layout the iteration actually runs on when rows are regular.
+// Rows are sorted by length inside windows of SELL_W rows (keeps the locality order to within a window),
+// cut into slices of 64, and every slice is stored column-major and padded to its longest row.  Lane r of a
+// wave owns row r of the slice: entry j of all 64 rows is one aligned 256 B / 512 B load, there is no
+// cross-lane reduction, no per-row pointer chase, and the epilogue operands are coalesced.  Row-structured
+// CSR kernels top out near 3 TB/s on this chip even without their gathers (measured, B3C_KR_NOGATHER);
+// flat 8-byte streams reach 5.6 TB/s.  Built once per balance call (about two passes over the matrix) and
+// reused by every SpMV.
+// ---------------------------------------------------------------------------------------------
+constexpr int SELL_W = 4096;
+
+__global__ void sell_keys(int64_t n, const int64_t *__restrict__ indptr, int64_t *__restrict__ keys, int32_t *__restrict__ vals)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int64_t len = indptr[i + 1] - indptr[i];
+        keys[i] = ((i / SELL_W) << 32) | (int64_t)(0x7FFFFFFFll - len);   // window ascending, length descending
+        vals[i] = (int32_t)i;
+    }
+}
+
+__global__ void sell_invert(int64_t n, const int32_t *__restrict__ sperm, int32_t *__restrict__ sinv)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) sinv[sperm[k]] = (int32_t)k;
+}
+
+__global__ void sell_slice_sizes(int64_t n, int64_t nsl, const int64_t *__restrict__ indptr,
+                                 const int32_t *__restrict__ sperm, int32_t *__restrict__ slen,
+                                 int64_t *__restrict__ sizes)
+{
+    int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx < nsl) {
+        const int32_t r = sperm[sidx * 64];            // longest row of the slice (sorted descending inside the window)
+        const int64_t len = indptr[r + 1] - indptr[r];
+        slen[sidx] = (int32_t)len;
+        sizes[sidx] = len * 64;
+    }
+    if (sidx == nsl) sizes[sidx] = 0;
+}
+
+__global__ void __launch_bounds__(BLK) sell_fill(int64_t n, int64_t nsl, const int64_t *__restrict__ indptr,
+                                                  const int32_t *__restrict__ indices, const double *__restrict__ a,
+                                                  const int32_t *__restrict__ sperm, const int32_t *__restrict__ sinv,
+                                                  const int32_t *__restrict__ slen, const int64_t *__restrict__ sptr,
+                                                  int32_t *__restrict__ cols, double *__restrict__ vals)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t sl = wave; sl < nsl; sl += nwave) {
+        const int64_t row = sl * 64 + lane;            // SELL row
+        const int L = slen[sl];
+        int64_t k0 = 0;
+        int len = 0;
+        if (row < n) {
+            const int32_t old = sperm[row];
+            k0 = indptr[old];
+            len = (int)(indptr[old + 1] - k0);
+        }
+        const int32_t self = row < n ? (int32_t)row : 0;
+        int32_t *__restrict__ cd = cols + sptr[sl] + lane;
+        double *__restrict__ vd = vals + sptr[sl] + lane;
+        for (int j = 0; j < L; j++) {
+            int32_t c = self;
+            double m = 0.0;
+            if (j < len) {
+                c = sinv[indices[k0 + j]];
+                m = a[k0 + j];
+            }
+            cd[(int64_t)j * 64] = c;
+            vd[(int64_t)j * 64] = m;
+        }
+    }
+}
+
+template <int UN>
+__global__ void __launch_bounds__(BLK) kr_kb_sell(int64_t r0, int64_t r1, int64_t n, const KRState *__restrict__ sin,
+                                                   KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
+                                                   int PS, const int64_t *__restrict__ sptr,
+                                                   const int32_t *__restrict__ slen, const int32_t *__restrict__ cols,
+                                                   const double *__restrict__ vals, const double *__restrict__ dfix,
+                                                   const double *__restrict__ u, const double *__restrict__ x,
+                                                   const double *__restrict__ p, double *__restrict__ v,
+                                                   double *__restrict__ rk, double *__restrict__ w,
+                                                   double *__restrict__ part_out)
+{
+    __shared__ double lds[BLK];
+    KRState st = *sin;
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
+    const bool inner = st.phase == A_INNER;
+    if (st.phase == A_INNER) st.phase = B_INNER;
+    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if (st.phase == P_DONE) return;
+
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    const int64_t s0 = r0 / 64, s1 = (r1 + 63) / 64;     // r0 is a multiple of 64
+    double contrib = 0.0;
+    for (int64_t sl = s0 + wave; sl < s1; sl += nwave) {
+        const int64_t row = sl * 64 + lane;
+        const bool live = row < r1 && row < n;
+        const int L = slen[sl];
+        const int32_t *__restrict__ ci = cols + sptr[sl] + lane;
+        const double *__restrict__ av = vals + sptr[sl] + lane;
+        double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0;
+        if (live) {
+            xi = x[row];
+            di = dfix[row] * u[row];
+            if (inner) { pi = p[row]; vi = v[row]; }
+        }
+        double acc0 = 0.0, acc1 = 0.0;
+        int j = 0;
+        for (; j + UN <= L; j += UN) {                  // L is wave-uniform: no predication in the main loop
+            int32_t c[UN];
+            double m[UN];
+#pragma unroll
+            for (int q = 0; q < UN; q++) {
+                c[q] = ci[(j + q) * 64];
+                m[q] = av[(j + q) * 64];
+            }
+            double g[UN];
+#pragma unroll
+            for (int q = 0; q < UN; q++) g[q] = u[(uint32_t)c[q]];
+#pragma unroll
+            for (int q = 0; q < UN; q += 2) {
+                acc0 += m[q] * g[q];
+                acc1 += m[q + 1] * g[q + 1];
+            }
+        }
+        for (; j < L; j++) acc0 += av[j * 64] * u[(uint32_t)ci[j * 64]];
+        if (live) {
+            const double t = (acc0 + acc1) + di;
             if (inner) {
                 const double wi = xi * t + vi * pi;
                 w[row] = wi;
@@ -738,12 +1014,25 @@ void launch_kb_stream(hipStream_t s, int grid, size_t shmem, int64_t n, int64_t 
 }
 
 template <int LPR, int UN>
+void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
+                    int PA, int PS, const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p,
+                    double *v, double *rk, double *w, double *part_out)
+{
+    hipLaunchKernelGGL((kr_kb_pipe<LPR, UN>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                       m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
+}
+
+template <int LPR, int UN>
 void launch_kb_rows(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
                     int PA, int PS, const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
                     double *rk, double *w, double *part_out)
 {
-    hipLaunchKernelGGL((kr_kb_rows<LPR, UN>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr, m->indices,
-                       (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
+    if (getenv("B3C_KR_NOGATHER"))   // wrong results by design: measures the kernel without its random gathers
+        hipLaunchKernelGGL((kr_kb_rows<LPR, UN, true>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
+    else
+        hipLaunchKernelGGL((kr_kb_rows<LPR, UN>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
 }
 
 }  // namespace
@@ -789,6 +1078,13 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     if (getenv("B3C_KR_ROWWAVE")) kform = "wave";
     const bool stream_kb = !dist && kform && !strcmp(kform, "stream") && maxdeg <= 4096;
     const bool rows_kb = dist || (!stream_kb && !(kform && !strcmp(kform, "wave")));
+    // default: sliced-ELL working layout when no row is extreme (a slice is as long as its longest row)
+    // sliced-ELL working layout: only on request (B3C_KR_KERNEL=sell).  Measured at C3: 1.41 ms per SpMV against
+    // 0.97 ms for the row-group form -- 64 rows per wave blow the gather working set out of the 32 KB L1.
+    const bool sell = rows_kb && kform && !strcmp(kform, "sell") && maxdeg <= 8192 && n >= 2048 && a->nnz >= (1 << 16);
+    const int64_t nsl = (n + 63) / 64;
+    const bool pipe_kb = rows_kb && !sell && !(kform && !strcmp(kform, "rows"));
+    const int lpr_p = avg > 64 ? 16 : avg > 24 ? 8 : 4;   // lanes per row of the pipelined form
     // rows form: lanes per row so that LPR*8 covers an average row
     const int lpr_r = avg > 128 ? 32 : avg > 64 ? 16 : avg > 32 ? 8 : 4;
     const int64_t nblk = a->nnz > 0 ? (a->nnz + KB_T - 1) / KB_T : 1;
@@ -797,6 +1093,8 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     // phase-2 group width: about two LDS reads per lane for an average row
     const int lpr2 = avg >= 64 ? 32 : avg >= 24 ? 16 : avg >= 10 ? 8 : 4;
     const int GS = stream_kb ? grid_for(nblk, 1, 8 * ctx->n_cu)
+                 : sell ? grid_for((nloc + 63) / 64, BLK / 64, 8 * ctx->n_cu)
+                 : pipe_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_p), 16 * ctx->n_cu)
                  : rows_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_r), 8 * ctx->n_cu)
                            : grid_for(n, rows_per_block, 8 * ctx->n_cu);
     const int P = G > GS ? G : GS;
@@ -844,6 +1142,44 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
         hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dfix.p, new2old.p, w.p);
         HIP_TRY(ctx, hipMemcpyAsync(dfix.p, w.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
         a = perm.m;
+    }
+    // ---- sliced-ELL working layout ----
+    DevBuf<int32_t> sperm(ctx, sell ? n : 1), sinv(ctx, sell ? n : 1), slen(ctx, sell ? nsl : 1);
+    DevBuf<int64_t> sptr(ctx, sell ? nsl + 1 : 1);
+    int32_t *scols = nullptr;
+    double *svals = nullptr;
+    struct SellGuard { b3c_ctx *c; int32_t **a; double **b; ~SellGuard() { c->release(*a); c->release(*b); } } sell_guard{ctx, &scols, &svals};
+    if (sell) {
+        DevBuf<int64_t> k_in(ctx, n), k_out(ctx, n), ssz(ctx, nsl + 1);
+        DevBuf<int32_t> v_in(ctx, n);
+        if (!sperm.p || !sinv.p || !slen.p || !sptr.p || !k_in.p || !k_out.p || !ssz.p || !v_in.p)
+            return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: SELL set-up");
+        const unsigned gn = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(sell_keys, dim3(gn), dim3(256), 0, s, n, a->indptr, k_in.p, v_in.p);
+        int wbits = 1;
+        while ((1ll << wbits) < (n + SELL_W - 1) / SELL_W + 1) wbits++;
+        size_t tb = 0;
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, sperm.p, (int)n, 0, 32 + wbits, s));
+        {
+            DevBuf<char> tmp(ctx, tb);
+            if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: SELL sort workspace");
+            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, sperm.p, (int)n, 0, 32 + wbits, s));
+        }
+        hipLaunchKernelGGL(sell_invert, dim3(gn), dim3(256), 0, s, n, sperm.p, sinv.p);
+        hipLaunchKernelGGL(sell_slice_sizes, dim3((unsigned)((nsl + 256) / 256)), dim3(256), 0, s, n, nsl, a->indptr, sperm.p,
+                           slen.p, ssz.p);
+        int rc = b3c_exclusive_scan_i64(ctx, ssz.p, sptr.p, nsl + 1);
+        if (rc) return rc;
+        int64_t tot = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&tot, sptr.p + nsl, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        scols = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(tot > 0 ? tot : 1));
+        svals = (double *)ctx->alloc(sizeof(double) * (size_t)(tot > 0 ? tot : 1));
+        if (!scols || !svals) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: SELL storage");
+        hipLaunchKernelGGL(sell_fill, dim3(grid_for(nsl, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, nsl, a->indptr, a->indices,
+                           (const double *)a->data, sperm.p, sinv.p, slen.p, sptr.p, scols, svals);
+        hipLaunchKernelGGL(kr_gather_f64, dim3(gn), dim3(256), 0, s, n, dfix.p, sperm.p, w.p);
+        HIP_TRY(ctx, hipMemcpyAsync(dfix.p, w.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     }
     if (stream_kb)
         hipLaunchKernelGGL(kr_row_blocks, dim3((unsigned)((nblk + 256) / 256)), dim3(256), 0, s, n, nblk, a->indptr, rb.p);
@@ -902,6 +1238,15 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
                 case 8: launch_kb_stream<8>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
                 default: launch_kb_stream<4>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
                 }
+            } else if (sell) {
+                hipLaunchKernelGGL(kr_kb_sell<8>, dim3(GS), dim3(BLK), 0, s, r0, r1, n, s0, s1, kbp, kbP, kbS, sptr.p, slen.p, scols,
+                                   svals, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+            } else if (rows_kb && pipe_kb) {
+                // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
+                if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
             } else if (rows_kb) {
                 switch (lpr_r) {
                 case 32: launch_kb_rows<32, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
@@ -967,6 +1312,10 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
         int rc = xchg(B3C_BUF_VEC);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(x.p, D.vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    }
+    if (sell) {
+        hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x.p, sinv.p, w.p);
+        HIP_TRY(ctx, hipMemcpyAsync(x.p, w.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     }
     if (reorder) {
         hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x.p, old2new.p, w.p);

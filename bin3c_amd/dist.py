@@ -48,7 +48,8 @@ def allgather_inplace(full, rank, world, group=None):
     mine = full[rank * cnt:(rank + 1) * cnt]
     backend = dist.get_backend(group)
     if backend == 'nccl':
-        dist.all_gather_into_tensor(full, mine, group=group)
+        # separate send buffer: the slice is small, and in-place (aliased) collectives are not worth the risk
+        dist.all_gather_into_tensor(full, mine.clone(), group=group)
     elif full.is_cuda:
         # gloo moves CUDA tensors only for all_reduce/broadcast (single-GPU CI): gather = sum with zeros
         keep = mine.clone()

@@ -14,7 +14,7 @@ n2o, o2n = ctx.locality_order(counts)
 work = ctx.permute(counts, n2o)
 a = ctx.site_norm(work, sm.sites[n2o])
 by = 12.0 * sm.nnz + 20.0 * n
-for form in ['rows', 'stream', 'wave', 'rows']:
+for form in ['pipe', 'rows', 'stream', 'sell', 'wave', 'pipe']:
     os.environ['B3C_KR_KERNEL'] = form
     for rep in range(2):
         t = time.time(); _, x, info = ctx.kr_balance(a); dt = time.time() - t
