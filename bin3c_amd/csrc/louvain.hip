@@ -288,6 +288,12 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int n_
         u64 *vals = use_lds ? lv : gvals + goff[i];
 
         long long own = 0;
+        // A lane that turns an EMPTY slot into its community "claims" it; each distinct community is claimed exactly
+        // once per node, so evaluating the claimed slots visits every candidate without scanning (and re-clearing)
+        // the whole table.  Nodes of at most 256 entries keep their claims in four registers per lane.
+        const bool small = deg <= 256;
+        uint32_t claim[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        bool any_claim = false;
         for (int64_t base = s; base < e; base += 256) {
             int32_t j[4];
             u64 qv[4];
@@ -308,7 +314,11 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int n_
                 uint32_t slot = hash_slot(c[t], lg);
                 for (;;) {
                     int32_t prev = atomicCAS(&keys[slot], EMPTY, c[t]);
-                    if (prev == EMPTY || prev == c[t]) { atomicAdd(&vals[slot], qv[t]); break; }
+                    if (prev == EMPTY || prev == c[t]) {
+                        atomicAdd(&vals[slot], qv[t]);
+                        if (prev == EMPTY) { claim[t] = slot; any_claim = true; }
+                        break;
+                    }
                     slot = (slot + 1) & mask;
                 }
             }
@@ -319,14 +329,29 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int n_
 
         Best b;
         b.gain = 0; b.com = a; b.have = 0;
-        for (uint32_t t = lane; t <= mask; t += 64) {
-            const int32_t c = keys[t];
-            if (c != EMPTY) {
-                const u64 d = vals[t];
-                keys[t] = EMPTY;
-                vals[t] = 0;
-                const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
-                best_take(b, g, c);
+        if (small) {
+            if (__ballot(any_claim)) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (claim[t] == 0xFFFFFFFFu) continue;
+                    const int32_t c = keys[claim[t]];
+                    const u64 d = vals[claim[t]];
+                    keys[claim[t]] = EMPTY;
+                    vals[claim[t]] = 0;
+                    const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
+                    best_take(b, g, c);
+                }
+            }
+        } else {
+            for (uint32_t t = lane; t <= mask; t += 64) {
+                const int32_t c = keys[t];
+                if (c != EMPTY) {
+                    const u64 d = vals[t];
+                    keys[t] = EMPTY;
+                    vals[t] = 0;
+                    const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
+                    best_take(b, g, c);
+                }
             }
         }
         if (lane == 0) {

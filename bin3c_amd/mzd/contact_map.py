@@ -234,6 +234,18 @@ class ContactMap(object):
         cm.order = SeqOrder(cm.seq_info)
         return cm
 
+    def __setstate__(self, state):
+        """Also accepts the attribute dictionary of a map pickled by the reference (old-style class, no private
+        fields): its cached ``processed_map`` becomes the host copy, device handles start empty."""
+        state = dict(state)
+        if 'processed_map' in state:
+            state['_processed_host'] = state.pop('processed_map')
+        for k in ('_processed_host', '_hot', '_ctx'):
+            state.setdefault(k, None)
+        self.__dict__.update(state)
+        if isinstance(self.order, SeqOrder) and self.order.order.dtype != SeqOrder.STRUCT_TYPE:
+            self.order.order = self.order.order.astype(SeqOrder.STRUCT_TYPE)
+
     def __getstate__(self):
         d = self.__dict__.copy()
         d['_processed_host'] = self.processed_map      # materialise before the device handles go away

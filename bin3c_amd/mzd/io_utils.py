@@ -40,11 +40,23 @@ def save_object(file_name, obj):
         pickle.dump(obj, out_h, protocol=pickle.HIGHEST_PROTOCOL)
 
 
+class _RefUnpickler(pickle.Unpickler):
+    """Resolve the reference's module paths (``mzd.contact_map.ContactMap`` ...) and Python-2 names onto this package,
+    so that a ``contact_map.p.gz`` written by bin3C itself loads here."""
+
+    _MODULES = {'mzd.contact_map': 'bin3c_amd.mzd.contact_map', 'mzd.cluster': 'bin3c_amd.mzd.cluster',
+                'mzd.exceptions': 'bin3c_amd.mzd.exceptions', 'mzd.io_utils': 'bin3c_amd.mzd.io_utils',
+                'mzd.utils': 'bin3c_amd.mzd.utils', '__builtin__': 'builtins', 'copy_reg': 'copyreg'}
+
+    def find_class(self, module, name):
+        return pickle.Unpickler.find_class(self, self._MODULES.get(module, module), name)
+
+
 def load_object(file_name):
-    """Inverse of save_object; also reads Python-2 pickles of plain data (io_utils.py:24-32)."""
+    """Inverse of save_object (io_utils.py:24-32); also reads the Python-2 / cPickle files of the reference."""
     with open_input(file_name) as in_h:
         try:
-            return pickle.load(in_h)
+            return _RefUnpickler(in_h).load()
         except UnicodeDecodeError:
             in_h.seek(0)
-            return pickle.load(in_h, encoding='latin1')
+            return _RefUnpickler(in_h, encoding='latin1').load()

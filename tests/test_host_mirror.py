@@ -141,3 +141,25 @@ def test_contact_map_surface_pickles_without_device(tmp_path):
     back = io_utils.load_object(str(tmp_path / 'contact_map.p.gz'))
     assert (back.seq_map != cm.seq_map).nnz == 0 and back.processed_map is None
     assert np.array_equal(back.order.order, cm.order.order)
+
+
+def test_reference_module_paths_resolve_on_load(tmp_path):
+    """A pickle that names the reference's classes (mzd.contact_map.*) loads onto the mirror."""
+    import gzip
+    import pickle
+    import pickletools
+    from bin3c_amd.mzd import io_utils
+    from bin3c_amd.mzd.contact_map import ContactMap, SeqOrder
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(200, 3000, 4)
+    cm = ContactMap.from_arrays(sm.to_scipy(), sm.lengths, sm.sites)
+    raw = pickle.dumps(cm, protocol=2)
+    assert b'bin3c_amd.mzd.contact_map' in raw
+    # rewrite the module path the way the reference would have written it
+    raw = raw.replace(b'cbin3c_amd.mzd.contact_map\n', b'cmzd.contact_map\n')
+    assert b'cmzd.contact_map\n' in raw and b'bin3c_amd.mzd.contact_map' not in raw
+    with gzip.open(str(tmp_path / 'ref_map.p.gz'), 'wb') as h:
+        h.write(raw)
+    back = io_utils.load_object(str(tmp_path / 'ref_map.p.gz'))
+    assert isinstance(back, ContactMap) and isinstance(back.order, SeqOrder)
+    assert back.total_seq == 200 and (back.seq_map != cm.seq_map).nnz == 0
