@@ -59,7 +59,7 @@ SYMBOLS = [
     ('b3c_louvain', C.c_int, [_VP, _VP, C.c_double, C.c_int, C.c_int, _VP, C.POINTER(LouvainInfo)]),
     ('b3c_graph_quantise', C.c_int, [_VP, _VP, C.c_double, _VP, C.POINTER(C.c_int32)]),
     ('b3c_locality_order', C.c_int, [_VP, _VP, _VP, _VP]),
-    ('b3c_mat_permute', C.c_int, [_VP, _VP, _VP, C.POINTER(_VP)]),
+    ('b3c_mat_permute', C.c_int, [_VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
     ('b3c_mat_ids', C.c_int, [_VP, _VP, _VP]),
     ('b3c_version', C.c_char_p, []),
 ]
@@ -226,11 +226,12 @@ class Context(object):
         self._check(self.lib.b3c_locality_order(self.h, mat.h, _ptr(n2o), _ptr(o2n)))
         return n2o, o2n
 
-    def permute(self, mat, new2old):
+    def permute(self, mat, new2old, unsorted=False):
+        """P A P^T; unsorted=True skips re-sorting the columns inside each row (fast, not canonical CSR)."""
         if isinstance(new2old, np.ndarray):
             new2old = np.ascontiguousarray(new2old, dtype=np.int32)
         h = _VP()
-        self._check(self.lib.b3c_mat_permute(self.h, mat.h, _ptr(new2old), C.byref(h)))
+        self._check(self.lib.b3c_mat_permute(self.h, mat.h, _ptr(new2old), 1 if unsorted else 0, C.byref(h)))
         return Mat(self, h)
 
     def mat_ids(self, mat):

@@ -93,6 +93,9 @@ struct b3c_mat {
     // values are bitwise symmetric (a_ij == a_ji): set by b3c_scale_sym_graph, kept by compress / permute;
     // lets Louvain take the edge weight straight from the entry instead of searching its mirror
     bool value_symmetric = false;
+    // column indices ascend inside every row (canonical CSR).  b3c_mat_permute with B3C_PERMUTE_UNSORTED clears it;
+    // kernels that look an entry up then scan the row instead of bisecting it
+    bool sorted_cols = true;
 };
 
 #define HIP_TRY(ctx, expr)                                                                          \

@@ -282,6 +282,7 @@ extern "C" int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *
                      (const uint32_t *)counts->data, ds.p, (double *)m->data);
     }
     m->ordered = counts->ordered;
+    m->sorted_cols = counts->sorted_cols;
     if (counts->ids) {
         m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
         if (!m->ids) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_site_norm"); }
@@ -373,6 +374,7 @@ extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask,
     }
     o->ordered = a->ordered;
     o->value_symmetric = a->value_symmetric;
+    o->sorted_cols = a->sorted_cols;      // compaction keeps the relative order inside a row
     if (a->ids && n) {
         DevBuf<int64_t> keep_o(ctx, n + 1), rank_o(ctx, n + 1);
         o->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1));

@@ -21,7 +21,8 @@
 
 int b3c_exclusive_scan_i64(b3c_ctx *ctx, const int64_t *in, int64_t *out, int64_t count);
 int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new);
-int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out);
+int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out,
+                    bool sort_cols);
 
 namespace {
 
@@ -887,6 +888,36 @@ __global__ void kr_diag_fix(int64_t n, const int64_t *__restrict__ indptr, const
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_zero, (unsigned long long)__popcll(b));
 }
 
+// the same for rows whose columns are not ascending (B3C_PERMUTE_UNSORTED layouts): one wave scans the row
+__global__ void __launch_bounds__(BLK) kr_diag_fix_scan(int64_t n, const int64_t *__restrict__ indptr,
+                                                         const int32_t *__restrict__ indices,
+                                                         const double *__restrict__ a, double *__restrict__ dfix,
+                                                         unsigned long long *n_zero)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    unsigned long long zeros = 0;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        double d = 0.0;
+        for (int64_t k = s + lane; k < e; k += 64)
+            if (indices[k] == (int32_t)row) d = a[k];
+        // at most one lane found it (no duplicates)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double t = __shfl_down(d, o, 64);
+            d = d != 0.0 ? d : t;
+        }
+        if (lane == 0) {
+            const int z = d == 0.0;
+            dfix[row] = z ? 1.0 : 0.0;
+            zeros += z;
+        }
+    }
+    if (lane == 0 && zeros) atomicAdd(n_zero, zeros);
+}
+
 // Fast path of the symmetry guard: two independent order-free 64-bit checksums of the strictly upper
 // entries keyed (i, j, bits) and of the strictly lower entries keyed (j, i, bits).  Equal checksums
 // (2^-128 collision odds) mean the matrix is BITWISE symmetric, which implies the reference's
@@ -945,8 +976,9 @@ __global__ void __launch_bounds__(BLK) kr_sym_hash(int64_t n, const int64_t *__r
 }
 
 // is_hermitian restated sparsely (sparse_utils.py:10-18): count entries with |a_ij - a_ji| >= tol
-__global__ void kr_asym_count(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                              const double *__restrict__ a, double tol, unsigned long long *n_bad)
+__global__ void kr_asym_count(int64_t n, int sorted, const int64_t *__restrict__ indptr,
+                              const int32_t *__restrict__ indices, const double *__restrict__ a, double tol,
+                              unsigned long long *n_bad)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
@@ -959,9 +991,13 @@ __global__ void kr_asym_count(int64_t n, const int64_t *__restrict__ indptr, con
             if (j == row) continue;
             int64_t lo = indptr[j], hi = indptr[j + 1];
             const int64_t je = hi;
-            while (lo < hi) {
-                int64_t mid = (lo + hi) >> 1;
-                if (indices[mid] < row) lo = mid + 1; else hi = mid;
+            if (sorted) {
+                while (lo < hi) {
+                    int64_t mid = (lo + hi) >> 1;
+                    if (indices[mid] < row) lo = mid + 1; else hi = mid;
+                }
+            } else {
+                while (lo < je && indices[lo] != (int32_t)row) lo++;    // unsorted layout: scan (exact path only)
             }
             double t = (lo < je && indices[lo] == (int32_t)row) ? a[lo] : 0.0;
             // zero-diagonal substitution never touches off-diagonal entries
@@ -1112,8 +1148,12 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     int *flags = (int *)(counters.p + 2);
 
     HIP_TRY(ctx, hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * 4, s));
-    hipLaunchKernelGGL(kr_diag_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, a->indices,
-                       (const double *)a->data, dfix.p, counters.p);
+    if (a->sorted_cols)
+        hipLaunchKernelGGL(kr_diag_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, a->indices,
+                           (const double *)a->data, dfix.p, counters.p);
+    else
+        hipLaunchKernelGGL(kr_diag_fix_scan, dim3(grid_for(n, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr, a->indices,
+                           (const double *)a->data, dfix.p, counters.p);
     {
         DevBuf<unsigned long long> hs(ctx, 4);
         if (!hs.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
@@ -1125,8 +1165,8 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
         HIP_TRY(ctx, hipStreamSynchronize(s));
         info->bitwise_symmetric = hh[0] == hh[2] && hh[1] == hh[3];
         if (!info->bitwise_symmetric || getenv("B3C_KR_EXACT_SYMCHECK"))
-            hipLaunchKernelGGL(kr_asym_count, dim3(grid_for(n, 4, 8 * ctx->n_cu)), dim3(256), 0, s, n, a->indptr,
-                               a->indices, (const double *)a->data, tol, counters.p + 1);
+            hipLaunchKernelGGL(kr_asym_count, dim3(grid_for(n, 4, 8 * ctx->n_cu)), dim3(256), 0, s, n, a->sorted_cols ? 1 : 0,
+                               a->indptr, a->indices, (const double *)a->data, tol, counters.p + 1);
     }
 
     // locality-ordered working copy (see reorder.hip): the iteration runs in the new numbering,
@@ -1138,7 +1178,7 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
         if (!new2old.p || !old2new.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
         int rc = b3c_locality_order_dev(ctx, a, new2old.p, old2new.p);
         if (rc) return rc;
-        if ((rc = b3c_permute_csr(ctx, a, new2old.p, old2new.p, &perm.m))) return rc;
+        if ((rc = b3c_permute_csr(ctx, a, new2old.p, old2new.p, &perm.m, false))) return rc;
         hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dfix.p, new2old.p, w.p);
         HIP_TRY(ctx, hipMemcpyAsync(dfix.p, w.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
         a = perm.m;

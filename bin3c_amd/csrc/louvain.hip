@@ -23,7 +23,8 @@
 
 int b3c_exclusive_scan_i64(b3c_ctx *ctx, const int64_t *in, int64_t *out, int64_t count);
 int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int32_t *old2new);
-int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out);
+int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out,
+                    bool sort_cols);
 
 namespace {
 
@@ -54,7 +55,7 @@ struct LvGraph {
 __global__ void __launch_bounds__(BLK) k_graph_w(int64_t n, const int64_t *__restrict__ indptr,
                                                   const int32_t *__restrict__ indices,
                                                   const double *__restrict__ a, const int32_t *__restrict__ ids,
-                                                  double scl, double *__restrict__ w,
+                                                  int sorted, double scl, double *__restrict__ w,
                                                   double *__restrict__ part_max)
 {
     __shared__ double lds[WPB];
@@ -92,8 +93,14 @@ __global__ void __launch_bounds__(BLK) k_graph_w(int64_t n, const int64_t *__res
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     if (lo[t] < hi[t]) {
-                        const int64_t mid = (lo[t] + hi[t]) >> 1;
-                        if (indices[mid] < (int32_t)row) lo[t] = mid + 1; else hi[t] = mid;
+                        if (sorted) {
+                            const int64_t mid = (lo[t] + hi[t]) >> 1;
+                            if (indices[mid] < (int32_t)row) lo[t] = mid + 1; else hi[t] = mid;
+                        } else if (indices[lo[t]] == (int32_t)row) {
+                            hi[t] = lo[t];                      // found: stop scanning this one
+                        } else {
+                            lo[t]++;
+                        }
                         any = true;
                     }
                 }
@@ -252,7 +259,7 @@ __host__ __device__ __forceinline__ int table_lg(int64_t deg)
 // Loads first: every lane pulls four (index, weight) pairs, then the four community gathers, then inserts, so
 // that a wave keeps ~3 KB of independent loads in flight instead of one dependent chain per 64 entries.
 template <int CAP>
-__global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int n_sub, int round, u64 m2,
+__global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int skip_upto, int n_sub, int round, u64 m2,
                                                     const int64_t *__restrict__ indptr,
                                                     const int32_t *__restrict__ indices,
                                                     const int64_t *__restrict__ q, const int32_t *__restrict__ ids,
@@ -280,6 +287,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int n_
         if (ki == 0) continue;
         const int64_t s = indptr[i], e = indptr[i + 1];
         const int64_t deg = e - s;
+        if (deg <= skip_upto) continue;      // short nodes are taken by k_lv_decide_g
         const int32_t a = com[i];
         const int lg = table_lg(deg);
         const bool use_lds = (1ll << lg) <= CAP;
@@ -367,6 +375,212 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int n_
         }
         if (use_lds) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped, software-pipelined form of the neighbour scan for nodes of at most LPR*UN entries (all but the
+// hubs).  LPR lanes own a node and hold its UN entries per lane in registers; while the community gathers of
+// node t are in flight, the record, the entries and the own-community of the group's next node are already
+// being fetched.  After the first sweeps nearly every neighbour sits in the node's own community, which is
+// summed in registers; only groups that saw a foreign community take turns on the wave's LDS table.
+// The node list of a sub-round is fixed for a level (the bucket depends on the id only), so it is built once.
+// ---------------------------------------------------------------------------------------------
+struct NodeRec {
+    int32_t node;
+    int32_t deg;
+    int64_t start;
+};
+
+__global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, int round, int max_deg,
+                                const int64_t *__restrict__ indptr, const int32_t *__restrict__ ids,
+                                const int64_t *__restrict__ kdeg, int64_t *__restrict__ flag)
+{
+    int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < r1) {
+        const int64_t deg = indptr[i + 1] - indptr[i];
+        const int32_t id = ids ? ids[i] : (int32_t)i;
+        flag[i - r0] = bucket_of(id, n_sub) == (uint32_t)round && kdeg[i] != 0 && deg <= max_deg;
+    }
+    if (i == r1) flag[i - r0] = 0;
+}
+
+__global__ void k_lv_list_fill(int64_t r0, int64_t r1, const int64_t *__restrict__ flag, const int64_t *__restrict__ pos,
+                               const int64_t *__restrict__ indptr, NodeRec *__restrict__ list)
+{
+    int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < r1 && flag[i - r0]) {
+        NodeRec rec;
+        rec.node = (int32_t)i;
+        rec.start = indptr[i];
+        rec.deg = (int32_t)(indptr[i + 1] - rec.start);
+        list[pos[i - r0]] = rec;
+    }
+}
+
+template <int LPR, int UN>
+__global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt, const NodeRec *__restrict__ list, u64 m2,
+                                                      const int32_t *__restrict__ indices,
+                                                      const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
+                                                      const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
+                                                      const int32_t *__restrict__ csize, int32_t *__restrict__ nxt)
+{
+    constexpr int CAP = 512;                       // >= 1.25 * LPR * UN + 1
+    constexpr int LG = 9;
+    static_assert(LPR * UN * 5 / 4 + 1 <= CAP, "table too small");
+    __shared__ int32_t skeys[WPB][CAP];
+    __shared__ u64 svals[WPB][CAP];
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int sub = lane / LPR, sl = lane % LPR;
+    int32_t *keys = skeys[wib];
+    u64 *vals = svals[wib];
+    for (int t = lane; t < CAP; t += 64) { keys[t] = EMPTY; vals[t] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+    const int64_t step = (int64_t)gridDim.x * WPB * RPW;
+    int64_t pos = ((int64_t)blockIdx.x * WPB + wib) * RPW + sub;
+    // current node
+    int32_t i = -1, a = 0;
+    int deg = 0;
+    long long ki = 0;
+    int64_t start = 0;
+    int32_t j[UN];
+    if (pos < cnt) {
+        const NodeRec rec = list[pos];
+        i = rec.node;
+        deg = rec.deg;
+        start = rec.start;
+        a = com[i];
+        ki = kdeg[i];
+        const int32_t *__restrict__ ci = indices + rec.start;
+#pragma unroll
+        for (int t = 0; t < UN; t++) {
+            const int e = t * LPR + sl;
+            j[t] = e < deg ? ci[e] : i;
+        }
+    }
+    // the loop runs while ANY group of the wave still has a node (groups take turns on the shared table)
+    while (__ballot(i >= 0)) {
+        // 1. record of the group's next node
+        const int64_t posn = pos + step;
+        NodeRec recn;
+        recn.node = -1; recn.deg = 0; recn.start = 0;
+        if (i >= 0 && posn < cnt) recn = list[posn];
+        // 2. community gathers and weights of the current node, own-community total
+        int32_t cm[UN];
+        u64 qv[UN];
+        {
+            const int64_t *__restrict__ qi = q + start;
+#pragma unroll
+            for (int t = 0; t < UN; t++) {
+                cm[t] = j[t] != i ? com[j[t]] : EMPTY;
+                qv[t] = t * LPR + sl < deg ? (u64)qi[t * LPR + sl] : 0;
+            }
+        }
+        long long ta = 0;
+        if (i >= 0 && sl == 0) ta = tot[a];
+        // 3. neighbour ids and own community of the next node (its weights are fetched next to its gathers)
+        int32_t an = 0;
+        long long kin = 0;
+        int32_t j2[UN];
+        {
+            const int32_t inn = recn.node;
+            if (inn >= 0) { an = com[inn]; kin = kdeg[inn]; }
+            const int32_t *__restrict__ ci = indices + recn.start;
+#pragma unroll
+            for (int t = 0; t < UN; t++) {
+                const int e = t * LPR + sl;
+                j2[t] = e < recn.deg ? ci[e] : inn;
+            }
+        }
+        // 4. own-community weight in registers; does the group see any foreign community?
+        long long own = 0;
+        bool foreign = false;
+#pragma unroll
+        for (int t = 0; t < UN; t++) {
+            if (cm[t] == EMPTY) continue;
+            if (cm[t] == a) own += (long long)qv[t];
+            else foreign = true;
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) own += __shfl_down(own, o, LPR);
+        const u64 fmask = __ballot(foreign);
+        Best b;
+        b.gain = 0; b.com = a; b.have = 0;
+        // 5. groups with foreign neighbours take the wave's table one after the other
+        for (int gsel = 0; gsel < RPW; gsel++) {
+            const u64 gbits = (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull)) << (gsel * LPR);
+            if (!(fmask & gbits)) continue;                     // wave-uniform
+            if (sub == gsel) {
+#pragma unroll
+                for (int t = 0; t < UN; t++) {
+                    uint32_t mine = 0xFFFFFFFFu;
+                    if (cm[t] != EMPTY && cm[t] != a) {
+                        uint32_t slot = hash_slot(cm[t], LG);
+                        for (;;) {
+                            const int32_t prev = atomicCAS(&keys[slot], EMPTY, cm[t]);
+                            if (prev == EMPTY || prev == cm[t]) {
+                                atomicAdd(&vals[slot], qv[t]);
+                                if (prev == EMPTY) mine = slot;
+                                break;
+                            }
+                            slot = (slot + 1) & (CAP - 1);
+                        }
+                    }
+                    j[t] = (int32_t)mine;                       // j is dead: reuse it for the claimed slot
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (sub == gsel) {
+#pragma unroll
+                for (int t = 0; t < UN; t++) qv[t] = j[t] != -1 ? (u64)tot[cm[t]] : 0;     // qv is dead: holds tot[c] now
+#pragma unroll
+                for (int t = 0; t < UN; t++) {
+                    if (j[t] == -1) continue;
+                    const u64 d = vals[j[t]];
+                    keys[j[t]] = EMPTY;
+                    vals[j[t]] = 0;
+                    const i128 g = (i128)d * (i128)m2 - (i128)(long long)qv[t] * (i128)ki;
+                    best_take(b, g, cm[t]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        if (i >= 0 && sl == 0) {
+            // staying: i removed from its own community first (python-louvain __remove)
+            const i128 g = (i128)own * (i128)m2 - (i128)(ta - ki) * (i128)ki;
+            best_take(b, g, a);
+        }
+        // arg-max inside the group
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            long long hi = __shfl_down((long long)(b.gain >> 64), o, LPR);
+            u64 lo = (u64)__shfl_down((long long)(u64)b.gain, o, LPR);
+            int32_t c = __shfl_down(b.com, o, LPR);
+            int32_t hv = __shfl_down(b.have, o, LPR);
+            i128 g = ((i128)hi << 64) | (i128)lo;
+            if (hv && (!b.have || g > b.gain || (g == b.gain && c < b.com))) {
+                b.gain = g;
+                b.com = c;
+                b.have = 1;
+            }
+        }
+        if (i >= 0 && sl == 0) {
+            int32_t best = b.have ? b.com : a;
+            if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
+            nxt[i] = best;
+        }
+        // 6. advance
+        pos = posn;
+        i = recn.node;
+        deg = recn.deg;
+        start = recn.start;
+        a = an;
+        ki = kin;
+#pragma unroll
+        for (int t = 0; t < UN; t++) j[t] = j2[t];
     }
 }
 
@@ -592,8 +806,8 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
     if (a->value_symmetric)
         hipLaunchKernelGGL(k_graph_w_sym, dim3(g), dim3(BLK), 0, s, nnz, (const double *)a->data, scl, w.p, part.p);
     else
-        hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, ids, scl,
-                           w.p, part.p);
+        hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, ids,
+                           a->sorted_cols ? 1 : 0, scl, w.p, part.p);
     std::vector<double> hp(g);
     HIP_TRY(ctx, hipMemcpyAsync(hp.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -670,7 +884,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     if (reorder) {
         if (!new2old.p || !old2new.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
         if ((rc = b3c_locality_order_dev(ctx, a, new2old.p, old2new.p))) return rc;
-        if ((rc = b3c_permute_csr(ctx, a, new2old.p, old2new.p, &perm.m))) return rc;
+        if ((rc = b3c_permute_csr(ctx, a, new2old.p, old2new.p, &perm.m, false))) return rc;
         a = perm.m;
     }
     const int32_t *ids0 = reorder ? new2old.p : a->ids;
@@ -737,6 +951,30 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(gvals.p, 0, sizeof(u64) * (size_t)gtab, s));
         }
 
+        // node lists of the grouped kernel: per sub-round, the nodes of this rank with at most `short_max` entries
+        const double avgdeg = (double)g.nnz / (double)n;
+        const int short_max = avgdeg * 1.3 <= 32 ? 32 : avgdeg * 1.3 <= 64 ? 64 : avgdeg * 1.3 <= 128 ? 128 : 256;
+        const bool grouped = n >= 4096 && getenv("B3C_LV_NO_GROUPED") == nullptr;
+        const int64_t nloc = r1 - r0;
+        DevBuf<NodeRec> nlist(ctx, grouped ? nloc : 1);
+        std::vector<int64_t> loff(n_sub + 1, 0);
+        if (grouped) {
+            DevBuf<int64_t> lflag(ctx, nloc + 1), lpos(ctx, nloc + 1);
+            if (!nlist.p || !lflag.p || !lpos.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: node lists"); }
+            const unsigned gl = (unsigned)((nloc + 256) / 256);
+            for (int r = 0; r < n_sub; r++) {
+                hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, r, short_max, g.indptr, ids, kdeg.p, lflag.p);
+                if ((rc = b3c_exclusive_scan_i64(ctx, lflag.p, lpos.p, nloc + 1))) { free_graph(ctx, g); return rc; }
+                int64_t cntr = 0;
+                HIP_TRY(ctx, hipMemcpyAsync(&cntr, lpos.p + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(ctx, hipStreamSynchronize(s));
+                hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, lflag.p, lpos.p, g.indptr, nlist.p + loff[r]);
+                loff[r + 1] = loff[r] + cntr;
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+        }
+        const bool need_wave_kernel = !grouped || maxdeg > short_max;
+
         auto modularity = [&](double *out) -> int {
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64) * 5, s));
             hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2);
@@ -772,17 +1010,34 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 1, 0, sizeof(u64), s));
             for (int r = 0; r < n_sub; r++) {
                 evs.rec();
-#define LV_DECIDE(C)                                                                                       \
-    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gwl), dim3(BLK), 0, s, r0, r1, n_sub, r, m2, g.indptr, g.indices, g.q, ids,  \
-                       kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p)
-                switch (cap) {
-                case 128: LV_DECIDE(128); break;
-                case 256: LV_DECIDE(256); break;
-                case 512: LV_DECIDE(512); break;
-                case 1024: LV_DECIDE(1024); break;
-                default: LV_DECIDE(2048); break;
+                if (grouped && loff[r + 1] > loff[r]) {
+                    const int64_t cntr = loff[r + 1] - loff[r];
+                    const NodeRec *lst = nlist.p + loff[r];
+#define LV_DECIDE_G(L, U)                                                                                                \
+    hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, \
+                       m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p)
+                    switch (short_max) {
+                    case 256: if (getenv("B3C_LV_SHAPE") && !strcmp(getenv("B3C_LV_SHAPE"), "16x16")) { LV_DECIDE_G(16, 16); } else { LV_DECIDE_G(32, 8); } break;
+                    case 128: LV_DECIDE_G(16, 8); break;
+                    case 64: LV_DECIDE_G(8, 8); break;
+                    default: LV_DECIDE_G(4, 8); break;
+                    }
+#undef LV_DECIDE_G
                 }
+                if (need_wave_kernel) {
+                    const int skip = grouped ? short_max : -1;
+#define LV_DECIDE(C)                                                                                                     \
+    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gwl), dim3(BLK), 0, s, r0, r1, skip, n_sub, r, m2, g.indptr, g.indices, g.q, ids, \
+                       kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p)
+                    switch (cap) {
+                    case 128: LV_DECIDE(128); break;
+                    case 256: LV_DECIDE(256); break;
+                    case 512: LV_DECIDE(512); break;
+                    case 1024: LV_DECIDE(1024); break;
+                    default: LV_DECIDE(2048); break;
+                    }
 #undef LV_DECIDE
+                }
                 evs.rec();
                 if (dist && D.allgather(D.user, B3C_BUF_LABELS) != 0)
                     return ctx->fail(B3C_E_HIP, "b3c_louvain: all-gather callback failed");

@@ -209,6 +209,44 @@ __global__ void __launch_bounds__(BLK) k_perm_keys(int64_t n, const int64_t *__r
     }
 }
 
+// rows moved, columns relabelled, order inside a row kept as it was (i.e. no longer ascending)
+template <typename T>
+__global__ void __launch_bounds__(BLK) k_permute_rows(int64_t n, const int64_t *__restrict__ indptr,
+                                                       const int32_t *__restrict__ indices, const T *__restrict__ a,
+                                                       const int32_t *__restrict__ new2old,
+                                                       const int32_t *__restrict__ old2new,
+                                                       const int64_t *__restrict__ out_indptr,
+                                                       int32_t *__restrict__ out_indices, T *__restrict__ out_a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t k = wave; k < n; k += nwave) {
+        const int32_t old = new2old[k];
+        const int64_t s = indptr[old];
+        const int len = (int)(indptr[old + 1] - s);
+        const int64_t o = out_indptr[k];
+        for (int base = 0; base < len; base += 256) {
+            int32_t c[4];
+            T v[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int e = base + t * 64 + lane;
+                const bool ok = e < len;
+                c[t] = ok ? indices[s + e] : 0;
+                v[t] = ok ? a[s + e] : T(0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) c[t] = old2new[c[t]];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int e = base + t * 64 + lane;
+                if (e < len) { out_indices[o + e] = c[t]; out_a[o + e] = v[t]; }
+            }
+        }
+    }
+}
+
 __global__ void k_cols_from_keys(int64_t nnz, int64_t n, const int64_t *__restrict__ keys, int32_t *__restrict__ indices)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -304,18 +342,28 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
 }
 
 // Symmetric permutation P A P^T into a new canonical CSR (columns sorted in the new numbering).
-int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out)
+int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out,
+                    bool sort_cols)
 {
     hipStream_t s = ctx->stream;
     const int64_t n = a->n, nnz = a->nnz;
     b3c_mat *m = nullptr;
     int rc = b3c_mat_alloc(ctx, n, nnz, a->kind, &m);
     if (rc) return rc;
-    DevBuf<int64_t> deg(ctx, n + 1), k_in(ctx, nnz), k_out(ctx, nnz);
+    DevBuf<int64_t> deg(ctx, n + 1), k_in(ctx, sort_cols ? nnz : 1), k_out(ctx, sort_cols ? nnz : 1);
     if (!deg.p || !k_in.p || !k_out.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr"); }
     hipLaunchKernelGGL(k_new_degrees, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, a->indptr, new2old, deg.p);
     if ((rc = b3c_exclusive_scan_i64(ctx, deg.p, m->indptr, n + 1))) { b3c_mat_free(ctx, m); return rc; }
-    if (nnz) {
+    m->sorted_cols = a->sorted_cols && sort_cols;
+    if (nnz && !sort_cols) {
+        const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
+        if (a->kind == B3C_F64)
+            hipLaunchKernelGGL(k_permute_rows<double>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data,
+                               new2old, old2new, m->indptr, m->indices, (double *)m->data);
+        else
+            hipLaunchKernelGGL(k_permute_rows<uint32_t>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
+                               (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
+    } else if (nnz) {
         hipLaunchKernelGGL(k_perm_keys<double>, dim3(grid_for(n, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr,
                            a->indices, old2new, k_in.p);
         int end_bit = 1;
@@ -358,7 +406,7 @@ extern "C" int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2o
     return b3c_copy_out(ctx, old2new, o2n.p, sizeof(int32_t) * (size_t)a->n);
 }
 
-extern "C" int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, b3c_mat **out)
+extern "C" int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, int flags, b3c_mat **out)
 {
     if (!ctx) return B3C_E_ARG;
     if (!a || !new2old || !out) return ctx->fail(B3C_E_ARG, "b3c_mat_permute: bad argument");
@@ -371,7 +419,7 @@ extern "C" int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ne
     const unsigned gn = (unsigned)((n + 255) / 256);
     if (n) hipLaunchKernelGGL(k_invert_perm, dim3(gn), dim3(256), 0, ctx->stream, n, n2o.p, o2n.p);
     b3c_mat *m = nullptr;
-    if ((rc = b3c_permute_csr(ctx, a, n2o.p, o2n.p, &m))) return rc;
+    if ((rc = b3c_permute_csr(ctx, a, n2o.p, o2n.p, &m, !(flags & B3C_PERMUTE_UNSORTED)))) return rc;
     // caller-side id of every row: compose with the input's ids if it was permuted before
     m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
     if (!m->ids) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_mat_permute"); }

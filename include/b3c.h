@@ -131,7 +131,10 @@ int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old /*host|d
  * own internal ordering, site_norm / compress carry the ids along, and b3c_louvain hashes and
  * tie-breaks on the ids so that its labels equal those computed on `a` (returned per ROW of the
  * permuted matrix).  Same mechanism as ContactMap._reorder_seq (contact_map.py:1066-1085). */
-int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old /*host|dev*/, b3c_mat **out);
+#define B3C_PERMUTE_UNSORTED 1 /* move rows and relabel columns only: the order inside a row is kept, so columns no
+                                * longer ascend.  ~7x cheaper than the canonical form (no sort of the entries); every
+                                * libb3c entry point accepts such a matrix, but it is not canonical CSR on download. */
+int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old /*host|dev*/, int flags, b3c_mat **out);
 
 /* Caller-side row ids of a permuted (and possibly compressed) matrix, int32[n] host|dev.
  * Returns 1 and writes nothing when the matrix carries no ids (identity). */

@@ -148,3 +148,30 @@ def test_graph_form_scaling_matches_reference_graph_weights(ctx):
     m = sp.csr_matrix((data, g['in_indices'], g['in_indptr']), shape=(n, n))
     assert (m != m.T).nnz == 0
     np.testing.assert_allclose(data, g["out_data"], rtol=5e-16)      # two roundings each side
+
+
+def test_kr_on_permuted_layouts(ctx):
+    """Canonical and unsorted (B3C_PERMUTE_UNSORTED) permutations: same x after mapping back, same warn counters."""
+    g = np.load(os.path.join(GOLDEN, 'kr_zero_diag.npz'))
+    n = g['in_indptr'].shape[0] - 1
+    mat = ctx.upload(g['in_indptr'], g['in_indices'], g['in_data'])
+    perm = np.random.RandomState(3).permutation(n).astype(np.int32)
+    for unsorted in (False, True):
+        pm = ctx.permute(mat, perm, unsorted=unsorted)
+        ip, ix, _ = pm.download()
+        sorted_rows = all(np.all(np.diff(ix[ip[r]:ip[r + 1]]) > 0) for r in range(n))
+        assert sorted_rows == (not unsorted)
+        _, xp, info = ctx.kr_balance(pm)
+        assert info.n_zero_diag == 40 and info.n_iter == int(g['n_iter']) and info.bitwise_symmetric == 1
+        x = np.empty(n)
+        x[perm] = xp
+        np.testing.assert_allclose(x, g['x'], rtol=1e-9)
+        pm.free()
+    # asymmetric beyond tol on an unsorted layout -> exact (scanning) guard path
+    d = g['in_data'].copy()
+    rows = np.repeat(np.arange(n), np.diff(g['in_indptr']))
+    k = np.flatnonzero(rows < g['in_indices'])[7]
+    d[k] += 0.5
+    pm = ctx.permute(ctx.upload(g['in_indptr'], g['in_indices'], d), perm, unsorted=True)
+    _, _, info = ctx.kr_balance(pm, check=False)
+    assert info.is_symmetric == 0

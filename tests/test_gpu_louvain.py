@@ -112,8 +112,9 @@ def test_labels_do_not_depend_on_storage_order(ctx, oracle_lib):
     q = oracle_lib.quantise(w, oracle_lib.quant_shift(ip, ix, w))
     ref = oracle_lib.louvain_bsp(ip, ix, q, n_sub=4)
     mat = ctx.upload(ip, ix, a)
-    for perm in (np.random.RandomState(1).permutation(gr['n']).astype(np.int32), ctx.locality_order(mat)[0]):
-        pm = ctx.permute(mat, perm)
+    rperm = np.random.RandomState(1).permutation(gr['n']).astype(np.int32)
+    for perm, unsorted in ((rperm, False), (ctx.locality_order(mat)[0], False), (rperm, True)):
+        pm = ctx.permute(mat, perm, unsorted=unsorted)      # unsorted rows exercise the scanning mirror lookup
         ids = ctx.mat_ids(pm)
         assert np.array_equal(ids, perm)
         labels_p, info = ctx.louvain(pm, scl, n_sub=4)
