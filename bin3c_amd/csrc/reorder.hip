@@ -14,6 +14,7 @@
 // caller's numbering.
 #include "common.hpp"
 
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 int b3c_exclusive_scan_i64(b3c_ctx *ctx, const int64_t *in, int64_t *out, int64_t count);
@@ -247,6 +248,80 @@ __global__ void __launch_bounds__(BLK) k_permute_rows(int64_t n, const int64_t *
     }
 }
 
+// rows moved, columns relabelled AND re-sorted inside the row by a bitonic network in LDS (one wave per row):
+// canonical output without the 201M-key global radix sort.  Rows longer than CAPR take the global path.
+template <typename T, int CAPR>
+__global__ void __launch_bounds__(BLK) k_permute_rows_sorted(int64_t n, const int64_t *__restrict__ indptr,
+                                                              const int32_t *__restrict__ indices,
+                                                              const T *__restrict__ a,
+                                                              const int32_t *__restrict__ new2old,
+                                                              const int32_t *__restrict__ old2new,
+                                                              const int64_t *__restrict__ out_indptr,
+                                                              int32_t *__restrict__ out_indices, T *__restrict__ out_a)
+{
+    __shared__ int32_t skey[BLK / 64][CAPR];
+    __shared__ T sval[BLK / 64][CAPR];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    int32_t *key = skey[wib];
+    T *val = sval[wib];
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + wib;
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t k = wave; k < n; k += nwave) {
+        const int32_t old = new2old[k];
+        const int64_t s = indptr[old];
+        const int len = (int)(indptr[old + 1] - s);
+        const int64_t o = out_indptr[k];
+        int N = 64;
+        while (N < len) N <<= 1;
+        for (int e = lane; e < N; e += 64) {
+            if (e < len) {
+                key[e] = old2new[indices[s + e]];
+                val[e] = a[s + e];
+            } else {
+                key[e] = 0x7FFFFFFF;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int kk = 2; kk <= N; kk <<= 1) {
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (int idx = lane; idx < N; idx += 64) {
+                    const int ixj = idx ^ jj;
+                    if (ixj > idx) {
+                        const int32_t ka = key[idx], kb = key[ixj];
+                        const bool asc = (idx & kk) == 0;
+                        if ((ka > kb) == asc) {
+                            key[idx] = kb;
+                            key[ixj] = ka;
+                            const T va = val[idx];
+                            val[idx] = val[ixj];
+                            val[ixj] = va;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+        }
+        for (int e = lane; e < len; e += 64) {
+            out_indices[o + e] = key[e];
+            out_a[o + e] = val[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+}
+
+__global__ void k_max_len(int64_t n, const int64_t *__restrict__ indptr, unsigned long long *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long d = i < n ? indptr[i + 1] - indptr[i] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        long long t = __shfl_down(d, o, 64);
+        d = t > d ? t : d;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)d);
+}
+
 __global__ void k_cols_from_keys(int64_t nnz, int64_t n, const int64_t *__restrict__ keys, int32_t *__restrict__ indices)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -350,12 +425,31 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
     b3c_mat *m = nullptr;
     int rc = b3c_mat_alloc(ctx, n, nnz, a->kind, &m);
     if (rc) return rc;
-    DevBuf<int64_t> deg(ctx, n + 1), k_in(ctx, sort_cols ? nnz : 1), k_out(ctx, sort_cols ? nnz : 1);
-    if (!deg.p || !k_in.p || !k_out.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr"); }
+    DevBuf<int64_t> deg(ctx, n + 1);
+    if (!deg.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr"); }
     hipLaunchKernelGGL(k_new_degrees, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, a->indptr, new2old, deg.p);
     if ((rc = b3c_exclusive_scan_i64(ctx, deg.p, m->indptr, n + 1))) { b3c_mat_free(ctx, m); return rc; }
     m->sorted_cols = a->sorted_cols && sort_cols;
-    if (nnz && !sort_cols) {
+    // canonical output: per-row LDS sort when every row fits, else the global radix sort below
+    unsigned long long maxlen = 0;
+    if (nnz && sort_cols) {
+        DevBuf<unsigned long long> ml(ctx, 1);
+        if (!ml.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr"); }
+        HIP_TRY(ctx, hipMemsetAsync(ml.p, 0, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_max_len, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, ml.p);
+        HIP_TRY(ctx, hipMemcpyAsync(&maxlen, ml.p, sizeof(maxlen), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    constexpr int CAPR = 512;
+    if (nnz && sort_cols && maxlen <= CAPR && getenv("B3C_PERMUTE_GLOBAL_SORT") == nullptr) {
+        const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
+        if (a->kind == B3C_F64)
+            hipLaunchKernelGGL((k_permute_rows_sorted<double, CAPR>), dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
+                               (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
+        else
+            hipLaunchKernelGGL((k_permute_rows_sorted<uint32_t, CAPR>), dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
+                               (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
+    } else if (nnz && !sort_cols) {
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
         if (a->kind == B3C_F64)
             hipLaunchKernelGGL(k_permute_rows<double>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data,
@@ -364,6 +458,8 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
             hipLaunchKernelGGL(k_permute_rows<uint32_t>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
                                (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
     } else if (nnz) {
+        DevBuf<int64_t> k_in(ctx, nnz), k_out(ctx, nnz);
+        if (!k_in.p || !k_out.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort keys"); }
         hipLaunchKernelGGL(k_perm_keys<double>, dim3(grid_for(n, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr,
                            a->indices, old2new, k_in.p);
         int end_bit = 1;

@@ -99,7 +99,8 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
             n2o = torch.empty(n, dtype=torch.int32, device=dev)
             o2n = torch.empty(n, dtype=torch.int32, device=dev)
             ctx._check(ctx.lib.b3c_locality_order(ctx.h, counts.h, _native._ptr(n2o), _native._ptr(o2n)))
-            work = ctx.permute(counts, n2o, unsorted=True)     # rows moved + columns relabelled; no re-sort needed
+            # canonical (columns re-sorted inside each row): unsorted rows cost the SpMV 12 % more than the sort saves
+            work = ctx.permute(counts, n2o)
             idx = n2o.long()
             sites_t, lengths_t = sites_t[idx], lengths_t[idx]
         res._n2o, res._o2n = n2o, o2n
