@@ -56,6 +56,8 @@ SYMBOLS = [
     ('b3c_compress', C.c_int, [_VP, _VP, _VP, C.POINTER(_VP)]),
     ('b3c_max_value', C.c_int, [_VP, _VP, C.POINTER(C.c_double)]),
     ('b3c_kr_balance', C.c_int, [_VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, _VP, C.POINTER(KRInfo)]),
+    ('b3c_kr_balance_counts', C.c_int, [_VP, _VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, _VP, C.POINTER(KRInfo)]),
+    ('b3c_normalise_scale', C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
     ('b3c_louvain', C.c_int, [_VP, _VP, C.c_double, C.c_int, C.c_int, _VP, C.POINTER(LouvainInfo)]),
     ('b3c_graph_quantise', C.c_int, [_VP, _VP, C.c_double, _VP, C.POINTER(C.c_int32)]),
     ('b3c_locality_order', C.c_int, [_VP, _VP, _VP, _VP]),
@@ -287,6 +289,27 @@ class Context(object):
         if check:
             self._check(rc)
         return rc, x, info
+
+    def kr_balance_counts(self, counts, sites, tol=1e-6, delta=0.1, Delta=3.0, max_iter=1000, x_out=None, check=True):
+        """KR on the raw count matrix with 1/sites folded in (8 B per entry streamed) -> (rc, x, KRInfo)"""
+        if isinstance(sites, np.ndarray):
+            sites = np.ascontiguousarray(sites, dtype=np.float64)
+        x = np.empty(counts.n, dtype=np.float64) if x_out is None else x_out
+        info = KRInfo()
+        rc = self.lib.b3c_kr_balance_counts(self.h, counts.h, _ptr(sites), tol, delta, Delta, int(max_iter), _ptr(x),
+                                            C.byref(info))
+        if check:
+            self._check(rc)
+        return rc, x, info
+
+    def normalise_scale(self, counts, sites, x, graph_form=False):
+        if isinstance(sites, np.ndarray):
+            sites = np.ascontiguousarray(sites, dtype=np.float64)
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, dtype=np.float64)
+        h = _VP()
+        self._check(self.lib.b3c_normalise_scale(self.h, counts.h, _ptr(sites), _ptr(x), 1 if graph_form else 0, C.byref(h)))
+        return Mat(self, h)
 
     # ---- Louvain ----
     def louvain(self, mat, scl=1.0, n_sub=0, max_sweeps=0, labels_out=None):

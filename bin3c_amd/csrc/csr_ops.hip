@@ -69,6 +69,33 @@ __global__ void __launch_bounds__(BLK) k_scale_sym_graph(int64_t n, const int64_
     });
 }
 
+// site normalisation (contact_map.py:100-113, 1103-1108) fused with the final scaling of KR (sparse_utils.py:223-224):
+// a = counts * (1 / (s_i * s_j)) exactly as the reference forms it, then x_i*(a*x_j) or, in graph form, x_hi*(a*x_lo)
+template <int LPR>
+__global__ void __launch_bounds__(BLK) k_norm_scale(int64_t n, const int64_t *__restrict__ indptr,
+                                                     const int32_t *__restrict__ indices,
+                                                     const uint32_t *__restrict__ counts,
+                                                     const double *__restrict__ sites, const double *__restrict__ x,
+                                                     const int32_t *__restrict__ ids, int graph_form,
+                                                     double *__restrict__ out)
+{
+    for_rows<LPR>(n, indptr, [&](int64_t row, int64_t k) {
+        const int32_t j = indices[k];
+        double si = sites[row], sj = sites[j];
+        si = si == 0.0 ? 1.0 : si;
+        sj = sj == 0.0 ? 1.0 : sj;
+        const double a = (double)counts[k] * (1.0 / (si * sj));
+        const double xr = x[row], xj = x[j];
+        if (graph_form) {
+            const int32_t idr = ids ? ids[row] : (int32_t)row, idj = ids ? ids[j] : j;
+            const double xhi = idr >= idj ? xr : xj, xlo = idr >= idj ? xj : xr;
+            out[k] = xhi * (a * xlo);
+        } else {
+            out[k] = xr * (a * xj);
+        }
+    });
+}
+
 // max_offdiag (sparse_utils.py:269-281), symmetric input: row maximum with the diagonal skipped
 template <int LPR>
 __global__ void __launch_bounds__(BLK) k_max_offdiag_rows(int64_t n, const int64_t *__restrict__ indptr,
@@ -329,6 +356,43 @@ extern "C" int b3c_scale_sym_graph(b3c_ctx *ctx, b3c_mat *a, const double *x)
     a->value_symmetric = true;
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return B3C_OK;
+}
+
+extern "C" int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const double *sites, const double *x, int graph_form,
+                                   b3c_mat **out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!counts || counts->kind != B3C_U32 || !sites || !x || !out) return ctx->fail(B3C_E_ARG, "b3c_normalise_scale: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = counts->n;
+    b3c_mat *m = nullptr;
+    int rc = b3c_mat_alloc(ctx, n, counts->nnz, B3C_F64, &m);
+    if (rc) return rc;
+    DevBuf<double> ds(ctx, n), dx(ctx, n);
+    if (!ds.p || !dx.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale"); }
+    if ((rc = b3c_copy_in(ctx, ds.p, sites, sizeof(double) * (size_t)n)) || (rc = b3c_copy_in(ctx, dx.p, x, sizeof(double) * (size_t)n))) {
+        b3c_mat_free(ctx, m);
+        return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(m->indptr, counts->indptr, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(m->indices, counts->indices, sizeof(int32_t) * (size_t)counts->nnz, hipMemcpyDeviceToDevice, ctx->stream));
+    if (n) {
+        const int lpr = pick_lpr(counts);
+        DISPATCH_LPR(lpr, k_norm_scale, row_grid(ctx, n, lpr), ctx->stream, n, counts->indptr, counts->indices,
+                     (const uint32_t *)counts->data, ds.p, dx.p, counts->ids, graph_form ? 1 : 0, (double *)m->data);
+    }
+    m->ordered = counts->ordered;
+    m->sorted_cols = counts->sorted_cols;
+    m->value_symmetric = graph_form != 0;
+    if (counts->ids) {
+        m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+        if (!m->ids) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale"); }
+        HIP_TRY(ctx, hipMemcpyAsync(m->ids, counts->ids, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out = m;
     return B3C_OK;
 }
 

@@ -107,8 +107,11 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
                                               double *__restrict__ x, double *__restrict__ y, double *__restrict__ p,
                                               double *__restrict__ Z, const double *__restrict__ rk,
                                               const double *__restrict__ v, double *__restrict__ u,
-                                              double *__restrict__ part_out, int *__restrict__ flags)
+                                              const double *__restrict__ rs, double *__restrict__ part_out,
+                                              int *__restrict__ flags)
 {
+    // rs != nullptr: the matrix is stored as raw counts C and A = diag(rs) C diag(rs); the SpMV operand is then
+    // rs * (x*p) and the kernel that consumes it multiplies the row sum by rs again (see kr_kb_pipe)
     __shared__ double lds[BLK];
     KRState st = *sin;
     int yone = 0;
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
     const int64_t stride = (int64_t)gridDim.x * BLK;
     int64_t i = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x;
     if (entered == P_INIT) {
-        for (; i < n; i += stride) { x[i] = 1.0; u[i] = 1.0; }  // :126-127,134
+        for (; i < n; i += stride) { x[i] = 1.0; u[i] = rs ? rs[i] : 1.0; }  // :126-127,134
         return;
     }
     if (st.phase == A_INNER) {
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
                 double z = rk[i] / v[i];  // :158
                 Z[i] = z;
                 p[i] = z;                 // :159
-                u[i] = x[i] * z;
+                u[i] = rs ? rs[i] * (x[i] * z) : x[i] * z;
                 acc += rk[i] * z;         // :160
             }
             block_partial<0>(acc, part_out, lds);
@@ -173,7 +176,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
             for (; i < n; i += stride) {
                 double pn = Z[i] + beta * p[i];  // :163
                 p[i] = pn;
-                u[i] = x[i] * pn;
+                u[i] = rs ? rs[i] * (x[i] * pn) : x[i] * pn;
             }
         }
         return;
@@ -187,7 +190,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
         if (cut) yy += gamma * (alpha * p[i]);
         double xn = x[i] * yy;
         x[i] = xn;
-        u[i] = xn;
+        u[i] = rs ? rs[i] * xn : xn;
         bad |= (xn != xn);
     }
     if (bad) atomicOr(&flags[0], 1);
@@ -470,11 +473,12 @@ __global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t r0, int64_t n, const K
 // wait behind the indptr -> entries -> gather chain of the row before.  Measured at C3 (ordered matrix): 0.72 ms per
 // SpMV = 3.37 TB/s algorithmic, against 0.88 ms un-pipelined; non-temporal loads of the matrix stream made it slower.
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int UN>
+template <int LPR, int UN, typename VT>
 __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const KRState *__restrict__ sin,
                                                    KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
                                                    int PS, const int64_t *__restrict__ indptr,
-                                                   const int32_t *__restrict__ indices, const double *__restrict__ a,
+                                                   const int32_t *__restrict__ indices, const VT *__restrict__ a,
+                                                   const double *__restrict__ rs,
                                                    const double *__restrict__ dfix, const double *__restrict__ u,
                                                    const double *__restrict__ x, const double *__restrict__ p,
                                                    double *__restrict__ v, double *__restrict__ rk,
@@ -501,20 +505,20 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
     int64_t s = 0;
     int len = 0;
     int32_t c[UN];
-    double m[UN];
+    VT m[UN];                                   // kept RAW: converting at load time would force the wait up here
     if (row < n) {
         s = indptr[row];
         len = (int)(indptr[row + 1] - s);
     }
     {
         const int32_t *__restrict__ ci = indices + s;
-        const double *__restrict__ av = a + s;
+        const VT *__restrict__ av = a + s;
 #pragma unroll
         for (int q = 0; q < UN; q++) {
             const int i = q * LPR + sl;
             const bool ok = i < len;
             c[q] = ok ? ci[i] : 0;
-            m[q] = ok ? av[i] : 0.0;
+            m[q] = ok ? av[i] : VT(0);
         }
     }
     while (row < n) {
@@ -527,44 +531,46 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
             lenn = (int)(indptr[rown + 1] - sn);
         }
         // 2. this row: epilogue operands and gathers
-        double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0;
+        double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0, ri = 1.0;
         if (sl == 0) {
             xi = x[row];
-            di = dfix[row] * u[row];
             if (inner) { pi = p[row]; vi = v[row]; }
+            // unit diagonal where A's is zero, applied to the UNSCALED operand x*p (inner) or x (outer)
+            di = dfix[row] * (inner ? xi * pi : xi);
+            if (rs) ri = rs[row];
         }
         double g[UN];
 #pragma unroll
         for (int q = 0; q < UN; q++) g[q] = u[(uint32_t)c[q]];
         // 3. first chunk of the next row
         int32_t c2[UN];
-        double m2[UN];
+        VT m2[UN];
         {
             const int32_t *__restrict__ ci = indices + sn;
-            const double *__restrict__ av = a + sn;
+            const VT *__restrict__ av = a + sn;
 #pragma unroll
             for (int q = 0; q < UN; q++) {
                 const int i = q * LPR + sl;
                 const bool ok = i < lenn;
                 c2[q] = ok ? ci[i] : 0;
-                m2[q] = ok ? av[i] : 0.0;
+                m2[q] = ok ? av[i] : VT(0);
             }
         }
         double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < UN; q++) acc += m[q] * g[q];
+        for (int q = 0; q < UN; q++) acc += (double)m[q] * g[q];
         // rows longer than one chunk: plain loop over the rest
         for (int base = CH; base < len; base += CH) {
 #pragma unroll
             for (int q = 0; q < UN; q++) {
                 const int i = base + q * LPR + sl;
-                if (i < len) acc += a[s + i] * u[(uint32_t)indices[s + i]];
+                if (i < len) acc += (double)a[s + i] * u[(uint32_t)indices[s + i]];
             }
         }
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
         if (sl == 0) {
-            const double t = acc + di;
+            const double t = acc * ri + di;
             if (inner) {
                 const double wi = xi * t + vi * pi;
                 w[row] = wi;
@@ -868,8 +874,9 @@ __global__ void __launch_bounds__(BLK) kr_kd(int64_t r0, int64_t n, KRParams prm
 // set-up kernels
 // ---------------------------------------------------------------------------------------------
 // dfix[i] = 1 where the diagonal of row i is zero or absent (sparse_utils.py:110-115)
+template <typename VT>
 __global__ void kr_diag_fix(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                            const double *__restrict__ a, double *__restrict__ dfix, unsigned long long *n_zero)
+                            const VT *__restrict__ a, double *__restrict__ dfix, unsigned long long *n_zero)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int z = 0;
@@ -880,7 +887,7 @@ __global__ void kr_diag_fix(int64_t n, const int64_t *__restrict__ indptr, const
             int64_t mid = (lo + hi) >> 1;
             if (indices[mid] < i) lo = mid + 1; else hi = mid;
         }
-        double d = (lo < e && indices[lo] == i) ? a[lo] : 0.0;
+        double d = (lo < e && indices[lo] == i) ? (double)a[lo] : 0.0;
         z = d == 0.0;
         dfix[i] = z ? 1.0 : 0.0;
     }
@@ -889,9 +896,10 @@ __global__ void kr_diag_fix(int64_t n, const int64_t *__restrict__ indptr, const
 }
 
 // the same for rows whose columns are not ascending (B3C_PERMUTE_UNSORTED layouts): one wave scans the row
+template <typename VT>
 __global__ void __launch_bounds__(BLK) kr_diag_fix_scan(int64_t n, const int64_t *__restrict__ indptr,
                                                          const int32_t *__restrict__ indices,
-                                                         const double *__restrict__ a, double *__restrict__ dfix,
+                                                         const VT *__restrict__ a, double *__restrict__ dfix,
                                                          unsigned long long *n_zero)
 {
     const int lane = threadIdx.x & 63;
@@ -902,7 +910,7 @@ __global__ void __launch_bounds__(BLK) kr_diag_fix_scan(int64_t n, const int64_t
         const int64_t s = indptr[row], e = indptr[row + 1];
         double d = 0.0;
         for (int64_t k = s + lane; k < e; k += 64)
-            if (indices[k] == (int32_t)row) d = a[k];
+            if (indices[k] == (int32_t)row) d = (double)a[k];
         // at most one lane found it (no duplicates)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -929,8 +937,12 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
     return z ^ (z >> 31);
 }
 
+__device__ __forceinline__ unsigned long long value_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned long long value_bits(uint32_t v) { return (unsigned long long)v; }
+
+template <typename VT>
 __global__ void __launch_bounds__(BLK) kr_sym_hash(int64_t n, const int64_t *__restrict__ indptr,
-                                                    const int32_t *__restrict__ indices, const double *__restrict__ a,
+                                                    const int32_t *__restrict__ indices, const VT *__restrict__ a,
                                                     unsigned long long *__restrict__ sums)
 {
     const int lane = threadIdx.x & 63;
@@ -947,7 +959,7 @@ __global__ void __launch_bounds__(BLK) kr_sym_hash(int64_t n, const int64_t *__r
                 const int64_t k = base + t * 64 + lane;
                 const bool ok = k < e;
                 j[t] = ok ? indices[k] : (int32_t)row;
-                b[t] = ok ? (unsigned long long)__double_as_longlong(a[k]) : 0ull;
+                b[t] = ok ? value_bits(a[k]) : 0ull;
             }
 #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -976,9 +988,11 @@ __global__ void __launch_bounds__(BLK) kr_sym_hash(int64_t n, const int64_t *__r
 }
 
 // is_hermitian restated sparsely (sparse_utils.py:10-18): count entries with |a_ij - a_ji| >= tol
+// `sites` != nullptr: entries are raw counts and a_ij = c_ij * (1 / (s_i * s_j)) (contact_map.py:110-113)
+template <typename VT>
 __global__ void kr_asym_count(int64_t n, int sorted, const int64_t *__restrict__ indptr,
-                              const int32_t *__restrict__ indices, const double *__restrict__ a, double tol,
-                              unsigned long long *n_bad)
+                              const int32_t *__restrict__ indices, const VT *__restrict__ a,
+                              const double *__restrict__ sites, double tol, unsigned long long *n_bad)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
@@ -999,9 +1013,10 @@ __global__ void kr_asym_count(int64_t n, int sorted, const int64_t *__restrict__
             } else {
                 while (lo < je && indices[lo] != (int32_t)row) lo++;    // unsorted layout: scan (exact path only)
             }
-            double t = (lo < je && indices[lo] == (int32_t)row) ? a[lo] : 0.0;
+            double t = (lo < je && indices[lo] == (int32_t)row) ? (double)a[lo] : 0.0;
+            const double f = sites ? 1.0 / (sites[row] * sites[j]) : 1.0;
             // zero-diagonal substitution never touches off-diagonal entries
-            if (fabs(a[k] - t) >= tol) bad++;
+            if (fabs((double)a[k] * f - t * f) >= tol) bad++;
         }
     }
     bad = (unsigned long long)wave_sum_ll((long long)bad);
@@ -1030,6 +1045,17 @@ __global__ void __launch_bounds__(BLK) kr_fold(const double *__restrict__ part, 
     if (threadIdx.x == 0) *dst = r;
 }
 
+// sites 0 -> 1 (contact_map.py:1103-1108) and the row/column scale 1/s of the count form
+__global__ void kr_site_scale(int64_t n, double *__restrict__ sites, double *__restrict__ rs)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double sv = sites[i] == 0.0 ? 1.0 : sites[i];
+        sites[i] = sv;
+        rs[i] = 1.0 / sv;
+    }
+}
+
 template <int LPR>
 void launch_kb(hipStream_t s, int grid, int64_t n, const KRState *sin, KRState *sout, const double *partA, int PA,
                const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
@@ -1051,11 +1077,15 @@ void launch_kb_stream(hipStream_t s, int grid, size_t shmem, int64_t n, int64_t 
 
 template <int LPR, int UN>
 void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
-                    int PA, int PS, const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p,
-                    double *v, double *rk, double *w, double *part_out)
+                    int PA, int PS, const b3c_mat *m, const double *rs, const double *dfix, const double *u, const double *x,
+                    const double *p, double *v, double *rk, double *w, double *part_out)
 {
-    hipLaunchKernelGGL((kr_kb_pipe<LPR, UN>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                       m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
+    if (m->kind == B3C_U32)
+        hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
+    else
+        hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, double>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
 }
 
 template <int LPR, int UN>
@@ -1073,11 +1103,10 @@ void launch_kb_rows(hipStream_t s, int grid, int64_t r0, int64_t n, const KRStat
 
 }  // namespace
 
-extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double delta, double Delta,
-                              int64_t max_iter, double *x_out, b3c_kr_info *info)
+static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_in, double tol, double delta, double Delta,
+                           int64_t max_iter, double *x_out, b3c_kr_info *info)
 {
-    if (!ctx) return B3C_E_ARG;
-    if (!a || a->kind != B3C_F64 || !x_out || !info) return ctx->fail(B3C_E_ARG, "b3c_kr_balance: bad argument");
+    const bool counts = a->kind == B3C_U32;     // A = diag(1/s) C diag(1/s), never materialised
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     memset(info, 0, sizeof(*info));
     const int64_t n = a->n;
@@ -1112,6 +1141,7 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     // SpMV form: "rows" (default), "stream" (LDS-staged CSR-stream) or "wave" (plain wave-per-row)
     const char *kform = getenv("B3C_KR_KERNEL");
     if (getenv("B3C_KR_ROWWAVE")) kform = "wave";
+    if (counts) kform = "pipe";                  // the count form exists for the pipelined kernel only
     const bool stream_kb = !dist && kform && !strcmp(kform, "stream") && maxdeg <= 4096;
     const bool rows_kb = dist || (!stream_kb && !(kform && !strcmp(kform, "wave")));
     // default: sliced-ELL working layout when no row is extreme (a slice is as long as its longest row)
@@ -1148,25 +1178,41 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     int *flags = (int *)(counters.p + 2);
 
     HIP_TRY(ctx, hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * 4, s));
-    if (a->sorted_cols)
-        hipLaunchKernelGGL(kr_diag_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, a->indices,
-                           (const double *)a->data, dfix.p, counters.p);
-    else
-        hipLaunchKernelGGL(kr_diag_fix_scan, dim3(grid_for(n, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr, a->indices,
-                           (const double *)a->data, dfix.p, counters.p);
+    // count form: sanitised sites and their reciprocals on the device
+    DevBuf<double> sd(ctx, counts ? n : 1), rsd(ctx, counts ? n : 1);
+    const double *rs = nullptr;
+    if (counts) {
+        if (!sd.p || !rsd.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts");
+        int rc = b3c_copy_in(ctx, sd.p, sites_in, sizeof(double) * (size_t)n);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kr_site_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, sd.p, rsd.p);
+        rs = rsd.p;
+    }
+    const unsigned gn1 = (unsigned)((n + 255) / 256);
+    const int gscan = grid_for(n, BLK / 64, 16 * ctx->n_cu);
+    if (counts) {
+        if (a->sorted_cols) hipLaunchKernelGGL(kr_diag_fix<uint32_t>, dim3(gn1), dim3(256), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, counters.p);
+        else hipLaunchKernelGGL(kr_diag_fix_scan<uint32_t>, dim3(gscan), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, counters.p);
+    } else {
+        if (a->sorted_cols) hipLaunchKernelGGL(kr_diag_fix<double>, dim3(gn1), dim3(256), 0, s, n, a->indptr, a->indices, (const double *)a->data, dfix.p, counters.p);
+        else hipLaunchKernelGGL(kr_diag_fix_scan<double>, dim3(gscan), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, dfix.p, counters.p);
+    }
     {
         DevBuf<unsigned long long> hs(ctx, 4);
         if (!hs.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
         HIP_TRY(ctx, hipMemsetAsync(hs.p, 0, sizeof(unsigned long long) * 4, s));
-        hipLaunchKernelGGL(kr_sym_hash, dim3(grid_for(n, 4, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr, a->indices,
-                           (const double *)a->data, hs.p);
+        const int gh = grid_for(n, 4, 16 * ctx->n_cu);
+        if (counts) hipLaunchKernelGGL(kr_sym_hash<uint32_t>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, hs.p);
+        else hipLaunchKernelGGL(kr_sym_hash<double>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, hs.p);
         unsigned long long hh[4];
         HIP_TRY(ctx, hipMemcpyAsync(hh, hs.p, sizeof(hh), hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
         info->bitwise_symmetric = hh[0] == hh[2] && hh[1] == hh[3];
-        if (!info->bitwise_symmetric || getenv("B3C_KR_EXACT_SYMCHECK"))
-            hipLaunchKernelGGL(kr_asym_count, dim3(grid_for(n, 4, 8 * ctx->n_cu)), dim3(256), 0, s, n, a->sorted_cols ? 1 : 0,
-                               a->indptr, a->indices, (const double *)a->data, tol, counters.p + 1);
+        if (!info->bitwise_symmetric || getenv("B3C_KR_EXACT_SYMCHECK")) {
+            const int ga = grid_for(n, 4, 8 * ctx->n_cu);
+            if (counts) hipLaunchKernelGGL(kr_asym_count<uint32_t>, dim3(ga), dim3(256), 0, s, n, a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const uint32_t *)a->data, (const double *)sd.p, tol, counters.p + 1);
+            else hipLaunchKernelGGL(kr_asym_count<double>, dim3(ga), dim3(256), 0, s, n, a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const double *)a->data, (const double *)nullptr, tol, counters.p + 1);
+        }
     }
 
     // locality-ordered working copy (see reorder.hip): the iteration runs in the new numbering,
@@ -1178,9 +1224,13 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
         if (!new2old.p || !old2new.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
         int rc = b3c_locality_order_dev(ctx, a, new2old.p, old2new.p);
         if (rc) return rc;
-        if ((rc = b3c_permute_csr(ctx, a, new2old.p, old2new.p, &perm.m, false))) return rc;
+        if ((rc = b3c_permute_csr(ctx, a, new2old.p, old2new.p, &perm.m, true))) return rc;
         hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dfix.p, new2old.p, w.p);
         HIP_TRY(ctx, hipMemcpyAsync(dfix.p, w.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        if (counts) {
+            hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, rsd.p, new2old.p, w.p);
+            HIP_TRY(ctx, hipMemcpyAsync(rsd.p, w.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        }
         a = perm.m;
     }
     // ---- sliced-ELL working layout ----
@@ -1253,7 +1303,7 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
             KRState *s0 = states.p + (t & 1), *s1 = states.p + ((t + 1) & 1);
             // KA consumes part0 (rk.Z or gamma), may produce part1 (rk.Z for k == 1)
             hipLaunchKernelGGL(kr_ka, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : part0.p, dist ? D.world : G,
-                               dist ? 4 : 1, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, part1.p, flags);
+                               dist ? 4 : 1, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, rs, part1.p, flags);
             if (dist) {
                 hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part1.p, G, 0, my_scal);
                 int rc;
@@ -1283,10 +1333,10 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
                                    svals, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
             } else if (rows_kb && pipe_kb) {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
-                if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
             } else if (rows_kb) {
                 switch (lpr_r) {
                 case 32: launch_kb_rows<32, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
@@ -1389,4 +1439,21 @@ extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double
     if (h.rc == B3C_E_NOCONV)
         return ctx->fail(B3C_E_NOCONV, "matrix balancing failed to converge in %lld iterations", (long long)h.n_iter);
     return B3C_OK;
+}
+
+extern "C" int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double delta, double Delta,
+                              int64_t max_iter, double *x_out, b3c_kr_info *info)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a || a->kind != B3C_F64 || !x_out || !info) return ctx->fail(B3C_E_ARG, "b3c_kr_balance: bad argument");
+    return kr_balance_impl(ctx, a, nullptr, tol, delta, Delta, max_iter, x_out, info);
+}
+
+extern "C" int b3c_kr_balance_counts(b3c_ctx *ctx, const b3c_mat *counts, const double *sites, double tol, double delta,
+                                     double Delta, int64_t max_iter, double *x_out, b3c_kr_info *info)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!counts || counts->kind != B3C_U32 || !sites || !x_out || !info)
+        return ctx->fail(B3C_E_ARG, "b3c_kr_balance_counts: bad argument");
+    return kr_balance_impl(ctx, counts, sites, tol, delta, Delta, max_iter, x_out, info);
 }

@@ -121,26 +121,20 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
                     mask_w = mask_w[n2o.long()]
             t['mask'] = time.perf_counter() - t0
 
+            # contact_map.py:933 + :939 (-> sparse_utils.py:90): site normalisation folded into the balancing of the
+            # raw counts (8 bytes per entry instead of 12), then one pass writes the balanced map: normalisation
+            # exactly as the reference forms it and X A X (sparse_utils.py:223-224).  A bitwise-symmetric A (the
+            # normal case: counts are symmetric by construction) is written in graph form so that Louvain needs no
+            # mirror lookups; otherwise exactly as scipy does.
             t0 = time.perf_counter()
-            a = ctx.site_norm(work, sites_t)                               # contact_map.py:929-933
-            t['norm'] = time.perf_counter() - t0
+            x_w = torch.empty(n, dtype=torch.float64, device=dev)
+            rc, _, res.kr_info = ctx.kr_balance_counts(work, sites_t, tol=tol, x_out=x_w, check=False)
+            ctx._check(rc)
+            a = ctx.normalise_scale(work, sites_t, x_w, graph_form=bool(res.kr_info.bitwise_symmetric))
+            t['kr'] = time.perf_counter() - t0
         finally:
             if work is not counts:
                 work.free()
-
-        t0 = time.perf_counter()
-        x_w = torch.empty(n, dtype=torch.float64, device=dev)
-        rc, _, res.kr_info = ctx.kr_balance(a, tol=tol, x_out=x_w, check=False)   # contact_map.py:939 -> sparse_utils.py:90
-        if rc != _native.OK:
-            a.free()
-            ctx._check(rc)
-        # sparse_utils.py:223-224.  A bitwise-symmetric A (the normal case: counts are symmetric by construction)
-        # is scaled in graph form so that Louvain needs no mirror lookups; otherwise exactly as scipy does.
-        if res.kr_info.bitwise_symmetric:
-            ctx.scale_sym_graph(a, x_w)
-        else:
-            ctx.scale_sym(a, x_w)
-        t['kr'] = time.perf_counter() - t0
         res.processed = a
 
         labels_t = None

@@ -178,6 +178,20 @@ int b3c_max_value(b3c_ctx *ctx, const b3c_mat *a, double *out);
 int b3c_kr_balance(b3c_ctx *ctx, const b3c_mat *a, double tol, double delta, double Delta, int64_t max_iter,
                    double *x /*host|dev*/, b3c_kr_info *info);
 
+/* The same balancing on the RAW COUNT matrix: A = diag(1/s) C diag(1/s) is never materialised, the SpMV streams
+ * 8 bytes per stored entry (uint32 count + int32 column) instead of 12 and folds the two 1/s factors into its operand
+ * and its row epilogue.  Replaces the pair contact_map.py:933 (_norm_seq) + :939 (_bisto_seq) of prepare_seq_map.
+ * Mathematically identical to b3c_kr_balance(b3c_site_norm(counts, sites)); x agrees to rounding (the reference
+ * rounds 1/(s_i*s_j) once per entry, this form rounds 1/s_i and 1/s_j) -- tests hold it to 1e-9 of the reference. */
+int b3c_kr_balance_counts(b3c_ctx *ctx, const b3c_mat *counts, const double *sites /*host|dev*/, double tol, double delta,
+                          double Delta, int64_t max_iter, double *x /*host|dev*/, b3c_kr_info *info);
+
+/* Companion of b3c_kr_balance_counts: out_ij = x_i * (a_ij * x_j) with a_ij = counts_ij * (1 / (s_i * s_j)) formed
+ * exactly as contact_map.py:110-113 does, i.e. bit-identical to b3c_site_norm + b3c_scale_sym (graph_form = 0) or
+ * + b3c_scale_sym_graph (graph_form != 0; requires b3c_kr_info.bitwise_symmetric).  One pass instead of two. */
+int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const double *sites /*host|dev*/, const double *x /*host|dev*/,
+                        int graph_form, b3c_mat **out);
+
 /* ---- Louvain ------------------------------------------------------------------------------- */
 
 /* to_graph's weight scaling (cluster.py:316-321) + louvain.cluster / community.best_partition

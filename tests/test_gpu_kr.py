@@ -175,3 +175,27 @@ def test_kr_on_permuted_layouts(ctx):
     pm = ctx.permute(ctx.upload(g['in_indptr'], g['in_indices'], d), perm, unsorted=True)
     _, _, info = ctx.kr_balance(pm, check=False)
     assert info.is_symmetric == 0
+
+
+@pytest.mark.parametrize('n,e,seed', [(1500, 40000, 23), (40000, 1300000, 21)])
+def test_kr_on_raw_counts_equals_kr_on_normalised_matrix(ctx, oracle_lib, n, e, seed):
+    """b3c_kr_balance_counts (8 B/entry, 1/sites folded in) against the oracle on the explicitly normalised matrix,
+    and b3c_normalise_scale against site_norm + scale_sym bit for bit."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(n, e, seed)
+    sm.sites[::97] = 0.0                                               # zero sites count as one (contact_map.py:1107)
+    nd = oracle_lib.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
+    rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
+    counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    _, x, info = ctx.kr_balance_counts(counts, sm.sites)
+    assert info.n_iter == st.n_iter and info.n_zero_diag == st.n_zero_diag and info.bitwise_symmetric == 1
+    np.testing.assert_allclose(x, xo, rtol=1e-9)
+    a = ctx.site_norm(counts, sm.sites)
+    ctx.scale_sym(a, x)
+    _, _, want = a.download(structure=False)
+    got = ctx.normalise_scale(counts, sm.sites, x, graph_form=False)
+    assert np.array_equal(got.download(structure=False)[2], want)
+    a2 = ctx.site_norm(counts, sm.sites)
+    ctx.scale_sym_graph(a2, x)
+    got = ctx.normalise_scale(counts, sm.sites, x, graph_form=True)
+    assert np.array_equal(got.download(structure=False)[2], a2.download(structure=False)[2])
