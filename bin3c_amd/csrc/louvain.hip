@@ -247,6 +247,12 @@ __device__ __forceinline__ Best best_wave_reduce(Best b)
     return b;
 }
 
+struct NodeRec {
+    int32_t node;
+    int32_t deg;
+    int64_t start;
+};
+
 // table entries needed for a node of degree deg (worst case: every neighbour in its own community)
 __host__ __device__ __forceinline__ int table_lg(int64_t deg)
 {
@@ -259,7 +265,8 @@ __host__ __device__ __forceinline__ int table_lg(int64_t deg)
 // Loads first: every lane pulls four (index, weight) pairs, then the four community gathers, then inserts, so
 // that a wave keeps ~3 KB of independent loads in flight instead of one dependent chain per 64 entries.
 template <int CAP>
-__global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int skip_upto, int n_sub, int round, u64 m2,
+__global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const NodeRec *__restrict__ hubs, int skip_upto,
+                                                    int n_sub, int round, u64 m2,
                                                     const int64_t *__restrict__ indptr,
                                                     const int32_t *__restrict__ indices,
                                                     const int64_t *__restrict__ q, const int32_t *__restrict__ ids,
@@ -280,7 +287,9 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int sk
     for (int t = lane; t < CAP; t += 64) { lk[t] = EMPTY; lv[t] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
-    for (int64_t i = r0 + wave; i < n; i += nwave) {   // rows [r0, n) of this rank
+    // hubs != nullptr: iterate the prepared list hubs[r0 .. n) of this sub-round; else rows [r0, n) of this rank
+    for (int64_t it = r0 + wave; it < n; it += nwave) {
+        const int64_t i = hubs ? hubs[it].node : it;
         const int32_t id = ids ? ids[i] : (int32_t)i;
         if (bucket_of(id, n_sub) != (uint32_t)round) continue;
         const long long ki = kdeg[i];
@@ -386,12 +395,6 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, int sk
 // summed in registers; only groups that saw a foreign community take turns on the wave's LDS table.
 // The node list of a sub-round is fixed for a level (the bucket depends on the id only), so it is built once.
 // ---------------------------------------------------------------------------------------------
-struct NodeRec {
-    int32_t node;
-    int32_t deg;
-    int64_t start;
-};
-
 __global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, int round, int max_deg,
                                 const int64_t *__restrict__ indptr, const int32_t *__restrict__ ids,
                                 const int64_t *__restrict__ kdeg, int64_t *__restrict__ flag)
@@ -400,7 +403,9 @@ __global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, int round, in
     if (i < r1) {
         const int64_t deg = indptr[i + 1] - indptr[i];
         const int32_t id = ids ? ids[i] : (int32_t)i;
-        flag[i - r0] = bucket_of(id, n_sub) == (uint32_t)round && kdeg[i] != 0 && deg <= max_deg;
+        // max_deg > 0: nodes with at most max_deg entries; max_deg < 0: nodes with MORE than -max_deg entries
+        const bool len_ok = max_deg >= 0 ? deg <= max_deg : deg > -max_deg;
+        flag[i - r0] = bucket_of(id, n_sub) == (uint32_t)round && kdeg[i] != 0 && len_ok;
     }
     if (i == r1) flag[i - r0] = 0;
 }
@@ -706,6 +711,75 @@ __global__ void __launch_bounds__(BLK) k_make_pairs(int64_t n, int64_t kc, const
     }
 }
 
+// Pre-reduced pairs: per node ONE pair for everything that stays inside its new community (loops doubled) and one
+// pair per entry that leaves it.  After convergence ~90 % of the entries are internal, so the sort below handles
+// n + (foreign entries) keys instead of nnz.
+__global__ void __launch_bounds__(BLK) k_pairs_count(int64_t n, const int64_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ indices, const int32_t *__restrict__ cn,
+                                                      int64_t *__restrict__ cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        const int32_t c1 = cn[row];
+        int f = 0;
+        for (int64_t base = s; base < e; base += 256) {
+            int32_t j[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                j[t] = k < e ? indices[k] : (int32_t)row;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) f += (j[t] != (int32_t)row && cn[j[t]] != c1) ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) f += __shfl_down(f, o, 64);
+        if (lane == 0) cnt[row] = e > s ? f + 1 : 0;      // +1: the node's own-community pair
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[n] = 0;
+}
+
+__global__ void __launch_bounds__(BLK) k_pairs_fill(int64_t n, int64_t kc, const int64_t *__restrict__ indptr,
+                                                     const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
+                                                     const int32_t *__restrict__ cn, const int64_t *__restrict__ pos,
+                                                     int64_t *__restrict__ keys, int64_t *__restrict__ vals)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        if (e == s) continue;
+        const int64_t c1 = cn[row];
+        int64_t o = pos[row] + 1;                           // slot pos[row] holds the own-community pair
+        long long own = 0;
+        for (int64_t base = s; base < e; base += 64) {
+            const int64_t k = base + lane;
+            int32_t j = (int32_t)row;
+            long long qv = 0;
+            if (k < e) { j = indices[k]; qv = q[k]; }
+            const int32_t c2 = k < e ? cn[j] : (int32_t)c1;
+            const bool foreign = k < e && j != (int32_t)row && c2 != (int32_t)c1;
+            if (k < e && !foreign) own += j == (int32_t)row ? 2 * qv : qv;   // loops doubled so the internal total halves exactly
+            const unsigned long long b = __ballot(foreign);
+            if (foreign) {
+                const int at = __popcll(b & ((1ull << lane) - 1ull));
+                keys[o + at] = c1 * kc + c2;
+                vals[o + at] = qv;
+            }
+            o += __popcll(b);
+        }
+        own = wave_sum_ll(own);
+        if (lane == 0) {
+            keys[pos[row]] = c1 * kc + c1;
+            vals[pos[row]] = own;
+        }
+    }
+}
+
 __global__ void k_rows_from_keys(int64_t kc, int64_t nu, const int64_t *__restrict__ ukeys,
                                  int64_t *__restrict__ indptr)
 {
@@ -974,6 +1048,24 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipStreamSynchronize(s));
         }
         const bool need_wave_kernel = !grouped || maxdeg > short_max;
+        // the hubs that the grouped kernel leaves out, per sub-round (usually a handful)
+        DevBuf<NodeRec> hlist(ctx, grouped && need_wave_kernel ? nloc : 1);
+        std::vector<int64_t> hoff(n_sub + 1, 0);
+        if (grouped && need_wave_kernel) {
+            DevBuf<int64_t> lflag(ctx, nloc + 1), lpos(ctx, nloc + 1);
+            if (!hlist.p || !lflag.p || !lpos.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hub lists"); }
+            const unsigned gl = (unsigned)((nloc + 256) / 256);
+            for (int r = 0; r < n_sub; r++) {
+                hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, r, -short_max, g.indptr, ids, kdeg.p, lflag.p);
+                if ((rc = b3c_exclusive_scan_i64(ctx, lflag.p, lpos.p, nloc + 1))) { free_graph(ctx, g); return rc; }
+                int64_t cntr = 0;
+                HIP_TRY(ctx, hipMemcpyAsync(&cntr, lpos.p + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(ctx, hipStreamSynchronize(s));
+                hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, lflag.p, lpos.p, g.indptr, hlist.p + hoff[r]);
+                hoff[r + 1] = hoff[r] + cntr;
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+        }
 
         auto modularity = [&](double *out) -> int {
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64) * 5, s));
@@ -1024,10 +1116,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     }
 #undef LV_DECIDE_G
                 }
-                if (need_wave_kernel) {
-                    const int skip = grouped ? short_max : -1;
+                if (need_wave_kernel && (!grouped || hoff[r + 1] > hoff[r])) {
+                    // all rows of this rank (small levels), or just the hubs the grouped kernel left out
+                    const NodeRec *hubs = grouped ? hlist.p + hoff[r] : nullptr;
+                    const int64_t w0 = grouped ? 0 : r0, w1 = grouped ? hoff[r + 1] - hoff[r] : r1;
+                    const int gwh = grid_for(w1 - w0, WPB, 16 * ctx->n_cu);
 #define LV_DECIDE(C)                                                                                                     \
-    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gwl), dim3(BLK), 0, s, r0, r1, skip, n_sub, r, m2, g.indptr, g.indices, g.q, ids, \
+    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gwh), dim3(BLK), 0, s, w0, w1, hubs, -1, n_sub, r, m2, g.indptr, g.indices, g.q, ids, \
                        kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p)
                     switch (cap) {
                     case 128: LV_DECIDE(128); break;
@@ -1075,13 +1170,19 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         info->n_comm = (int32_t)kc;
 
         // ---- induced graph: sort (community pair) keys, sum weights ----
-        const int64_t m = g.nnz;
+        DevBuf<int64_t> pcnt(ctx, n + 1), ppos(ctx, n + 1);
+        if (!pcnt.p || !ppos.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation counts"); }
+        hipLaunchKernelGGL(k_pairs_count, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, cn.p, pcnt.p);
+        if ((rc = b3c_exclusive_scan_i64(ctx, pcnt.p, ppos.p, n + 1))) { free_graph(ctx, g); return rc; }
+        int64_t m = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&m, ppos.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
         DevBuf<int64_t> k_in(ctx, m), k_out(ctx, m), v_in(ctx, m), v_out(ctx, m), nruns(ctx, 1);
         if (!k_in.p || !k_out.p || !v_in.p || !v_out.p || !nruns.p) {
             free_graph(ctx, g);
             return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation buffers");
         }
-        hipLaunchKernelGGL(k_make_pairs, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, k_in.p, v_in.p);
+        hipLaunchKernelGGL(k_pairs_fill, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, ppos.p, k_in.p, v_in.p);
         int end_bit = 1;
         while (end_bit < 63 && ((unsigned __int128)1 << end_bit) < (unsigned __int128)kc * (unsigned __int128)kc) end_bit++;
         size_t tb = 0;

@@ -1,0 +1,21 @@
+"""F64 vs raw-count KR on the same ordered map (development probe; GPU box only)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ['B3C_PROFILE'] = '1'
+import numpy as np
+from bin3c_amd.pipeline import make_context
+from bin3c_amd.synth import make_synth, CONFIGS
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'C2'
+n, E, seed, law = CONFIGS[cfg]
+sm = make_synth(n, E, seed, law)
+ctx = make_context(0)
+counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
+n2o, o2n = ctx.locality_order(counts)
+work = ctx.permute(counts, n2o)
+sites = sm.sites[n2o]
+a = ctx.site_norm(work, sites)
+for rep in range(3):
+    t = time.time(); _, x1, i1 = ctx.kr_balance(a); d1 = time.time() - t
+    t = time.time(); _, x2, i2 = ctx.kr_balance_counts(work, sites); d2 = time.time() - t
+    print('f64: %.2f ms (spmv %.2f, %d it)   counts: %.2f ms (spmv %.2f, %d it)   max rel diff %.2e' % (
+        d1 * 1e3, i1.spmv_ms, i1.n_iter, d2 * 1e3, i2.spmv_ms, i2.n_iter, np.max(np.abs(x1 - x2) / x1)))
