@@ -30,6 +30,20 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def measured_traffic(config, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes on this workload); None when no measurement is on file."""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        with open(path) as fh:
+            rec = json.load(fh).get(config, {})
+        if rec and rec.get('kernel', '').split()[0] == kernel.split()[0]:
+            return rec.get('hbm_bytes_per_launch')
+    except (IOError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(sample_n, sample_e, seed):
     """Oracle (scalar C port of the reference path) on a bounded sample of the same workload, 1 thread."""
     import oracle
@@ -140,10 +154,12 @@ def main():
         n_acc = int(last.mask.sum())
         if spmv_ms >= move_ms:
             per_launch = 12.0 * nnz + 20.0 * n             # one KR SpMV
+            streamed = 8.0 * nnz + 36.0 * n                # what kr_kb_pipe<uint32> physically reads/writes (raw counts)
             avg_ms = spmv_ms / max(spmv_n, 1)
-            kname = 'kr_kb (CSR SpMV + fused KR epilogue)'
+            kname = 'kr_kb_pipe (CSR SpMV on raw counts + fused KR epilogue)'
         else:
             per_launch = (16.0 * move_nnz + 28.0 * move_rows) / max(move_n, 1)   # Louvain sweep / n_sub
+            streamed = per_launch
             avg_ms = move_ms / max(move_n, 1)
             kname = 'k_lv_decide (Louvain delta-Q neighbour scan)'
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
@@ -164,8 +180,8 @@ def main():
                        'stage_ms': {k: v / args.steps * 1e3 for k, v in stage.items()},
                        'kernel_ms': {'kr_spmv_total': spmv_ms / args.steps, 'louvain_decide_total': move_ms / args.steps}},
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'bytes_per_launch': per_launch, 'avg_launch_ms': avg_ms},
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(args.config, kname),
+                         'bytes_per_launch': per_launch, 'bytes_streamed_per_launch': streamed, 'avg_launch_ms': avg_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             sample = {'C1': (1000, 50000), 'C2': (100000, 5000000), 'C3': (200000, 10000000)}[args.config]

@@ -8,7 +8,8 @@ from bin3c_amd.synth import make_synth, CONFIGS
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'C2'
 n, E, seed, law = CONFIGS[cfg]
 sm = make_synth(n, E, seed, law)
-ctx = make_context(0)
+from bin3c_amd import _native
+ctx = make_context(0) if os.environ.get('B3C_PROBE_STREAM', 'torch') == 'torch' else _native.Context(0)
 counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
 n2o, o2n = ctx.locality_order(counts)
 work = ctx.permute(counts, n2o)
