@@ -91,23 +91,25 @@ def main():
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
     from bin3c_amd.pipeline import make_context, run_hot_path
-    from bin3c_amd.synth import CONFIGS, make_synth
+    from bin3c_amd.synth import CONFIGS, make_edges
 
     n, n_edges, seed, law = CONFIGS[args.config]
     sharded = world > 1 and args.mode == 'sharded'
     # sharded: every rank builds the same map and owns a row range of it; replicas: one map per rank
-    sm = make_synth(n, n_edges, seed if sharded else seed + rank, law)
-    e_true = sm.n_edges
     ctx = make_context(local_rank)
+    # pair stream drawn on the host (numpy RandomState, deterministic), accumulated into the symmetric count matrix on
+    # the device (b3c_coo_symmetrise: the ingest tail, bit-identical to synth.symmetrise_to_csr)
+    lo, hi, cnt, diag, lengths_h, sites_h, _genome = make_edges(n, n_edges, seed if sharded else seed + rank, law)
+    counts, e_true = ctx.coo_symmetrise(n, lo, hi, cnt, diag)
+    del lo, hi, cnt
     sess = None
     if sharded:
         from bin3c_amd.dist import DistSession
         sess = DistSession(ctx, n)
-    counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
     # inputs resident in HBM before the timed region: the count matrix and the two per-contig tables
-    sites = torch.as_tensor(sm.sites, device='cuda')
-    lengths = torch.as_tensor(sm.lengths.astype(np.int64), device='cuda')
-    nnz = sm.nnz
+    sites = torch.as_tensor(sites_h, device='cuda')
+    lengths = torch.as_tensor(lengths_h.astype(np.int64), device='cuda')
+    nnz = counts.nnz
     min_len, min_sig = 1000, 5
 
     def barrier():

@@ -60,6 +60,7 @@ SYMBOLS = [
     ('b3c_normalise_scale', C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
     ('b3c_louvain', C.c_int, [_VP, _VP, C.c_double, C.c_int, C.c_int, _VP, C.POINTER(LouvainInfo)]),
     ('b3c_graph_quantise', C.c_int, [_VP, _VP, C.c_double, _VP, C.POINTER(C.c_int32)]),
+    ('b3c_coo_symmetrise', C.c_int, [_VP, C.c_int64, C.c_int64, _VP, _VP, _VP, _VP, C.POINTER(_VP), C.POINTER(C.c_int64)]),
     ('b3c_locality_order', C.c_int, [_VP, _VP, _VP, _VP]),
     ('b3c_mat_permute', C.c_int, [_VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
     ('b3c_mat_ids', C.c_int, [_VP, _VP, _VP]),
@@ -219,6 +220,24 @@ class Context(object):
         h = _VP()
         self._check(self.lib.b3c_mat_upload(self.h, n, nnz, _ptr(indptr), _ptr(indices), _ptr(data), kind, C.byref(h)))
         return Mat(self, h)
+
+    # ---- ingest tail ----
+    def coo_symmetrise(self, n, lo, hi, counts, diag=None):
+        """pair stream -> (symmetric uint32 CSR Mat, undirected off-diagonal edge count)"""
+        if isinstance(lo, np.ndarray):
+            lo = np.ascontiguousarray(lo, dtype=np.int64)
+            hi = np.ascontiguousarray(hi, dtype=np.int64)
+            counts = np.ascontiguousarray(counts, dtype=np.uint32)
+            m = lo.shape[0]
+        else:
+            m = lo.numel()
+        if isinstance(diag, np.ndarray):
+            diag = np.ascontiguousarray(diag, dtype=np.uint32)
+        h = _VP()
+        ne = C.c_int64()
+        self._check(self.lib.b3c_coo_symmetrise(self.h, int(n), int(m), _ptr(lo), _ptr(hi), _ptr(counts), _ptr(diag), C.byref(h),
+                                                C.byref(ne)))
+        return Mat(self, h), ne.value
 
     # ---- locality ordering ----
     def locality_order(self, mat):

@@ -119,6 +119,16 @@ int b3c_mat_download(b3c_ctx *ctx, const b3c_mat *m, int64_t *indptr, int32_t *i
 /* Raw device pointers of a matrix (for zero-copy consumers such as torch tensors). */
 int b3c_mat_device_ptrs(const b3c_mat *m, void **indptr, void **indices, void **data);
 
+/* ---- ingest tail: pair stream -> symmetric count matrix ------------------------------------- */
+
+/* Sparse2DAccumulator.get_coo (sparse_utils.py:246-266) on the device: `m` observations (lo[k], hi[k], counts[k])
+ * in any order and orientation are summed per unordered pair (saturating at 2^32-1), self pairs are dropped, the
+ * strict upper triangle is mirrored, and diag[n] (NULL: none) supplies the self-contact counts.  Result: canonical
+ * symmetric B3C_U32 CSR, the input of the cluster path.  n_edges (may be NULL) receives the number of undirected
+ * off-diagonal edges.  lo/hi: int64[m], counts: uint32[m], diag: uint32[n]; all host|dev. */
+int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int64_t *lo, const int64_t *hi, const uint32_t *counts,
+                       const uint32_t *diag, b3c_mat **out, int64_t *n_edges);
+
 /* ---- locality ordering (performance only; results never depend on it) -------------------- */
 
 /* Order the contigs of a symmetric matrix so that strongly linked ones are adjacent (three Boruvka
