@@ -117,3 +117,46 @@ def compress(_m, _mask, ctx=None):
         mat.free()
     n = ip.shape[0] - 1
     return scisp.csr_matrix((data.astype(_m.dtype, copy=False), ix, ip), shape=(n, n)).tocoo()
+
+
+class Coo4D(object):
+    """Minimal stand-in for the pydata ``sparse.COO`` objects of the tip-based path (absent from this image): the
+    three attributes the reference touches -- ``coords`` (4 x nnz), ``data`` (nnz), ``shape`` (N, N, 2, 2)."""
+
+    def __init__(self, coords, data, shape):
+        self.coords = np.asarray(coords)
+        self.data = np.asarray(data)
+        self.shape = tuple(shape)
+        assert self.coords.shape == (4, self.data.shape[0]) and len(self.shape) == 4
+
+    @property
+    def nnz(self):
+        return self.data.shape[0]
+
+    def astype(self, dtype):
+        return Coo4D(self.coords, self.data.astype(dtype), self.shape)
+
+
+def dotdot(_m, _a):
+    """
+    dot(A.T, dot(M, A)) for a diagonal A given by its trace ``_a`` on a 4-D sparse tensor (sparse_utils.py:480-492):
+    every stored element is scaled by ``_a[i] * _a[j]``, in place.
+    """
+    _a = np.asarray(_a)
+    _m.data *= _a[_m.coords[0]] * _a[_m.coords[1]]
+    return _m
+
+
+def kr_biostochastic_4d(m4d, **kwargs):
+    """
+    Knight-Ruiz for an N x N x 2 x 2 tip tensor (sparse_utils.py:495-508): scale factors from the N x N matrix of
+    2 x 2 block sums (balanced on the GPU), then every tensor element scaled by a_i * a_j.
+
+    :param m4d: object with ``coords`` (4 x nnz), ``data``, ``shape`` -- pydata sparse.COO or :class:`Coo4D`
+    :return: (scaled tensor as float, scale factors)
+    """
+    n = m4d.shape[0]
+    data = np.asarray(m4d.data, dtype=np.float64)
+    m2d = scisp.coo_matrix((data, (np.asarray(m4d.coords[0]), np.asarray(m4d.coords[1]))), shape=(n, n)).tocsr()
+    _, scl = kr_biostochastic(m2d, **kwargs)
+    return dotdot(m4d.astype(np.float64), scl), scl

@@ -199,3 +199,24 @@ def test_kr_on_raw_counts_equals_kr_on_normalised_matrix(ctx, oracle_lib, n, e, 
     ctx.scale_sym_graph(a2, x)
     got = ctx.normalise_scale(counts, sm.sites, x, graph_form=True)
     assert np.array_equal(got.download(structure=False)[2], a2.download(structure=False)[2])
+
+
+def test_kr_4d_wrapper(ctx):
+    """kr_biostochastic_4d / dotdot (sparse_utils.py:480-508) on a synthetic N x N x 2 x 2 tip tensor."""
+    from bin3c_amd.mzd import sparse_utils
+    g = np.load(os.path.join(GOLDEN, 'kr_random1000.npz'))
+    n = g['in_indptr'].shape[0] - 1
+    rows = np.repeat(np.arange(n), np.diff(g['in_indptr']))
+    rs = np.random.RandomState(4)
+    # split every 2-D entry into its 2x2 block so that the block sums reproduce the fixture matrix
+    parts = rs.dirichlet(np.ones(4), size=rows.shape[0])
+    coords = np.vstack([np.repeat(rows, 4), np.repeat(g['in_indices'], 4), np.tile([0, 0, 1, 1], rows.shape[0]),
+                        np.tile([0, 1, 0, 1], rows.shape[0])])
+    data = (parts * g['in_data'][:, None]).ravel()
+    t = sparse_utils.Coo4D(coords, data, (n, n, 2, 2))
+    out, scl = sparse_utils.kr_biostochastic_4d(t, ctx=ctx)
+    np.testing.assert_allclose(scl, g['x'], rtol=1e-9)
+    np.testing.assert_allclose(out.data, data * scl[coords[0]] * scl[coords[1]], rtol=1e-15)
+    # block sums of the scaled tensor are the balanced matrix
+    back = sp.coo_matrix((out.data, (coords[0], coords[1])), shape=(n, n)).tocsr()
+    np.testing.assert_allclose(np.asarray(back.sum(axis=1)).ravel(), 1.0, atol=5e-6)
