@@ -692,25 +692,6 @@ __global__ void k_update_labels(int64_t n0, int32_t *__restrict__ labels, const 
     }
 }
 
-__global__ void __launch_bounds__(BLK) k_make_pairs(int64_t n, int64_t kc, const int64_t *__restrict__ indptr,
-                                                     const int32_t *__restrict__ indices,
-                                                     const int64_t *__restrict__ q, const int32_t *__restrict__ cn,
-                                                     int64_t *__restrict__ keys, int64_t *__restrict__ vals)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * WPB;
-    for (int64_t row = wave; row < n; row += nwave) {
-        const int64_t s = indptr[row], e = indptr[row + 1];
-        const int64_t c1 = cn[row];
-        for (int64_t k = s + lane; k < e; k += 64) {
-            const int32_t j = indices[k];
-            keys[k] = c1 * kc + cn[j];
-            vals[k] = j == (int32_t)row ? 2 * q[k] : q[k];   // loops doubled so the internal total halves exactly
-        }
-    }
-}
-
 // Pre-reduced pairs: per node ONE pair for everything that stays inside its new community (loops doubled) and one
 // pair per entry that leaves it.  After convergence ~90 % of the entries are internal, so the sort below handles
 // n + (foreign entries) keys instead of nnz.
