@@ -609,11 +609,42 @@ __global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int roun
         com[i] = b;
         cnt++;
     }
-    u64 bal = __ballot(cnt != 0);
-    if (bal) {
-        long long c = wave_sum_ll(cnt);
-        if ((threadIdx.x & 63) == 0) atomicAdd(moved, (u64)c);
+    __shared__ int bcnt;
+    if (threadIdx.x == 0) bcnt = 0;
+    __syncthreads();
+    const long long c = wave_sum_ll(cnt);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&bcnt, (int)c);
+    __syncthreads();
+    if (threadIdx.x == 0 && bcnt) atomicAdd(moved, (u64)bcnt);
+}
+
+// the same over a prepared node list (single-GPU: only the nodes of the sub-round are visited)
+__global__ void __launch_bounds__(BLK) k_lv_apply_list(int64_t cnt, const NodeRec *__restrict__ list,
+                                                        const int64_t *__restrict__ kdeg, int64_t *__restrict__ tot,
+                                                        int32_t *__restrict__ com, const int32_t *__restrict__ nxt,
+                                                        int32_t *__restrict__ csize, u64 *__restrict__ moved)
+{
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    int c = 0;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < cnt; t += stride) {
+        const int32_t i = list[t].node;
+        const int32_t a = com[i], b = nxt[i];
+        if (a == b) continue;
+        const long long ki = kdeg[i];
+        atomicAdd((u64 *)&tot[a], (u64)(-ki));
+        atomicAdd((u64 *)&tot[b], (u64)ki);
+        atomicSub(&csize[a], 1);
+        atomicAdd(&csize[b], 1);
+        com[i] = b;
+        c++;
     }
+    __shared__ int bcnt;
+    if (threadIdx.x == 0) bcnt = 0;
+    __syncthreads();
+    const long long w = wave_sum_ll(c);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&bcnt, (int)w);
+    __syncthreads();
+    if (threadIdx.x == 0 && bcnt) atomicAdd(moved, (u64)bcnt);
 }
 
 // I2 = sum_i ( sum_{j != i, com j == com i} q_ij + 2 q_ii )
@@ -655,11 +686,15 @@ __global__ void __launch_bounds__(BLK) k_lv_tot2(int64_t n, const int64_t *__res
     l1 = (u64)wave_sum_ll((long long)l1);
     l2 = (u64)wave_sum_ll((long long)l2);
     l3 = (u64)wave_sum_ll((long long)l3);
-    if ((threadIdx.x & 63) == 0) {
-        if (l0) atomicAdd(&limbs[0], l0);
-        if (l1) atomicAdd(&limbs[1], l1);
-        if (l2) atomicAdd(&limbs[2], l2);
-        if (l3) atomicAdd(&limbs[3], l3);
+    // per-block fold first: thousands of waves hammering four addresses serialise in the atomic unit
+    __shared__ u64 red[WPB][4];
+    const int wib = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wib][0] = l0; red[wib][1] = l1; red[wib][2] = l2; red[wib][3] = l3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        u64 t = 0;
+        for (int w = 0; w < WPB; w++) t += red[w][threadIdx.x];
+        if (t) atomicAdd(&limbs[threadIdx.x], t);
     }
 }
 
@@ -1118,8 +1153,17 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (dist && D.allgather(D.user, B3C_BUF_LABELS) != 0)
                     return ctx->fail(B3C_E_HIP, "b3c_louvain: all-gather callback failed");
                 info->n_move_launch++;
-                hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt_p,
-                                   csize.p, ctr.p + 1);
+                if (grouped && !dist) {
+                    // only the nodes that decided in this sub-round can have moved
+                    const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
+                    if (c1) hipLaunchKernelGGL(k_lv_apply_list, dim3(grid_for(c1, BLK, 4 * ctx->n_cu)), dim3(BLK), 0, s, c1,
+                                               nlist.p + loff[r], kdeg.p, tot.p, com.p, nxt_p, csize.p, ctr.p + 1);
+                    if (c2) hipLaunchKernelGGL(k_lv_apply_list, dim3(grid_for(c2, BLK, 4 * ctx->n_cu)), dim3(BLK), 0, s, c2,
+                                               hlist.p + hoff[r], kdeg.p, tot.p, com.p, nxt_p, csize.p, ctr.p + 1);
+                } else {
+                    hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt_p,
+                                       csize.p, ctr.p + 1);
+                }
             }
             info->move_nnz += g.nnz;
             info->move_rows += g.n;
