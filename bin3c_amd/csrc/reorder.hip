@@ -294,6 +294,59 @@ __global__ void __launch_bounds__(BLK) k_permute_rows_sorted(int64_t n, const in
     }
 }
 
+// Packed form of the same: when (new column << PB | position in the row) fits 32 bits, only that one word per entry
+// goes through the bitonic network (a third of the LDS traffic); the values are fetched afterwards by position.
+template <typename T, int CAPR>
+__global__ void __launch_bounds__(BLK) k_permute_rows_packed(int64_t n, int pb, const int64_t *__restrict__ indptr,
+                                                              const int32_t *__restrict__ indices,
+                                                              const T *__restrict__ a,
+                                                              const int32_t *__restrict__ new2old,
+                                                              const int32_t *__restrict__ old2new,
+                                                              const int64_t *__restrict__ out_indptr,
+                                                              int32_t *__restrict__ out_indices, T *__restrict__ out_a)
+{
+    __shared__ uint32_t skey[BLK / 64][CAPR];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    uint32_t *key = skey[wib];
+    const uint32_t pmask = (1u << pb) - 1u;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + wib;
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t k = wave; k < n; k += nwave) {
+        const int32_t old = new2old[k];
+        const int64_t s = indptr[old];
+        const int len = (int)(indptr[old + 1] - s);
+        const int64_t o = out_indptr[k];
+        int N = 64;
+        while (N < len) N <<= 1;
+        for (int e = lane; e < N; e += 64)
+            key[e] = e < len ? ((uint32_t)old2new[indices[s + e]] << pb) | (uint32_t)e : 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int kk = 2; kk <= N; kk <<= 1) {
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (int idx = lane; idx < N; idx += 64) {
+                    const int ixj = idx ^ jj;
+                    if (ixj > idx) {
+                        const uint32_t ka = key[idx], kb = key[ixj];
+                        const bool asc = (idx & kk) == 0;
+                        if ((ka > kb) == asc) {
+                            key[idx] = kb;
+                            key[ixj] = ka;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+        }
+        for (int e = lane; e < len; e += 64) {
+            const uint32_t kv = key[e];
+            out_indices[o + e] = (int32_t)(kv >> pb);
+            out_a[o + e] = a[s + (kv & pmask)];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+}
+
 __global__ void k_max_len(int64_t n, const int64_t *__restrict__ indptr, unsigned long long *__restrict__ out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -427,7 +480,17 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
     constexpr int CAPR = 512;
     if (nnz && sort_cols && maxlen <= CAPR && getenv("B3C_PERMUTE_GLOBAL_SORT") == nullptr) {
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
-        if (a->kind == B3C_F64)
+        int pb = 6, nb = 1;
+        while ((1ull << pb) < maxlen) pb++;
+        while ((1ll << nb) < n) nb++;
+        if (pb + nb <= 32) {      // (new column, position) packs into one word: sort keys only
+            if (a->kind == B3C_F64)
+                hipLaunchKernelGGL((k_permute_rows_packed<double, CAPR>), dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
+                                   (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
+            else
+                hipLaunchKernelGGL((k_permute_rows_packed<uint32_t, CAPR>), dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
+                                   (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
+        } else if (a->kind == B3C_F64)
             hipLaunchKernelGGL((k_permute_rows_sorted<double, CAPR>), dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
                                (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
         else
