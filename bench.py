@@ -8,9 +8,15 @@ mask compaction -> weight scaling -> Louvain labels on the host (bin3c_amd/pipel
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3]
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL): the ranks work on
-contig-row ranges of ONE map (bin3c_amd/dist.py; strong scaling, `--mode sharded`, the default) or on one
-independent map each (`--mode replicas`, weak scaling, no data-path collective).
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  `--mode`:
+  replicas  one independent map per GPU (weak scaling, no data-path collective)
+  sharded   contig-row ranges of ONE map over all GPUs (strong scaling; bin3c_amd/dist.py: an all-gather per
+            SpMV / Louvain sub-round plus packed scalar all-gathers)
+  auto      (default) sharded when a map is too large to be worth keeping on one GPU (more than SHARD_MIN_NNZ
+            stored entries per rank), else replicas -- a C3 step takes ~90 ms on one GPU and its KR part is 62
+            dependent ticks of four reductions each, so sharding ONE such map is latency bound
+            while one map per GPU uses all of every GPU.  In auto/replicas mode one extra, untimed sharded step
+            on rank 0's map is run AFTER the JSON line as a live check of the RCCL path (result on stderr).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -27,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+SHARD_MIN_NNZ = 400e6    # auto mode: shard one map only above this many stored entries per rank
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -75,7 +82,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='C3', choices=['C1', 'C2', 'C3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--mode', default='sharded', choices=['sharded', 'replicas'], help='N > 1 only')
+    ap.add_argument('--mode', default='auto', choices=['auto', 'sharded', 'replicas'], help='N > 1 only')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -86,15 +93,22 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False and libb3c has no CPU path')
+    if os.environ.get('B3C_BENCH_ONE_GPU'):      # test hook: all ranks share cuda:0 (tests/test_dist.py, gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('B3C_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from bin3c_amd.pipeline import make_context, run_hot_path
     from bin3c_amd.synth import CONFIGS, make_edges
 
     n, n_edges, seed, law = CONFIGS[args.config]
-    sharded = world > 1 and args.mode == 'sharded'
+    sharded = world > 1 and (args.mode == 'sharded' or
+                             (args.mode == 'auto' and (2 * n_edges + n) / world > SHARD_MIN_NNZ))
     # sharded: every rank builds the same map and owns a row range of it; replicas: one map per rank
     ctx = make_context(local_rank)
     # pair stream drawn on the host (numpy RandomState, deterministic), accumulated into the symmetric count matrix on
@@ -138,10 +152,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        red_dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        ee = torch.tensor([float(e_true)], dtype=torch.float64, device='cuda')
+        ee = torch.tensor([float(e_true)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ee, op=dist.ReduceOp.SUM)
         e_total = float(e_true) if sharded else float(ee.item())
         if sess is not None:
@@ -188,10 +203,47 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sample = {'C1': (1000, 50000), 'C2': (100000, 5000000), 'C3': (200000, 10000000)}[args.config]
             out['cpu_baseline'] = cpu_baseline(sample[0], sample[1], seed)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if world > 1 and not sharded:
+        sharded_check(ctx, rank, world, n, n_edges, seed, law, last if rank == 0 else None, min_len, min_sig)
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
+
+
+def sharded_check(ctx, rank, world, n, n_edges, seed, law, ref, min_len, min_sig):
+    """Untimed live check of the row-sharded RCCL path on rank 0's map, after the JSON line has been printed.
+    A watchdog ends the process (exit code 0: the measurement is already out) should a collective never return."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    from bin3c_amd.dist import DistSession
+    from bin3c_amd.pipeline import run_hot_path
+    from bin3c_amd.synth import make_edges
+    watchdog = threading.Timer(300.0, lambda: (sys.stderr.write('[bench] sharded check timed out\n'), os._exit(0)))
+    watchdog.daemon = True
+    watchdog.start()
+    try:
+        lo, hi, cnt, diag, lengths_h, sites_h, _ = make_edges(n, n_edges, seed, law)      # rank 0's map on every rank
+        counts, _e = ctx.coo_symmetrise(n, lo, hi, cnt, diag)
+        sess = DistSession(ctx, n)
+        run_hot_path(ctx, counts, sites_h, lengths_h, min_len, min_sig)                    # communicator set-up
+        dist.barrier()
+        t0 = time.perf_counter()
+        res = run_hot_path(ctx, counts, sites_h, lengths_h, min_len, min_sig)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sess.check()
+        sess.close()
+        if rank == 0:
+            same = (res.kr_info.n_iter == ref.kr_info.n_iter and np.allclose(res.x, ref.x, rtol=1e-9, atol=0) and
+                    res.lv_info.n_comm == ref.lv_info.n_comm and bool(np.array_equal(res.mask, ref.mask)))
+            sys.stderr.write('[bench] sharded check on {} GPUs: {:.1f} ms/step, {} exchanges, agrees with the single-GPU result: {}\n'
+                             .format(world, dt * 1e3, sess.n_exchanges, same))
+    except Exception as ex:                                     # the check must never cost the measurement
+        sys.stderr.write('[bench] sharded check failed: {!r}\n'.format(ex))
+    finally:
+        watchdog.cancel()
 
 
 if __name__ == '__main__':

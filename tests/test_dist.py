@@ -36,3 +36,26 @@ def test_sharding_host_logic_two_ranks_cpu():
 def test_sharded_hot_path_two_ranks_one_gpu():
     text = _launch('gpu', 900)
     assert 'rank 0 gpu ok' in text and 'rank 1 gpu ok' in text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['auto', 'sharded'])
+def test_bench_two_ranks_one_gpu(mode):
+    """bench.py as the driver launches it for N = 2 (gloo + one shared GPU stand in for RCCL + two GPUs)."""
+    import json
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--config', 'C2', '--mode', mode]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1', B3C_BENCH_BACKEND='gloo',
+               B3C_BENCH_ONE_GPU='1')
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['unit'] == 'edges/s' and 'roofline' in d
+    if mode == 'sharded':
+        assert d['scaling'] == 'strong'
+    else:
+        assert d['scaling'] == 'weak'
+        assert 'sharded check on 2 GPUs' in out.stderr.decode() and 'agrees with the single-GPU result: True' in out.stderr.decode()
