@@ -171,7 +171,8 @@ def main():
         n_acc = int(last.mask.sum())
         if spmv_ms >= move_ms:
             per_launch = 12.0 * nnz + 20.0 * n             # one KR SpMV
-            streamed = 8.0 * nnz + 36.0 * n                # what kr_kb_pipe<uint32> physically reads/writes (raw counts)
+            vb = last.kr_info.value_bits / 8.0             # 2 when all counts fit 16 bits, else 4 (8: fp64 matrix)
+            streamed = (4.0 + vb) * nnz + 36.0 * n         # what kr_kb_pipe physically reads/writes
             avg_ms = spmv_ms / max(spmv_n, 1)
             kname = 'kr_kb_pipe (CSR SpMV on raw counts + fused KR epilogue)'
         else:

@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t r0, int64_t n, const K
 // wait behind the indptr -> entries -> gather chain of the row before.  Measured at C3 (ordered matrix): 0.72 ms per
 // SpMV = 3.37 TB/s algorithmic, against 0.88 ms un-pipelined; non-temporal loads of the matrix stream made it slower.
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int UN, typename VT>
+template <int LPR, int UN, typename VT, bool NOGATHER = false>
 __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const KRState *__restrict__ sin,
                                                    KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
                                                    int PS, const int64_t *__restrict__ indptr,
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
         }
         double g[UN];
 #pragma unroll
-        for (int q = 0; q < UN; q++) g[q] = u[(uint32_t)c[q]];
+        for (int q = 0; q < UN; q++) g[q] = NOGATHER ? u[row + (c[q] & 1)] : u[(uint32_t)c[q]];   // NOGATHER: timing probe only
         // 3. first chunk of the next row
         int32_t c2[UN];
         VT m2[UN];
@@ -1049,6 +1049,26 @@ __global__ void __launch_bounds__(BLK) kr_fold(const double *__restrict__ part, 
     if (threadIdx.x == 0) *dst = r;
 }
 
+// count form: when every count fits 16 bits the SpMV streams a uint16 copy of the values (6 B per entry instead of 8)
+__global__ void kr_max_u32(int64_t nnz, const uint32_t *__restrict__ a, unsigned int *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int m = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) m = a[k] > m ? a[k] : m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int t = (unsigned int)__shfl_down((int)m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+__global__ void kr_narrow_u16(int64_t nnz, const uint32_t *__restrict__ a, uint16_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) out[k] = (uint16_t)a[k];
+}
+
 // sites 0 -> 1 (contact_map.py:1103-1108) and the row/column scale 1/s of the count form
 __global__ void kr_site_scale(int64_t n, double *__restrict__ sites, double *__restrict__ rs)
 {
@@ -1081,10 +1101,16 @@ void launch_kb_stream(hipStream_t s, int grid, size_t shmem, int64_t n, int64_t 
 
 template <int LPR, int UN>
 void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
-                    int PA, int PS, const b3c_mat *m, const double *rs, const double *dfix, const double *u, const double *x,
-                    const double *p, double *v, double *rk, double *w, double *part_out)
+                    int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
+                    const double *x, const double *p, double *v, double *rk, double *w, double *part_out)
 {
-    if (m->kind == B3C_U32)
+    if (m->kind == B3C_U32 && getenv("B3C_KR_NOGATHER"))   // wrong results by design: the kernel without its random gathers
+        hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t, true>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
+    else if (m->kind == B3C_U32 && v16)
+        hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint16_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out);
+    else if (m->kind == B3C_U32)
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
                            m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
     else
@@ -1237,6 +1263,23 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         }
         a = perm.m;
     }
+    // count form: 16-bit copy of the values when they all fit (built on the matrix the iteration runs on)
+    DevBuf<uint16_t> v16buf(ctx, counts ? a->nnz : 1);
+    const uint16_t *v16 = nullptr;
+    if (counts && a->nnz && getenv("B3C_KR_NO_U16") == nullptr) {
+        DevBuf<unsigned int> mx(ctx, 1);
+        if (!mx.p || !v16buf.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts");
+        HIP_TRY(ctx, hipMemsetAsync(mx.p, 0, sizeof(unsigned int), s));
+        const int gq = grid_for(a->nnz, 1024, 8 * ctx->n_cu);
+        hipLaunchKernelGGL(kr_max_u32, dim3(gq), dim3(256), 0, s, a->nnz, (const uint32_t *)a->data, mx.p);
+        unsigned int hmx = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&hmx, mx.p, sizeof(hmx), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (hmx <= 0xFFFFu) {
+            hipLaunchKernelGGL(kr_narrow_u16, dim3(gq), dim3(256), 0, s, a->nnz, (const uint32_t *)a->data, v16buf.p);
+            v16 = v16buf.p;
+        }
+    }
     // ---- sliced-ELL working layout ----
     DevBuf<int32_t> sperm(ctx, sell ? n : 1), sinv(ctx, sell ? n : 1), slen(ctx, sell ? nsl : 1);
     DevBuf<int64_t> sptr(ctx, sell ? nsl + 1 : 1);
@@ -1337,10 +1380,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                                    svals, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
             } else if (rows_kb && pipe_kb) {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
-                if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
             } else if (rows_kb) {
                 switch (lpr_r) {
                 case 32: launch_kb_rows<32, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
@@ -1428,6 +1471,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     info->hit_Delta = h.hit_Delta;
     info->rout = h.rout;
     info->n_spmv = h.n_iter + 1;
+    info->value_bits = counts ? (v16 ? 16 : 32) : 64;
     if (prof) {
         double ms = 0.0;
         long long cnt = 0;

@@ -50,7 +50,7 @@ typedef struct {
     double spmv_ms;       /* device time spent in the SpMV kernel (HIP events), 0 if not measured */
     int64_t n_spmv;       /* SpMV launches that did work */
     int32_t bitwise_symmetric; /* 1: a_ij == a_ji exactly (checksum path); precondition of b3c_scale_sym_graph */
-    int32_t reserved;
+    int32_t value_bits;   /* width of the matrix values the SpMV streamed: 64 (fp64), 32 (counts) or 16 (counts <= 65535) */
 } b3c_kr_info;
 
 typedef struct {

@@ -116,3 +116,41 @@ def test_cli_mksynth_then_cluster(tmp_path):
     assert os.path.exists(os.path.join(d2, 'clustering.mcl')) and os.path.exists(os.path.join(d2, 'bin3C.log'))
     log = open(os.path.join(d2, 'bin3C.log')).read()
     assert 'Clustering contact graph using method: louvain' in log and 'User set random seed: 7' in log
+
+
+def test_cluster_map_on_prepared_and_on_reloaded_maps(ctx, tmp_path):
+    """Three routes to the same clustering: fresh map; map prepared first (balanced map stays in HBM); map pickled after
+    preparation and reloaded (balanced map comes back from the host cache, contact_map.py:941-945 / cluster.py:308-309)."""
+    from bin3c_amd.mzd import cluster, io_utils
+    g = np.load(os.path.join(GOLDEN, 'pipeline.npz'))
+
+    def as_sets(cl):
+        return {frozenset(v['seq_ids'].tolist()) for v in cl.values()}
+
+    cm1 = _cm_from_fixture(g)
+    cm1._ctx = ctx
+    fresh = cluster.cluster_map(cm1, seed=1, method='louvain', work_dir=str(tmp_path))
+
+    cm2 = _cm_from_fixture(g)
+    cm2._ctx = ctx
+    cm2.set_primary_acceptance_mask()
+    cm2.prepare_seq_map(norm=True, bisto=True)
+    assert cm2._hot is not None and cm2._processed_host is None            # still only in HBM
+    prepared = cluster.cluster_map(cm2, seed=1, method='louvain', work_dir=str(tmp_path))
+    assert as_sets(prepared) == as_sets(fresh)
+
+    cm2._ctx = None
+    io_utils.save_object(str(tmp_path / 'prepared.p'), cm2)               # materialises processed_map on the host
+    cm3 = io_utils.load_object(str(tmp_path / 'prepared.p.gz'))
+    assert cm3.processed_map is not None and cm3._hot is None
+    np.testing.assert_allclose(cm3.bisto_scale, g['x'], rtol=1e-9)
+    cm3._ctx = ctx
+    reloaded = cluster.cluster_map(cm3, seed=1, method='louvain', work_dir=str(tmp_path))
+    assert as_sets(reloaded) == as_sets(fresh)
+    # a stricter mask on the same prepared map re-uses the balanced matrix (no second KR)
+    stricter = cluster.cluster_map(cm3, seed=1, method='louvain', min_len=4000, min_sig=int(g['min_sig']),
+                                   work_dir=str(tmp_path))
+    kept = np.concatenate([v['seq_ids'] for v in stricter.values()])
+    assert np.all(g['lengths'][kept] >= 4000)
+    for c in (cm1, cm2, cm3):
+        c._ctx = None

@@ -15,10 +15,10 @@ n2o, o2n = ctx.locality_order(counts)
 work = ctx.permute(counts, n2o)
 sites = sm.sites[n2o]
 a = ctx.site_norm(work, sites)
-for shp in ['16x16', '16x24', '32x8', '8x32', '16x12', '32x12', '16x16']:
-    os.environ['B3C_KR_PIPE_SHAPE'] = shp
+for mode in ['u16', 'u32', 'u16']:
+    os.environ.pop('B3C_KR_NO_U16', None)
+    if mode == 'u32':
+        os.environ['B3C_KR_NO_U16'] = '1'
     for rep in range(2):
-        t = time.time(); _, x1, i1 = ctx.kr_balance(a); d1 = time.time() - t
-        t = time.time(); _, x2, i2 = ctx.kr_balance_counts(work, sites); d2 = time.time() - t
-    print('%-6s f64: %.2f ms (spmv avg %.0f us, %d it)   counts: %.2f ms (spmv avg %.0f us)' % (
-        shp, d1 * 1e3, i1.spmv_ms / i1.n_spmv * 1e3, i1.n_iter, d2 * 1e3, i2.spmv_ms / i2.n_spmv * 1e3))
+        t = time.time(); rc, x2, i2 = ctx.kr_balance_counts(work, sites); d2 = time.time() - t
+    print('%-9s counts: %.2f ms (spmv avg %.0f us over %d)' % (mode, d2 * 1e3, i2.spmv_ms / i2.n_spmv * 1e3, i2.n_spmv))
