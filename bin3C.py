@@ -6,15 +6,16 @@ clustering.p.gz, bin3C.log -- running mask -> normalise -> KR -> Louvain on the 
 
 ``mkmap`` (BAM/FASTA ingest, bin3C.py:60-74) is outside the accelerated path; ``mksynth`` writes a
 synthetic contact_map.p.gz of the same object type so that the cluster stage can be exercised end to end.
-Reports, per-cluster FASTA and plots (bin3C.py:193-211) are downstream I/O of the reference and are not
-produced here.
+The cluster heat-map (bin3C.py:208-211, cluster_plot.png) is drawn from a raster that is permuted and
+block-reduced on the device; reports and per-cluster FASTA (bin3C.py:199-206) are downstream I/O of the
+reference and are not produced here.
 """
 import argparse
 import logging
 import os
 import sys
 
-from bin3c_amd.mzd.cluster import cluster_map, write_mcl
+from bin3c_amd.mzd.cluster import cluster_map, plot_clusters, write_mcl
 from bin3c_amd.mzd.exceptions import ApplicationException
 from bin3c_amd.mzd.io_utils import load_object, save_object
 from bin3c_amd.mzd.utils import make_dir, make_random_seed
@@ -47,7 +48,7 @@ def build_parser():
     cmd_cluster.add_argument('-s', '--seed', default=None, help='Random seed')
     cmd_cluster.add_argument('--no-report', default=False, action='store_true', help='Accepted for compatibility')
     cmd_cluster.add_argument('--no-spades', default=False, action='store_true', help='Accepted for compatibility')
-    cmd_cluster.add_argument('--no-plot', default=False, action='store_true', help='Accepted for compatibility')
+    cmd_cluster.add_argument('--no-plot', default=False, action='store_true', help='Do not generate a clustered heatmap')
     cmd_cluster.add_argument('--no-fasta', default=False, action='store_true', help='Accepted for compatibility')
     cmd_cluster.add_argument('--only-large', default=False, action='store_true', help='Accepted for compatibility')
     cmd_cluster.add_argument('--algo', default='louvain', choices=['louvain', 'infomap', 'mcl', 'slm', 'simap'],
@@ -129,6 +130,11 @@ def main(argv=None):
             write_mcl(cm, os.path.join(args.OUTDIR, 'clustering.mcl'), clustering)
             save_object(os.path.join(args.OUTDIR, 'clustering.p'), clustering)
             logger.info('Wrote {} clusters'.format(len(clustering)))
+            if not args.no_plot:
+                # the entire clustering (bin3C.py:208-211)
+                plot_clusters(cm, os.path.join(args.OUTDIR, 'cluster_plot.png'), clustering,
+                              max_image_size=ifelse(args.max_image, RUNTIME_DEFAULTS['max_image']),
+                              ordered_only=False, simple=False, permute=True)
     except ApplicationException as ex:
         logger.error(ex.message)
         return 1

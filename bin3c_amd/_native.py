@@ -55,6 +55,7 @@ SYMBOLS = [
     ('b3c_scale_sym_graph', C.c_int, [_VP, _VP, _VP]),
     ('b3c_compress', C.c_int, [_VP, _VP, _VP, C.POINTER(_VP)]),
     ('b3c_max_value', C.c_int, [_VP, _VP, C.POINTER(C.c_double)]),
+    ('b3c_downsample', C.c_int, [_VP, _VP, C.c_int64, C.c_int, C.POINTER(_VP)]),
     ('b3c_kr_balance', C.c_int, [_VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, _VP, C.POINTER(KRInfo)]),
     ('b3c_kr_balance_counts', C.c_int, [_VP, _VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, _VP, C.POINTER(KRInfo)]),
     ('b3c_normalise_scale', C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
@@ -292,6 +293,11 @@ class Context(object):
             mask = np.ascontiguousarray(mask, dtype=np.uint8)
         h = _VP()
         self._check(self.lib.b3c_compress(self.h, mat.h, _ptr(mask), C.byref(h)))
+        return Mat(self, h)
+
+    def downsample(self, mat, block_size, method='mean'):
+        h = _VP()
+        self._check(self.lib.b3c_downsample(self.h, mat.h, int(block_size), {'mean': 0, 'max': 1}[method], C.byref(h)))
         return Mat(self, h)
 
     def max_value(self, mat):

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'libb3c.so')
-SOURCES = ['api.hip', 'csr_ops.hip', 'kr.hip', 'louvain.hip', 'reorder.hip', 'accumulate.hip']
+SOURCES = ['api.hip', 'csr_ops.hip', 'kr.hip', 'louvain.hip', 'reorder.hip', 'accumulate.hip', 'downsample.hip']
 
 
 def _stale():

@@ -20,6 +20,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from .contact_map import SeqOrder
+from .exceptions import NoRemainingClustersException
 from .utils import app_path
 
 logger = logging.getLogger(__name__)
@@ -262,6 +263,67 @@ def _run_external(method, g, seed, work_dir, base_name):
         subprocess.check_call(['java', '-jar', need(app_path('external', 'ModularityOptimizer.jar')), edge_file, ofile,
                                '1', '2.0', '3', '10', '10', str(seed), '1'], stdout=stdout, stderr=subprocess.STDOUT)
     return read_table(ofile, seq_col=None, cl_col=0)
+
+
+def enable_clusters(contact_map, clustering, cl_list=None, ordered_only=True, min_extent=None):
+    """
+    Given a clustering and list of cluster ids (or none), enable (unmask) the related sequences in the contact map
+    (cluster.py:327-387). If a requested cluster has not been ordered, it will be dropped.
+
+    :return: the filtered list of cluster ids in ascending numerical order
+    """
+    if cl_list is None:
+        cl_list = clustering.keys()
+    if min_extent is None:
+        min_extent = contact_map.min_extent
+    if min_extent:
+        cl_list = [k for k in cl_list if clustering[k]['extent'] >= min_extent]
+        logger.info('Clusters passing minimum extent criterion: {}'.format(len(cl_list)))
+        if len(cl_list) == 0:
+            raise NoRemainingClustersException('No clusters passed min_extent criterion of >= {}'.format(min_extent))
+    if ordered_only:
+        cl_list = [k for k in cl_list if 'order' in clustering[k]]
+        logger.info('Clusters passing ordered-only criterion: {}'.format(len(cl_list)))
+        if len(cl_list) == 0:
+            raise NoRemainingClustersException('No clusters passed ordered-only criterion')
+    cl_list = sorted(cl_list)
+    if ordered_only:
+        cmb_ord = np.hstack([clustering[k]['order'] for k in cl_list])
+    else:
+        cmb_ord = np.hstack([SeqOrder.asindex(clustering[k]['seq_ids']) for k in cl_list])
+    if len(cmb_ord) == 0:
+        raise NoRemainingClustersException('No requested cluster contained ordering information')
+    logger.info('Total number of sequences in the clustering: {}'.format(len(cmb_ord)))
+    _mask = np.zeros_like(contact_map.order.mask_vector(), dtype=np.bool_)
+    _mask[cmb_ord['index']] = True
+    _mask &= contact_map.get_primary_acceptance_mask()
+    logger.info('After joining with active sequence mask map: {}'.format(_mask.sum()))
+    contact_map.order.set_mask_only(_mask)
+    contact_map.order.set_order_and_orientation(cmb_ord, implicit_excl=True)
+    return cl_list
+
+
+def plot_clusters(contact_map, fname, clustering, cl_list=None, simple=True, permute=False, max_image_size=None,
+                  ordered_only=False, min_extent=None, use_taxo=False, flatten=False, **kwargs):
+    """
+    Plot the contact map, annotating the map with cluster names and boundaries (cluster.py:390-449). For large
+    contact maps the raster is block-reduced on the device (``max_image_size``).
+    """
+    if cl_list is None:
+        logger.info('Plotting heatmap of complete solution')
+    else:
+        logger.info('Plotting heatmap for {} specified clusters'.format(len(cl_list)))
+    assert simple or contact_map.bin_size is None, 'extent (binned) maps are outside the accelerated path'
+    if contact_map.processed_map is None:
+        contact_map.prepare_seq_map(norm=True, bisto=True)
+    cl_list = enable_clusters(contact_map, clustering, cl_list=cl_list, ordered_only=ordered_only, min_extent=min_extent)
+    tick_locs = np.cumsum([0] + [len(clustering[k]['seq_ids']) for k in cl_list])
+    if use_taxo:
+        _labels = [clustering[cl_id]['taxon'] for cl_id in cl_list]
+    else:
+        _labels = [clustering[cl_id]['name'] for cl_id in cl_list]
+    contact_map.plot(fname, permute=permute, simple=simple, tick_locs=tick_locs, tick_labs=_labels,
+                     max_image_size=max_image_size, flatten=flatten, **kwargs)
 
 
 def write_mcl(contact_map, fname, clustering):

@@ -421,9 +421,91 @@ class ContactMap(object):
         return _map
 
     def _reorder_seq(self, _map, flatten=False):
-        """contact_map.py:1066-1085: P A P^T with P[i, order[i]] = 1."""
+        """contact_map.py:1066-1085: P A P^T with P[i, order[i]] = 1 (b3c_mat_permute on the device)."""
         assert sp.isspmatrix(_map), 'reordering expects a sparse matrix type'
         _order = self.order.gapless_positions()
+        assert not (self.is_tipbased() and flatten), 'tip-based maps are outside the accelerated path'
         assert _map.shape[0] == _order.shape[0], 'supplied map and unmasked order are different sizes'
-        c = _map.tocsr()
-        return c[_order][:, _order]
+        ctx = self._context()
+        c = sparse_utils._canonical_csr(_map, None if _map.dtype == np.uint32 else np.float64)
+        mat = ctx.upload(c.indptr, c.indices, c.data)
+        try:
+            out = ctx.permute(mat, np.ascontiguousarray(_order, dtype=np.int32))
+            try:
+                ip, ix, data = out.download()
+            finally:
+                out.free()
+        finally:
+            mat.free()
+        return sp.csr_matrix((data.astype(_map.dtype, copy=False), ix, ip), shape=_map.shape)
+
+    MAX_RASTER_CELLS = 400 * 1000 * 1000      # dense float64 raster limit (3.2 GB)
+
+    def plot_matrix(self, simple=True, norm=True, permute=False, zero_diag=None, alpha=0.01, max_image_size=None,
+                    tick_locs=None, flatten=False):
+        """
+        The raster behind ContactMap.plot (contact_map.py:1316-1357) without the drawing: masked / permuted
+        subspace of the processed map, x100, optionally block-reduced on the device (sparse_utils.downsample),
+        densified and log(x + alpha) transformed.
+
+        :return: (2-D ndarray of log intensities, tick_locs rescaled like contact_map.py:1348)
+        """
+        assert simple or self.bin_size is None, 'extent (binned) maps are outside the accelerated path'
+        if self.processed_map is None:
+            self.prepare_seq_map(norm=norm, bisto=True)
+        _map = self.get_subspace(permute=permute, marginalise=False if flatten else True, flatten=flatten).tolil()
+        if zero_diag is None:
+            _map.setdiag(0)
+        _map = _map.tocsr()
+        _map *= 100
+        if max_image_size is not None:
+            full_size = _map.shape
+            if np.max(full_size) > max_image_size:
+                reduce_factor = int(np.ceil(np.max(full_size) / float(max_image_size)))
+                logger.info('Full {} image reduction factor: {}'.format(full_size, reduce_factor))
+                _map = sparse_utils.downsample(_map, reduce_factor, ctx=self._context())
+                if tick_locs is not None:
+                    tick_locs = np.floor(np.asarray(tick_locs).astype(float) / reduce_factor)
+                logger.info('Map has been reduced from {} to {}'.format(full_size, _map.shape))
+        if _map.shape[0] * _map.shape[1] > self.MAX_RASTER_CELLS:
+            raise MemoryError('a {} x {} raster would not fit in host memory: set max_image_size'.format(*_map.shape))
+        _map = _map.toarray()
+        if zero_diag:
+            logger.debug('Removing diagonal')
+            np.fill_diagonal(_map, 0)
+        return np.log(_map + alpha), tick_locs
+
+    def plot(self, fname, simple=False, tick_locs=None, tick_labs=None, norm=True, permute=False, pattern_only=False,
+             dpi=180, width=25, height=22, zero_diag=None, alpha=0.01, robust=False, max_image_size=None,
+             flatten=False):
+        """contact_map.py:1285-1382. The raster comes from :meth:`plot_matrix`; drawing needs matplotlib, which is the
+        reference's presentation layer and not part of the accelerated path -- without it the raster is written as
+        ``fname + '.npy'`` next to the tick positions so that it can be rendered elsewhere."""
+        assert not pattern_only, 'pattern_only (spy) plots are outside the accelerated path'
+        img, tick_locs = self.plot_matrix(simple=simple, norm=norm, permute=permute, zero_diag=zero_diag, alpha=alpha,
+                                          max_image_size=max_image_size, tick_locs=tick_locs, flatten=flatten)
+        try:
+            import matplotlib
+            matplotlib.use('Agg')
+            import matplotlib.pyplot as plt
+        except ImportError:
+            np.save(fname + '.npy', img)
+            if tick_locs is not None:
+                np.save(fname + '.ticks.npy', np.asarray(tick_locs))
+            logger.warning('matplotlib is not installed: raster saved as {}.npy'.format(fname))
+            return
+        fig = plt.figure()
+        fig.set_figwidth(width)
+        fig.set_figheight(height)
+        ax = fig.add_subplot(111)
+        ax.imshow(img, interpolation='nearest', aspect='equal')
+        if tick_locs is not None:
+            ax.set_xticks(np.asarray(tick_locs))
+            ax.set_yticks(np.asarray(tick_locs))
+            if tick_labs is not None:
+                mid = (np.asarray(tick_locs)[:-1] + np.asarray(tick_locs)[1:]) / 2.0
+                ax.set_xticks(mid, minor=True)
+                ax.set_xticklabels(tick_labs, minor=True, rotation=45, ha='right', fontsize=10)
+                ax.set_xticklabels([])
+        fig.savefig(fname, dpi=dpi)
+        plt.close(fig)

@@ -2,6 +2,7 @@
 Host-side mirror of the reference's ``mzd/sparse_utils.py`` for the hot path: same function names,
 arguments, return types, log lines and exceptions, with the arithmetic done by libb3c on the MI355X.
 
+    downsample         mzd/sparse_utils.py:48-87
     kr_biostochastic   mzd/sparse_utils.py:90-224
     max_offdiag        mzd/sparse_utils.py:269-281
     compress           mzd/sparse_utils.py:284-314
@@ -29,6 +30,45 @@ def _canonical_csr(m, dtype=None):
     c.sum_duplicates()
     c.sort_indices()
     return c
+
+
+def downsample(m, block_size, method='mean', ctx=None):
+    """
+    Perform a down-sampling of a 2D matrix (scipy.sparse or ndarray) by a factor of block_size in each dimension
+    (sparse_utils.py:48-87). Block size must be an integer larger than 1. When employing mean method, zero padding
+    on edges is not compensated for.
+
+    :param m: a matrix (scipy.sparse or ndarray)
+    :param block_size: an integer reduction factor
+    :param method: per block mean or maximum.
+    :return: scipy.sparse.csr_matrix
+    """
+    assert isinstance(m, (np.ndarray, scisp.spmatrix)), 'supplied array must be of type np.ndarray or scipy.spmatrix'
+    assert block_size > 1 and isinstance(block_size, int), 'block_size must be an integer larger than 1'
+    if method not in ('mean', 'max'):
+        return m                       # the reference falls through both branches and returns its COO untouched
+    ctx = ctx or _native.default_context()
+    in_dtype = m.dtype
+    c = _canonical_csr(scisp.csr_matrix(m), np.float64)
+    rows, cols = c.shape
+    side = max(rows, cols)
+    if rows != cols:                   # libb3c maps are square: embed (the extra cells are implicit zeros, like padding)
+        c.resize((side, side))
+    mat = ctx.upload(c.indptr, c.indices, c.data)
+    try:
+        out = ctx.downsample(mat, block_size, method)
+        try:
+            ip, ix, data = out.download()
+        finally:
+            out.free()
+    finally:
+        mat.free()
+    nb = ip.shape[0] - 1
+    r = scisp.csr_matrix((data, ix, ip), shape=(nb, nb))
+    out_shape = (-(-rows // block_size), -(-cols // block_size))
+    if out_shape != r.shape:
+        r = r[:out_shape[0], :out_shape[1]]
+    return r.astype(in_dtype) if method == 'max' and in_dtype != np.float64 else r
 
 
 def kr_biostochastic(m, tol=1e-6, x0=None, delta=0.1, Delta=3, max_iter=1000, ctx=None):

@@ -179,6 +179,14 @@ int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask /*host|dev*
 /* _map.max() (cluster.py:316). */
 int b3c_max_value(b3c_ctx *ctx, const b3c_mat *a, double *out);
 
+/* downsample (sparse_utils.py:48-87; caller ContactMap.plot, contact_map.py:1340-1349): reduce a float64 canonical
+ * CSR map by block_size in each dimension.  The result is ceil(n / block_size) square, zero padded at the edge.
+ * B3C_DS_MEAN: block sum times 1/block_size^2 (padding not compensated, as in the reference);
+ * B3C_DS_MAX : block maximum, implicit zeros taking part.  Deterministic (no floating-point atomics). */
+#define B3C_DS_MEAN 0
+#define B3C_DS_MAX 1
+int b3c_downsample(b3c_ctx *ctx, const b3c_mat *a, int64_t block_size, int method, b3c_mat **out);
+
 /* ---- Knight-Ruiz --------------------------------------------------------------------------- */
 
 /* kr_biostochastic (sparse_utils.py:90-224) minus the final scaling (use b3c_scale_sym):

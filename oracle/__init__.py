@@ -164,3 +164,20 @@ def modularity(indptr, indices, w, labels):
     ww = np.ascontiguousarray(w, dtype=np.float64)
     lab = np.ascontiguousarray(labels, dtype=np.int32)
     return lib().orc_modularity(C.c_int64(ip.shape[0] - 1), _p(ip), _p(ix), _p(ww), _p(lab))
+
+
+def downsample_dense(m, block_size, method='mean'):
+    """Dense numpy restatement of mzd/sparse_utils.py:48-87 (`downsample`): zero-pad to a multiple of block_size,
+    view as (R/b, b, C/b, b) and reduce axes (1, 3); mean = block sum times 1/b^2 (:81-82), max = block maximum
+    with the zero cells taking part (:83-84).  PARITY UNPINNED: the reference body needs pydata `sparse`
+    (sparse_utils.py:4, :77), which is not installed here, so its text cannot be executed for golden vectors.
+    Small inputs only (densifies)."""
+    import numpy as np
+    m = np.asarray(m.todense()) if hasattr(m, 'todense') else np.asarray(m)
+    b = int(block_size)
+    pr, pc = (-m.shape[0]) % b, (-m.shape[1]) % b
+    p = np.pad(m, ((0, pr), (0, pc)))
+    v = p.reshape(p.shape[0] // b, b, p.shape[1] // b, b)
+    if method == 'mean':
+        return v.sum(axis=(1, 3)) * (1.0 / b ** 2)
+    return v.max(axis=(1, 3))

@@ -114,6 +114,7 @@ def test_cli_mksynth_then_cluster(tmp_path):
     acc = lab >= 0
     assert acc.sum() > 900 and graphs.same_partition(lab[acc], sm.genome[acc])
     assert os.path.exists(os.path.join(d2, 'clustering.mcl')) and os.path.exists(os.path.join(d2, 'bin3C.log'))
+    assert os.path.exists(os.path.join(d2, 'cluster_plot.png')) or os.path.exists(os.path.join(d2, 'cluster_plot.png.npy'))
     log = open(os.path.join(d2, 'bin3C.log')).read()
     assert 'Clustering contact graph using method: louvain' in log and 'User set random seed: 7' in log
 

@@ -49,8 +49,20 @@ def test_full_size_properties(ctx, cfg):
     assert res.lv_info.modularity > 0.9
     # (4) determinism and layout independence
     from bin3c_amd.pipeline import run_hot_path
-    again = run_hot_path(ctx, counts, sites, lengths, 1000, 5)
+    again = run_hot_path(ctx, counts, sites, lengths, 1000, 5, keep=True)
     assert np.array_equal(again.x, res.x) and np.array_equal(again.labels, res.labels)
+    # (5) heat-map block reduction of the balanced map: mass is conserved, the maximum survives
+    b = 250 if cfg == 'C3' else 25
+    ds_max = ctx.downsample(again.processed, b, 'max')
+    assert ctx.max_value(ds_max) == ctx.max_value(again.processed)
+    ds_max.free()
+    ds = ctx.downsample(again.processed, b, 'mean')
+    assert ds.n == -(-n // b)
+    if cfg == 'C2':
+        total = again.processed.download(structure=False)[2].sum()
+        np.testing.assert_allclose(ds.download(structure=False)[2].sum() * b * b, total, rtol=1e-11)
+    ds.free()
+    again.free()
     if cfg == 'C2':
         plain = run_hot_path(ctx, counts, sites, lengths, 1000, 5, reorder=False)
         assert plain.kr_info.n_iter == res.kr_info.n_iter

@@ -88,3 +88,12 @@ def test_cluster_pipeline_stages_bit_exact(oracle_lib):
     import scipy.sparse as sp
     W = sp.csr_matrix((w, ix, ip), shape=(m, m))
     assert (W != W.T).nnz == 0
+
+
+def test_downsample_restatement_known_answers(oracle_lib):
+    oracle = oracle_lib
+    """oracle.downsample_dense (sparse_utils.py:48-87) on a case worked by hand: 3x3 -> padded 4x4 -> 2x2"""
+    m = np.array([[1.0, 2.0, 0.0], [3.0, 4.0, 5.0], [0.0, 6.0, -7.0]])
+    np.testing.assert_array_equal(oracle.downsample_dense(m, 2, 'mean'), [[10 / 4.0, 5 / 4.0], [6 / 4.0, -7 / 4.0]])
+    np.testing.assert_array_equal(oracle.downsample_dense(m, 2, 'max'), [[4.0, 5.0], [6.0, 0.0]])
+    assert oracle.downsample_dense(np.ones((5, 7)), 3, 'mean').shape == (2, 3)
