@@ -9,14 +9,13 @@ mask compaction -> weight scaling -> Louvain labels on the host (bin3c_amd/pipel
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3]
 
 N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  `--mode`:
-  replicas  one independent map per GPU (weak scaling, no data-path collective)
-  sharded   contig-row ranges of ONE map over all GPUs (strong scaling; bin3c_amd/dist.py: an all-gather per
-            SpMV / Louvain sub-round plus packed scalar all-gathers)
-  auto      (default) sharded when a map is too large to be worth keeping on one GPU (more than SHARD_MIN_NNZ
-            stored entries per rank), else replicas -- a C3 step takes ~90 ms on one GPU and its KR part is 62
-            dependent ticks of four reductions each, so sharding ONE such map is latency bound
-            while one map per GPU uses all of every GPU.  In auto/replicas mode one extra, untimed sharded step
-            on rank 0's map is run AFTER the JSON line as a live check of the RCCL path (result on stderr).
+  sharded   contig-row ranges of ONE map over all GPUs (BASELINE.json configs[3]; strong scaling; bin3c_amd/dist.py:
+            an all-gather per SpMV / Louvain sub-round plus packed scalar all-gathers)
+  replicas  one map per GPU (weak scaling, no data-path collective)
+  auto      (default) both, replicas first: `value` is the SHARDED figure ("scaling": "strong") and the replica
+            throughput is reported beside it under "replicas".  The sharded leg runs under a watchdog: should the
+            RCCL path fail or never return, the line is printed with the replica figure as `value` ("scaling":
+            "weak") and the failure under "sharded".
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -33,7 +32,6 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-SHARD_MIN_NNZ = 400e6    # auto mode: shard one map only above this many stored entries per rank
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -107,19 +105,13 @@ def main():
     from bin3c_amd.synth import CONFIGS, make_edges
 
     n, n_edges, seed, law = CONFIGS[args.config]
-    sharded = world > 1 and (args.mode == 'sharded' or
-                             (args.mode == 'auto' and (2 * n_edges + n) / world > SHARD_MIN_NNZ))
-    # sharded: every rank builds the same map and owns a row range of it; replicas: one map per rank
     ctx = make_context(local_rank)
     # pair stream drawn on the host (numpy RandomState, deterministic), accumulated into the symmetric count matrix on
-    # the device (b3c_coo_symmetrise: the ingest tail, bit-identical to synth.symmetrise_to_csr)
-    lo, hi, cnt, diag, lengths_h, sites_h, _genome = make_edges(n, n_edges, seed if sharded else seed + rank, law)
+    # the device (b3c_coo_symmetrise: the ingest tail, bit-identical to synth.symmetrise_to_csr).  Every rank builds
+    # the same map: the replica leg processes one copy per GPU, the sharded leg one copy over all GPUs.
+    lo, hi, cnt, diag, lengths_h, sites_h, _genome = make_edges(n, n_edges, seed, law)
     counts, e_true = ctx.coo_symmetrise(n, lo, hi, cnt, diag)
     del lo, hi, cnt
-    sess = None
-    if sharded:
-        from bin3c_amd.dist import DistSession
-        sess = DistSession(ctx, n)
     # inputs resident in HBM before the timed region: the count matrix and the two per-contig tables
     sites = torch.as_tensor(sites_h, device='cuda')
     lengths = torch.as_tensor(lengths_h.astype(np.int64), device='cuda')
@@ -132,51 +124,49 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    last = None
-    for _ in range(args.warmup):
-        last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig)
-    barrier()
-    t0 = time.perf_counter()
-    stage = {}
-    spmv_ms = spmv_n = move_ms = move_n = move_nnz = move_rows = 0
-    for _ in range(args.steps):
-        last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig)
-        for k, v in last.timings.items():
-            stage[k] = stage.get(k, 0.0) + v
-        spmv_ms += last.kr_info.spmv_ms
-        spmv_n += last.kr_info.n_spmv
-        move_ms += last.lv_info.move_ms
-        move_n += last.lv_info.n_move_launch
-        move_nnz += last.lv_info.move_nnz
-        move_rows += last.lv_info.move_rows
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        red_dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ee = torch.tensor([float(e_true)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(ee, op=dist.ReduceOp.SUM)
-        e_total = float(e_true) if sharded else float(ee.item())
-        if sess is not None:
-            sess.check()
-    else:
-        e_total = float(e_true)
+    def timed_leg():
+        """W warm-up steps, then exactly K timed steps between barriers; time = max over ranks."""
+        acc = {'stage': {}, 'spmv_ms': 0.0, 'spmv_n': 0, 'move_ms': 0.0, 'move_n': 0, 'move_nnz': 0, 'move_rows': 0}
+        last = None
+        for _ in range(args.warmup):
+            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig)
+            for k, v in last.timings.items():
+                acc['stage'][k] = acc['stage'].get(k, 0.0) + v
+            acc['spmv_ms'] += last.kr_info.spmv_ms
+            acc['spmv_n'] += last.kr_info.n_spmv
+            acc['move_ms'] += last.lv_info.move_ms
+            acc['move_n'] += last.lv_info.n_move_launch
+            acc['move_nnz'] += last.lv_info.move_nnz
+            acc['move_rows'] += last.lv_info.move_rows
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            red_dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+            tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, last, acc
 
-    if rank == 0:
+    def line(dt, last, acc, sharded, extra):
         ms_per_step = dt / args.steps * 1e3
+        e_total = float(e_true) if (sharded or world == 1) else float(e_true) * world
         value = e_total * args.steps / dt
-        # dominant kernel by accumulated device time
+        spmv_ms, spmv_n, move_ms, move_n = acc['spmv_ms'], acc['spmv_n'], acc['move_ms'], acc['move_n']
         n_acc = int(last.mask.sum())
+        # dominant kernel by accumulated device time (this rank's launches: a row range of the map when sharded)
+        share = 1.0 / world if sharded else 1.0
         if spmv_ms >= move_ms:
-            per_launch = 12.0 * nnz + 20.0 * n             # one KR SpMV
+            per_launch = (12.0 * nnz + 20.0 * n) * share   # SURVEY 8(d): one KR SpMV
             vb = last.kr_info.value_bits / 8.0             # 2 when all counts fit 16 bits, else 4 (8: fp64 matrix)
-            streamed = (4.0 + vb) * nnz + 36.0 * n         # what kr_kb_pipe physically reads/writes
+            streamed = ((4.0 + vb) * nnz + 36.0 * n) * share   # what kr_kb_pipe physically reads/writes
             avg_ms = spmv_ms / max(spmv_n, 1)
             kname = 'kr_kb_pipe (CSR SpMV on raw counts + fused KR epilogue)'
         else:
-            per_launch = (16.0 * move_nnz + 28.0 * move_rows) / max(move_n, 1)   # Louvain sweep / n_sub
+            per_launch = (16.0 * acc['move_nnz'] + 28.0 * acc['move_rows']) / max(move_n, 1)   # SURVEY 8(d): Louvain sweep / n_sub
             streamed = per_launch
             avg_ms = move_ms / max(move_n, 1)
             kname = 'k_lv_decide (Louvain delta-Q neighbour scan)'
@@ -195,56 +185,74 @@ def main():
                        'accepted_contigs': n_acc, 'kr_spmv_per_step': int(spmv_n // args.steps),
                        'louvain_sweeps_per_step': int(last.lv_info.n_sweeps), 'louvain_levels': int(last.lv_info.n_levels),
                        'communities': int(last.lv_info.n_comm), 'modularity': last.lv_info.modularity,
-                       'stage_ms': {k: v / args.steps * 1e3 for k, v in stage.items()},
+                       'stage_ms': {k: v / args.steps * 1e3 for k, v in acc['stage'].items()},
                        'kernel_ms': {'kr_spmv_total': spmv_ms / args.steps, 'louvain_decide_total': move_ms / args.steps}},
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(args.config, kname),
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': measured_traffic(args.config, kname) if not sharded else None,
                          'bytes_per_launch': per_launch, 'bytes_streamed_per_launch': streamed, 'avg_launch_ms': avg_ms},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            sample = {'C1': (1000, 50000), 'C2': (100000, 5000000), 'C3': (200000, 10000000)}[args.config]
-            out['cpu_baseline'] = cpu_baseline(sample[0], sample[1], seed)
-        print(json.dumps(out), flush=True)
-    if world > 1 and not sharded:
-        sharded_check(ctx, rank, world, n, n_edges, seed, law, last if rank == 0 else None, min_len, min_sig)
+        out.update(extra)
+        return out
+
+    def emit(out):
+        if rank == 0:
+            if world == 1 and not args.no_cpu_baseline:
+                sample = {'C1': (1000, 50000), 'C2': (100000, 5000000), 'C3': (200000, 10000000)}[args.config]
+                out['cpu_baseline'] = cpu_baseline(sample[0], sample[1], seed)
+            print(json.dumps(out), flush=True)
+
+    want_replicas = world == 1 or args.mode in ('auto', 'replicas')
+    want_sharded = world > 1 and args.mode in ('auto', 'sharded')
+    rep = None
+    if want_replicas:
+        dt, last, acc = timed_leg()
+        rep = line(dt, last, acc, False, {})
+        rep_ref = last
+    if not want_sharded:
+        emit(rep)
+    else:
+        import threading
+        from bin3c_amd.dist import DistSession
+
+        def give_up(why):
+            # the replica measurement (if any) is already in hand: print it rather than lose the run
+            if rank == 0:
+                if rep is not None:
+                    rep['sharded'] = {'error': why}
+                    print(json.dumps(rep), flush=True)
+                else:
+                    sys.stderr.write('[bench] sharded leg failed: {}\n'.format(why))
+            os._exit(0 if rep is not None else 1)
+
+        watchdog = threading.Timer(float(os.environ.get('B3C_BENCH_WATCHDOG', '240')),
+                                   lambda: give_up('timed out (a collective never returned)'))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            sess = DistSession(ctx, n)
+            if os.environ.get('B3C_BENCH_FAIL_SHARDED'):          # test hook (tests/test_dist.py)
+                raise RuntimeError('sharded leg disabled by B3C_BENCH_FAIL_SHARDED')
+            dt, last, acc = timed_leg()
+            sess.check()
+            n_exchanges = sess.n_exchanges
+            sess.close()
+        except Exception as ex:
+            watchdog.cancel()
+            give_up(repr(ex))
+        watchdog.cancel()
+        extra = {'exchanges_per_step': n_exchanges // (args.steps + args.warmup)}
+        if rep is not None:
+            extra['replicas'] = {'value': rep['value'], 'unit': 'edges/s', 'ms_per_step': rep['ms_per_step'],
+                                 'scaling': 'weak', 'parallelism': rep['config']['parallelism']}
+            if rank == 0:
+                extra['agrees_with_single_gpu'] = bool(
+                    last.kr_info.n_iter == rep_ref.kr_info.n_iter and np.allclose(last.x, rep_ref.x, rtol=1e-9, atol=0)
+                    and last.lv_info.n_comm == rep_ref.lv_info.n_comm and np.array_equal(last.mask, rep_ref.mask))
+        emit(line(dt, last, acc, True, extra))
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
-
-
-def sharded_check(ctx, rank, world, n, n_edges, seed, law, ref, min_len, min_sig):
-    """Untimed live check of the row-sharded RCCL path on rank 0's map, after the JSON line has been printed.
-    A watchdog ends the process (exit code 0: the measurement is already out) should a collective never return."""
-    import threading
-    import torch
-    import torch.distributed as dist
-    from bin3c_amd.dist import DistSession
-    from bin3c_amd.pipeline import run_hot_path
-    from bin3c_amd.synth import make_edges
-    watchdog = threading.Timer(300.0, lambda: (sys.stderr.write('[bench] sharded check timed out\n'), os._exit(0)))
-    watchdog.daemon = True
-    watchdog.start()
-    try:
-        lo, hi, cnt, diag, lengths_h, sites_h, _ = make_edges(n, n_edges, seed, law)      # rank 0's map on every rank
-        counts, _e = ctx.coo_symmetrise(n, lo, hi, cnt, diag)
-        sess = DistSession(ctx, n)
-        run_hot_path(ctx, counts, sites_h, lengths_h, min_len, min_sig)                    # communicator set-up
-        dist.barrier()
-        t0 = time.perf_counter()
-        res = run_hot_path(ctx, counts, sites_h, lengths_h, min_len, min_sig)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        sess.check()
-        sess.close()
-        if rank == 0:
-            same = (res.kr_info.n_iter == ref.kr_info.n_iter and np.allclose(res.x, ref.x, rtol=1e-9, atol=0) and
-                    res.lv_info.n_comm == ref.lv_info.n_comm and bool(np.array_equal(res.mask, ref.mask)))
-            sys.stderr.write('[bench] sharded check on {} GPUs: {:.1f} ms/step, {} exchanges, agrees with the single-GPU result: {}\n'
-                             .format(world, dt * 1e3, sess.n_exchanges, same))
-    except Exception as ex:                                     # the check must never cost the measurement
-        sys.stderr.write('[bench] sharded check failed: {!r}\n'.format(ex))
-    finally:
-        watchdog.cancel()
 
 
 if __name__ == '__main__':

@@ -38,24 +38,39 @@ def test_sharded_hot_path_two_ranks_one_gpu():
     assert 'rank 0 gpu ok' in text and 'rank 1 gpu ok' in text
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['auto', 'sharded'])
-def test_bench_two_ranks_one_gpu(mode):
-    """bench.py as the driver launches it for N = 2 (gloo + one shared GPU stand in for RCCL + two GPUs)."""
+def _bench_two_ranks(mode, **extra_env):
     import json
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
            '--config', 'C2', '--mode', mode]
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1', B3C_BENCH_BACKEND='gloo',
-               B3C_BENCH_ONE_GPU='1')
+               B3C_BENCH_ONE_GPU='1', **extra_env)
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['unit'] == 'edges/s' and 'roofline' in d
-    if mode == 'sharded':
-        assert d['scaling'] == 'strong'
-    else:
-        assert d['scaling'] == 'weak'
-        assert 'sharded check on 2 GPUs' in out.stderr.decode() and 'agrees with the single-GPU result: True' in out.stderr.decode()
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['auto', 'sharded', 'replicas'])
+def test_bench_two_ranks_one_gpu(mode):
+    """bench.py as the driver launches it for N = 2 (gloo + one shared GPU stand in for RCCL + two GPUs)."""
+    d = _bench_two_ranks(mode)
+    if mode == 'replicas':
+        assert d['scaling'] == 'weak' and 'replicas x2' in d['config']['parallelism']
+        return
+    assert d['scaling'] == 'strong' and d['exchanges_per_step'] > 100
+    assert 'contig-row ranges of one map over 2 GPUs' in d['config']['parallelism']
+    if mode == 'auto':
+        assert d['replicas']['value'] > 0 and d['replicas']['scaling'] == 'weak' and d['agrees_with_single_gpu'] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('how', ['exception', 'watchdog'])
+def test_bench_keeps_the_replica_line_when_the_sharded_leg_fails(how):
+    env = {'B3C_BENCH_FAIL_SHARDED': '1'} if how == 'exception' else {'B3C_BENCH_WATCHDOG': '0.01'}
+    d = _bench_two_ranks('auto', **env)
+    assert d['scaling'] == 'weak' and 'error' in d['sharded'] and 'replicas x2' in d['config']['parallelism']
