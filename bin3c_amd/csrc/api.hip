@@ -90,8 +90,9 @@ int b3c_mat_alloc(b3c_ctx *ctx, int64_t n, int64_t nnz, int kind, b3c_mat **out)
     m->kind = kind;
     size_t esz = kind == B3C_U32 ? 4 : 8;
     m->indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(n + 1));
-    m->indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)nnz);
-    m->data = ctx->alloc(esz * (size_t)nnz);
+    // 32 bytes of slack: kernels that read the entry streams as 4-element vectors may touch up to 3 entries past nnz
+    m->indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)nnz + 32);
+    m->data = ctx->alloc(esz * (size_t)nnz + 32);
     if (!m->indptr || !m->indices || !m->data) {
         ctx->release(m->indptr);
         ctx->release(m->indices);

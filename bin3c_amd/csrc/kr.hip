@@ -593,6 +593,156 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
 }
 
 // ---------------------------------------------------------------------------------------------
+// KB, pipelined row groups with FOUR consecutive entries per lane and load: the index stream is read as 16-byte
+// and the value stream as 8/16/32-byte vectors (element aligned only: a row starts anywhere).  The texture
+// addresser handles 4 lane addresses per clock whatever their width, so the scalar form above spends 16 cycles
+// per wave on every 256 B of indices and every 128 B of 16-bit values; here the same cycles move 1 KB / 512 B.
+// Lanes may read up to 3 entries past the end of their row (masked afterwards): the matrix arrays carry 32 B of slack.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct alignas(sizeof(T)) Vec4 {
+    T v[4];
+};
+
+template <int LPR, int UN, typename VT, int PROBE = 0>
+__global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KRState *__restrict__ sin,
+                                                  KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
+                                                  int PS, const int64_t *__restrict__ indptr,
+                                                  const int32_t *__restrict__ indices, const VT *__restrict__ a,
+                                                  const double *__restrict__ rs,
+                                                  const double *__restrict__ dfix, const double *__restrict__ u,
+                                                  const double *__restrict__ x, const double *__restrict__ p,
+                                                  double *__restrict__ v, double *__restrict__ rk,
+                                                  double *__restrict__ w, double *__restrict__ part_out)
+{
+    __shared__ double lds[BLK];
+    KRState st = *sin;
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
+    const bool inner = st.phase == A_INNER;
+    if (st.phase == A_INNER) st.phase = B_INNER;
+    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if (st.phase == P_DONE) return;
+
+    constexpr int RPW = 64 / LPR;
+    constexpr int CH = LPR * UN * 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t step = (int64_t)gridDim.x * (BLK / 64) * RPW;
+    double contrib = 0.0;
+
+    int64_t row = r0 + wave * RPW + sub;
+    int64_t s = 0;
+    int len = 0;
+    Vec4<int32_t> c[UN];
+    Vec4<VT> m[UN];                             // kept RAW: converting at load time would force the wait up here
+    if (row < n) {
+        s = indptr[row];
+        len = (int)(indptr[row + 1] - s);
+    }
+#pragma unroll
+    for (int q = 0; q < UN; q++) {
+        const int i = (q * LPR + sl) * 4;
+        if (i < len) {
+            c[q] = *(const Vec4<int32_t> *)(indices + s + i);
+            m[q] = *(const Vec4<VT> *)(a + s + i);
+        } else {
+            c[q] = Vec4<int32_t>{{0, 0, 0, 0}};
+            m[q] = Vec4<VT>{{VT(0), VT(0), VT(0), VT(0)}};
+        }
+    }
+    while (row < n) {
+        const int64_t rown = row + step;
+        // 1. pointers of the next row (latency hidden behind this row's gathers)
+        int64_t sn = 0;
+        int lenn = 0;
+        if (rown < n) {
+            sn = indptr[rown];
+            lenn = (int)(indptr[rown + 1] - sn);
+        }
+        // 2. this row: epilogue operands and gathers
+        double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0, ri = 1.0;
+        if (sl == 0) {
+            xi = x[row];
+            if (inner) { pi = p[row]; vi = v[row]; }
+            di = dfix[row] * (inner ? xi * pi : xi);
+            if (rs) ri = rs[row];
+        }
+        double g[UN][4];
+#pragma unroll
+        for (int q = 0; q < UN; q++) {
+            const int i = (q * LPR + sl) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (PROBE == 1) {      // timing probe only (wrong results): the 4 lanes of a quad gather from ONE 32-byte block
+                    const int lead = __builtin_amdgcn_mov_dpp(c[q].v[j], 0x00, 0xf, 0xf, true);
+                    g[q][j] = u[i + j < len ? (uint32_t)((lead & ~3) | (lane & 3)) : 0u];
+                } else
+                    g[q][j] = u[i + j < len ? (uint32_t)c[q].v[j] : 0u];
+            }
+        }
+        // 3. first chunk of the next row
+        Vec4<int32_t> c2[UN];
+        Vec4<VT> m2[UN];
+#pragma unroll
+        for (int q = 0; q < UN; q++) {
+            const int i = (q * LPR + sl) * 4;
+            if (i < lenn) {
+                c2[q] = *(const Vec4<int32_t> *)(indices + sn + i);
+                m2[q] = *(const Vec4<VT> *)(a + sn + i);
+            } else {
+                c2[q] = Vec4<int32_t>{{0, 0, 0, 0}};
+                m2[q] = Vec4<VT>{{VT(0), VT(0), VT(0), VT(0)}};
+            }
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < UN; q++) {
+            const int i = (q * LPR + sl) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc += (i + j < len ? (double)m[q].v[j] : 0.0) * g[q][j];
+        }
+        // rows longer than one chunk: plain loop over the rest
+        for (int base = CH; base < len; base += CH) {
+#pragma unroll
+            for (int q = 0; q < UN; q++) {
+                const int i = base + (q * LPR + sl) * 4;
+                if (i < len) {
+                    const Vec4<int32_t> cc = *(const Vec4<int32_t> *)(indices + s + i);
+                    const Vec4<VT> mm = *(const Vec4<VT> *)(a + s + i);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (i + j < len) acc += (double)mm.v[j] * u[(uint32_t)cc.v[j]];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
+        if (sl == 0) {
+            const double t = acc * ri + di;
+            if (inner) {
+                const double wi = xi * t + vi * pi;
+                w[row] = wi;
+                contrib += pi * wi;
+            } else {
+                const double vn = xi * t;
+                const double r = 1.0 - vn;
+                v[row] = vn;
+                rk[row] = r;
+                contrib += r * r;
+            }
+        }
+        row = rown;
+        s = sn;
+        len = lenn;
+#pragma unroll
+        for (int q = 0; q < UN; q++) { c[q] = c2[q]; m[q] = m2[q]; }
+    }
+    block_partial<0>(contrib, part_out, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
 // KB, sliced-ELL form (SELL-64-sigma): the layout the iteration actually runs on when rows are regular.
 // Rows are sorted by length inside windows of SELL_W rows (keeps the locality order to within a window),
 // cut into slices of 64, and every slice is stored column-major and padded to its longest row.  Lane r of a
@@ -1119,6 +1269,25 @@ void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRStat
 }
 
 template <int LPR, int UN>
+void launch_kb_vec(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
+                   int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
+                   const double *x, const double *p, double *v, double *rk, double *w, double *part_out)
+{
+    if (m->kind == B3C_U32 && v16 && getenv("B3C_KR_QUADPROBE"))
+        hipLaunchKernelGGL((kr_kb_vec<LPR, UN, uint16_t, 1>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out);
+    else if (m->kind == B3C_U32 && v16)
+        hipLaunchKernelGGL((kr_kb_vec<LPR, UN, uint16_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out);
+    else if (m->kind == B3C_U32)
+        hipLaunchKernelGGL((kr_kb_vec<LPR, UN, uint32_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
+    else
+        hipLaunchKernelGGL((kr_kb_vec<LPR, UN, double>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
+                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
+}
+
+template <int LPR, int UN>
 void launch_kb_rows(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
                     int PA, int PS, const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
                     double *rk, double *w, double *part_out)
@@ -1190,7 +1359,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int lpr2 = avg >= 64 ? 32 : avg >= 24 ? 16 : avg >= 10 ? 8 : 4;
     const int GS = stream_kb ? grid_for(nblk, 1, 8 * ctx->n_cu)
                  : sell ? grid_for((nloc + 63) / 64, BLK / 64, 8 * ctx->n_cu)
-                 : pipe_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_p), 16 * ctx->n_cu)
+                 : pipe_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_p), (getenv("B3C_KR_GSMUL") ? atoi(getenv("B3C_KR_GSMUL")) : 16) * ctx->n_cu)
                  : rows_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_r), 8 * ctx->n_cu)
                            : grid_for(n, rows_per_block, 8 * ctx->n_cu);
     const int P = G > GS ? G : GS;
@@ -1264,7 +1433,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         a = perm.m;
     }
     // count form: 16-bit copy of the values when they all fit (built on the matrix the iteration runs on)
-    DevBuf<uint16_t> v16buf(ctx, counts ? a->nnz : 1);
+    DevBuf<uint16_t> v16buf(ctx, counts ? a->nnz + 16 : 1);     // slack: kr_kb_vec reads whole 4-entry vectors
     const uint16_t *v16 = nullptr;
     if (counts && a->nnz && getenv("B3C_KR_NO_U16") == nullptr) {
         DevBuf<unsigned int> mx(ctx, 1);
@@ -1337,6 +1506,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 
     int t = 0;  // state ping-pong index
     const int BATCH = 8;
+    const int vec_shape = getenv("B3C_KR_VEC") ? atoi(getenv("B3C_KR_VEC")) : 0;   // other kr_kb_vec<LPR, UN> shapes, e.g. 164; -1: scalar-load form
     long long ticks = 0;
     // sharded: a kernel's block partials are folded into this rank's slot of the packed scalar buffer and
     // all-gathered; the consumer then reduces `world` values (stride 4) in rank order instead of P block partials
@@ -1380,7 +1550,15 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                                    svals, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
             } else if (rows_kb && pipe_kb) {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
-                if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (vec_shape == 88) launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (vec_shape == 162) launch_kb_vec<16, 2>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (vec_shape == 48) launch_kb_vec<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (vec_shape == 324) launch_kb_vec<32, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (avg > 128 && a->kind == B3C_U32 && vec_shape >= 0)    // 4 entries per lane and load: 0.505 vs 0.544 ms at C3
+                    launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
                 else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
                 else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
                 else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);

@@ -16,6 +16,7 @@
 // The order only affects speed: all results are returned in the caller's numbering.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
@@ -395,7 +396,8 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     hipStream_t s = ctx->stream;
     const int64_t n = a->n;
     if (n == 0) return B3C_OK;
-    constexpr int ROUNDS = 3;
+    int ROUNDS = 3;
+    if (const char *e = getenv("B3C_ORDER_ROUNDS")) ROUNDS = std::max(1, std::min(12, atoi(e)));
     DevBuf<int32_t> p0(ctx, n), p1(ctx, n), lab(ctx, (size_t)n * ROUNDS), kin(ctx, n), kout(ctx, n), vout(ctx, n);
     DevBuf<unsigned long long> cbest(ctx, n);
     DevBuf<int> changed(ctx, 1);
