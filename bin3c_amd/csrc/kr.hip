@@ -604,7 +604,7 @@ struct alignas(sizeof(T)) Vec4 {
     T v[4];
 };
 
-template <int LPR, int UN, typename VT, int PROBE = 0>
+template <int LPR, int UN, typename VT>
 __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KRState *__restrict__ sin,
                                                   KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
                                                   int PS, const int64_t *__restrict__ indptr,
@@ -674,13 +674,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
         for (int q = 0; q < UN; q++) {
             const int i = (q * LPR + sl) * 4;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (PROBE == 1) {      // timing probe only (wrong results): the 4 lanes of a quad gather from ONE 32-byte block
-                    const int lead = __builtin_amdgcn_mov_dpp(c[q].v[j], 0x00, 0xf, 0xf, true);
-                    g[q][j] = u[i + j < len ? (uint32_t)((lead & ~3) | (lane & 3)) : 0u];
-                } else
-                    g[q][j] = u[i + j < len ? (uint32_t)c[q].v[j] : 0u];
-            }
+            for (int j = 0; j < 4; j++) g[q][j] = u[i + j < len ? (uint32_t)c[q].v[j] : 0u];
         }
         // 3. first chunk of the next row
         Vec4<int32_t> c2[UN];
@@ -1273,10 +1267,7 @@ void launch_kb_vec(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState
                    int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
                    const double *x, const double *p, double *v, double *rk, double *w, double *part_out)
 {
-    if (m->kind == B3C_U32 && v16 && getenv("B3C_KR_QUADPROBE"))
-        hipLaunchKernelGGL((kr_kb_vec<LPR, UN, uint16_t, 1>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out);
-    else if (m->kind == B3C_U32 && v16)
+    if (m->kind == B3C_U32 && v16)
         hipLaunchKernelGGL((kr_kb_vec<LPR, UN, uint16_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
                            m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out);
     else if (m->kind == B3C_U32)

@@ -670,6 +670,42 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
     if (lane == 0 && acc) atomicAdd(i2, (u64)acc);
 }
 
+// Change of I2 caused by the moves a sub-round is about to apply (com = labels before, nxt = labels after; nxt == com
+// for every node that does not move).  An off-diagonal entry (v, u) changes its indicator only if v or u moves; scanning
+// the rows of the MOVERS covers the entries (v, *) directly and, by symmetry of the graph, the mirror entries (u, v) of
+// the neighbours that stay -- hence the factor two for those.  Exact integer arithmetic, any order.
+__global__ void __launch_bounds__(BLK) k_lv_delta_internal(int64_t cnt, const NodeRec *__restrict__ list,
+                                                            const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
+                                                            const int32_t *__restrict__ com, const int32_t *__restrict__ nxt,
+                                                            u64 *__restrict__ i2)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    long long acc = 0;
+    for (int64_t t = wave; t < cnt; t += nwave) {
+        const NodeRec rec = list[t];
+        const int32_t a = com[rec.node], b = nxt[rec.node];
+        if (a == b) continue;
+        for (int64_t k = rec.start + lane; k < rec.start + rec.deg; k += 64) {
+            const int32_t j = indices[k];
+            if (j == rec.node) continue;
+            const int32_t cj = com[j], nj = nxt[j];
+            const int d = (int)(nj == b) - (int)(cj == a);
+            if (d) acc += (long long)d * q[k] * (cj == nj ? 2 : 1);
+        }
+    }
+    acc = wave_sum_ll(acc);
+    __shared__ long long red[WPB];
+    if (lane == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long tsum = 0;
+        for (int w = 0; w < WPB; w++) tsum += red[w];
+        if (tsum) atomicAdd(i2, (u64)tsum);
+    }
+}
+
 // T2 = sum_c tot_c^2 as four 32-bit limbs, each accumulated in a u64
 __global__ void __launch_bounds__(BLK) k_lv_tot2(int64_t n, const int64_t *__restrict__ tot, u64 *__restrict__ limbs)
 {
@@ -1083,9 +1119,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipStreamSynchronize(s));
         }
 
-        auto modularity = [&](double *out) -> int {
-            HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64) * 5, s));
-            hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2);
+        // full: recount the internal weight; otherwise ctr[2] was kept up to date by k_lv_delta_internal
+        auto modularity = [&](double *out, bool full) -> int {
+            HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
+            if (full) {
+                HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64), s));
+                hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2);
+            }
             hipLaunchKernelGGL(k_lv_tot2, dim3(gv), dim3(BLK), 0, s, n, tot.p, ctr.p + 3);
             u64 h[8];
             HIP_TRY(ctx, hipMemcpyAsync(h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -1109,13 +1149,18 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         };
 
         double cur_mod, new_mod;
-        if ((rc = modularity(&new_mod))) { free_graph(ctx, g); return rc; }
+        if ((rc = modularity(&new_mod, true))) { free_graph(ctx, g); return rc; }
         int sweep = 0;
+        u64 prev_moved = ~0ull;
+        const int incr_div = getenv("B3C_LV_INCR_DIV") ? atoi(getenv("B3C_LV_INCR_DIV")) : 4;
         for (;;) {
             cur_mod = new_mod;
             sweep++;
             info->n_sweeps++;
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 1, 0, sizeof(u64), s));
+            // few movers expected (the sweep before moved under a quarter of the nodes): track the internal weight through
+            // the movers' rows instead of rescanning the whole graph after the sweep
+            const bool incr = grouped && prev_moved != ~0ull && prev_moved * (u64)incr_div < (u64)n && getenv("B3C_LV_NO_INCR") == nullptr;
             for (int r = 0; r < n_sub; r++) {
                 evs.rec();
                 if (grouped && loff[r + 1] > loff[r]) {
@@ -1153,6 +1198,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (dist && D.allgather(D.user, B3C_BUF_LABELS) != 0)
                     return ctx->fail(B3C_E_HIP, "b3c_louvain: all-gather callback failed");
                 info->n_move_launch++;
+                if (incr) {
+                    const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
+                    if (c1) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c1, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c1,
+                                               nlist.p + loff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2);
+                    if (c2) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c2, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c2,
+                                               hlist.p + hoff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2);
+                }
                 if (grouped && !dist) {
                     // only the nodes that decided in this sub-round can have moved
                     const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
@@ -1171,8 +1223,10 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemcpyAsync(&moved, ctr.p + 1, sizeof(u64), hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
             info->n_moves += (int64_t)moved;
+            if (getenv("B3C_LV_DEBUG")) fprintf(stderr, "[b3c] level %d sweep %d: %llu of %lld nodes moved\n", (int)info->n_levels, sweep, (unsigned long long)moved, (long long)n);
             if (moved == 0) break;
-            if ((rc = modularity(&new_mod))) { free_graph(ctx, g); return rc; }
+            prev_moved = moved;
+            if ((rc = modularity(&new_mod, !incr))) { free_graph(ctx, g); return rc; }
             if (new_mod - cur_mod < PL_MIN) break;
             if (max_sweeps > 0 && sweep >= max_sweeps) break;
         }
