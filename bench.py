@@ -49,6 +49,25 @@ def measured_traffic(config, kernel):
     return None
 
 
+def measured_copy_gbs():
+    """Achievable HBM rate on this box: device-to-device copy of 1 GiB (read + write), best of 5, torch stream."""
+    import torch
+    a = torch.empty(1 << 28, dtype=torch.float32, device='cuda')
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    best = None
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None or ms < best else best
+    del a, b
+    return 2.0 * (1 << 30) / (best * 1e-3) / 1e9
+
+
 def cpu_baseline(sample_n, sample_e, seed):
     """Oracle (scalar C port of the reference path) on a bounded sample of the same workload, 1 thread."""
     import oracle
@@ -162,9 +181,9 @@ def main():
         if spmv_ms >= move_ms:
             per_launch = (12.0 * nnz + 20.0 * n) * share   # one KR SpMV
             vb = last.kr_info.value_bits / 8.0             # 2 when all counts fit 16 bits, else 4 (8: fp64 matrix)
-            streamed = ((4.0 + vb) * nnz + 36.0 * n) * share   # what kr_kb_pipe physically reads/writes
+            streamed = ((4.0 + vb) * nnz + 36.0 * n) * share   # what the SpMV kernel physically reads/writes
             avg_ms = spmv_ms / max(spmv_n, 1)
-            kname = 'kr_kb_pipe (CSR SpMV on raw counts + fused KR epilogue)'
+            kname = 'kr_kb_vec (CSR SpMV on raw counts + fused KR epilogue)'
         else:
             per_launch = (16.0 * acc['move_nnz'] + 28.0 * acc['move_rows']) / max(move_n, 1)   # Louvain sweep / n_sub
             streamed = per_launch
@@ -197,6 +216,8 @@ def main():
 
     def emit(out):
         if rank == 0:
+            if world == 1:
+                out['roofline']['copy_gbs'] = measured_copy_gbs()     # what a plain copy reaches on this box, beside `peak`
             if world == 1 and not args.no_cpu_baseline:
                 sample = {'C1': (1000, 50000), 'C2': (100000, 5000000), 'C3': (200000, 10000000)}[args.config]
                 out['cpu_baseline'] = cpu_baseline(sample[0], sample[1], seed)
