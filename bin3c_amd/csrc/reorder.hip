@@ -106,26 +106,27 @@ __global__ void __launch_bounds__(BLK) k_best_external(int64_t n, const int64_t 
         const int64_t s = indptr[row], e = indptr[row + 1];
         const int32_t li = label[row];
         unsigned long long best = 0;
-        int64_t k = s + sl;
-        for (; k + 3 * LPR < e; k += 4 * LPR) {
-            int32_t j0 = indices[k], j1 = indices[k + LPR], j2 = indices[k + 2 * LPR], j3 = indices[k + 3 * LPR];
-            float v0 = (float)a[k], v1 = (float)a[k + LPR], v2 = (float)a[k + 2 * LPR], v3 = (float)a[k + 3 * LPR];
-            int32_t l0 = label[j0], l1 = label[j1], l2 = label[j2], l3 = label[j3];
-            unsigned long long c0 = ((unsigned long long)__float_as_uint(v0) << 32) | (0xFFFFFFFFu - (uint32_t)l0);
-            unsigned long long c1 = ((unsigned long long)__float_as_uint(v1) << 32) | (0xFFFFFFFFu - (uint32_t)l1);
-            unsigned long long c2 = ((unsigned long long)__float_as_uint(v2) << 32) | (0xFFFFFFFFu - (uint32_t)l2);
-            unsigned long long c3 = ((unsigned long long)__float_as_uint(v3) << 32) | (0xFFFFFFFFu - (uint32_t)l3);
-            if (l0 != li && v0 > 0.f && c0 > best) best = c0;
-            if (l1 != li && v1 > 0.f && c1 > best) best = c1;
-            if (l2 != li && v2 > 0.f && c2 > best) best = c2;
-            if (l3 != li && v3 > 0.f && c3 > best) best = c3;
-        }
-        for (; k < e; k += LPR) {
-            int32_t j = indices[k];
-            float v = (float)a[k];
-            int32_t l = label[j];
-            unsigned long long c = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (uint32_t)l);
-            if (l != li && v > 0.f && c > best) best = c;
+        // four masked slots per lane and pass: all index loads, then all label gathers are in flight together (a slot past
+        // the end of the row points at the row itself, whose label is li, so it never wins)
+        for (int64_t base = s; base < e; base += 4 * LPR) {
+            int32_t j[4];
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t k = base + q * LPR + sl;
+                const bool ok = k < e;
+                const int64_t kc = ok ? k : s;
+                j[q] = ok ? indices[kc] : (int32_t)row;
+                v[q] = ok ? (float)a[kc] : 0.f;
+            }
+            int32_t l[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) l[q] = label[j[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned long long c = ((unsigned long long)__float_as_uint(v[q]) << 32) | (0xFFFFFFFFu - (uint32_t)l[q]);
+                if (l[q] != li && v[q] > 0.f && c > best) best = c;
+            }
         }
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) {
