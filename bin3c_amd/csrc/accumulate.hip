@@ -131,8 +131,7 @@ extern "C" int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int6
             if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_coo_symmetrise: reduce workspace");
             HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(tmp.p, tb, k_out.p, ukeys.p, v_out.p, usums.p, nruns.p, hipcub::Sum(), (int)m, s));
         }
-        HIP_TRY(ctx, hipMemcpyAsync(&u, nruns.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &u, nruns.p, sizeof(int64_t)); if (rb_) return rb_; }
     }
 
     // 2. mirror + diagonal, sort by (row, col)
@@ -158,8 +157,7 @@ extern "C" int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int6
         HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_count_valid, dim3(grid_for(total, 1024, 16 * ctx->n_cu)), dim3(256), 0, s, total, e_out.p, cnt.p);
         unsigned long long hc = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &hc, cnt.p, sizeof(hc)); if (rb_) return rb_; }
         nnz = (int64_t)hc;
     }
     b3c_mat *mat = nullptr;
@@ -179,8 +177,7 @@ extern "C" int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int6
         if (diag && n) {
             HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s));
             hipLaunchKernelGGL(k_count_valid, dim3(grid_for(n, 1024, 4 * ctx->n_cu)), dim3(256), 0, s, n, e_in.p + 2 * u, cnt.p);
-            HIP_TRY(ctx, hipMemcpyAsync(&hd, cnt.p, sizeof(hd), hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipStreamSynchronize(s));
+            { const int rb_ = b3c_readback(ctx, &hd, cnt.p, sizeof(hd)); if (rb_) return rb_; }
         }
         *n_edges = (nnz - (int64_t)hd) / 2;
     }

@@ -26,6 +26,7 @@ extern "C" int b3c_ctx_create(int device, void *stream, b3c_ctx **out)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
+    if (hipHostMalloc(&ctx->pin, B3C_PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->pin = nullptr;
     *out = ctx;
     return B3C_OK;
 }
@@ -37,6 +38,7 @@ extern "C" int b3c_ctx_destroy(b3c_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->trim();
     for (auto &kv : ctx->live) (void)hipFree(kv.first);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -79,6 +81,20 @@ int b3c_copy_out(b3c_ctx *ctx, void *dst, const void *src, size_t bytes)
     if (bytes == 0) return B3C_OK;
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return B3C_OK;
+}
+
+int b3c_readback(b3c_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return B3C_OK;
+    if (bytes > B3C_PIN_BYTES || !ctx->pin) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return B3C_OK;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(dst, ctx->pin, bytes);
     return B3C_OK;
 }
 

@@ -26,6 +26,7 @@ struct b3c_ctx {
     int64_t bytes = 0;
     int n_cu = 256;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *pin = nullptr;      // pinned host staging for small read-backs (a pageable destination costs a staged copy)
     b3c_dist dist;            // row-sharded multi-GPU execution (b3c_ctx_set_dist); world <= 1: off
     bool has_dist = false;
 
@@ -157,3 +158,6 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 int b3c_mat_alloc(b3c_ctx *ctx, int64_t n, int64_t nnz, int kind, b3c_mat **out);
 int b3c_copy_in(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
 int b3c_copy_out(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
+// device -> host read-back of a few values the host logic waits for: through the context's pinned buffer, then sync
+int b3c_readback(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
+constexpr size_t B3C_PIN_BYTES = 64 * 1024;

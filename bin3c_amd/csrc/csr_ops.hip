@@ -413,8 +413,7 @@ extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask,
     if (n) hipLaunchKernelGGL(k_mask_to_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, keep.p);
     if ((rc = b3c_exclusive_scan_i64(ctx, keep.p, newid.p, n + 1))) return rc;
     int64_t m = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&m, newid.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    { const int rb_ = b3c_readback(ctx, &m, newid.p + n, sizeof(int64_t)); if (rb_) return rb_; }
     HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, sizeof(int64_t) * (size_t)(m + 1), s));
     const int lpr = pick_lpr(a);
     if (n) {
@@ -422,8 +421,7 @@ extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask,
     }
     if ((rc = b3c_exclusive_scan_i64(ctx, cnt.p, optr.p, m + 1))) return rc;
     int64_t nnz = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&nnz, optr.p + m, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    { const int rb_ = b3c_readback(ctx, &nnz, optr.p + m, sizeof(int64_t)); if (rb_) return rb_; }
     b3c_mat *o = nullptr;
     if ((rc = b3c_mat_alloc(ctx, m, nnz, a->kind, &o))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(o->indptr, optr.p, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToDevice, s));
@@ -464,8 +462,7 @@ extern "C" int b3c_max_value(b3c_ctx *ctx, const b3c_mat *a, double *out)
     if (!part.p) return ctx->fail(B3C_E_NOMEM, "b3c_max_value");
     hipLaunchKernelGGL(k_max_value, dim3(g), dim3(BLK), 0, ctx->stream, a->nnz, (const double *)a->data, part.p);
     std::vector<double> h(g);
-    HIP_TRY(ctx, hipMemcpyAsync(h.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int rb_ = b3c_readback(ctx, h.data(), part.p, sizeof(double) * g); if (rb_) return rb_; }
     double m = -INFINITY;
     for (int i = 0; i < g; i++) m = h[i] > m ? h[i] : m;
     // implicit zeros take part in scipy's max unless the matrix is completely dense

@@ -318,8 +318,7 @@ extern "C" int b3c_downsample(b3c_ctx *ctx, const b3c_mat *a, int64_t block_size
     int rc;
     if ((rc = b3c_exclusive_scan_i64(ctx, cnt.p, optr.p, nb + 1))) return rc;
     int64_t nnz = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&nnz, optr.p + nb, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    { const int rb_ = b3c_readback(ctx, &nnz, optr.p + nb, sizeof(int64_t)); if (rb_) return rb_; }
     b3c_mat *o = nullptr;
     if ((rc = b3c_mat_alloc(ctx, nb, nnz, B3C_F64, &o))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(o->indptr, optr.p, sizeof(int64_t) * (size_t)(nb + 1), hipMemcpyDeviceToDevice, s));

@@ -1325,8 +1325,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (!md.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
         HIP_TRY(ctx, hipMemsetAsync(md.p, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(kr_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, md.p);
-        HIP_TRY(ctx, hipMemcpyAsync(&maxdeg, md.p, sizeof(maxdeg), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &maxdeg, md.p, sizeof(maxdeg)); if (rb_) return rb_; }
     }
     // SpMV form: "rows" (default), "stream" (LDS-staged CSR-stream) or "wave" (plain wave-per-row)
     const char *kform = getenv("B3C_KR_KERNEL");
@@ -1395,8 +1394,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (counts) hipLaunchKernelGGL(kr_sym_hash<uint32_t>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, hs.p);
         else hipLaunchKernelGGL(kr_sym_hash<double>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, hs.p);
         unsigned long long hh[4];
-        HIP_TRY(ctx, hipMemcpyAsync(hh, hs.p, sizeof(hh), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, hh, hs.p, sizeof(hh)); if (rb_) return rb_; }
         info->bitwise_symmetric = hh[0] == hh[2] && hh[1] == hh[3];
         if (!info->bitwise_symmetric || getenv("B3C_KR_EXACT_SYMCHECK")) {
             const int ga = grid_for(n, 4, 8 * ctx->n_cu);
@@ -1433,8 +1431,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         const int gq = grid_for(a->nnz, 1024, 8 * ctx->n_cu);
         hipLaunchKernelGGL(kr_max_u32, dim3(gq), dim3(256), 0, s, a->nnz, (const uint32_t *)a->data, mx.p);
         unsigned int hmx = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&hmx, mx.p, sizeof(hmx), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &hmx, mx.p, sizeof(hmx)); if (rb_) return rb_; }
         if (hmx <= 0xFFFFu) {
             hipLaunchKernelGGL(kr_narrow_u16, dim3(gq), dim3(256), 0, s, a->nnz, (const uint32_t *)a->data, v16buf.p);
             v16 = v16buf.p;
@@ -1468,8 +1465,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         int rc = b3c_exclusive_scan_i64(ctx, ssz.p, sptr.p, nsl + 1);
         if (rc) return rc;
         int64_t tot = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&tot, sptr.p + nsl, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &tot, sptr.p + nsl, sizeof(int64_t)); if (rb_) return rb_; }
         scols = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(tot > 0 ? tot : 1));
         svals = (double *)ctx->alloc(sizeof(double) * (size_t)(tot > 0 ? tot : 1));
         if (!scols || !svals) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: SELL storage");
@@ -1601,8 +1597,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             t++;
             ticks++;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(&h, states.p + (t & 1), sizeof(h), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &h, states.p + (t & 1), sizeof(h)); if (rb_) return rb_; }
         if (h.phase == P_DONE) break;
         if (ticks > 200000 + 16 * (long long)max_iter)
             return ctx->fail(B3C_E_NOCONV, "b3c_kr_balance: inner iteration did not terminate after %lld SpMVs", ticks);

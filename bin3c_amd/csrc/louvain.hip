@@ -935,8 +935,7 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
         hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, ids,
                            a->sorted_cols ? 1 : 0, scl, w.p, part.p);
     std::vector<double> hp(g);
-    HIP_TRY(ctx, hipMemcpyAsync(hp.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    { const int rb_ = b3c_readback(ctx, hp.data(), part.p, sizeof(double) * g); if (rb_) return rb_; }
     double wmax = 0.0;
     for (int i = 0; i < g; i++) wmax = hp[i] > wmax ? hp[i] : wmax;
     int shift = 0;
@@ -946,8 +945,7 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
         HIP_TRY(ctx, hipMemsetAsync(total.p, 0, sizeof(u64), s));
         hipLaunchKernelGGL(k_quant_total, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, w.p, 20 - e, total.p);
         u64 tot = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&tot, total.p, sizeof(u64), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &tot, total.p, sizeof(u64)); if (rb_) return rb_; }
         int bits = 0;
         while (bits < 64 && (tot >> bits)) bits++;
         shift = 61 - (bits - 20 + e);
@@ -1055,8 +1053,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                            nxt_p, csize.p, ctr.p);
         hipLaunchKernelGGL(k_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
         u64 hc[8];
-        HIP_TRY(ctx, hipMemcpyAsync(hc, ctr.p, sizeof(hc), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, hc, ctr.p, sizeof(hc)); if (rb_) return rb_; }
         const u64 m2 = hc[0];
         const int64_t maxdeg = (int64_t)hc[7];
         if (m2 == 0) break;   // no links: every node alone (generate_dendrogram special case)
@@ -1067,8 +1064,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap, g.indptr, gsz.p);
         if ((rc = b3c_exclusive_scan_i64(ctx, gsz.p, goff.p, n + 1))) { free_graph(ctx, g); return rc; }
         int64_t gtab = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&gtab, goff.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &gtab, goff.p + n, sizeof(int64_t)); if (rb_) return rb_; }
         DevBuf<int32_t> gkeys(ctx, gtab + 1);
         DevBuf<u64> gvals(ctx, gtab + 1);
         if (!gkeys.p || !gvals.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hub tables"); }
@@ -1092,8 +1088,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, r, short_max, g.indptr, ids, kdeg.p, lflag.p);
                 if ((rc = b3c_exclusive_scan_i64(ctx, lflag.p, lpos.p, nloc + 1))) { free_graph(ctx, g); return rc; }
                 int64_t cntr = 0;
-                HIP_TRY(ctx, hipMemcpyAsync(&cntr, lpos.p + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(ctx, hipStreamSynchronize(s));
+                { const int rb_ = b3c_readback(ctx, &cntr, lpos.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
                 hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, lflag.p, lpos.p, g.indptr, nlist.p + loff[r]);
                 loff[r + 1] = loff[r] + cntr;
             }
@@ -1111,8 +1106,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, r, -short_max, g.indptr, ids, kdeg.p, lflag.p);
                 if ((rc = b3c_exclusive_scan_i64(ctx, lflag.p, lpos.p, nloc + 1))) { free_graph(ctx, g); return rc; }
                 int64_t cntr = 0;
-                HIP_TRY(ctx, hipMemcpyAsync(&cntr, lpos.p + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(ctx, hipStreamSynchronize(s));
+                { const int rb_ = b3c_readback(ctx, &cntr, lpos.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
                 hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, lflag.p, lpos.p, g.indptr, hlist.p + hoff[r]);
                 hoff[r + 1] = hoff[r] + cntr;
             }
@@ -1134,8 +1128,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, ctr.p + 2, sizeof(u64), hipMemcpyDeviceToDevice, s));
                 if (D.allgather(D.user, B3C_BUF_ISUM) != 0) return ctx->fail(B3C_E_HIP, "b3c_louvain: all-gather callback failed");
                 std::vector<int64_t> parts(2 * (size_t)D.world);
-                HIP_TRY(ctx, hipMemcpyAsync(parts.data(), D.isum, sizeof(int64_t) * parts.size(), hipMemcpyDeviceToHost, s));
-                HIP_TRY(ctx, hipStreamSynchronize(s));
+                { const int rb_ = b3c_readback(ctx, parts.data(), D.isum, sizeof(int64_t) * parts.size()); if (rb_) return rb_; }
                 u64 tot_i2 = 0;
                 for (int r = 0; r < D.world; r++) tot_i2 += (u64)parts[2 * (size_t)r];
                 h[2] = tot_i2;
@@ -1220,8 +1213,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             info->move_nnz += g.nnz;
             info->move_rows += g.n;
             u64 moved = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(&moved, ctr.p + 1, sizeof(u64), hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipStreamSynchronize(s));
+            { const int rb_ = b3c_readback(ctx, &moved, ctr.p + 1, sizeof(u64)); if (rb_) return rb_; }
             info->n_moves += (int64_t)moved;
             if (getenv("B3C_LV_DEBUG")) fprintf(stderr, "[b3c] level %d sweep %d: %llu of %lld nodes moved\n", (int)info->n_levels, sweep, (unsigned long long)moved, (long long)n);
             if (moved == 0) break;
@@ -1254,8 +1246,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         hipLaunchKernelGGL(k_pairs_count, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, cn.p, pcnt.p);
         if ((rc = b3c_exclusive_scan_i64(ctx, pcnt.p, ppos.p, n + 1))) { free_graph(ctx, g); return rc; }
         int64_t m = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&m, ppos.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &m, ppos.p + n, sizeof(int64_t)); if (rb_) return rb_; }
         DevBuf<int64_t> k_in(ctx, m), k_out(ctx, m), v_in(ctx, m), v_out(ctx, m), nruns(ctx, 1);
         if (!k_in.p || !k_out.p || !v_in.p || !v_out.p || !nruns.p) {
             free_graph(ctx, g);
@@ -1281,8 +1272,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                                                            hipcub::Sum(), (int)m, s));
         }
         int64_t nu = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&nu, nruns.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &nu, nruns.p, sizeof(int64_t)); if (rb_) return rb_; }
 
         LvGraph h;
         h.n = kc; h.nnz = nu; h.owned = true;

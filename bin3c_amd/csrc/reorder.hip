@@ -380,8 +380,7 @@ static int forest_roots(b3c_ctx *ctx, int64_t n, int32_t *p0, int32_t *p1, int *
         HIP_TRY(ctx, hipMemsetAsync(changed, 0, sizeof(int), s));
         hipLaunchKernelGGL(k_jump, dim3(gn), dim3(256), 0, s, n, cur, nxt, changed);
         int h = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &h, changed, sizeof(int)); if (rb_) return rb_; }
         int32_t *t = cur; cur = nxt; nxt = t;
         if (!h) break;
     }
@@ -477,8 +476,7 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
         if (!ml.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr"); }
         HIP_TRY(ctx, hipMemsetAsync(ml.p, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_max_len, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, ml.p);
-        HIP_TRY(ctx, hipMemcpyAsync(&maxlen, ml.p, sizeof(maxlen), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        { const int rb_ = b3c_readback(ctx, &maxlen, ml.p, sizeof(maxlen)); if (rb_) return rb_; }
     }
     constexpr int CAPR = 512;
     if (nnz && sort_cols && maxlen <= CAPR && getenv("B3C_PERMUTE_GLOBAL_SORT") == nullptr) {
