@@ -349,6 +349,91 @@ __global__ void __launch_bounds__(BLK) k_permute_rows_packed(int64_t n, int pb, 
     }
 }
 
+// Register form of the packed sort: lane l holds the R keys of positions l*R .. l*R+R-1, so the compare-exchange
+// stages with distance < R stay inside a lane and the others are one cross-lane shuffle per key -- 84 LDS-pipe operations
+// for a 256-entry row against 576 for the in-LDS network above, which is bound by exactly that pipe (C3: 4.6 -> see
+// DESIGN.md).  Loads and stores are R consecutive entries per lane.
+template <int R>
+__device__ __forceinline__ void bitonic_regs(uint32_t (&k)[R], int lane)
+{
+    constexpr int N = 64 * R;
+#pragma unroll
+    for (int kk = 2; kk <= N; kk <<= 1) {
+#pragma unroll
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            if (jj < R) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((r & jj) == 0) {
+                        const bool asc = (((lane * R + r) & kk) == 0);
+                        const uint32_t a = k[r], b = k[r | jj];
+                        const bool sw = (a > b) == asc;
+                        k[r] = sw ? b : a;
+                        k[r | jj] = sw ? a : b;
+                    }
+                }
+            } else {
+                const int lx = jj / R;
+                const bool lower = (lane & lx) == 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint32_t other = (uint32_t)__shfl_xor((int)k[r], lx, 64);
+                    const bool asc = (((lane * R + r) & kk) == 0);
+                    const uint32_t mn = k[r] < other ? k[r] : other, mx = k[r] < other ? other : k[r];
+                    k[r] = (lower == asc) ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int R>
+__device__ __forceinline__ void permute_row_regs(int lane, int pb, int len, const int32_t *__restrict__ ci,
+                                                 const T *__restrict__ av, const int32_t *__restrict__ old2new,
+                                                 int32_t *__restrict__ oi, T *__restrict__ oa)
+{
+    const uint32_t pmask = (1u << pb) - 1u;
+    uint32_t k[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int e = lane * R + r;
+        k[r] = e < len ? ((uint32_t)old2new[ci[e]] << pb) | (uint32_t)e : 0xFFFFFFFFu;
+    }
+    bitonic_regs<R>(k, lane);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int e = lane * R + r;
+        if (e < len) {
+            oi[e] = (int32_t)(k[r] >> pb);
+            oa[e] = av[k[r] & pmask];
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLK) k_permute_rows_regs(int64_t n, int pb, const int64_t *__restrict__ indptr,
+                                                            const int32_t *__restrict__ indices, const T *__restrict__ a,
+                                                            const int32_t *__restrict__ new2old,
+                                                            const int32_t *__restrict__ old2new,
+                                                            const int64_t *__restrict__ out_indptr,
+                                                            int32_t *__restrict__ out_indices, T *__restrict__ out_a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t k = wave; k < n; k += nwave) {
+        const int32_t old = new2old[k];
+        const int64_t s = indptr[old];
+        const int len = (int)(indptr[old + 1] - s);
+        const int64_t o = out_indptr[k];
+        // wave-uniform choice of the network size
+        if (len <= 64) permute_row_regs<T, 1>(lane, pb, len, indices + s, a + s, old2new, out_indices + o, out_a + o);
+        else if (len <= 128) permute_row_regs<T, 2>(lane, pb, len, indices + s, a + s, old2new, out_indices + o, out_a + o);
+        else if (len <= 256) permute_row_regs<T, 4>(lane, pb, len, indices + s, a + s, old2new, out_indices + o, out_a + o);
+        else permute_row_regs<T, 8>(lane, pb, len, indices + s, a + s, old2new, out_indices + o, out_a + o);
+    }
+}
+
 __global__ void k_max_len(int64_t n, const int64_t *__restrict__ indptr, unsigned long long *__restrict__ out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -485,7 +570,14 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
         while ((1ull << pb) < maxlen) pb++;
         while ((1ll << nb) < n) nb++;
         if (pb + nb <= 32) {      // (new column, position) packs into one word: sort keys only
-            if (a->kind == B3C_F64)
+            if (getenv("B3C_PERMUTE_LDS") == nullptr) {      // register network (default); the LDS network stays for comparison
+                if (a->kind == B3C_F64)
+                    hipLaunchKernelGGL(k_permute_rows_regs<double>, dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
+                                       (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
+                else
+                    hipLaunchKernelGGL(k_permute_rows_regs<uint32_t>, dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
+                                       (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
+            } else if (a->kind == B3C_F64)
                 hipLaunchKernelGGL((k_permute_rows_packed<double, CAPR>), dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
                                    (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
             else
