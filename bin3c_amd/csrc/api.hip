@@ -39,6 +39,7 @@ extern "C" int b3c_ctx_destroy(b3c_ctx *ctx)
     ctx->trim();
     for (auto &kv : ctx->live) (void)hipFree(kv.first);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -26,6 +26,14 @@ struct b3c_ctx {
     int64_t bytes = 0;
     int n_cu = 256;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> evpool;   // timing events are recycled (creating one costs a driver call per launch timed)
+    hipEvent_t ev_get()
+    {
+        if (!evpool.empty()) { hipEvent_t e = evpool.back(); evpool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
+    void ev_put(hipEvent_t e) { if (e) evpool.push_back(e); }
     void *pin = nullptr;      // pinned host staging for small read-backs (a pageable destination costs a staged copy)
     b3c_dist dist;            // row-sharded multi-GPU execution (b3c_ctx_set_dist); world <= 1: off
     bool has_dist = false;

@@ -1490,6 +1490,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // profiling of the SpMV kernel: event pairs around every KB launch
     const bool prof = ctx->ev0 != nullptr && getenv("B3C_PROFILE") != nullptr;
     std::vector<hipEvent_t> evs;
+    std::vector<long long> ev_tick;        // which SpMV (0-based) each event pair brackets
+    constexpr long long PROF_EVERY = 4;
 
     int t = 0;  // state ping-pong index
     const int BATCH = 8;
@@ -1515,11 +1517,13 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             }
             t++;
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
-            if (prof) {
-                hipEvent_t e0, e1;
-                HIP_TRY(ctx, hipEventCreate(&e0));
-                HIP_TRY(ctx, hipEventCreate(&e1));
+            // every PROF_EVERY-th SpMV is bracketed by events (an event pair costs ~12 us of idle GPU and two driver calls)
+            const bool timed = prof && ticks % PROF_EVERY == 0;
+            if (timed) {
+                hipEvent_t e0 = ctx->ev_get(), e1 = ctx->ev_get();
+                if (!e0 || !e1) return ctx->fail(B3C_E_HIP, "b3c_kr_balance: hipEventCreate failed");
                 evs.push_back(e0); evs.push_back(e1);
+                ev_tick.push_back(ticks);
                 HIP_TRY(ctx, hipEventRecord(e0, s));
             }
             // KB consumes part1 (from KA, G partials), produces part0 (GS partials)
@@ -1564,7 +1568,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             case 8: launch_kb<8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
             default: launch_kb<4>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
             }
-            if (prof) HIP_TRY(ctx, hipEventRecord(evs.back(), s));
+            if (timed) HIP_TRY(ctx, hipEventRecord(evs.back(), s));
             if (dist) {
                 hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part0.p, GS, 0, my_scal);
                 int rc;
@@ -1641,11 +1645,13 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         long long cnt = 0;
         for (size_t e = 0; e + 1 < evs.size(); e += 2) {
             float f = 0.f;
-            if (cnt < info->n_spmv && hipEventElapsedTime(&f, evs[e], evs[e + 1]) == hipSuccess) { ms += f; cnt++; }
-            (void)hipEventDestroy(evs[e]);
-            (void)hipEventDestroy(evs[e + 1]);
+            // launches after convergence are no-ops: only SpMV number < n_spmv did work
+            if (ev_tick[e / 2] < info->n_spmv && hipEventElapsedTime(&f, evs[e], evs[e + 1]) == hipSuccess) { ms += f; cnt++; }
+            ctx->ev_put(evs[e]);
+            ctx->ev_put(evs[e + 1]);
         }
-        info->spmv_ms = ms;
+        // sampled mean x number of SpMVs that did work
+        info->spmv_ms = cnt ? ms / (double)cnt * (double)info->n_spmv : 0.0;
     }
     if (h.rc == B3C_E_NAN) return ctx->fail(B3C_E_NAN, "scale vector has developed invalid values (NANs)!");
     if (h.rc == B3C_E_NOCONV)

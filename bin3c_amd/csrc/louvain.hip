@@ -899,11 +899,12 @@ struct Events {
     std::vector<hipEvent_t> ev;
     bool on = false;
     hipStream_t s;
+    b3c_ctx *ctx = nullptr;
     void rec()
     {
         if (!on) return;
-        hipEvent_t e;
-        if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); ev.push_back(e); }
+        hipEvent_t e = ctx->ev_get();
+        if (e) { (void)hipEventRecord(e, s); ev.push_back(e); }
     }
     double total_ms()
     {
@@ -912,7 +913,7 @@ struct Events {
             float f = 0;
             if (hipEventElapsedTime(&f, ev[i], ev[i + 1]) == hipSuccess) ms += f;
         }
-        for (auto e : ev) (void)hipEventDestroy(e);
+        for (auto e : ev) ctx->ev_put(e);
         ev.clear();
         return ms;
     }
@@ -997,6 +998,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     Events evs;
     evs.on = getenv("B3C_PROFILE") != nullptr;
     evs.s = s;
+    evs.ctx = ctx;
 
     // Locality: a matrix that the caller has not ordered (b3c_mat_permute) gets an internal ordered
     // working copy; community ids, sub-round hashing and tie-breaks stay in the caller's numbering
@@ -1113,8 +1115,10 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipStreamSynchronize(s));
         }
 
-        // full: recount the internal weight; otherwise ctr[2] was kept up to date by k_lv_delta_internal
-        auto modularity = [&](double *out, bool full) -> int {
+        // full: recount the internal weight; otherwise ctr[2] was kept up to date by k_lv_delta_internal.  The sums are
+        // launched before the move count of the sweep is known and come back with it in ONE read-back (a host round
+        // trip costs as much as k_lv_tot2); moved == 0 leaves *out alone.
+        auto modularity = [&](double *out, bool full, u64 *moved) -> int {
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
             if (full) {
                 HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64), s));
@@ -1122,7 +1126,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             }
             hipLaunchKernelGGL(k_lv_tot2, dim3(gv), dim3(BLK), 0, s, n, tot.p, ctr.p + 3);
             u64 h[8];
-            HIP_TRY(ctx, hipMemcpyAsync(h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, s));
+            { const int rb_ = b3c_readback(ctx, h, ctr.p, sizeof(h)); if (rb_) return rb_; }
+            if (moved) {
+                *moved = h[1];
+                if (h[1] == 0) return B3C_OK;
+            }
             if (dist) {
                 // integer partial sums of the ranks: exact, so the order of the final addition is irrelevant
                 HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, ctr.p + 2, sizeof(u64), hipMemcpyDeviceToDevice, s));
@@ -1133,7 +1141,6 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 for (int r = 0; r < D.world; r++) tot_i2 += (u64)parts[2 * (size_t)r];
                 h[2] = tot_i2;
             }
-            HIP_TRY(ctx, hipStreamSynchronize(s));
             unsigned __int128 t2 = (unsigned __int128)h[3] + ((unsigned __int128)h[4] << 32) +
                                    ((unsigned __int128)h[5] << 64) + ((unsigned __int128)h[6] << 96);
             i128 num = (i128)m2 * (i128)h[2] - (i128)t2;
@@ -1142,7 +1149,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         };
 
         double cur_mod, new_mod;
-        if ((rc = modularity(&new_mod, true))) { free_graph(ctx, g); return rc; }
+        if ((rc = modularity(&new_mod, true, nullptr))) { free_graph(ctx, g); return rc; }
         int sweep = 0;
         u64 prev_moved = ~0ull;
         const int incr_div = getenv("B3C_LV_INCR_DIV") ? atoi(getenv("B3C_LV_INCR_DIV")) : 4;
@@ -1213,12 +1220,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             info->move_nnz += g.nnz;
             info->move_rows += g.n;
             u64 moved = 0;
-            { const int rb_ = b3c_readback(ctx, &moved, ctr.p + 1, sizeof(u64)); if (rb_) return rb_; }
+            if ((rc = modularity(&new_mod, !incr, &moved))) { free_graph(ctx, g); return rc; }
             info->n_moves += (int64_t)moved;
             if (getenv("B3C_LV_DEBUG")) fprintf(stderr, "[b3c] level %d sweep %d: %llu of %lld nodes moved\n", (int)info->n_levels, sweep, (unsigned long long)moved, (long long)n);
             if (moved == 0) break;
             prev_moved = moved;
-            if ((rc = modularity(&new_mod, !incr))) { free_graph(ctx, g); return rc; }
             if (new_mod - cur_mod < PL_MIN) break;
             if (max_sweeps > 0 && sweep >= max_sweeps) break;
         }

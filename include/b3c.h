@@ -47,7 +47,8 @@ typedef struct {
     int64_t hit_delta;    /* times the delta bound cut the inner loop (sparse_utils.py:171) */
     int64_t hit_Delta;    /* times the Delta bound cut the inner loop (sparse_utils.py:179) */
     double rout;          /* final squared residual */
-    double spmv_ms;       /* device time spent in the SpMV kernel (HIP events), 0 if not measured */
+    double spmv_ms;       /* device time spent in the SpMV kernel: mean over the launches bracketed by HIP events (every
+                           * 4th one, B3C_PROFILE=1) times n_spmv; 0 if not measured */
     int64_t n_spmv;       /* SpMV launches that did work */
     int32_t bitwise_symmetric; /* 1: a_ij == a_ji exactly (checksum path); precondition of b3c_scale_sym_graph */
     int32_t value_bits;   /* width of the matrix values the SpMV streamed: 64 (fp64), 32 (counts) or 16 (counts <= 65535) */
