@@ -62,10 +62,20 @@ template <int OP>  // 0 sum, 1 min, 2 max
 __device__ double reduce_partials(const double *__restrict__ part, int P, int stride, double *lds)
 {
     const int t = threadIdx.x;
-    double v = OP == 0 ? 0.0 : (OP == 1 ? INFINITY : -INFINITY);
-    for (int i = t; i < P; i += BLK) {
-        double q = part[(size_t)i * stride];
-        v = OP == 0 ? v + q : (OP == 1 ? fmin(v, q) : fmax(v, q));
+    constexpr double ident = OP == 0 ? 0.0 : (OP == 1 ? INFINITY : -INFINITY);
+    double v = ident;
+    // up to 16 partials per thread, ALL loaded before the first one is consumed (a load-use loop costs one memory latency
+    // per partial: 16 us for 4096 of them, in every block of every KA/KC/KD launch); folded in the same order as before
+    constexpr int U = 16;
+    for (int base = 0; base < P; base += BLK * U) {
+        double q[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + t + u * BLK;
+            q[u] = i < P ? part[(size_t)i * stride] : ident;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) v = OP == 0 ? v + q[u] : (OP == 1 ? fmin(v, q[u]) : fmax(v, q[u]));
     }
     lds[t] = v;
     __syncthreads();
@@ -1196,15 +1206,33 @@ __global__ void __launch_bounds__(BLK) kr_fold(const double *__restrict__ part, 
 // count form: when every count fits 16 bits the SpMV streams a uint16 copy of the values (6 B per entry instead of 8)
 __global__ void kr_max_u32(int64_t nnz, const uint32_t *__restrict__ a, unsigned int *__restrict__ out)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // 16-byte loads, four in flight per thread; one atomic per block
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    const int64_t full = nnz & ~(int64_t)3;
     unsigned int m = 0;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) m = a[k] > m ? a[k] : m;
+    const int64_t k0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+#pragma unroll 4
+    for (int64_t k = k0; k < full; k += stride) {
+        const uint4 v = *(const uint4 *)(a + k);
+        const unsigned int m01 = v.x > v.y ? v.x : v.y, m23 = v.z > v.w ? v.z : v.w;
+        const unsigned int mv = m01 > m23 ? m01 : m23;
+        m = mv > m ? mv : m;
+    }
+    if (k0 == 0)
+        for (int64_t k = full; k < nnz; k++) m = a[k] > m ? a[k] : m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned int t = (unsigned int)__shfl_down((int)m, o, 64);
         m = t > m ? t : m;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    __shared__ unsigned int red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int b = red[0];
+        for (unsigned w = 1; w < blockDim.x / 64; w++) b = red[w] > b ? red[w] : b;
+        if (b) atomicMax(out, b);
+    }
 }
 
 __global__ void kr_narrow_u16(int64_t nnz, const uint32_t *__restrict__ a, uint16_t *__restrict__ out)
