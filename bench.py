@@ -42,7 +42,8 @@ def measured_traffic(config, kernel):
     try:
         with open(path) as fh:
             rec = json.load(fh).get(config, {})
-        if rec and rec.get('kernel', '').split()[0] == kernel.split()[0]:
+        base = lambda name: name.replace('<', ' ').split()[0] if name else ''
+        if rec and base(rec.get('kernel', '')) == base(kernel):
             return rec.get('hbm_bytes_per_launch')
     except (IOError, ValueError):
         pass
