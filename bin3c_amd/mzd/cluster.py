@@ -20,7 +20,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from .contact_map import SeqOrder
-from .exceptions import NoRemainingClustersException
+from .exceptions import NoneAcceptedException, NoRemainingClustersException
 from .utils import app_path
 
 logger = logging.getLogger(__name__)
@@ -151,6 +151,8 @@ def _louvain_device(contact_map, min_len, min_sig):
     else:
         mask = contact_map.set_primary_acceptance_mask(min_len, min_sig, update=True)
     contact_map.order.set_mask_only(mask)
+    if contact_map.order.count_accepted() < 1:          # prepare_seq_map, contact_map.py:926-927
+        raise NoneAcceptedException()
     ctx = contact_map._context()
     hot = contact_map._hot
     if hot is not None and hot.processed is not None:

@@ -174,6 +174,14 @@ def _cluster_stage(ctx, res, mask_w, n_sub=0):
     else:
         sub = ctx.compress(a, mask_w)
         res.sub = sub
+    if sub.n == 0 or sub.nnz == 0:
+        # nothing passed the acceptance mask: the reference raises NoneAcceptedException one level up
+        # (contact_map.py:927); at this level the answer is simply "no accepted contigs, no labels"
+        res.scl = None
+        res.lv_info = _native.LouvainInfo()
+        t['compress'] = time.perf_counter() - t0
+        t['louvain'] = 0.0
+        return torch.full((sub.n,), -1, dtype=torch.int32, device=mask_w.device)
     res.scl = 1.0 / ctx.max_value(sub)                                     # cluster.py:316
     t['compress'] = time.perf_counter() - t0
 

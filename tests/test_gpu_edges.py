@@ -1,0 +1,84 @@
+"""
+GPU suite: shapes that steer libb3c onto its less travelled kernels, each against the oracle --
+rows long enough for the 4-entries-per-lane SpMV (average > 128) with 16-bit and with 32-bit counts, rows past one
+pipelined chunk (> 256) and past the register sort of the permutation (> 512), and degenerate maps.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _counts_case(n, e, seed, scale=1):
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(n, e, seed)
+    counts = (sm.counts.astype(np.uint64) * scale).astype(np.uint32)
+    return sm, counts
+
+
+@pytest.mark.parametrize('n,e,seed,scale,bits', [
+    (3000, 300000, 31, 1, 16),       # average row 201: kr_kb_vec<8,8,uint16>
+    (3000, 300000, 32, 3000, 32),    # the same with counts beyond 65535: kr_kb_vec<8,8,uint32>
+    (1200, 400000, 33, 1, 16),       # average row 667: tail loop of the SpMV, global-sort path of the permutation
+])
+def test_long_rows_counts_path_matches_oracle(ctx, oracle_lib, n, e, seed, scale, bits):
+    from bin3c_amd.pipeline import run_hot_path
+    sm, cnt = _counts_case(n, e, seed, scale)
+    assert (cnt.max() > 0xFFFF) == (bits == 32)
+    nd = oracle_lib.site_norm(sm.indptr, sm.indices, cnt.astype(np.float64), sm.sites)
+    rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
+    assert rc == oracle_lib.OK
+    counts = ctx.upload(sm.indptr, sm.indices, cnt)
+    for reorder in (False, True):
+        res = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5, reorder=reorder, cluster=False)
+        assert res.kr_info.value_bits == bits and res.kr_info.n_iter == st.n_iter
+        np.testing.assert_allclose(res.x, xo, rtol=1e-9)
+    # the permutation itself, rows past the register network included
+    perm = np.random.RandomState(seed).permutation(n).astype(np.int32)
+    pm = ctx.permute(counts, perm)
+    ip, ix, d = pm.download()
+    c = sp.csr_matrix((cnt, sm.indices, sm.indptr), shape=(n, n))
+    want = c[perm][:, perm]
+    want.sort_indices()
+    assert np.array_equal(ip, want.indptr) and np.array_equal(ix, want.indices) and np.array_equal(d, want.data)
+    pm.free()
+    counts.free()
+
+
+def test_degenerate_maps(ctx):
+    """1 x 1, diagonal-only and everything-masked maps"""
+    from bin3c_amd.pipeline import run_hot_path
+    # 1 x 1: x = 1 / sqrt(a / s^2)
+    one = ctx.upload(np.array([0, 1]), np.array([0]), np.array([7], dtype=np.uint32))
+    _, x, info = ctx.kr_balance_counts(one, np.array([2.0]))
+    np.testing.assert_allclose(x, [1.0 / np.sqrt(7.0 / 4.0)], rtol=1e-5)      # KR stops at its residual tolerance
+    assert info.n_zero_diag == 0
+    one.free()
+    # diagonal only, one zero on the diagonal (treated as one, sparse_utils.py:110-115)
+    n = 50
+    d = np.arange(1, n + 1, dtype=np.uint32)
+    d[7] = 0
+    keep = d > 0
+    ip = np.concatenate([[0], np.cumsum(keep)]).astype(np.int64)
+    diag = ctx.upload(ip, np.flatnonzero(keep).astype(np.int32), d[keep])
+    _, x, info = ctx.kr_balance_counts(diag, np.ones(n))
+    want = 1.0 / np.sqrt(np.where(d > 0, d, 1).astype(np.float64))
+    np.testing.assert_allclose(x, want, rtol=1e-5)
+    assert info.n_zero_diag == 1
+    # nothing passes the acceptance mask (no off-diagonal signal): empty sub-map, no labels, no crash
+    res = run_hot_path(ctx, diag, np.ones(n), np.full(n, 5000), 1000, 5)
+    assert res.mask.sum() == 0 and res.labels.shape[0] == 0
+    diag.free()
+
+
+def test_cluster_map_raises_when_everything_is_filtered(ctx, tmp_path):
+    from bin3c_amd.mzd.cluster import cluster_map
+    from bin3c_amd.mzd.contact_map import ContactMap
+    from bin3c_amd.mzd.exceptions import NoneAcceptedException
+    n = 30
+    m = sp.identity(n, dtype=np.uint32, format='csr') * 9
+    cm = ContactMap.from_arrays(m, np.full(n, 5000), np.ones(n), min_len=1000, min_sig=5)
+    cm._ctx = ctx
+    with pytest.raises(NoneAcceptedException):
+        cluster_map(cm, seed=1, method='louvain', work_dir=str(tmp_path))
