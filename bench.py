@@ -96,8 +96,8 @@ def cpu_baseline(sample_n, sample_e, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='C3', choices=['C1', 'C2', 'C3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mode', default='auto', choices=['auto', 'sharded', 'replicas'], help='N > 1 only')
