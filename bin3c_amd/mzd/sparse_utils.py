@@ -124,17 +124,19 @@ def max_offdiag(_m, ctx=None):
     """
     assert scisp.isspmatrix(_m), 'Input matrix is not a scipy.sparse object'
     ctx = ctx or _native.default_context()
-    if _m.dtype == np.uint32:
-        c = _canonical_csr(_m)
-        mat = ctx.upload(c.indptr, c.indices, c.data)
-        try:
-            return ctx.max_offdiag_u32(mat, assume_symmetric=False)
-        finally:
-            mat.free()
-    # other dtypes are not on the hot path (seq_map is uint32, sparse_utils.py:237): same semantics via scipy
-    c = _m.tolil(True)
-    c.setdiag(0)
-    return np.asarray(c.tocsr().max(axis=0).todense()).ravel()
+    # the reference's only caller passes the uint32 sequence map (sparse_utils.py:237, contact_map.py:899); other
+    # non-negative integer maps are taken when their values fit, anything else is refused -- there is no host path
+    if _m.dtype != np.uint32:
+        c = _m.tocsr()
+        if not np.issubdtype(c.dtype, np.integer) or (c.nnz and (c.data.min() < 0 or c.data.max() > 0xFFFFFFFF)):
+            raise TypeError('max_offdiag runs on the device for uint32 count maps only (got {})'.format(_m.dtype))
+        _m = c.astype(np.uint32)
+    c = _canonical_csr(_m)
+    mat = ctx.upload(c.indptr, c.indices, c.data)
+    try:
+        return ctx.max_offdiag_u32(mat, assume_symmetric=False)
+    finally:
+        mat.free()
 
 
 def compress(_m, _mask, ctx=None):

@@ -82,3 +82,21 @@ def test_cluster_map_raises_when_everything_is_filtered(ctx, tmp_path):
     cm._ctx = ctx
     with pytest.raises(NoneAcceptedException):
         cluster_map(cm, seed=1, method='louvain', work_dir=str(tmp_path))
+
+
+def test_max_offdiag_integer_dtypes_and_refusal(ctx):
+    """sparse_utils.max_offdiag: integer maps go to the device as uint32, anything else is refused (no host path)"""
+    from bin3c_amd.mzd import sparse_utils
+    rs = np.random.RandomState(4)
+    d = rs.poisson(0.3, size=(40, 40))
+    d = d + d.T
+    want = d.copy()
+    np.fill_diagonal(want, 0)
+    want = want.max(axis=0)
+    for dt in (np.uint32, np.int64, np.int32):
+        got = sparse_utils.max_offdiag(sp.lil_matrix(d.astype(dt)), ctx=ctx)
+        assert np.array_equal(got, want)
+    with pytest.raises(TypeError):
+        sparse_utils.max_offdiag(sp.csr_matrix(d.astype(np.float64)), ctx=ctx)
+    with pytest.raises(TypeError):
+        sparse_utils.max_offdiag(sp.csr_matrix(-d.astype(np.int64)), ctx=ctx)
