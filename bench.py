@@ -19,6 +19,7 @@ N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RC
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -150,6 +151,8 @@ def main():
         last = None
         for _ in range(args.warmup):
             last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig)
+        gc.collect()
+        gc.disable()            # a generation-2 collection in the middle of a step shows up as a 20 ms hole in the GPU timeline
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -164,6 +167,7 @@ def main():
             acc['move_rows'] += last.lv_info.move_rows
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             red_dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
             tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
