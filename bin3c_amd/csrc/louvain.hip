@@ -1170,7 +1170,10 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, \
                        m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p)
                     switch (short_max) {
-                    case 256: if (getenv("B3C_LV_SHAPE") && !strcmp(getenv("B3C_LV_SHAPE"), "16x16")) { LV_DECIDE_G(16, 16); } else { LV_DECIDE_G(32, 8); } break;
+                    case 256:      // C3 sweep of shapes, ms of delta-Q scan per step: 64x4 11.3, 32x8 12.2, 16x16 22.4
+                        if (getenv("B3C_LV_SHAPE") && !strcmp(getenv("B3C_LV_SHAPE"), "32x8")) { LV_DECIDE_G(32, 8); }
+                        else { LV_DECIDE_G(64, 4); }
+                        break;
                     case 128: LV_DECIDE_G(16, 8); break;
                     case 64: LV_DECIDE_G(8, 8); break;
                     default: LV_DECIDE_G(4, 8); break;
