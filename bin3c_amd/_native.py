@@ -59,6 +59,7 @@ SYMBOLS = [
     ('b3c_kr_balance', C.c_int, [_VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, _VP, C.POINTER(KRInfo)]),
     ('b3c_kr_balance_counts', C.c_int, [_VP, _VP, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, _VP, C.POINTER(KRInfo)]),
     ('b3c_normalise_scale', C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
+    ('b3c_normalise_scale_compress', C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, C.POINTER(_VP)]),
     ('b3c_louvain', C.c_int, [_VP, _VP, C.c_double, C.c_int, C.c_int, _VP, C.POINTER(LouvainInfo)]),
     ('b3c_graph_quantise', C.c_int, [_VP, _VP, C.c_double, _VP, C.POINTER(C.c_int32)]),
     ('b3c_coo_symmetrise', C.c_int, [_VP, C.c_int64, C.c_int64, _VP, _VP, _VP, _VP, C.POINTER(_VP), C.POINTER(C.c_int64)]),
@@ -334,6 +335,19 @@ class Context(object):
             x = np.ascontiguousarray(x, dtype=np.float64)
         h = _VP()
         self._check(self.lib.b3c_normalise_scale(self.h, counts.h, _ptr(sites), _ptr(x), 1 if graph_form else 0, C.byref(h)))
+        return Mat(self, h)
+
+    def normalise_scale_compress(self, counts, sites, x, mask, graph_form=False):
+        """masked sub-map of the balanced map straight from the counts (the full balanced map is not written)"""
+        if isinstance(sites, np.ndarray):
+            sites = np.ascontiguousarray(sites, dtype=np.float64)
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, dtype=np.float64)
+        if isinstance(mask, np.ndarray):
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        h = _VP()
+        self._check(self.lib.b3c_normalise_scale_compress(self.h, counts.h, _ptr(sites), _ptr(x), 1 if graph_form else 0,
+                                                          _ptr(mask), C.byref(h)))
         return Mat(self, h)
 
     # ---- Louvain ----

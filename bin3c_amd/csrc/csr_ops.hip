@@ -396,10 +396,93 @@ extern "C" int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const do
     return B3C_OK;
 }
 
+// compress of the balanced map WITHOUT materialising it: the kept entries are computed on the fly from the raw counts
+// exactly as k_norm_scale computes them (same expression, same operand order: bit-identical values)
+__global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices,
+                                                           const uint32_t *__restrict__ counts,
+                                                           const double *__restrict__ sites, const double *__restrict__ x,
+                                                           const int32_t *__restrict__ ids, int graph_form,
+                                                           const uint8_t *__restrict__ mask,
+                                                           const int64_t *__restrict__ newid,
+                                                           const int64_t *__restrict__ out_indptr,
+                                                           int32_t *__restrict__ out_indices, double *__restrict__ out_a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t row = wave; row < n; row += nwave) {
+        if (!mask[row]) continue;
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        int64_t o = out_indptr[newid[row]];
+        double si = sites[row];
+        si = si == 0.0 ? 1.0 : si;
+        const double xr = x[row];
+        const int32_t idr = ids ? ids[row] : (int32_t)row;
+        for (int64_t base = s; base < e; base += 64) {
+            const int64_t k = base + lane;
+            int32_t j = 0;
+            bool keep = false;
+            if (k < e) {
+                j = indices[k];
+                keep = mask[j] != 0;
+            }
+            const unsigned long long b = __ballot(keep);
+            if (keep) {
+                const int pos = __popcll(b & ((1ull << lane) - 1ull));
+                double sj = sites[j];
+                sj = sj == 0.0 ? 1.0 : sj;
+                const double a = (double)counts[k] * (1.0 / (si * sj));
+                const double xj = x[j];
+                double val;
+                if (graph_form) {
+                    const int32_t idj = ids ? ids[j] : j;
+                    const double xhi = idr >= idj ? xr : xj, xlo = idr >= idj ? xj : xr;
+                    val = xhi * (a * xlo);
+                } else {
+                    val = xr * (a * xj);
+                }
+                out_indices[o + pos] = (int32_t)newid[j];
+                out_a[o + pos] = val;
+            }
+            o += __popcll(b);
+        }
+    }
+}
+
+struct NormScale {          // when set, compress_impl computes the values from raw counts (k_compress_fill_ns)
+    const double *sites, *x;
+    int graph_form;
+};
+
+static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, const NormScale *ns, b3c_mat **out);
+
 extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, b3c_mat **out)
 {
     if (!ctx) return B3C_E_ARG;
     if (!a || !mask || !out) return ctx->fail(B3C_E_ARG, "b3c_compress: bad argument");
+    return compress_impl(ctx, a, mask, nullptr, out);
+}
+
+extern "C" int b3c_normalise_scale_compress(b3c_ctx *ctx, const b3c_mat *counts, const double *sites, const double *x,
+                                            int graph_form, const uint8_t *mask, b3c_mat **out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!counts || counts->kind != B3C_U32 || !sites || !x || !mask || !out)
+        return ctx->fail(B3C_E_ARG, "b3c_normalise_scale_compress: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = counts->n;
+    DevBuf<double> ds(ctx, n), dx(ctx, n);
+    if (!ds.p || !dx.p) return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress");
+    int rc;
+    if ((rc = b3c_copy_in(ctx, ds.p, sites, sizeof(double) * (size_t)n)) || (rc = b3c_copy_in(ctx, dx.p, x, sizeof(double) * (size_t)n)))
+        return rc;
+    const NormScale ns{ds.p, dx.p, graph_form ? 1 : 0};
+    return compress_impl(ctx, counts, mask, &ns, out);
+}
+
+static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, const NormScale *ns, b3c_mat **out)
+{
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t n = a->n;
     hipStream_t s = ctx->stream;
@@ -423,11 +506,14 @@ extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask,
     int64_t nnz = 0;
     { const int rb_ = b3c_readback(ctx, &nnz, optr.p + m, sizeof(int64_t)); if (rb_) return rb_; }
     b3c_mat *o = nullptr;
-    if ((rc = b3c_mat_alloc(ctx, m, nnz, a->kind, &o))) return rc;
+    if ((rc = b3c_mat_alloc(ctx, m, nnz, ns ? B3C_F64 : a->kind, &o))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(o->indptr, optr.p, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToDevice, s));
     if (n) {
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
-        if (a->kind == B3C_F64)
+        if (ns)
+            hipLaunchKernelGGL(k_compress_fill_ns, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data,
+                               ns->sites, ns->x, a->ids, ns->graph_form, dm.p, newid.p, optr.p, o->indices, (double *)o->data);
+        else if (a->kind == B3C_F64)
             hipLaunchKernelGGL(k_compress_fill<double>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
                                (const double *)a->data, dm.p, newid.p, optr.p, o->indices, (double *)o->data);
         else
@@ -435,7 +521,7 @@ extern "C" int b3c_compress(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask,
                                (const uint32_t *)a->data, dm.p, newid.p, optr.p, o->indices, (uint32_t *)o->data);
     }
     o->ordered = a->ordered;
-    o->value_symmetric = a->value_symmetric;
+    o->value_symmetric = ns ? ns->graph_form != 0 : a->value_symmetric;
     o->sorted_cols = a->sorted_cols;      // compaction keeps the relative order inside a row
     if (a->ids && n) {
         DevBuf<int64_t> keep_o(ctx, n + 1), rank_o(ctx, n + 1);

@@ -155,7 +155,7 @@ def _louvain_device(contact_map, min_len, min_sig):
         raise NoneAcceptedException()
     ctx = contact_map._context()
     hot = contact_map._hot
-    if hot is not None and hot.processed is not None:
+    if hot is not None and hot.has_processed():
         res = cluster_prepared(ctx, hot, mask)
     elif contact_map.processed_map is not None:
         # a map that was prepared in an earlier session: upload the cached balanced matrix

@@ -71,7 +71,8 @@ class HotPathResult(object):
         self.mask = None            # bool[n]     primary acceptance mask (contact_map.py:888-905)
         self.signal = None          # uint32[n]   max_offdiag
         self.x = None               # float64[n]  bisto_scale (contact_map.py:941)
-        self.processed = None       # _native.Mat balanced full map, device resident (processed_map :945)
+        self._processed = None      # _native.Mat balanced full map, device resident (processed_map :945); see `processed`
+        self._lazy = None           # (ctx, counts in the working order, sites, x, graph_form, owned) to form it on demand
         self.sub = None             # _native.Mat masked sub-map (get_subspace :977-981); None if nothing masked
         self.scl = None             # 1 / max (cluster.py:316)
         self.labels = None          # int32[n_accepted] community per accepted (gapless) contig, -1 = not in graph
@@ -81,11 +82,32 @@ class HotPathResult(object):
         self.perm = (None, None)    # (new2old, old2new) int32 host arrays of the locality ordering, or (None, None)
         self._n2o = self._o2n = None  # the same on the device
 
+    @property
+    def processed(self):
+        """The balanced full map in HBM.  The cluster step itself never needs it (the masked sub-map is formed straight
+        from the counts, b3c_normalise_scale_compress), so it is written on first access: 2.4 GB at C3."""
+        if self._processed is None and self._lazy is not None:
+            ctx, work, sites_t, x_w, graph_form, _owned = self._lazy
+            import torch
+            with torch.cuda.stream(ctx.torch_stream):
+                self._processed = ctx.normalise_scale(work, sites_t, x_w, graph_form=graph_form)
+        return self._processed
+
+    @processed.setter
+    def processed(self, mat):
+        self._processed = mat
+
+    def has_processed(self):
+        """the balanced map is in HBM or can be formed without the caller's help"""
+        return self._processed is not None or self._lazy is not None
+
     def free(self):
-        for m in (self.processed, self.sub):
+        for m in (self._processed, self.sub):
             if m is not None:
                 m.free()
-        self.processed = self.sub = None
+        if self._lazy is not None and self._lazy[5]:
+            self._lazy[1].free()
+        self._processed = self.sub = self._lazy = None
 
 
 def acceptance_mask(ctx, counts, lengths, min_len, min_sig):
@@ -158,12 +180,17 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
             x_w = torch.empty(n, dtype=torch.float64, device=dev)
             rc, _, res.kr_info = ctx.kr_balance_counts(work, sites_t, tol=tol, x_out=x_w, check=False)
             ctx._check(rc)
-            a = ctx.normalise_scale(work, sites_t, x_w, graph_form=bool(res.kr_info.bitwise_symmetric))
             t['kr'] = time.perf_counter() - t0
-        finally:
+        except Exception:
             if work is not counts:
                 work.free()
-        res.processed = a
+            raise
+        # the balanced map (normalisation exactly as the reference forms it, then X A X, sparse_utils.py:223-224; graph
+        # form when A is bitwise symmetric so that Louvain needs no mirror lookups) is formed on demand from these
+        graph_form = bool(res.kr_info.bitwise_symmetric)
+        res._lazy = (ctx, work, sites_t, x_w, graph_form, work is not counts)
+        if work is counts and keep:
+            res.processed                      # the caller owns `counts` and may free it: materialise now
 
         labels_t = None
         if cluster:
@@ -192,15 +219,19 @@ def _cluster_stage(ctx, res, mask_w, n_sub=0):
     """get_subspace + to_graph scaling + Louvain on the device-resident balanced map; mask_w in the map's row order."""
     import torch
     t = res.timings
-    a = res.processed
     t0 = time.perf_counter()
     if res.sub is not None:
         res.sub.free()
         res.sub = None
     if bool(mask_w.all().item()):                                          # contact_map.py:977: compress only if needed
-        sub = a
+        sub = res.processed
+    elif res._processed is not None:
+        sub = ctx.compress(res._processed, mask_w)
+        res.sub = sub
     else:
-        sub = ctx.compress(a, mask_w)
+        # get_subspace of the balanced map without writing the balanced map: values straight from the counts
+        _c, work, sites_t, x_w, graph_form, _owned = res._lazy
+        sub = ctx.normalise_scale_compress(work, sites_t, x_w, mask_w, graph_form=graph_form)
         res.sub = sub
     if sub.n == 0 or sub.nnz == 0:
         # nothing passed the acceptance mask: the reference raises NoneAcceptedException one level up

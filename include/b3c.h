@@ -211,6 +211,13 @@ int b3c_kr_balance_counts(b3c_ctx *ctx, const b3c_mat *counts, const double *sit
 int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const double *sites /*host|dev*/, const double *x /*host|dev*/,
                         int graph_form, b3c_mat **out);
 
+/* The same followed by b3c_compress (get_subspace, contact_map.py:977-981) in ONE pass: the kept entries of the balanced
+ * map are computed straight from the counts, bit-identical to b3c_normalise_scale + b3c_compress, and the full balanced
+ * map (2.4 GB at 1M contigs / 100M edges) is never written.  For callers that only need the masked sub-map -- the cluster
+ * step; processed_map itself (contact_map.py:945) stays available through b3c_normalise_scale. */
+int b3c_normalise_scale_compress(b3c_ctx *ctx, const b3c_mat *counts, const double *sites /*host|dev*/,
+                                 const double *x /*host|dev*/, int graph_form, const uint8_t *mask /*host|dev*/, b3c_mat **out);
+
 /* ---- Louvain ------------------------------------------------------------------------------- */
 
 /* to_graph's weight scaling (cluster.py:316-321) + louvain.cluster / community.best_partition
