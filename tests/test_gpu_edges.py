@@ -100,3 +100,25 @@ def test_max_offdiag_integer_dtypes_and_refusal(ctx):
         sparse_utils.max_offdiag(sp.csr_matrix(d.astype(np.float64)), ctx=ctx)
     with pytest.raises(TypeError):
         sparse_utils.max_offdiag(sp.csr_matrix(-d.astype(np.int64)), ctx=ctx)
+
+
+@pytest.mark.parametrize('graph_form', [False, True])
+def test_fused_sub_map_is_bit_identical(ctx, graph_form):
+    """b3c_normalise_scale_compress == b3c_normalise_scale followed by b3c_compress, on a permuted (id-carrying) matrix"""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(4000, 150000, 41)
+    sm.sites[::53] = 0.0
+    rs = np.random.RandomState(6)
+    perm = rs.permutation(sm.n).astype(np.int32)
+    counts = ctx.permute(ctx.upload(sm.indptr, sm.indices, sm.counts), perm)
+    sites = np.ascontiguousarray(sm.sites[perm])
+    x = rs.uniform(0.5, 2.0, sm.n)
+    mask = rs.rand(sm.n) < 0.8
+    full = ctx.normalise_scale(counts, sites, x, graph_form=graph_form)
+    want = ctx.compress(full, mask)
+    got = ctx.normalise_scale_compress(counts, sites, x, mask, graph_form=graph_form)
+    for a, b in zip(got.download(), want.download()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ctx.mat_ids(got), ctx.mat_ids(want))
+    for m in (full, want, got, counts):
+        m.free()
