@@ -1541,7 +1541,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             if (dist) {
                 hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part1.p, G, 0, my_scal);
                 int rc;
-                if ((rc = xchg(B3C_BUF_SCAL)) || (rc = xchg(B3C_BUF_VEC))) return rc;
+                if ((rc = xchg(B3C_BUF_SCAL_VEC))) return rc;
             }
             t++;
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);

@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _native
 
-BUF_VEC, BUF_SCAL, BUF_LABELS, BUF_ISUM = 0, 1, 2, 3
+BUF_VEC, BUF_SCAL, BUF_LABELS, BUF_ISUM, BUF_SCAL_VEC = 0, 1, 2, 3, 4
 
 
 class B3CDist(C.Structure):
@@ -93,8 +93,9 @@ class DistSession(object):
         import torch
         try:
             with torch.cuda.stream(self.ctx.torch_stream):    # the stream libb3c launches on: ordered with its kernels
-                allgather_inplace(self._bufs[buf_id], self.rank, self.world, self.group)
-            self.n_exchanges += 1
+                for b in ((BUF_SCAL, BUF_VEC) if buf_id == BUF_SCAL_VEC else (buf_id,)):
+                    allgather_inplace(self._bufs[b], self.rank, self.world, self.group)
+                    self.n_exchanges += 1
             return 0
         except Exception as ex:                                # never let an exception cross the C frame
             self._error = ex

@@ -93,6 +93,7 @@ int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
 #define B3C_BUF_SCAL 1    /* double[world*4]      KR partial sums / min / max      */
 #define B3C_BUF_LABELS 2  /* int32[world*chunk]   Louvain decided communities      */
 #define B3C_BUF_ISUM 3    /* int64[world*2]       Louvain integer partial sums     */
+#define B3C_BUF_SCAL_VEC 4 /* B3C_BUF_SCAL, then B3C_BUF_VEC, in one call (one host round trip per SpMV less) */
 typedef int (*b3c_allgather_fn)(void *user, int buffer_id);
 typedef struct {
     int32_t rank, world;
