@@ -401,7 +401,7 @@ extern "C" int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const do
 __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices,
                                                            const uint32_t *__restrict__ counts,
-                                                           const double *__restrict__ sites, const double *__restrict__ x,
+                                                           const double2 *__restrict__ sx,      // (site count, x) per row
                                                            const int32_t *__restrict__ ids, int graph_form,
                                                            const uint8_t *__restrict__ mask,
                                                            const int64_t *__restrict__ newid,
@@ -415,9 +415,9 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
         if (!mask[row]) continue;
         const int64_t s = indptr[row], e = indptr[row + 1];
         int64_t o = out_indptr[newid[row]];
-        double si = sites[row];
-        si = si == 0.0 ? 1.0 : si;
-        const double xr = x[row];
+        const double2 pr = sx[row];
+        const double si = pr.x == 0.0 ? 1.0 : pr.x;
+        const double xr = pr.y;
         const int32_t idr = ids ? ids[row] : (int32_t)row;
         for (int64_t base = s; base < e; base += 64) {
             const int64_t k = base + lane;
@@ -430,10 +430,10 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
             const unsigned long long b = __ballot(keep);
             if (keep) {
                 const int pos = __popcll(b & ((1ull << lane) - 1ull));
-                double sj = sites[j];
-                sj = sj == 0.0 ? 1.0 : sj;
+                const double2 pj = sx[j];             // one 16-byte gather instead of two 8-byte ones
+                const double sj = pj.x == 0.0 ? 1.0 : pj.x;
                 const double a = (double)counts[k] * (1.0 / (si * sj));
-                const double xj = x[j];
+                const double xj = pj.y;
                 double val;
                 if (graph_form) {
                     const int32_t idj = ids ? ids[j] : j;
@@ -451,9 +451,15 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
 }
 
 struct NormScale {          // when set, compress_impl computes the values from raw counts (k_compress_fill_ns)
-    const double *sites, *x;
+    const double2 *sx;      // (site count, x) per row
     int graph_form;
 };
+
+__global__ void k_pack_sx(int64_t n, const double *__restrict__ sites, const double *__restrict__ x, double2 *__restrict__ sx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sx[i] = make_double2(sites[i], x[i]);
+}
 
 static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, const NormScale *ns, b3c_mat **out);
 
@@ -477,7 +483,10 @@ extern "C" int b3c_normalise_scale_compress(b3c_ctx *ctx, const b3c_mat *counts,
     int rc;
     if ((rc = b3c_copy_in(ctx, ds.p, sites, sizeof(double) * (size_t)n)) || (rc = b3c_copy_in(ctx, dx.p, x, sizeof(double) * (size_t)n)))
         return rc;
-    const NormScale ns{ds.p, dx.p, graph_form ? 1 : 0};
+    DevBuf<double2> sx(ctx, n + 1);
+    if (!sx.p) return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress");
+    if (n) hipLaunchKernelGGL(k_pack_sx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ds.p, dx.p, sx.p);
+    const NormScale ns{sx.p, graph_form ? 1 : 0};
     return compress_impl(ctx, counts, mask, &ns, out);
 }
 
@@ -512,7 +521,7 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
         if (ns)
             hipLaunchKernelGGL(k_compress_fill_ns, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data,
-                               ns->sites, ns->x, a->ids, ns->graph_form, dm.p, newid.p, optr.p, o->indices, (double *)o->data);
+                               ns->sx, a->ids, ns->graph_form, dm.p, newid.p, optr.p, o->indices, (double *)o->data);
         else if (a->kind == B3C_F64)
             hipLaunchKernelGGL(k_compress_fill<double>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
                                (const double *)a->data, dm.p, newid.p, optr.p, o->indices, (double *)o->data);
