@@ -397,55 +397,68 @@ extern "C" int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const do
 }
 
 // compress of the balanced map WITHOUT materialising it: the kept entries are computed on the fly from the raw counts
-// exactly as k_norm_scale computes them (same expression, same operand order: bit-identical values)
+// exactly as k_norm_scale computes them (same expression, same operand order: bit-identical values).  Per column two
+// packed gathers -- (new id or -1 if masked, caller-side id), then for kept entries (site count, x) -- and up to 256
+// entries of a row in flight at once.
 __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices,
                                                            const uint32_t *__restrict__ counts,
                                                            const double2 *__restrict__ sx,      // (site count, x) per row
-                                                           const int32_t *__restrict__ ids, int graph_form,
-                                                           const uint8_t *__restrict__ mask,
-                                                           const int64_t *__restrict__ newid,
+                                                           const int2 *__restrict__ ni,         // (new id | -1, caller-side id)
+                                                           int graph_form,
                                                            const int64_t *__restrict__ out_indptr,
                                                            int32_t *__restrict__ out_indices, double *__restrict__ out_a)
 {
+    constexpr int U = 4;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
     for (int64_t row = wave; row < n; row += nwave) {
-        if (!mask[row]) continue;
+        const int2 nr = ni[row];
+        if (nr.x < 0) continue;
         const int64_t s = indptr[row], e = indptr[row + 1];
-        int64_t o = out_indptr[newid[row]];
+        int64_t o = out_indptr[nr.x];
         const double2 pr = sx[row];
         const double si = pr.x == 0.0 ? 1.0 : pr.x;
         const double xr = pr.y;
-        const int32_t idr = ids ? ids[row] : (int32_t)row;
-        for (int64_t base = s; base < e; base += 64) {
-            const int64_t k = base + lane;
-            int32_t j = 0;
-            bool keep = false;
-            if (k < e) {
-                j = indices[k];
-                keep = mask[j] != 0;
+        const int32_t idr = nr.y;
+        for (int64_t base = s; base < e; base += 64 * U) {
+            int32_t j[U];
+            uint32_t c[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                const int64_t k = base + t * 64 + lane;
+                const bool ok = k < e;
+                j[t] = ok ? indices[k] : -1;
+                c[t] = ok ? counts[k] : 0u;
             }
-            const unsigned long long b = __ballot(keep);
-            if (keep) {
-                const int pos = __popcll(b & ((1ull << lane) - 1ull));
-                const double2 pj = sx[j];             // one 16-byte gather instead of two 8-byte ones
-                const double sj = pj.x == 0.0 ? 1.0 : pj.x;
-                const double a = (double)counts[k] * (1.0 / (si * sj));
-                const double xj = pj.y;
-                double val;
-                if (graph_form) {
-                    const int32_t idj = ids ? ids[j] : j;
-                    const double xhi = idr >= idj ? xr : xj, xlo = idr >= idj ? xj : xr;
-                    val = xhi * (a * xlo);
-                } else {
-                    val = xr * (a * xj);
+            int2 nj[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) nj[t] = j[t] >= 0 ? ni[j[t]] : make_int2(-1, 0);
+            double2 pj[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) pj[t] = nj[t].x >= 0 ? sx[j[t]] : make_double2(1.0, 0.0);
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                const bool keep = nj[t].x >= 0;
+                const unsigned long long b = __ballot(keep);
+                if (keep) {
+                    const int pos = __popcll(b & ((1ull << lane) - 1ull));
+                    const double sj = pj[t].x == 0.0 ? 1.0 : pj[t].x;
+                    const double a = (double)c[t] * (1.0 / (si * sj));
+                    const double xj = pj[t].y;
+                    double val;
+                    if (graph_form) {
+                        const double xhi = idr >= nj[t].y ? xr : xj, xlo = idr >= nj[t].y ? xj : xr;
+                        val = xhi * (a * xlo);
+                    } else {
+                        val = xr * (a * xj);
+                    }
+                    out_indices[o + pos] = nj[t].x;
+                    out_a[o + pos] = val;
                 }
-                out_indices[o + pos] = (int32_t)newid[j];
-                out_a[o + pos] = val;
+                o += __popcll(b);
             }
-            o += __popcll(b);
         }
     }
 }
@@ -454,6 +467,13 @@ struct NormScale {          // when set, compress_impl computes the values from 
     const double2 *sx;      // (site count, x) per row
     int graph_form;
 };
+
+__global__ void k_pack_ni(int64_t n, const uint8_t *__restrict__ mask, const int64_t *__restrict__ newid,
+                          const int32_t *__restrict__ ids, int2 *__restrict__ ni)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ni[i] = make_int2(mask[i] ? (int)newid[i] : -1, ids ? ids[i] : (int)i);
+}
 
 __global__ void k_pack_sx(int64_t n, const double *__restrict__ sites, const double *__restrict__ x, double2 *__restrict__ sx)
 {
@@ -519,9 +539,14 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
     HIP_TRY(ctx, hipMemcpyAsync(o->indptr, optr.p, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToDevice, s));
     if (n) {
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
-        if (ns)
+        if (ns) {
+            DevBuf<int2> ni(ctx, n + 1);
+            if (!ni.p) { b3c_mat_free(ctx, o); return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
+            hipLaunchKernelGGL(k_pack_ni, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, newid.p, a->ids, ni.p);
             hipLaunchKernelGGL(k_compress_fill_ns, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data,
-                               ns->sx, a->ids, ns->graph_form, dm.p, newid.p, optr.p, o->indices, (double *)o->data);
+                               ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data);
+            HIP_TRY(ctx, hipStreamSynchronize(s));       // `ni` goes back to the pool at the end of this scope
+        }
         else if (a->kind == B3C_F64)
             hipLaunchKernelGGL(k_compress_fill<double>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
                                (const double *)a->data, dm.p, newid.p, optr.p, o->indices, (double *)o->data);
