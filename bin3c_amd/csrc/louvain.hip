@@ -192,7 +192,19 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
     for (int64_t row = wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         long long d = 0;
-        for (int64_t k = s + lane; k < e; k += 64) d += indices[k] == (int32_t)row ? 2 * q[k] : q[k];
+        for (int64_t base = s; base < e; base += 256) {
+            int32_t j[4];
+            long long w[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                const bool ok = k < e;
+                j[t] = ok ? indices[k] : -1;
+                w[t] = ok ? q[k] : 0;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) d += j[t] == (int32_t)row ? 2 * w[t] : w[t];
+        }
         d = wave_sum_ll(d);
         if (lane == 0) {
             const int32_t id = ids ? ids[row] : (int32_t)row;   // community ids live in the caller's numbering
@@ -660,10 +672,25 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
     for (int64_t row = r0 + wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         const int32_t a = com[row];
-        for (int64_t k = s + lane; k < e; k += 64) {
-            const int32_t j = indices[k];
-            if (j == (int32_t)row) acc += 2 * q[k];
-            else if (com[j] == a) acc += q[k];
+        // four 64-entry slices in flight: index and weight loads first, then the label gathers (integer sums: any order)
+        for (int64_t base = s; base < e; base += 256) {
+            int32_t j[4];
+            long long w[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                const bool ok = k < e;
+                j[t] = ok ? indices[k] : -1;
+                w[t] = ok ? q[k] : 0;
+            }
+            int32_t c[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) c[t] = j[t] >= 0 ? com[j[t]] : -1;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (j[t] == (int32_t)row) acc += 2 * w[t];
+                else if (j[t] >= 0 && c[t] == a) acc += w[t];
+            }
         }
     }
     acc = wave_sum_ll(acc);
