@@ -115,7 +115,9 @@ def main():
     if os.environ.get('B3C_BENCH_ONE_GPU'):      # test hook: all ranks share cuda:0 (tests/test_dist.py, gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # test hook: a one-rank process group exercises the RCCL code path of the sharded leg on a single GPU
+    one_rank_group = world == 1 and bool(os.environ.get('B3C_BENCH_FORCE_SHARDED')) and 'RANK' in os.environ
+    if world > 1 or one_rank_group:
         backend = os.environ.get('B3C_BENCH_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
@@ -140,7 +142,7 @@ def main():
     min_len, min_sig = 1000, 5
 
     def barrier():
-        if world > 1:
+        if world > 1 or one_rank_group:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.sync()
@@ -229,7 +231,7 @@ def main():
             print(json.dumps(out), flush=True)
 
     want_replicas = world == 1 or args.mode in ('auto', 'replicas')
-    want_sharded = world > 1 and args.mode in ('auto', 'sharded')
+    want_sharded = (world > 1 or one_rank_group) and args.mode in ('auto', 'sharded')
     rep = None
     if want_replicas:
         dt, last, acc = timed_leg()
@@ -276,7 +278,7 @@ def main():
                     last.kr_info.n_iter == rep_ref.kr_info.n_iter and np.allclose(last.x, rep_ref.x, rtol=1e-9, atol=0)
                     and last.lv_info.n_comm == rep_ref.lv_info.n_comm and np.array_equal(last.mask, rep_ref.mask))
         emit(line(dt, last, acc, True, extra))
-    if world > 1:
+    if world > 1 or one_rank_group:
         dist.destroy_process_group()
     ctx.close()
 

@@ -1,6 +1,8 @@
 // Context and matrix management for libb3c (see include/b3c.h).
 #include "common.hpp"
 
+#include <cstdlib>
+
 extern "C" const char *b3c_version(void) { return "b3c 0.1 (gfx950)"; }
 
 extern "C" int b3c_ctx_create(int device, void *stream, b3c_ctx **out)
@@ -64,7 +66,9 @@ extern "C" int b3c_ctx_set_dist(b3c_ctx *ctx, const b3c_dist *dist)
         !dist->vec || !dist->scal || !dist->labels || !dist->isum)
         return ctx->fail(B3C_E_ARG, "b3c_ctx_set_dist: bad argument");
     ctx->dist = *dist;
-    ctx->has_dist = dist->world > 1;
+    // B3C_DIST_FORCE: run the sharded code path (callbacks, exchange buffers) with a single rank too -- a test hook that
+    // lets one GPU exercise the RCCL plumbing of the caller
+    ctx->has_dist = dist->world > 1 || (dist->world == 1 && getenv("B3C_DIST_FORCE") != nullptr);
     return B3C_OK;
 }
 

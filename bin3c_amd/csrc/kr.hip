@@ -1335,7 +1335,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     }
 
     // multi-GPU: this rank's row range (single GPU: everything)
-    const bool dist = ctx->has_dist && ctx->dist.world > 1;
+    const bool dist = ctx->has_dist;
     const b3c_dist &D = ctx->dist;
     if (dist && (int64_t)D.world * D.chunk < n) return ctx->fail(B3C_E_ARG, "b3c_kr_balance: dist buffers too small for n");
     const int64_t r0 = dist ? std::min<int64_t>(n, (int64_t)D.rank * D.chunk) : 0;

@@ -1069,7 +1069,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             return ctx->fail(B3C_E_NOMEM, "b3c_louvain: level buffers");
         }
         // multi-GPU: level 0 is row-sharded (decide + internal-weight scan); induced graphs are tiny and replicated
-        const bool dist = ctx->has_dist && ctx->dist.world > 1 && first && (int64_t)ctx->dist.world * ctx->dist.chunk >= n;
+        const bool dist = ctx->has_dist && first && (int64_t)ctx->dist.world * ctx->dist.chunk >= n;
         const b3c_dist &D = ctx->dist;
         const int64_t r0 = dist ? std::min<int64_t>(n, (int64_t)D.rank * D.chunk) : 0;
         const int64_t r1 = dist ? std::min<int64_t>(n, r0 + D.chunk) : n;

@@ -74,3 +74,23 @@ def test_bench_keeps_the_replica_line_when_the_sharded_leg_fails(how):
     env = {'B3C_BENCH_FAIL_SHARDED': '1'} if how == 'exception' else {'B3C_BENCH_WATCHDOG': '0.01'}
     d = _bench_two_ranks('auto', **env)
     assert d['scaling'] == 'weak' and 'error' in d['sharded'] and 'replicas x2' in d['config']['parallelism']
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_over_rccl():
+    """The sharded leg with the real RCCL backend and ONE rank (B3C_DIST_FORCE keeps the sharded code path on for a
+    world of one): every exchange goes C -> ctypes callback -> torch.distributed all_gather_into_tensor on libb3c's
+    stream.  Exercises the RCCL plumbing a single GPU can exercise; the xGMI transport needs the driver's multi-GPU run."""
+    import json
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+           '--config', 'C2', '--no-cpu-baseline']
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1', B3C_BENCH_FORCE_SHARDED='1',
+               B3C_DIST_FORCE='1')
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['scaling'] == 'strong' and d['exchanges_per_step'] > 100 and d['agrees_with_single_gpu'] is True
+    assert 'sharded' not in d and d['replicas']['value'] > 0
