@@ -16,6 +16,7 @@ xGMI is point to point (7 links per GPU), the vector exchange is 1-8 MB per rank
 latency bound, so each exchange is ONE collective and nothing is exchanged that can be recomputed.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -48,8 +49,11 @@ def allgather_inplace(full, rank, world, group=None):
     mine = full[rank * cnt:(rank + 1) * cnt]
     backend = dist.get_backend(group)
     if backend == 'nccl':
-        # separate send buffer: the slice is small, and in-place (aliased) collectives are not worth the risk
-        dist.all_gather_into_tensor(full, mine.clone(), group=group)
+        # in place: the send buffer is this rank's slice of the receive buffer (NCCL/RCCL define this case -- sendbuff ==
+        # recvbuff + rank * count -- and torch's FSDP all-gathers the same way); saves a copy kernel per exchange
+        if os.environ.get('B3C_DIST_COPY_SEND'):
+            mine = mine.clone()
+        dist.all_gather_into_tensor(full, mine, group=group)
     elif full.is_cuda:
         # gloo moves CUDA tensors only for all_reduce/broadcast (single-GPU CI): gather = sum with zeros
         keep = mine.clone()
