@@ -70,28 +70,35 @@ def measured_copy_gbs():
     return 2.0 * (1 << 30) / (best * 1e-3) / 1e9
 
 
-def cpu_baseline(sample_n, sample_e, seed):
-    """Oracle (scalar C port of the reference path) on a bounded sample of the same workload, 1 thread."""
+def cpu_baseline(sample_n, sample_e, seed, threads=1):
+    """Oracle (scalar C port of the reference path) on a bounded sample of the same workload.  threads > 1: the SpMV, the
+    site normalisation and the final scaling run row-parallel (OpenMP); compress and the sequential Louvain stay serial,
+    as python-louvain's semantics are."""
     import oracle
     from bin3c_amd.synth import make_synth
     oracle.build()
     sm = make_synth(sample_n, sample_e, seed)
     e_true = sm.n_edges
-    t0 = time.perf_counter()
-    sig = oracle.max_offdiag_u32(sm.indptr, sm.indices, sm.counts)
-    mask = (sm.lengths >= 1000) & (sig >= 5)
-    nd = oracle.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
-    rc, x, st = oracle.kr_balance(sm.indptr, sm.indices, nd)
-    proc = oracle.scale_sym(sm.indptr, sm.indices, nd, x)
-    m, ip, ix, a = oracle.compress(sm.indptr, sm.indices, proc, mask)
-    scl = 1.0 / oracle.max_value(ip, a)
-    w = oracle.graph_weights(ip, ix, a, scl)
-    r = oracle.louvain_seq(ip, ix, w)
-    dt = time.perf_counter() - t0
-    return {'value': e_true / dt, 'unit': 'edges/s', 'cores': 1, 'kind': 'port',
+    oracle.set_threads(threads)
+    try:
+        t0 = time.perf_counter()
+        sig = oracle.max_offdiag_u32(sm.indptr, sm.indices, sm.counts)
+        mask = (sm.lengths >= 1000) & (sig >= 5)
+        nd = oracle.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
+        rc, x, st = oracle.kr_balance(sm.indptr, sm.indices, nd)
+        t_kr = time.perf_counter() - t0
+        proc = oracle.scale_sym(sm.indptr, sm.indices, nd, x)
+        m, ip, ix, a = oracle.compress(sm.indptr, sm.indices, proc, mask)
+        scl = 1.0 / oracle.max_value(ip, a)
+        w = oracle.graph_weights(ip, ix, a, scl)
+        r = oracle.louvain_seq(ip, ix, w)
+        dt = time.perf_counter() - t0
+    finally:
+        oracle.set_threads(1)
+    return {'value': e_true / dt, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
             'sample': 'hic-synth-v1 n={} E={} seed={}: full mask+norm+KR({} SpMV)+compress+sequential Louvain '
-                      '({} sweeps) in {:.1f}s on 1 host thread'.format(sample_n, e_true, seed, st.n_iter + 1,
-                                                                       r['n_sweeps'], dt)}
+                      '({} sweeps) in {:.1f}s (mask+norm+KR {:.1f}s) on {} host thread{}'.format(
+                          sample_n, e_true, seed, st.n_iter + 1, r['n_sweeps'], dt, t_kr, threads, 's' if threads > 1 else '')}
 
 
 def main():
@@ -228,6 +235,10 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 sample = {'C1': (1000, 50000), 'C2': (100000, 5000000), 'C3': (200000, 10000000)}[args.config]
                 out['cpu_baseline'] = cpu_baseline(sample[0], sample[1], seed)
+                # SURVEY 8(d) iii: the same with the row-parallel loops on the host cores of this NUMA node (at most 64)
+                nthr = min(64, len(os.sched_getaffinity(0))) if hasattr(os, 'sched_getaffinity') else 1
+                if nthr > 1:
+                    out['cpu_baseline_mt'] = cpu_baseline(sample[0], sample[1], seed, threads=nthr)
             print(json.dumps(out), flush=True)
 
     want_replicas = world == 1 or args.mode in ('auto', 'replicas')

@@ -31,7 +31,7 @@ class KRStats(C.Structure):
 def build(force=False):
     """Compile oracle/_build/liboracle.so with gcc (a few seconds)."""
     out = os.path.join(_HERE, '_build', 'liboracle.so')
-    srcs = [os.path.join(_HERE, f) for f in ('kr.c', 'louvain_seq.c', 'louvain_bsp.c', 'oracle.h')]
+    srcs = [os.path.join(_HERE, f) for f in ('kr.c', 'louvain_seq.c', 'louvain_bsp.c', 'oracle.h', 'Makefile')]
     if force or not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         subprocess.check_call(['make', '-s', '-C', _HERE])
     return out
@@ -49,6 +49,11 @@ def lib():
         _LIB.orc_compress.restype = C.c_int64
         _LIB.orc_quant_shift.restype = C.c_int32
     return _LIB
+
+
+def set_threads(n):
+    """Threads of the row-parallel loops (SpMV, site normalisation, final scaling); 1 = the sequential oracle."""
+    lib().orc_set_threads(int(n))
 
 
 def _p(a):

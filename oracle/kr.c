@@ -15,10 +15,17 @@
 
 #include "oracle.h"
 
+/* Threads for the row-parallel loops below (bench.py's multi-thread CPU baseline; SURVEY section 8(d) iii).  With
+ * one thread (the default, and what every test uses) the pragmas are inert and the code is the plain sequential loop;
+ * with more, every row is still summed sequentially by one thread, so the SpMV result does not change. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 1 ? n : 1; }
+
 /* y = A x, row-sequential accumulation like scipy's csr_matvec (the m.dot() calls at
  * mzd/sparse_utils.py:136,165,196). */
 static void csr_matvec(int64_t n, const int64_t *ip, const int32_t *ix, const double *a, const double *x, double *y)
 {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int64_t i = 0; i < n; i++) {
         double s = 0.0;
         for (int64_t k = ip[i]; k < ip[i + 1]; k++) s += a[k] * x[ix[k]];
@@ -217,6 +224,7 @@ done:
 /* X.T * (_orig * X): mzd/sparse_utils.py:223-224 -> out_ij = x_i * (a_ij * x_j) on the ORIGINAL matrix */
 void orc_scale_sym(int64_t n, const int64_t *ip, const int32_t *ix, const double *a, const double *x, double *out)
 {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int64_t i = 0; i < n; i++)
         for (int64_t k = ip[i]; k < ip[i + 1]; k++) out[k] = x[i] * (a[k] * x[ix[k]]);
 }
@@ -224,6 +232,7 @@ void orc_scale_sym(int64_t n, const int64_t *ip, const int32_t *ix, const double
 /* fast_norm_fullseq_bysite, mzd/contact_map.py:100-113, with the sites==0 -> 1 rule of :1103-1108 */
 void orc_site_norm(int64_t n, const int64_t *ip, const int32_t *ix, const double *sites, double *a)
 {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int64_t i = 0; i < n; i++) {
         double si = sites[i] == 0.0 ? 1.0 : sites[i];
         for (int64_t k = ip[i]; k < ip[i + 1]; k++) {

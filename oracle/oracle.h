@@ -26,6 +26,9 @@ typedef struct {
     double rout;
 } orc_kr_stats;
 
+/* threads of the row-parallel loops (SpMV, site normalisation, final scaling); 1 = sequential (default) */
+void orc_set_threads(int n);
+
 int orc_kr_balance(int64_t n, const int64_t *ip, const int32_t *ix, const double *a, double tol, double delta,
                    double Delta, int64_t max_iter, double *x, orc_kr_stats *st);
 void orc_scale_sym(int64_t n, const int64_t *ip, const int32_t *ix, const double *a, const double *x, double *out);
