@@ -1,0 +1,20 @@
+"""GPU suite: a seeded slice of the randomised differential campaign (tools/fuzz_parity.py): random symmetric count maps
+-- sizes 3..4000, 1.5..400 contacts per row, hub rows, empty rows, zero diagonals, 16- and 32-bit counts, random masks --
+through KR, the balanced map, compress, the fused sub-map, Louvain, the permutation, max_offdiag and downsample, each
+compared with the CPU oracle (bit-exact except KR's x and the float reductions)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [7, 8])
+def test_random_maps_against_the_oracle(seed):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_parity.py'), '80', str(seed)],
+                         env=dict(os.environ, PYTHONPATH=ROOT), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and 'fuzz: 80 cases, 0 failures' in text, text[-3000:]
