@@ -296,9 +296,10 @@ class Context(object):
         self._check(self.lib.b3c_compress(self.h, mat.h, _ptr(mask), C.byref(h)))
         return Mat(self, h)
 
-    def downsample(self, mat, block_size, method='mean'):
+    def downsample(self, mat, block_size, method='mean', skip_diag=False):
         h = _VP()
-        self._check(self.lib.b3c_downsample(self.h, mat.h, int(block_size), {'mean': 0, 'max': 1}[method], C.byref(h)))
+        self._check(self.lib.b3c_downsample(self.h, mat.h, int(block_size), {'mean': 0, 'max': 1}[method] | (2 if skip_diag else 0),
+                                            C.byref(h)))
         return Mat(self, h)
 
     def max_value(self, mat):

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(DS_BLK) k_ds_fill(int64_t n, int64_t nb, uint3
                                                     const int32_t *__restrict__ indices, const double *__restrict__ data,
                                                     const int64_t *__restrict__ optr, int32_t *__restrict__ oidx,
                                                     double *odata, unsigned int *ocnt,
-                                                    double inv_area, unsigned long long area)
+                                                    double inv_area, unsigned long long area, int skip_diag)
 {
     __shared__ DsLds L;
     const int t = threadIdx.x;
@@ -130,9 +130,11 @@ __global__ void __launch_bounds__(DS_BLK) k_ds_fill(int64_t n, int64_t nb, uint3
                     const int64_t J = (int64_t)Jg - c0;
                     if (J < 0 || J >= DS_CHUNK) continue;
                     if (e > a0 && (uint32_t)indices[e - 1] / b == Jg) continue;     // not the head of its run
-                    double acc = data[e];
-                    unsigned int c = 1;
+                    const bool dg = skip_diag && (int64_t)indices[e] == r;         // a zeroed diagonal is an absent cell
+                    double acc = dg ? (MAX ? -INFINITY : 0.0) : data[e];
+                    unsigned int c = dg ? 0u : 1u;
                     for (int64_t f = e + 1; f < a1 && (uint32_t)indices[f] / b == Jg; f++) {
+                        if (skip_diag && (int64_t)indices[f] == r) continue;
                         acc = MAX ? fmax(acc, data[f]) : acc + data[f];
                         c++;
                     }
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(DS_BLK) k_dw_fill(int64_t n, int64_t nb, uint3
                                                     const int32_t *__restrict__ indices, const double *__restrict__ data,
                                                     const int64_t *__restrict__ optr, int32_t *__restrict__ oidx,
                                                     double *odata, unsigned int *ocnt, double inv_area,
-                                                    unsigned long long area)
+                                                    unsigned long long area, int skip_diag)
 {
     __shared__ DwLds LL[DS_BLK / 64];
     DwLds &L = LL[threadIdx.x >> 6];
@@ -259,9 +261,11 @@ __global__ void __launch_bounds__(DS_BLK) k_dw_fill(int64_t n, int64_t nb, uint3
                 // fixed shuffle tree, then the last lane of every segment updates the slot
                 const int64_t e = ee + lane;
                 const bool live = e < a1;
-                const uint32_t Jg = live ? (uint32_t)indices[e] / b : 0xffffffffu;
-                double acc = live ? data[e] : 0.0;
-                unsigned int c = 1;
+                const uint32_t col = live ? (uint32_t)indices[e] : 0u;
+                const uint32_t Jg = live ? col / b : 0xffffffffu;
+                const bool dg = skip_diag && live && (int64_t)col == r;            // a zeroed diagonal is an absent cell
+                double acc = live && !dg ? data[e] : (MAX ? -INFINITY : 0.0);
+                unsigned int c = dg ? 0u : 1u;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
                     const double pa = __shfl_up(acc, o, 64);
@@ -300,6 +304,8 @@ extern "C" int b3c_downsample(b3c_ctx *ctx, const b3c_mat *a, int64_t block_size
     if (!ctx) return B3C_E_ARG;
     if (!a || !out || a->kind != B3C_F64) return ctx->fail(B3C_E_ARG, "b3c_downsample: needs a float64 matrix");
     if (block_size < 2 || block_size > 0x7fffffffll) return ctx->fail(B3C_E_ARG, "b3c_downsample: block_size must be an integer larger than 1");
+    const int skip_diag = (method & B3C_DS_SKIP_DIAG) ? 1 : 0;
+    method &= ~B3C_DS_SKIP_DIAG;
     if (method != B3C_DS_MEAN && method != B3C_DS_MAX) return ctx->fail(B3C_E_ARG, "b3c_downsample: unknown method");
     if (!a->sorted_cols) return ctx->fail(B3C_E_ARG, "b3c_downsample: needs canonical CSR (ascending columns)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -330,20 +336,20 @@ extern "C" int b3c_downsample(b3c_ctx *ctx, const b3c_mat *a, int64_t block_size
             if (wave_form)
                 hipLaunchKernelGGL(k_dw_fill<true>, dim3(g), dim3(DS_BLK), 0, s, n, nb, (uint32_t)b, a->indptr, a->indices,
                                    (const double *)a->data, optr.p, o->indices, (double *)o->data, oc.p, 1.0 / area,
-                                   (unsigned long long)b * (unsigned long long)b);
+                                   (unsigned long long)b * (unsigned long long)b, skip_diag);
             else
                 hipLaunchKernelGGL(k_ds_fill<true>, dim3(g), dim3(DS_BLK), 0, s, n, nb, (uint32_t)b, a->indptr, a->indices,
                                    (const double *)a->data, optr.p, o->indices, (double *)o->data, oc.p, 1.0 / area,
-                                   (unsigned long long)b * (unsigned long long)b);
+                                   (unsigned long long)b * (unsigned long long)b, skip_diag);
             HIP_TRY(ctx, hipStreamSynchronize(s));
         } else if (wave_form)
             hipLaunchKernelGGL(k_dw_fill<false>, dim3(g), dim3(DS_BLK), 0, s, n, nb, (uint32_t)b, a->indptr, a->indices,
                                (const double *)a->data, optr.p, o->indices, (double *)o->data, (unsigned int *)nullptr,
-                               1.0 / area, (unsigned long long)b * (unsigned long long)b);
+                               1.0 / area, (unsigned long long)b * (unsigned long long)b, skip_diag);
         else
             hipLaunchKernelGGL(k_ds_fill<false>, dim3(g), dim3(DS_BLK), 0, s, n, nb, (uint32_t)b, a->indptr, a->indices,
                                (const double *)a->data, optr.p, o->indices, (double *)o->data, (unsigned int *)nullptr,
-                               1.0 / area, (unsigned long long)b * (unsigned long long)b);
+                               1.0 / area, (unsigned long long)b * (unsigned long long)b, skip_diag);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));

@@ -316,7 +316,7 @@ def plot_clusters(contact_map, fname, clustering, cl_list=None, simple=True, per
     else:
         logger.info('Plotting heatmap for {} specified clusters'.format(len(cl_list)))
     assert simple or contact_map.bin_size is None, 'extent (binned) maps are outside the accelerated path'
-    if contact_map.processed_map is None:
+    if not contact_map.has_processed_map():
         contact_map.prepare_seq_map(norm=True, bisto=True)
     cl_list = enable_clusters(contact_map, clustering, cl_list=cl_list, ordered_only=ordered_only, min_extent=min_extent)
     tick_locs = np.cumsum([0] + [len(clustering[k]['seq_ids']) for k in cl_list])

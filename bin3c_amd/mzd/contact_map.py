@@ -281,6 +281,10 @@ class ContactMap(object):
             self._processed_host = sp.csr_matrix((data, ix, ip), shape=(n, n))
         return self._processed_host
 
+    def has_processed_map(self):
+        """`processed_map is not None` without pulling a device-resident map to the host"""
+        return self._processed_host is not None or (self._hot is not None and self._hot.has_processed())
+
     @processed_map.setter
     def processed_map(self, value):
         self._processed_host = value
@@ -451,22 +455,54 @@ class ContactMap(object):
         :return: (2-D ndarray of log intensities, tick_locs rescaled like contact_map.py:1348)
         """
         assert simple or self.bin_size is None, 'extent (binned) maps are outside the accelerated path'
-        if self.processed_map is None:
+        if not self.has_processed_map():
             self.prepare_seq_map(norm=norm, bisto=True)
-        _map = self.get_subspace(permute=permute, marginalise=False if flatten else True, flatten=flatten).tolil()
-        if zero_diag is None:
-            _map.setdiag(0)
-        _map = _map.tocsr()
-        _map *= 100
-        if max_image_size is not None:
-            full_size = _map.shape
-            if np.max(full_size) > max_image_size:
-                reduce_factor = int(np.ceil(np.max(full_size) / float(max_image_size)))
-                logger.info('Full {} image reduction factor: {}'.format(full_size, reduce_factor))
-                _map = sparse_utils.downsample(_map, reduce_factor, ctx=self._context())
-                if tick_locs is not None:
-                    tick_locs = np.floor(np.asarray(tick_locs).astype(float) / reduce_factor)
-                logger.info('Map has been reduced from {} to {}'.format(full_size, _map.shape))
+        if self._hot is not None and self._hot.has_processed() and not self.is_tipbased():
+            # the balanced map is in HBM: mask, reorder and block-reduce there, only the raster crosses PCIe
+            from ..pipeline import device_subspace
+            ctx = self._context()
+            dm = device_subspace(ctx, self._hot, self.order.mask_vector(),
+                                 self.order.gapless_positions() if permute else None)
+            try:
+                full_size = (dm.n, dm.n)
+                if max_image_size is not None and dm.n > max_image_size:
+                    reduce_factor = int(np.ceil(dm.n / float(max_image_size)))
+                    logger.info('Full {} image reduction factor: {}'.format(full_size, reduce_factor))
+                    small = ctx.downsample(dm, reduce_factor, 'mean', skip_diag=zero_diag is None)
+                    try:
+                        ip, ix, data = small.download()
+                        nb = small.n
+                    finally:
+                        small.free()
+                    if tick_locs is not None:
+                        tick_locs = np.floor(np.asarray(tick_locs).astype(float) / reduce_factor)
+                    logger.info('Map has been reduced from {} to {}'.format(full_size, (nb, nb)))
+                    _map = sp.csr_matrix((data * 100, ix, ip), shape=(nb, nb))
+                else:
+                    if dm.n * dm.n > self.MAX_RASTER_CELLS:
+                        raise MemoryError('a {} x {} raster would not fit in host memory: set max_image_size'.format(*full_size))
+                    ip, ix, data = dm.download()
+                    _map = sp.csr_matrix((data, ix, ip), shape=full_size).tolil()
+                    if zero_diag is None:
+                        _map.setdiag(0)
+                    _map = _map.tocsr() * 100
+            finally:
+                dm.free()
+        else:
+            _map = self.get_subspace(permute=permute, marginalise=False if flatten else True, flatten=flatten).tolil()
+            if zero_diag is None:
+                _map.setdiag(0)
+            _map = _map.tocsr()
+            _map *= 100
+            if max_image_size is not None:
+                full_size = _map.shape
+                if np.max(full_size) > max_image_size:
+                    reduce_factor = int(np.ceil(np.max(full_size) / float(max_image_size)))
+                    logger.info('Full {} image reduction factor: {}'.format(full_size, reduce_factor))
+                    _map = sparse_utils.downsample(_map, reduce_factor, ctx=self._context())
+                    if tick_locs is not None:
+                        tick_locs = np.floor(np.asarray(tick_locs).astype(float) / reduce_factor)
+                    logger.info('Map has been reduced from {} to {}'.format(full_size, _map.shape))
         if _map.shape[0] * _map.shape[1] > self.MAX_RASTER_CELLS:
             raise MemoryError('a {} x {} raster would not fit in host memory: set max_image_size'.format(*_map.shape))
         _map = _map.toarray()

@@ -274,6 +274,35 @@ def cluster_prepared(ctx, res, mask, n_sub=0):
     return res
 
 
+def device_subspace(ctx, res, mask, order=None):
+    """get_subspace (contact_map.py:947-999) without leaving HBM: the balanced map under a caller-side mask, rows in
+    gapless caller order or, with `order` (SeqOrder.gapless_positions()), in that order.  -> _native.Mat (caller frees)."""
+    import torch
+    dev = torch.device('cuda', ctx.device)
+    with torch.cuda.stream(ctx.torch_stream):
+        mask_w = torch.as_tensor(np.asarray(mask, dtype=np.uint8), device=dev)
+        if res._n2o is not None:
+            mask_w = mask_w[res._n2o.long()]
+        if res._processed is not None or res._lazy is None:
+            sub = ctx.compress(res.processed, mask_w)
+        else:
+            _c, work, sites_t, x_w, graph_form, _owned = res._lazy
+            sub = ctx.normalise_scale_compress(work, sites_t, x_w, mask_w, graph_form=graph_form)
+        ids = ctx.mat_ids(sub)                       # gapless caller-side id of every row, None = already in caller order
+        m = sub.n
+        if ids is None and order is None:
+            return sub
+        inv = np.arange(m, dtype=np.int64)
+        if ids is not None:
+            inv = np.empty(m, dtype=np.int64)
+            inv[ids] = np.arange(m)
+        perm = inv if order is None else inv[np.asarray(order, dtype=np.int64)]
+        try:
+            return ctx.permute(sub, perm.astype(np.int32))
+        finally:
+            sub.free()
+
+
 def processed_to_host(ctx, res):
     """processed_map (contact_map.py:945) as host CSR arrays in the caller's numbering."""
     m = res.processed

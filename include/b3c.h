@@ -187,6 +187,7 @@ int b3c_max_value(b3c_ctx *ctx, const b3c_mat *a, double *out);
  * B3C_DS_MAX : block maximum, implicit zeros taking part.  Deterministic (no floating-point atomics). */
 #define B3C_DS_MEAN 0
 #define B3C_DS_MAX 1
+#define B3C_DS_SKIP_DIAG 2 /* or-ed into method: treat the diagonal as zeroed first (`_map.setdiag(0)`, contact_map.py:1324) */
 int b3c_downsample(b3c_ctx *ctx, const b3c_mat *a, int64_t block_size, int method, b3c_mat **out);
 
 /* ---- Knight-Ruiz --------------------------------------------------------------------------- */

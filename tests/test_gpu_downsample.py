@@ -162,3 +162,42 @@ def test_plot_writes_file(ctx, tmp_path):
     plot_clusters(cm, str(out), clustering, max_image_size=200, ordered_only=False, simple=False, permute=True,
                   width=4, height=4, dpi=50)
     assert out.exists() or (tmp_path / 'cluster_plot.png.npy').exists()
+
+
+def test_downsample_skip_diagonal(ctx, oracle):
+    """B3C_DS_SKIP_DIAG == setdiag(0) before the reduction (contact_map.py:1324), both kernel forms"""
+    for n, b in ((130, 3), (130, 16), (700, 50)):
+        m = _rand(n, n, 0.15, n + b)
+        m = (m + sp.diags(np.arange(1.0, n + 1.0))).tocsr()
+        z = m.tolil()
+        z.setdiag(0)
+        z = z.tocsr()
+        mat = ctx.upload(m.indptr, m.indices, m.data)
+        for method in ('mean', 'max'):
+            ds = ctx.downsample(mat, b, method, skip_diag=True)
+            ip, ix, d = ds.download()
+            got = sp.csr_matrix((d, ix, ip), shape=(ds.n, ds.n)).toarray()
+            np.testing.assert_allclose(got, oracle.downsample_dense(z, b, method), rtol=1e-14, atol=0)
+            ds.free()
+        mat.free()
+
+
+def test_raster_device_path_equals_host_path(ctx):
+    """plot_matrix from the device-resident balanced map against the host route through get_subspace/downsample"""
+    cm = _small_map(ctx)
+    cm.prepare_seq_map(norm=True, bisto=True)
+    rs = np.random.RandomState(3)
+    cm.order.set_order_only(rs.permutation(cm.order.accepted()), implicit_excl=True)
+    ticks = np.array([0, 100, 700])
+    for mis in (None, 90):
+        img_d, t_d = cm.plot_matrix(permute=True, max_image_size=mis, tick_locs=ticks)
+        hot, cm._hot = cm._hot, None                 # force the host route on the same (materialised) map
+        cm._processed_host = None
+        from bin3c_amd.pipeline import processed_to_host
+        ip, ix, data = processed_to_host(ctx, hot)
+        cm._processed_host = sp.csr_matrix((data, ix, ip), shape=(cm.total_seq, cm.total_seq))
+        img_h, t_h = cm.plot_matrix(permute=True, max_image_size=mis, tick_locs=ticks)
+        cm._hot = hot
+        cm._processed_host = None
+        np.testing.assert_allclose(img_d, img_h, rtol=1e-11, atol=1e-11)
+        assert (t_d is None and t_h is None) or np.array_equal(t_d, t_h)
