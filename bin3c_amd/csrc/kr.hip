@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
                                                    const double *__restrict__ dfix, const double *__restrict__ u,
                                                    const double *__restrict__ x, const double *__restrict__ p,
                                                    double *__restrict__ v, double *__restrict__ rk,
-                                                   double *__restrict__ w, double *__restrict__ part_out)
+                                                   double *__restrict__ w, double *__restrict__ part_out, int hub_len)
 {
     __shared__ double lds[BLK];
     KRState st = *sin;
@@ -519,6 +519,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
     if (row < n) {
         s = indptr[row];
         len = (int)(indptr[row + 1] - s);
+        if (len > hub_len) len = -1;         // hub rows belong to kr_kb_hub
     }
     {
         const int32_t *__restrict__ ci = indices + s;
@@ -539,6 +540,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
         if (rown < n) {
             sn = indptr[rown];
             lenn = (int)(indptr[rown + 1] - sn);
+            if (lenn > hub_len) lenn = -1;
         }
         // 2. this row: epilogue operands and gathers
         double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0, ri = 1.0;
@@ -579,7 +581,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
         }
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
-        if (sl == 0) {
+        if (sl == 0 && len >= 0) {
             const double t = acc * ri + di;
             if (inner) {
                 const double wi = xi * t + vi * pi;
@@ -623,7 +625,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
                                                   const double *__restrict__ dfix, const double *__restrict__ u,
                                                   const double *__restrict__ x, const double *__restrict__ p,
                                                   double *__restrict__ v, double *__restrict__ rk,
-                                                  double *__restrict__ w, double *__restrict__ part_out)
+                                                  double *__restrict__ w, double *__restrict__ part_out, int hub_len)
 {
     __shared__ double lds[BLK];
     KRState st = *sin;
@@ -650,6 +652,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
     if (row < n) {
         s = indptr[row];
         len = (int)(indptr[row + 1] - s);
+        if (len > hub_len) len = -1;         // hub rows belong to kr_kb_hub
     }
 #pragma unroll
     for (int q = 0; q < UN; q++) {
@@ -670,6 +673,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
         if (rown < n) {
             sn = indptr[rown];
             lenn = (int)(indptr[rown + 1] - sn);
+            if (lenn > hub_len) lenn = -1;
         }
         // 2. this row: epilogue operands and gathers
         double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0, ri = 1.0;
@@ -723,7 +727,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
         }
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
-        if (sl == 0) {
+        if (sl == 0 && len >= 0) {
             const double t = acc * ri + di;
             if (inner) {
                 const double wi = xi * t + vi * pi;
@@ -744,6 +748,85 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
         for (int q = 0; q < UN; q++) { c[q] = c2[q]; m[q] = m2[q]; }
     }
     block_partial<0>(contrib, part_out, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// KB for HUB rows (more than 256 / 512 entries; power-law contact maps have rows of 10^4..10^6): one workgroup per row,
+// 16-byte vector loads, four gathers in flight per thread and pass, fixed reduction tree.  The row-group kernels above
+// skip these rows; a hub costs them one 1024-entry pass after the other on eight lanes.  Reads the state the tick's KB
+// kernel consumed (the ping-pong slot it did not write) and publishes nothing; block b writes partial GS + b.
+// ---------------------------------------------------------------------------------------------
+constexpr int HUB_LEN = 256;
+
+__global__ void kr_hub_flags(int64_t r0, int64_t n, int hub_len, const int64_t *__restrict__ indptr, int64_t *__restrict__ flag)
+{
+    const int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) flag[i - r0] = (i < n && indptr[i + 1] - indptr[i] > hub_len) ? 1 : 0;
+}
+
+__global__ void kr_hub_fill(int64_t r0, int64_t n, const int64_t *__restrict__ flag, const int64_t *__restrict__ pos,
+                            int64_t *__restrict__ rows)
+{
+    const int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i - r0]) rows[pos[i - r0]] = i;
+}
+
+template <typename VT>
+__global__ void __launch_bounds__(BLK) kr_kb_hub(const int64_t *__restrict__ hub_rows, const KRState *__restrict__ sin,
+                                                  const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                  const VT *__restrict__ a, const double *__restrict__ rs,
+                                                  const double *__restrict__ dfix, const double *__restrict__ u,
+                                                  const double *__restrict__ x, const double *__restrict__ p,
+                                                  double *__restrict__ v, double *__restrict__ rk, double *__restrict__ w,
+                                                  double *__restrict__ part_out)
+{
+    __shared__ double lds[BLK];
+    const int32_t phase = sin->phase;
+    if (phase != A_INNER && phase != A_OUTER) {          // P_DONE (or anything that runs no SpMV): contribute nothing
+        if (threadIdx.x == 0) part_out[blockIdx.x] = 0.0;
+        return;
+    }
+    const bool inner = phase == A_INNER;
+    const int64_t row = hub_rows[blockIdx.x];
+    const int64_t s = indptr[row];
+    const int64_t len = indptr[row + 1] - s;
+    double acc = 0.0;
+    for (int64_t base = (int64_t)threadIdx.x * 4; base < len; base += BLK * 4) {
+        const Vec4<int32_t> c = *(const Vec4<int32_t> *)(indices + s + base);
+        const Vec4<VT> m = *(const Vec4<VT> *)(a + s + base);
+        double g[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) g[j] = u[base + j < len ? (uint32_t)c.v[j] : 0u];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc += (base + j < len ? (double)m.v[j] : 0.0) * g[j];
+    }
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int st = BLK / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) lds[threadIdx.x] += lds[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double xi = x[row];
+        const double ri = rs ? rs[row] : 1.0;
+        double contrib;
+        if (inner) {
+            const double pi = p[row];
+            const double t = lds[0] * ri + dfix[row] * (xi * pi);
+            const double wi = xi * t + v[row] * pi;
+            w[row] = wi;
+            contrib = pi * wi;
+        } else {
+            const double t = lds[0] * ri + dfix[row] * xi;
+            const double vn = xi * t;
+            const double r = 1.0 - vn;
+            v[row] = vn;
+            rk[row] = r;
+            contrib = r * r;
+        }
+        part_out[blockIdx.x] = contrib;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1274,36 +1357,36 @@ void launch_kb_stream(hipStream_t s, int grid, size_t shmem, int64_t n, int64_t 
 template <int LPR, int UN>
 void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
                     int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
-                    const double *x, const double *p, double *v, double *rk, double *w, double *part_out)
+                    const double *x, const double *p, double *v, double *rk, double *w, double *part_out, int hub_len)
 {
     if (m->kind == B3C_U32 && getenv("B3C_KR_NOGATHER"))   // wrong results by design: the kernel without its random gathers
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t, true>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
+                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
     else if (m->kind == B3C_U32 && v16)
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint16_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out);
+                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
     else if (m->kind == B3C_U32)
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
+                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
     else
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, double>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
+                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
 }
 
 template <int LPR, int UN>
 void launch_kb_vec(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
                    int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
-                   const double *x, const double *p, double *v, double *rk, double *w, double *part_out)
+                   const double *x, const double *p, double *v, double *rk, double *w, double *part_out, int hub_len)
 {
     if (m->kind == B3C_U32 && v16)
         hipLaunchKernelGGL((kr_kb_vec<LPR, UN, uint16_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out);
+                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
     else if (m->kind == B3C_U32)
         hipLaunchKernelGGL((kr_kb_vec<LPR, UN, uint32_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
+                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
     else
         hipLaunchKernelGGL((kr_kb_vec<LPR, UN, double>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out);
+                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
 }
 
 template <int LPR, int UN>
@@ -1355,6 +1438,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         hipLaunchKernelGGL(kr_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, md.p);
         { const int rb_ = b3c_readback(ctx, &maxdeg, md.p, sizeof(maxdeg)); if (rb_) return rb_; }
     }
+    // hub rows (kr_kb_hub): counted here (the count does not depend on the row order), listed once the working matrix is final
+    int64_t n_hub = 0;
+    DevBuf<int64_t> hub_flag(ctx, nloc + 2), hub_pos(ctx, nloc + 2);
+    if (!hub_flag.p || !hub_pos.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
     // SpMV form: "rows" (default), "stream" (LDS-staged CSR-stream) or "wave" (plain wave-per-row)
     const char *kform = getenv("B3C_KR_KERNEL");
     if (getenv("B3C_KR_ROWWAVE")) kform = "wave";
@@ -1380,7 +1467,14 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                  : pipe_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_p), (getenv("B3C_KR_GSMUL") ? atoi(getenv("B3C_KR_GSMUL")) : 16) * ctx->n_cu)
                  : rows_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_r), 8 * ctx->n_cu)
                            : grid_for(n, rows_per_block, 8 * ctx->n_cu);
-    const int P = G > GS ? G : GS;
+    // hub rows add one partial each behind the GS of the row-group kernel (at most nnz / HUB_LEN of them)
+    // threshold: twice the pipelined chunk of the row-group kernel that will run, at least HUB_LEN (sweep on a power-law
+    // map of 300k contigs / 28M entries, average row 93: 137 us per SpMV at 256, 151 at 512, 194 at 2048, 232 without)
+    const int hub_thr = getenv("B3C_KR_HUB_LEN") ? std::max(64, atoi(getenv("B3C_KR_HUB_LEN"))) : (avg > 128 ? 2 * HUB_LEN : HUB_LEN);
+    const bool hub_kb = pipe_kb && maxdeg > (unsigned long long)hub_thr && getenv("B3C_KR_NO_HUB") == nullptr;
+    const int64_t hub_cap = hub_kb ? a->nnz / hub_thr + 1 : 0;
+    const int hub_len = hub_kb ? hub_thr : 0x7fffffff;
+    const int P = (int)std::max<int64_t>(G, (int64_t)GS + hub_cap);
     DevBuf<int64_t> rb(ctx, nblk + 1);
     if (!rb.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
 
@@ -1449,6 +1543,19 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         }
         a = perm.m;
     }
+    // hub rows of the working matrix (this rank's range)
+    DevBuf<int64_t> hub_rows(ctx, hub_cap + 1);
+    if (!hub_rows.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
+    if (hub_kb && nloc > 0) {
+        const unsigned gh = (unsigned)((nloc + 256) / 256);
+        hipLaunchKernelGGL(kr_hub_flags, dim3(gh), dim3(256), 0, s, r0, r1, hub_len, a->indptr, hub_flag.p);
+        int rch;
+        if ((rch = b3c_exclusive_scan_i64(ctx, hub_flag.p, hub_pos.p, nloc + 1))) return rch;
+        { const int rb_ = b3c_readback(ctx, &n_hub, hub_pos.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
+        if (n_hub > hub_cap) return ctx->fail(B3C_E_HIP, "b3c_kr_balance: hub row count out of bounds");
+        if (n_hub) hipLaunchKernelGGL(kr_hub_fill, dim3(gh), dim3(256), 0, s, r0, r1, hub_flag.p, hub_pos.p, hub_rows.p);
+    }
+    const int GSP = GS + (int)n_hub;          // partials the SpMV step leaves behind: row groups + hub rows
     // count form: 16-bit copy of the values when they all fit (built on the matrix the iteration runs on)
     DevBuf<uint16_t> v16buf(ctx, counts ? a->nnz + 16 : 1);     // slack: kr_kb_vec reads whole 4-entry vectors
     const uint16_t *v16 = nullptr;
@@ -1569,18 +1676,18 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                                    svals, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
             } else if (rows_kb && pipe_kb) {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
-                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (vec_shape == 88) launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (vec_shape == 162) launch_kb_vec<16, 2>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (vec_shape == 48) launch_kb_vec<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (vec_shape == 324) launch_kb_vec<32, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                else if (vec_shape == 88) launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                else if (vec_shape == 162) launch_kb_vec<16, 2>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                else if (vec_shape == 48) launch_kb_vec<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                else if (vec_shape == 324) launch_kb_vec<32, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
                 else if (avg > 128 && a->kind == B3C_U32 && vec_shape >= 0)    // 4 entries per lane and load: 0.505 vs 0.544 ms at C3
-                    launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
+                    launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
             } else if (rows_kb) {
                 switch (lpr_r) {
                 case 32: launch_kb_rows<32, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
@@ -1596,16 +1703,27 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             case 8: launch_kb<8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
             default: launch_kb<4>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
             }
+            if (n_hub) {       // the rows the row-group kernel left out; same state slot, partials behind its GS
+                if (a->kind == B3C_U32 && v16)
+                    hipLaunchKernelGGL(kr_kb_hub<uint16_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices, v16,
+                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p + GS);
+                else if (a->kind == B3C_U32)
+                    hipLaunchKernelGGL(kr_kb_hub<uint32_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
+                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p + GS);
+                else
+                    hipLaunchKernelGGL(kr_kb_hub<double>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
+                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p + GS);
+            }
             if (timed) HIP_TRY(ctx, hipEventRecord(evs.back(), s));
             if (dist) {
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part0.p, GS, 0, my_scal);
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part0.p, GSP, 0, my_scal);
                 int rc;
                 if ((rc = xchg(B3C_BUF_SCAL))) return rc;
             }
             t++;
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
-            // KC consumes part0 (GS), produces part1/part2 (min/max, G)
-            hipLaunchKernelGGL(kr_kc, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : part0.p, dist ? D.world : GS,
+            // KC consumes part0 (GSP), produces part1/part2 (min/max, G)
+            hipLaunchKernelGGL(kr_kc, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : part0.p, dist ? D.world : GSP,
                                dist ? 4 : 1, y.p, p.p, part1.p, part2.p);
             if (dist) {
                 hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part1.p, G, 1, my_scal + 1);
