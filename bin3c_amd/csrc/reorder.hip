@@ -411,7 +411,7 @@ __device__ __forceinline__ void permute_row_regs(int lane, int pb, int len, cons
 }
 
 template <typename T>
-__global__ void __launch_bounds__(BLK) k_permute_rows_regs(int64_t n, int pb, const int64_t *__restrict__ indptr,
+__global__ void __launch_bounds__(BLK) k_permute_rows_regs(int64_t n, int pb, int max_len, const int64_t *__restrict__ indptr,
                                                             const int32_t *__restrict__ indices, const T *__restrict__ a,
                                                             const int32_t *__restrict__ new2old,
                                                             const int32_t *__restrict__ old2new,
@@ -426,12 +426,64 @@ __global__ void __launch_bounds__(BLK) k_permute_rows_regs(int64_t n, int pb, co
         const int64_t s = indptr[old];
         const int len = (int)(indptr[old + 1] - s);
         const int64_t o = out_indptr[k];
+        if (len > max_len) continue;                      // long rows: k_long_keys / k_long_scatter
         // wave-uniform choice of the network size
         if (len <= 64) permute_row_regs<T, 1>(lane, pb, len, indices + s, a + s, old2new, out_indices + o, out_a + o);
         else if (len <= 128) permute_row_regs<T, 2>(lane, pb, len, indices + s, a + s, old2new, out_indices + o, out_a + o);
         else if (len <= 256) permute_row_regs<T, 4>(lane, pb, len, indices + s, a + s, old2new, out_indices + o, out_a + o);
         else permute_row_regs<T, 8>(lane, pb, len, indices + s, a + s, old2new, out_indices + o, out_a + o);
     }
+}
+
+// ---- rows too long for the register network: their entries (and only theirs) go through a radix sort ----
+// flags / entry counts of the long NEW rows
+__global__ void k_long_flags(int64_t n, int max_len, const int64_t *__restrict__ out_indptr, int64_t *__restrict__ rflag,
+                             int64_t *__restrict__ ecnt)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n) return;
+    const int64_t len = k < n ? out_indptr[k + 1] - out_indptr[k] : 0;
+    rflag[k] = len > max_len ? 1 : 0;
+    ecnt[k] = len > max_len ? len : 0;
+}
+
+// key = (index among the long rows) << 32 | new column, payload = position of the entry in its old row
+__global__ void __launch_bounds__(BLK) k_long_keys(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                    const int32_t *__restrict__ new2old, const int32_t *__restrict__ old2new,
+                                                    const int64_t *__restrict__ rflag, const int64_t *__restrict__ rpos,
+                                                    const int64_t *__restrict__ epos, int32_t *__restrict__ long_rows,
+                                                    unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t k = wave; k < n; k += nwave) {
+        if (!rflag[k]) continue;
+        const int32_t old = new2old[k];
+        const int64_t s = indptr[old], len = indptr[old + 1] - s;
+        const unsigned long long hi = (unsigned long long)rpos[k] << 32;
+        if (lane == 0) long_rows[rpos[k]] = (int32_t)k;
+        const int64_t o = epos[k];
+        for (int64_t e = lane; e < len; e += 64) {
+            keys[o + e] = hi | (uint32_t)old2new[indices[s + e]];
+            vals[o + e] = (uint32_t)e;
+        }
+    }
+}
+
+template <typename T>
+__global__ void k_long_scatter(int64_t total, const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals,
+                               const int32_t *__restrict__ long_rows, const int64_t *__restrict__ epos,
+                               const int64_t *__restrict__ indptr, const T *__restrict__ a, const int32_t *__restrict__ new2old,
+                               const int64_t *__restrict__ out_indptr, int32_t *__restrict__ out_indices, T *__restrict__ out_a)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const unsigned long long key = keys[t];
+    const int32_t k = long_rows[key >> 32];
+    const int64_t dst = out_indptr[k] + (t - epos[k]);       // the sorted stream is the long rows one after the other
+    out_indices[dst] = (int32_t)(key & 0xFFFFFFFFull);
+    out_a[dst] = a[indptr[new2old[k]] + vals[t]];
 }
 
 __global__ void k_max_len(int64_t n, const int64_t *__restrict__ indptr, unsigned long long *__restrict__ out)
@@ -568,20 +620,66 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
         { const int rb_ = b3c_readback(ctx, &maxlen, ml.p, sizeof(maxlen)); if (rb_) return rb_; }
     }
     constexpr int CAPR = 512;
-    if (nnz && sort_cols && maxlen <= CAPR && getenv("B3C_PERMUTE_GLOBAL_SORT") == nullptr) {
+    int nb = 1;
+    while ((1ll << nb) < n) nb++;
+    const bool regs_ok = nnz && sort_cols && nb + 9 <= 32 && getenv("B3C_PERMUTE_GLOBAL_SORT") == nullptr &&
+                         getenv("B3C_PERMUTE_LDS") == nullptr;
+    if (regs_ok) {
+        // rows of up to CAPR entries: bitonic network in registers on packed (new column, position) keys ...
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
-        int pb = 6, nb = 1;
+        int pb = 6;
+        while ((1ull << pb) < std::min<unsigned long long>(maxlen, CAPR)) pb++;
+        if (a->kind == B3C_F64)
+            hipLaunchKernelGGL(k_permute_rows_regs<double>, dim3(g), dim3(BLK), 0, s, n, pb, CAPR, a->indptr, a->indices,
+                               (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
+        else
+            hipLaunchKernelGGL(k_permute_rows_regs<uint32_t>, dim3(g), dim3(BLK), 0, s, n, pb, CAPR, a->indptr, a->indices,
+                               (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
+        if (maxlen > CAPR) {
+            // ... and the longer ones (hubs) through ONE radix sort of just their entries: a single long row no longer sends
+            // the whole matrix down the global-sort path
+            DevBuf<int64_t> rflag(ctx, n + 1), ecnt(ctx, n + 1), rpos(ctx, n + 2), epos(ctx, n + 2);
+            if (!rflag.p || !ecnt.p || !rpos.p || !epos.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: long rows"); }
+            hipLaunchKernelGGL(k_long_flags, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, CAPR, m->indptr, rflag.p, ecnt.p);
+            if ((rc = b3c_exclusive_scan_i64(ctx, rflag.p, rpos.p, n + 1)) || (rc = b3c_exclusive_scan_i64(ctx, ecnt.p, epos.p, n + 1))) {
+                b3c_mat_free(ctx, m);
+                return rc;
+            }
+            int64_t tot[2] = {0, 0};
+            { const int rb_ = b3c_readback(ctx, &tot[0], rpos.p + n, sizeof(int64_t)); if (rb_) return rb_; }
+            { const int rb_ = b3c_readback(ctx, &tot[1], epos.p + n, sizeof(int64_t)); if (rb_) return rb_; }
+            const int64_t n_long = tot[0], n_ent = tot[1];
+            if (n_ent >= (1ll << 31)) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_ARG, "b3c_permute_csr: more than 2^31 entries in long rows"); }
+            DevBuf<int32_t> long_rows(ctx, n_long + 1);
+            DevBuf<unsigned long long> k_in(ctx, n_ent + 1), k_out(ctx, n_ent + 1);
+            DevBuf<uint32_t> v_in(ctx, n_ent + 1), v_out(ctx, n_ent + 1);
+            if (!long_rows.p || !k_in.p || !k_out.p || !v_in.p || !v_out.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: long rows"); }
+            hipLaunchKernelGGL(k_long_keys, dim3(grid_for(n, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr, a->indices, new2old,
+                               old2new, rflag.p, rpos.p, epos.p, long_rows.p, k_in.p, v_in.p);
+            int end_bit = 33;
+            while (end_bit < 64 && (1ll << (end_bit - 32)) < n_long) end_bit++;
+            size_t tb = 0;
+            hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)n_ent, 0, end_bit, s);
+            if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort sizing failed"); }
+            DevBuf<char> tmp(ctx, tb);
+            if (!tmp.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort workspace"); }
+            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)n_ent, 0, end_bit, s);
+            if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort failed"); }
+            const unsigned gs = (unsigned)((n_ent + 255) / 256);
+            if (a->kind == B3C_F64)
+                hipLaunchKernelGGL(k_long_scatter<double>, dim3(gs), dim3(256), 0, s, n_ent, k_out.p, v_out.p, long_rows.p, epos.p, a->indptr,
+                                   (const double *)a->data, new2old, m->indptr, m->indices, (double *)m->data);
+            else
+                hipLaunchKernelGGL(k_long_scatter<uint32_t>, dim3(gs), dim3(256), 0, s, n_ent, k_out.p, v_out.p, long_rows.p, epos.p, a->indptr,
+                                   (const uint32_t *)a->data, new2old, m->indptr, m->indices, (uint32_t *)m->data);
+            HIP_TRY(ctx, hipStreamSynchronize(s));       // the scratch above goes back to the pool here
+        }
+    } else if (nnz && sort_cols && maxlen <= CAPR && getenv("B3C_PERMUTE_GLOBAL_SORT") == nullptr) {
+        const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
+        int pb = 6;
         while ((1ull << pb) < maxlen) pb++;
-        while ((1ll << nb) < n) nb++;
-        if (pb + nb <= 32) {      // (new column, position) packs into one word: sort keys only
-            if (getenv("B3C_PERMUTE_LDS") == nullptr) {      // register network (default); the LDS network stays for comparison
-                if (a->kind == B3C_F64)
-                    hipLaunchKernelGGL(k_permute_rows_regs<double>, dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
-                                       (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
-                else
-                    hipLaunchKernelGGL(k_permute_rows_regs<uint32_t>, dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
-                                       (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
-            } else if (a->kind == B3C_F64)
+        if (pb + nb <= 32) {      // (new column, position) packs into one word: sort keys only (in-LDS network, for comparison)
+            if (a->kind == B3C_F64)
                 hipLaunchKernelGGL((k_permute_rows_packed<double, CAPR>), dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
                                    (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
             else
