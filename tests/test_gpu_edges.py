@@ -122,3 +122,35 @@ def test_fused_sub_map_is_bit_identical(ctx, graph_form):
     assert np.array_equal(ctx.mat_ids(got), ctx.mat_ids(want))
     for m in (full, want, got, counts):
         m.free()
+
+
+def test_very_long_hub_row(ctx, oracle_lib):
+    """a contig in contact with 200k others (power-law maps have such rows): kr_kb_hub and the long-row sort of the
+    permutation, against the oracle"""
+    from bin3c_amd.pipeline import run_hot_path
+    rs = np.random.RandomState(17)
+    n, hub, m = 250000, 123456, 750000
+    i = rs.randint(0, n, m)
+    j = rs.randint(0, n, m)
+    keep = i != j
+    others = rs.choice(n, 200000, replace=False)
+    others = others[others != hub]
+    rows = np.concatenate([i[keep], np.full(others.shape[0], hub)])
+    cols = np.concatenate([j[keep], others])
+    vals = np.concatenate([rs.geometric(0.3, int(keep.sum())), rs.geometric(0.5, others.shape[0])]).astype(np.uint64)
+    a = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    a = (a + a.T + sp.diags(rs.geometric(0.1, n).astype(np.uint64))).tocsr()
+    a.sum_duplicates()
+    a.sort_indices()
+    ip, ix, cnt = a.indptr.astype(np.int64), a.indices.astype(np.int32), a.data.astype(np.uint32)
+    assert np.diff(ip).max() > 190000
+    sites = rs.poisson(20, n).astype(np.float64)
+    nd = oracle_lib.site_norm(ip, ix, cnt.astype(np.float64), sites)
+    rc, xo, st = oracle_lib.kr_balance(ip, ix, nd)
+    assert rc == oracle_lib.OK
+    counts = ctx.upload(ip, ix, cnt)
+    for reorder in (False, True):
+        res = run_hot_path(ctx, counts, sites, np.full(n, 5000), 1000, 1, reorder=reorder, cluster=False)
+        assert res.kr_info.n_iter == st.n_iter
+        np.testing.assert_allclose(res.x, xo, rtol=1e-8)
+    counts.free()
