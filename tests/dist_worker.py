@@ -50,32 +50,37 @@ def gpu_mode(rank, world):
     from bin3c_amd.dist import DistSession
     from bin3c_amd.pipeline import make_context, run_hot_path
     from bin3c_amd.synth import make_synth
-    sm = make_synth(40000, 1300000, 21)
     ctx = make_context(0)
-    counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
-    single = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)            # before sharding is installed
-    sess = DistSession(ctx, sm.n)
-    res = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)
-    sess.check()
-    assert sess.n_exchanges > 5 * (res.kr_info.n_iter + 1), sess.n_exchanges
-    assert res.kr_info.n_iter == single.kr_info.n_iter
-    assert np.array_equal(res.mask, single.mask) and np.array_equal(res.signal, single.signal)
-    np.testing.assert_allclose(res.x, single.x, rtol=1e-10)
-    assert graphs.same_partition(res.labels, single.labels)
-    assert res.lv_info.n_sweeps == single.lv_info.n_sweeps and res.lv_info.n_levels == single.lv_info.n_levels
-    # all ranks hold identical results
-    lab = torch.as_tensor(res.labels.astype(np.int64))
-    ref = lab.clone()
-    dist.broadcast(ref, 0)
-    assert torch.equal(lab, ref)
-    xs = torch.as_tensor(res.x)
-    xr = xs.clone()
-    dist.broadcast(xr, 0)
-    assert torch.equal(xs, xr)
-    sess.close()
-    again = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)
-    assert np.array_equal(again.x, single.x) and np.array_equal(again.labels, single.labels)
-    print('rank %d gpu ok (%d exchanges)' % (rank, sess.n_exchanges))
+    total = 0
+    # a flat map, and a power-law one whose hub rows go through kr_kb_hub and the Louvain hub lists on both ranks
+    for args in ((40000, 1300000, 21), (30000, 900000, 9, 'powerlaw')):
+        sm = make_synth(*args)
+        counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
+        single = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)            # before sharding is installed
+        sess = DistSession(ctx, sm.n)
+        res = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)
+        sess.check()
+        assert sess.n_exchanges > 4 * (res.kr_info.n_iter + 1), sess.n_exchanges
+        assert res.kr_info.n_iter == single.kr_info.n_iter
+        assert np.array_equal(res.mask, single.mask) and np.array_equal(res.signal, single.signal)
+        np.testing.assert_allclose(res.x, single.x, rtol=1e-10)
+        assert graphs.same_partition(res.labels, single.labels)
+        assert res.lv_info.n_sweeps == single.lv_info.n_sweeps and res.lv_info.n_levels == single.lv_info.n_levels
+        # all ranks hold identical results
+        lab = torch.as_tensor(res.labels.astype(np.int64))
+        ref = lab.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(lab, ref)
+        xs = torch.as_tensor(res.x)
+        xr = xs.clone()
+        dist.broadcast(xr, 0)
+        assert torch.equal(xs, xr)
+        sess.close()
+        again = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)
+        assert np.array_equal(again.x, single.x) and np.array_equal(again.labels, single.labels)
+        total += sess.n_exchanges
+        counts.free()
+    print('rank %d gpu ok (%d exchanges)' % (rank, total))
     ctx.close()
 
 
