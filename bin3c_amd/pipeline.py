@@ -79,8 +79,16 @@ class HotPathResult(object):
         self.kr_info = None
         self.lv_info = None
         self.timings = {}
-        self.perm = (None, None)    # (new2old, old2new) int32 host arrays of the locality ordering, or (None, None)
-        self._n2o = self._o2n = None  # the same on the device
+        self._perm = None           # see `perm`
+        self._n2o = self._o2n = None  # locality ordering on the device (int32 new2old, old2new), or None
+
+    @property
+    def perm(self):
+        """(new2old, old2new) int32 host arrays of the locality ordering, or (None, None); copied from HBM on first access
+        (8 MB at C3 that the cluster step itself never needs on the host)"""
+        if self._perm is None:
+            self._perm = (None, None) if self._n2o is None else (self._n2o.cpu().numpy(), self._o2n.cpu().numpy())
+        return self._perm
 
     @property
     def processed(self):
@@ -202,7 +210,6 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
             back = o2n.long()
             mask_w, x_w = mask_w[back], x_w[back]
             signal_w = signal_w[back] if signal_w is not None else None
-            res.perm = (n2o.cpu().numpy(), o2n.cpu().numpy())
         res.mask = mask_w.cpu().numpy().astype(bool)
         if signal_w is not None:
             res.signal = signal_w.cpu().numpy().view(np.uint32)
