@@ -14,8 +14,9 @@ N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RC
   replicas  one map per GPU (weak scaling, no data-path collective)
   auto      (default) both, replicas first: `value` is the SHARDED figure ("scaling": "strong") and the replica
             throughput is reported beside it under "replicas".  The sharded leg runs under a watchdog: should the
-            RCCL path fail or never return, the line is printed with the replica figure as `value` ("scaling":
-            "weak") and the failure under "sharded".
+            RCCL path fail or never return, the run FAILS (non-zero exit status on every rank); the line is still
+            printed for the record with "value": null, the replica figure under "replicas" and the failure under
+            "sharded".
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -255,14 +256,19 @@ def main():
         from bin3c_amd.dist import DistSession
 
         def give_up(why):
-            # the replica measurement (if any) is already in hand: print it rather than lose the run
+            # a failed or hung sharded leg is a FAILED run: the replica figure (if any) is printed for the record with
+            # "value": null and the failure under "sharded", and every rank leaves with a non-zero status
             if rank == 0:
                 if rep is not None:
+                    rep['replicas'] = {'value': rep['value'], 'unit': 'edges/s', 'ms_per_step': rep['ms_per_step'],
+                                       'scaling': 'weak', 'parallelism': rep['config']['parallelism']}
+                    rep['value'] = None
+                    rep['scaling'] = 'strong'
                     rep['sharded'] = {'error': why}
                     print(json.dumps(rep), flush=True)
-                else:
-                    sys.stderr.write('[bench] sharded leg failed: {}\n'.format(why))
-            os._exit(0 if rep is not None else 1)
+                sys.stderr.write('[bench] sharded leg failed: {}\n'.format(why))
+                sys.stderr.flush()
+            os._exit(1)
 
         watchdog = threading.Timer(float(os.environ.get('B3C_BENCH_WATCHDOG', '240')),
                                    lambda: give_up('timed out (a collective never returned)'))

@@ -118,18 +118,18 @@ extern "C" int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int6
             return rc;
         hipLaunchKernelGGL(k_pair_keys, dim3(gm), dim3(256), 0, s, m, n, dlo.p, dhi.p, dc.p, k_in.p, v_in.p);
         size_t tb = 0;
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)m, 0, bits, s));
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)m, 0, bits, s));
         {
             DevBuf<char> tmp(ctx, tb);
             if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_coo_symmetrise: sort workspace");
-            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)m, 0, bits, s));
+            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)m, 0, bits, s));
         }
         tb = 0;
-        HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tb, k_out.p, ukeys.p, v_out.p, usums.p, nruns.p, hipcub::Sum(), (int)m, s));
+        HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tb, k_out.p, ukeys.p, v_out.p, usums.p, nruns.p, hipcub::Sum(), (int64_t)m, s));
         {
             DevBuf<char> tmp(ctx, tb);
             if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_coo_symmetrise: reduce workspace");
-            HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(tmp.p, tb, k_out.p, ukeys.p, v_out.p, usums.p, nruns.p, hipcub::Sum(), (int)m, s));
+            HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(tmp.p, tb, k_out.p, ukeys.p, v_out.p, usums.p, nruns.p, hipcub::Sum(), (int64_t)m, s));
         }
         { const int rb_ = b3c_readback(ctx, &u, nruns.p, sizeof(int64_t)); if (rb_) return rb_; }
     }
@@ -150,10 +150,10 @@ extern "C" int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int6
     if (total) {
         if (total >= (int64_t)INT32_MAX) return ctx->fail(B3C_E_ARG, "b3c_coo_symmetrise: more than 2^31 stored entries per call");
         size_t tb = 0;
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, e_in.p, e_out.p, w_in.p, w_out.p, (int)total, 0, 64, s));
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, e_in.p, e_out.p, w_in.p, w_out.p, (int64_t)total, 0, 64, s));
         DevBuf<char> tmp(ctx, tb);
         if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_coo_symmetrise: sort workspace");
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, e_in.p, e_out.p, w_in.p, w_out.p, (int)total, 0, 64, s));
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, e_in.p, e_out.p, w_in.p, w_out.p, (int64_t)total, 0, 64, s));
         HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_count_valid, dim3(grid_for(total, 1024, 16 * ctx->n_cu)), dim3(256), 0, s, total, e_out.p, cnt.p);
         unsigned long long hc = 0;

@@ -259,10 +259,10 @@ int row_grid(const b3c_ctx *ctx, int64_t n, int lpr)
 int b3c_exclusive_scan_i64(b3c_ctx *ctx, const int64_t *in, int64_t *out, int64_t count)
 {
     size_t tmp_bytes = 0;
-    HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, out, (int)count, ctx->stream));
+    HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, out, (int64_t)count, ctx->stream));
     DevBuf<char> tmp(ctx, tmp_bytes);
     if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "scan workspace");
-    HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, in, out, (int)count, ctx->stream));
+    HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, in, out, (int64_t)count, ctx->stream));
     return B3C_OK;
 }
 

@@ -1588,11 +1588,11 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         int wbits = 1;
         while ((1ll << wbits) < (n + SELL_W - 1) / SELL_W + 1) wbits++;
         size_t tb = 0;
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, sperm.p, (int)n, 0, 32 + wbits, s));
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, sperm.p, (int64_t)n, 0, 32 + wbits, s));
         {
             DevBuf<char> tmp(ctx, tb);
             if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: SELL sort workspace");
-            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, sperm.p, (int)n, 0, 32 + wbits, s));
+            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, sperm.p, (int64_t)n, 0, 32 + wbits, s));
         }
         hipLaunchKernelGGL(sell_invert, dim3(gn), dim3(256), 0, s, n, sperm.p, sinv.p);
         hipLaunchKernelGGL(sell_slice_sizes, dim3((unsigned)((nsl + 256) / 256)), dim3(256), 0, s, n, nsl, a->indptr, sperm.p,

@@ -1292,20 +1292,20 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         int end_bit = 1;
         while (end_bit < 63 && ((unsigned __int128)1 << end_bit) < (unsigned __int128)kc * (unsigned __int128)kc) end_bit++;
         size_t tb = 0;
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)m, 0, end_bit, s));
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)m, 0, end_bit, s));
         {
             DevBuf<char> tmp(ctx, tb);
             if (!tmp.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "sort workspace"); }
-            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)m, 0, end_bit, s));
+            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)m, 0, end_bit, s));
         }
         tb = 0;
         HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tb, k_out.p, k_in.p, v_out.p, v_in.p, nruns.p,
-                                                       hipcub::Sum(), (int)m, s));
+                                                       hipcub::Sum(), (int64_t)m, s));
         {
             DevBuf<char> tmp(ctx, tb);
             if (!tmp.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "reduce workspace"); }
             HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(tmp.p, tb, k_out.p, k_in.p, v_out.p, v_in.p, nruns.p,
-                                                           hipcub::Sum(), (int)m, s));
+                                                           hipcub::Sum(), (int64_t)m, s));
         }
         int64_t nu = 0;
         { const int rb_ = b3c_readback(ctx, &nu, nruns.p, sizeof(int64_t)); if (rb_) return rb_; }

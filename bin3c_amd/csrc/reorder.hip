@@ -583,12 +583,12 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     while ((1ll << bits) < n) bits++;
     hipLaunchKernelGGL(k_iota, dim3(gn), dim3(256), 0, s, n, new2old);
     size_t tb = 0;
-    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin.p, kout.p, new2old, vout.p, (int)n, 0, bits, s));
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin.p, kout.p, new2old, vout.p, (int64_t)n, 0, bits, s));
     DevBuf<char> tmp(ctx, tb);
     if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_locality_order: sort workspace");
     for (int r = 0; r < ROUNDS; r++) {
         hipLaunchKernelGGL(k_gather_i32, dim3(gn), dim3(256), 0, s, n, lab.p + (size_t)r * n, new2old, kin.p);
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kin.p, kout.p, new2old, vout.p, (int)n, 0, bits, s));
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kin.p, kout.p, new2old, vout.p, (int64_t)n, 0, bits, s));
         HIP_TRY(ctx, hipMemcpyAsync(new2old, vout.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
     }
     hipLaunchKernelGGL(k_invert_perm, dim3(gn), dim3(256), 0, s, n, new2old, old2new);
@@ -659,11 +659,11 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
             int end_bit = 33;
             while (end_bit < 64 && (1ll << (end_bit - 32)) < n_long) end_bit++;
             size_t tb = 0;
-            hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)n_ent, 0, end_bit, s);
+            hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)n_ent, 0, end_bit, s);
             if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort sizing failed"); }
             DevBuf<char> tmp(ctx, tb);
             if (!tmp.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort workspace"); }
-            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int)n_ent, 0, end_bit, s);
+            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)n_ent, 0, end_bit, s);
             if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort failed"); }
             const unsigned gs = (unsigned)((n_ent + 255) / 256);
             if (a->kind == B3C_F64)
@@ -709,16 +709,16 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
         size_t tb = 0;
         hipError_t e;
         if (a->kind == B3C_F64)
-            e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, (const double *)a->data, (double *)m->data, (int)nnz, 0, end_bit, s);
+            e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, (const double *)a->data, (double *)m->data, (int64_t)nnz, 0, end_bit, s);
         else
-            e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, (const uint32_t *)a->data, (uint32_t *)m->data, (int)nnz, 0, end_bit, s);
+            e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, (const uint32_t *)a->data, (uint32_t *)m->data, (int64_t)nnz, 0, end_bit, s);
         if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort sizing failed"); }
         DevBuf<char> tmp(ctx, tb);
         if (!tmp.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort workspace"); }
         if (a->kind == B3C_F64)
-            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, (const double *)a->data, (double *)m->data, (int)nnz, 0, end_bit, s);
+            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, (const double *)a->data, (double *)m->data, (int64_t)nnz, 0, end_bit, s);
         else
-            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, (const uint32_t *)a->data, (uint32_t *)m->data, (int)nnz, 0, end_bit, s);
+            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, (const uint32_t *)a->data, (uint32_t *)m->data, (int64_t)nnz, 0, end_bit, s);
         if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort failed"); }
         hipLaunchKernelGGL(k_cols_from_keys, dim3(grid_for(nnz, 1024, 16 * ctx->n_cu)), dim3(256), 0, s, nnz, n, k_out.p, m->indices);
     }

@@ -190,14 +190,15 @@ def _louvain_device(contact_map, min_len, min_sig):
     return {int(srt[bounds[i]]): order[bounds[i]:bounds[i + 1]] for i in range(len(first)) if srt[bounds[i]] >= 0}
 
 
-def cluster_map(contact_map, seed, method='louvain', min_len=None, min_sig=None, work_dir='.'):
+def cluster_map(contact_map, seed, method='infomap', min_len=None, min_sig=None, work_dir='.'):
     """
     Cluster a contact map into genome bins (cluster.py:44-226).
 
     :param contact_map: ContactMap
     :param seed: random seed handed to external solvers (the GPU Louvain is deterministic)
-    :param method: 'louvain' (GPU) or one of the reference's external solvers
-                   ('infomap', 'mcl', 'slm', 'simap') if its executable is present under external/
+    :param method: the reference's signature default 'infomap' is kept (cluster.py:44); 'louvain' runs the hot path on
+                   the GPU (what ``bin3C.py cluster`` passes here); 'infomap', 'mcl', 'slm', 'simap' need their
+                   executable under external/
     :return: {rank: {'seq_ids': ndarray, 'extent': int, 'name': str}} ordered by descending extent
     """
     assert os.path.exists(work_dir), 'supplied output path [{}] does not exist'.format(work_dir)
@@ -265,6 +266,10 @@ def _run_external(method, g, seed, work_dir, base_name):
         subprocess.check_call(['java', '-jar', need(app_path('external', 'ModularityOptimizer.jar')), edge_file, ofile,
                                '1', '2.0', '3', '10', '10', str(seed), '1'], stdout=stdout, stderr=subprocess.STDOUT)
     return read_table(ofile, seq_col=None, cl_col=0)
+
+
+# the reference's private names for the wire-format functions (cluster.py:57, :76, :111, :139)
+_read_mcl, _read_table, _read_tree, _write_edges = read_mcl, read_table, read_tree, write_edges
 
 
 def enable_clusters(contact_map, clustering, cl_list=None, ordered_only=True, min_extent=None):

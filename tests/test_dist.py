@@ -38,7 +38,7 @@ def test_sharded_hot_path_two_ranks_one_gpu():
     assert 'rank 0 gpu ok' in text and 'rank 1 gpu ok' in text
 
 
-def _bench_two_ranks(mode, **extra_env):
+def _bench_two_ranks(mode, expect_failure=False, **extra_env):
     import json
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
@@ -46,8 +46,12 @@ def _bench_two_ranks(mode, **extra_env):
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1', B3C_BENCH_BACKEND='gloo',
                B3C_BENCH_ONE_GPU='1', **extra_env)
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-    assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    if expect_failure:
+        assert out.returncode != 0, 'a failed sharded leg must fail the run'
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['unit'] == 'edges/s' and 'roofline' in d
@@ -70,10 +74,11 @@ def test_bench_two_ranks_one_gpu(mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('how', ['exception', 'watchdog'])
-def test_bench_keeps_the_replica_line_when_the_sharded_leg_fails(how):
+def test_bench_fails_loudly_when_the_sharded_leg_fails(how):
+    """a sharded leg that raises or hangs is a failed run (non-zero status, value null); the replica figure is kept beside it"""
     env = {'B3C_BENCH_FAIL_SHARDED': '1'} if how == 'exception' else {'B3C_BENCH_WATCHDOG': '0.01'}
-    d = _bench_two_ranks('auto', **env)
-    assert d['scaling'] == 'weak' and 'error' in d['sharded'] and 'replicas x2' in d['config']['parallelism']
+    d = _bench_two_ranks('auto', expect_failure=True, **env)
+    assert d['value'] is None and 'error' in d['sharded'] and d['replicas']['value'] > 0
 
 
 @pytest.mark.gpu
