@@ -25,7 +25,9 @@ class KRInfo(C.Structure):
     _fields_ = [('n_iter', C.c_int64), ('n_outer', C.c_int64), ('n_zero_diag', C.c_int64),
                 ('is_symmetric', C.c_int32), ('hit_max_iter', C.c_int32), ('hit_delta', C.c_int64),
                 ('hit_Delta', C.c_int64), ('rout', C.c_double), ('spmv_ms', C.c_double), ('n_spmv', C.c_int64),
-                ('bitwise_symmetric', C.c_int32), ('value_bits', C.c_int32)]
+                ('bitwise_symmetric', C.c_int32), ('value_bits', C.c_int32),
+                ('tcd_tiles', C.c_int64), ('tcd_dict_max', C.c_int64), ('tcd_dict_total', C.c_int64),
+                ('tcd_tail_entries', C.c_int64)]
 
 
 class LouvainInfo(C.Structure):

@@ -210,95 +210,10 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
 // KB: t = A u (+ unit diagonal where A's is zero), fused epilogue
 //   inner: w = x*t + v*p, partial p.w           (sparse_utils.py:165-166)
 //   outer: v = x*t, rk = 1 - v, partial rk.rk   (:196-199 and :136-139)
-// LPR lanes cooperate on one row; a wave holds 64/LPR rows.
+// Three forms, chosen by the matrix: kr_kb_tcd (16-bit counts, tile-local column dictionaries, operand gathered from
+// LDS), kr_kb_vec (32-bit counts with long rows) and kr_kb_pipe (fp64 matrices, short rows); kr_kb_hub takes the rows
+// that are too long for any of them.
 // ---------------------------------------------------------------------------------------------
-template <int LPR>
-__global__ void __launch_bounds__(BLK) kr_kb(int64_t n, const KRState *__restrict__ sin, KRState *__restrict__ sout,
-                                              const double *__restrict__ partA, int PA, int PS,
-                                              const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                              const double *__restrict__ a, const double *__restrict__ dfix,
-                                              const double *__restrict__ u, const double *__restrict__ x,
-                                              const double *__restrict__ p, double *__restrict__ v,
-                                              double *__restrict__ rk, double *__restrict__ w,
-                                              double *__restrict__ part_out)
-{
-    __shared__ double lds[BLK];
-    KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
-    const bool inner = st.phase == A_INNER;
-    if (st.phase == A_INNER) st.phase = B_INNER;
-    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase == P_DONE) return;
-
-    constexpr int RPW = 64 / LPR;                      // rows per wave
-    const int lane = threadIdx.x & 63;
-    const int sub = lane / LPR, sl = lane % LPR;
-    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
-    double contrib = 0.0;
-    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
-        const int64_t s = indptr[row], e = indptr[row + 1];
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int64_t k = s + sl;
-        for (; k + 3 * LPR < e; k += 4 * LPR) {
-            int32_t c0 = indices[k], c1 = indices[k + LPR], c2 = indices[k + 2 * LPR], c3 = indices[k + 3 * LPR];
-            double m0 = a[k], m1 = a[k + LPR], m2 = a[k + 2 * LPR], m3 = a[k + 3 * LPR];
-            a0 += m0 * u[c0];
-            a1 += m1 * u[c1];
-            a2 += m2 * u[c2];
-            a3 += m3 * u[c3];
-        }
-        for (; k < e; k += LPR) a0 += a[k] * u[indices[k]];
-        double t = (a0 + a1) + (a2 + a3);
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, LPR);
-        if (sl == 0) {
-            t += dfix[row] * u[row];
-            const double xi = x[row];
-            if (inner) {
-                const double pi = p[row];
-                const double wi = xi * t + v[row] * pi;
-                w[row] = wi;
-                contrib += pi * wi;
-            } else {
-                const double vi = xi * t;
-                const double r = 1.0 - vi;
-                v[row] = vi;
-                rk[row] = r;
-                contrib += r * r;
-            }
-        }
-    }
-    block_partial<0>(contrib, part_out, lds);
-}
-
-// ---------------------------------------------------------------------------------------------
-// KB, streaming form (the one that runs unless a row is too long for LDS): "CSR-stream".
-// A block owns the rows whose first entry falls in a window of T stored entries, so its entries are
-// one contiguous run.  Phase 1 streams that run with every thread keeping 8 independent (index,
-// value, gather) triples in flight and parks the products a_ij*u_j in LDS; phase 2 reduces each row
-// out of LDS with LPR lanes and runs the fused epilogue.  The wave-per-row kernel above keeps only
-// ~0.8 KB per wave in flight and is latency bound (measured 0.99 TB/s at C3); this one keeps
-// ~24 KB per block in flight.
-// ---------------------------------------------------------------------------------------------
-constexpr int KB_T = 2048;      // window of stored entries per row block
-constexpr int KB_UNROLL = 8;
-
-__global__ void kr_row_blocks(int64_t n, int64_t nblk, const int64_t *__restrict__ indptr, int64_t *__restrict__ rb)
-{
-    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nblk) return;
-    if (b == nblk) { rb[b] = n; return; }
-    const int64_t target = b * KB_T;
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (indptr[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    rb[b] = lo;
-}
-
 __global__ void kr_max_degree(int64_t n, const int64_t *__restrict__ indptr, unsigned long long *__restrict__ out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,172 +224,6 @@ __global__ void kr_max_degree(int64_t n, const int64_t *__restrict__ indptr, uns
         d = t > d ? t : d;
     }
     if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)d);
-}
-
-template <int LPR>
-__global__ void __launch_bounds__(BLK) kr_kb_stream(int64_t n, int64_t nblk, int lds_cap,
-                                                     const KRState *__restrict__ sin, KRState *__restrict__ sout,
-                                                     const double *__restrict__ partA, int PA, int PS,
-                                                     const int64_t *__restrict__ rb,
-                                                     const int64_t *__restrict__ indptr,
-                                                     const int32_t *__restrict__ indices, const double *__restrict__ a,
-                                                     const double *__restrict__ dfix, const double *__restrict__ u,
-                                                     const double *__restrict__ x, const double *__restrict__ p,
-                                                     double *__restrict__ v, double *__restrict__ rk,
-                                                     double *__restrict__ w, double *__restrict__ part_out)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *prod = smem;               // lds_cap doubles
-    double *lds = smem + lds_cap;      // BLK doubles for the reductions
-    KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
-    const bool inner = st.phase == A_INNER;
-    if (st.phase == A_INNER) st.phase = B_INNER;
-    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase == P_DONE) return;
-
-    const int tid = threadIdx.x;
-    const int grp = tid / LPR, sl = tid % LPR;
-    constexpr int NGRP = BLK / LPR;
-    double contrib = 0.0;
-    for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
-        const int64_t r0 = rb[b], r1 = rb[b + 1];
-        const int64_t k0 = indptr[r0], k1 = indptr[r1];
-        const int cnt = (int)(k1 - k0);
-        // phase 1: products into LDS, KB_UNROLL independent loads per thread
-        for (int base = 0; base < cnt; base += BLK * KB_UNROLL) {
-            int32_t c[KB_UNROLL];
-            double m[KB_UNROLL];
-#pragma unroll
-            for (int q = 0; q < KB_UNROLL; q++) {
-                const int i = base + q * BLK + tid;
-                const bool ok = i < cnt;
-                c[q] = ok ? indices[k0 + i] : 0;
-                m[q] = ok ? a[k0 + i] : 0.0;
-            }
-            double g[KB_UNROLL];
-#pragma unroll
-            for (int q = 0; q < KB_UNROLL; q++) g[q] = u[c[q]];
-#pragma unroll
-            for (int q = 0; q < KB_UNROLL; q++) {
-                const int i = base + q * BLK + tid;
-                if (i < cnt) prod[i] = m[q] * g[q];
-            }
-        }
-        __syncthreads();
-        // phase 2: row sums out of LDS + fused epilogue
-        const int nrows = (int)(r1 - r0);
-        for (int rr = grp; rr < nrows; rr += NGRP) {
-            const int64_t row = r0 + rr;
-            const int s = (int)(indptr[row] - k0), e = (int)(indptr[row + 1] - k0);
-            double t0 = 0.0, t1 = 0.0;
-            int k = s + sl;
-            for (; k + LPR < e; k += 2 * LPR) { t0 += prod[k]; t1 += prod[k + LPR]; }
-            if (k < e) t0 += prod[k];
-            double t = t0 + t1;
-#pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, LPR);
-            if (sl == 0) {
-                t += dfix[row] * u[row];
-                const double xi = x[row];
-                if (inner) {
-                    const double pi = p[row];
-                    const double wi = xi * t + v[row] * pi;
-                    w[row] = wi;
-                    contrib += pi * wi;
-                } else {
-                    const double vi = xi * t;
-                    const double r = 1.0 - vi;
-                    v[row] = vi;
-                    rk[row] = r;
-                    contrib += r * r;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    block_partial<0>(contrib, part_out, lds);
-}
-
-// ---------------------------------------------------------------------------------------------
-// KB, row-group form: LPR lanes own one row and pull UN entries each up front (indices and values
-// first, then all gathers), so a wave keeps 64*UN independent 12-byte triples in flight and 64/LPR
-// rows overlap their indptr -> entries -> gather -> epilogue chains.  No LDS, no barriers, 32-bit
-// offsets inside a row.  Rows longer than LPR*UN loop.  Chosen by average row length.
-// ---------------------------------------------------------------------------------------------
-template <int LPR, int UN, bool NOGATHER = false>
-__global__ void __launch_bounds__(BLK) kr_kb_rows(int64_t r0, int64_t n, const KRState *__restrict__ sin, KRState *__restrict__ sout,
-                                                   const double *__restrict__ partA, int PA, int PS,
-                                                   const int64_t *__restrict__ indptr,
-                                                   const int32_t *__restrict__ indices, const double *__restrict__ a,
-                                                   const double *__restrict__ dfix, const double *__restrict__ u,
-                                                   const double *__restrict__ x, const double *__restrict__ p,
-                                                   double *__restrict__ v, double *__restrict__ rk,
-                                                   double *__restrict__ w, double *__restrict__ part_out)
-{
-    __shared__ double lds[BLK];
-    KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
-    const bool inner = st.phase == A_INNER;
-    if (st.phase == A_INNER) st.phase = B_INNER;
-    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase == P_DONE) return;
-
-    constexpr int RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane / LPR, sl = lane % LPR;
-    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
-    double contrib = 0.0;
-    for (int64_t row = r0 + wave * RPW + sub; row < n; row += nwave * RPW) {
-        const int64_t s = indptr[row];
-        const int len = (int)(indptr[row + 1] - s);
-        const int32_t *__restrict__ ci = indices + s;
-        const double *__restrict__ av = a + s;
-        // epilogue operands do not depend on the row sum: issue them before the long loads
-        double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0;
-        if (sl == 0) {
-            xi = x[row];
-            di = dfix[row] * u[row];
-            if (inner) { pi = p[row]; vi = v[row]; }
-        }
-        double acc = 0.0;
-        for (int base = 0; base < len; base += LPR * UN) {
-            int32_t c[UN];
-            double m[UN];
-#pragma unroll
-            for (int q = 0; q < UN; q++) {
-                const int i = base + q * LPR + sl;
-                const bool ok = i < len;
-                c[q] = ok ? ci[i] : 0;
-                m[q] = ok ? av[i] : 0.0;
-            }
-            double g[UN];
-#pragma unroll
-            for (int q = 0; q < UN; q++) g[q] = NOGATHER ? u[row + (c[q] & 1)] : u[c[q]];   // NOGATHER: timing probe only
-#pragma unroll
-            for (int q = 0; q < UN; q++) acc += m[q] * g[q];
-        }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
-        if (sl == 0) {
-            const double t = acc + di;
-            if (inner) {
-                const double wi = xi * t + vi * pi;
-                w[row] = wi;
-                contrib += pi * wi;
-            } else {
-                const double vn = xi * t;
-                const double r = 1.0 - vn;
-                v[row] = vn;
-                rk[row] = r;
-                contrib += r * r;
-            }
-        }
-    }
-    block_partial<0>(contrib, part_out, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,6 +360,8 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
 // per wave on every 256 B of indices and every 128 B of 16-bit values; here the same cycles move 1 KB / 512 B.
 // Lanes may read up to 3 entries past the end of their row (masked afterwards): the matrix arrays carry 32 B of slack.
 // ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 template <typename T>
 struct alignas(sizeof(T)) Vec4 {
     T v[4];
@@ -830,155 +581,412 @@ __global__ void __launch_bounds__(BLK) kr_kb_hub(const int64_t *__restrict__ hub
 }
 
 // ---------------------------------------------------------------------------------------------
-// KB, sliced-ELL form (SELL-64-sigma): the layout the iteration actually runs on when rows are regular.
-// Rows are sorted by length inside windows of SELL_W rows (keeps the locality order to within a window),
-// cut into slices of 64, and every slice is stored column-major and padded to its longest row.  Lane r of a
-// wave owns row r of the slice: entry j of all 64 rows is one aligned 256 B / 512 B load, there is no
-// cross-lane reduction, no per-row pointer chase, and the epilogue operands are coalesced.  Row-structured
-// CSR kernels top out near 3 TB/s on this chip even without their gathers (measured, B3C_KR_NOGATHER);
-// flat 8-byte streams reach 5.6 TB/s.  Built once per balance call (about two passes over the matrix) and
-// reused by every SpMV.
+// KB on TILE-LOCAL COLUMN DICTIONARIES (the form the count matrix runs on when every count fits 16 bits).
+//
+// What bounds the CSR forms above is not HBM but the L1 look-up rate: every stored entry gathers one 8-byte operand
+// through the texture path, one tag look-up per lane (measured at C3: 2.3e8 look-ups per SpMV, the addresser busy 81 %
+// of the kernel).  In the locality order the rows of a tile of R consecutive contigs share most of their columns (they
+// belong to a few genomes).  Per tile the columns that occur MORE THAN ONCE form its dictionary (at most d1cap of them):
+// their operands are gathered once into LDS and such an entry reads its operand from LDS by a 16-bit dictionary index,
+// 4 bytes per entry (index << 16 | count).  The other entries of a row -- columns that occur once in the tile, i.e. the
+// inter-genome noise, ~12 % at C3 -- are moved to the END of the row and keep a 32-bit column in a parallel array of
+// which only those tails are ever touched; they gather from global memory as before, with dense lanes.
+// L1 look-ups per tile: one per dictionary column + one per tail entry, instead of one per entry.
+//
+//   kr_tcd_build   once per balance call, one workgroup per tile: two bitmaps (seen / seen more than once) of 2^19
+//                  columns per pass in LDS, prefix popcounts -> the sorted dictionary, then every row is rewritten:
+//                  dictionary entries from the front, tail entries from the back
+//   kr_kb_tcd      one workgroup per tile: row pointers and the tile's slices of x, p, v, 1/s, dfix come in as coalesced
+//                  vectors, the dictionary operands are gathered into LDS, rows are LPR-lane groups streaming 16-byte
+//                  vectors of packed entries (software pipelined, branch-free: buffer loads whose range check drops the
+//                  masked lanes), results leave through LDS as coalesced stores.
 // ---------------------------------------------------------------------------------------------
-constexpr int SELL_W = 4096;
+constexpr int TCD_TB = 1024;                          // threads of the build kernel (one workgroup per CU: 140 KB of LDS)
+constexpr int TCD_CHUNK_LG = 19;                      // columns per bitmap pass
+constexpr int TCD_WORDS = 1 << (TCD_CHUNK_LG - 5);    // 16384 words = 64 KB per bitmap
+constexpr int TCD_GROUPS = TCD_WORDS / 4;             // one 16-bit prefix per 128 columns
+constexpr int TCD_RMAX = 256;                         // rows per tile at most
+constexpr size_t TCD_BUILD_LDS = sizeof(uint32_t) * 2 * TCD_WORDS + sizeof(uint16_t) * TCD_GROUPS + sizeof(uint32_t) * (32 + 2 * TCD_RMAX);
 
-__global__ void sell_keys(int64_t n, const int64_t *__restrict__ indptr, int64_t *__restrict__ keys, int32_t *__restrict__ vals)
+__global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap,
+                                                        const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices,
+                                                        const uint32_t *__restrict__ counts, uint32_t *__restrict__ packed,
+                                                        int32_t *__restrict__ pcol, int32_t *__restrict__ n1_out,
+                                                        int32_t *__restrict__ dict_cols, int32_t *__restrict__ dict_cnt,
+                                                        unsigned long long *__restrict__ stats)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const int64_t len = indptr[i + 1] - indptr[i];
-        keys[i] = ((i / SELL_W) << 32) | (int64_t)(0x7FFFFFFFll - len);   // window ascending, length descending
-        vals[i] = (int32_t)i;
-    }
-}
-
-__global__ void sell_invert(int64_t n, const int32_t *__restrict__ sperm, int32_t *__restrict__ sinv)
-{
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) sinv[sperm[k]] = (int32_t)k;
-}
-
-__global__ void sell_slice_sizes(int64_t n, int64_t nsl, const int64_t *__restrict__ indptr,
-                                 const int32_t *__restrict__ sperm, int32_t *__restrict__ slen,
-                                 int64_t *__restrict__ sizes)
-{
-    int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (sidx < nsl) {
-        const int32_t r = sperm[sidx * 64];            // longest row of the slice (sorted descending inside the window)
-        const int64_t len = indptr[r + 1] - indptr[r];
-        slen[sidx] = (int32_t)len;
-        sizes[sidx] = len * 64;
-    }
-    if (sidx == nsl) sizes[sidx] = 0;
-}
-
-__global__ void __launch_bounds__(BLK) sell_fill(int64_t n, int64_t nsl, const int64_t *__restrict__ indptr,
-                                                  const int32_t *__restrict__ indices, const double *__restrict__ a,
-                                                  const int32_t *__restrict__ sperm, const int32_t *__restrict__ sinv,
-                                                  const int32_t *__restrict__ slen, const int64_t *__restrict__ sptr,
-                                                  int32_t *__restrict__ cols, double *__restrict__ vals)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
-    for (int64_t sl = wave; sl < nsl; sl += nwave) {
-        const int64_t row = sl * 64 + lane;            // SELL row
-        const int L = slen[sl];
-        int64_t k0 = 0;
-        int len = 0;
-        if (row < n) {
-            const int32_t old = sperm[row];
-            k0 = indptr[old];
-            len = (int)(indptr[old + 1] - k0);
-        }
-        const int32_t self = row < n ? (int32_t)row : 0;
-        int32_t *__restrict__ cd = cols + sptr[sl] + lane;
-        double *__restrict__ vd = vals + sptr[sl] + lane;
-        for (int j = 0; j < L; j++) {
-            int32_t c = self;
-            double m = 0.0;
-            if (j < len) {
-                c = sinv[indices[k0 + j]];
-                m = a[k0 + j];
+    extern __shared__ __attribute__((aligned(16))) uint32_t tsm[];
+    uint32_t *bm1 = tsm;                              // column seen
+    uint32_t *bm2 = tsm + TCD_WORDS;                  // column seen more than once
+    uint16_t *pre1 = (uint16_t *)(tsm + 2 * TCD_WORDS);   // dictionary columns of this pass before the group
+    uint32_t *wsum = tsm + 2 * TCD_WORDS + TCD_GROUPS / 2;    // 16 wave sums
+    uint32_t *nfront = wsum + 32;                     // per row: entries placed from the front / from the back so far
+    uint32_t *nback = nfront + TCD_RMAX;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t tile = blockIdx.x;
+    const int64_t ra = r0 + tile * R, rb = ra + R < r1 ? ra + R : r1;
+    uint4 *b14 = (uint4 *)bm1, *b24 = (uint4 *)bm2;
+    constexpr int GPT = TCD_GROUPS / TCD_TB;          // groups per thread
+    constexpr int NW = TCD_TB / 64;
+    for (int i = tid; i < 2 * TCD_RMAX; i += TCD_TB) nfront[i] = 0;
+    int32_t *__restrict__ dc = dict_cols + tile * (int64_t)d1cap;
+    int64_t a1 = 0;                                   // dictionary columns of the passes before (uncapped)
+    for (int64_t c0 = 0; c0 < ncols; c0 += (int64_t)1 << TCD_CHUNK_LG) {
+        for (int i = tid; i < TCD_WORDS / 4; i += TCD_TB) { b14[i] = make_uint4(0, 0, 0, 0); b24[i] = make_uint4(0, 0, 0, 0); }
+        __syncthreads();
+        for (int64_t row = ra + wv; row < rb; row += NW) {
+            const int64_t s = indptr[row];
+            const int len = (int)(indptr[row + 1] - s);
+            if (len > hub_len) continue;                        // hub rows run on the CSR arrays (kr_kb_hub)
+            for (int base = 0; base < len; base += 256) {
+                int64_t c[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) { const int k = base + t * 64 + lane; c[t] = k < len ? (int64_t)indices[s + k] - c0 : -1; }
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (c[t] >= 0 && c[t] < ((int64_t)1 << TCD_CHUNK_LG)) {
+                        const uint32_t bit = 1u << (c[t] & 31);
+                        const uint32_t old = atomicOr(&bm1[c[t] >> 5], bit);
+                        if (old & bit) atomicOr(&bm2[c[t] >> 5], bit);
+                    }
             }
-            cd[(int64_t)j * 64] = c;
-            vd[(int64_t)j * 64] = m;
         }
+        __syncthreads();
+        // per thread: its GPT groups of 128 columns
+        uint32_t e1[GPT], run1 = 0;
+#pragma unroll
+        for (int g = 0; g < GPT; g++) {
+            const uint4 m2 = b24[tid * GPT + g];
+            e1[g] = run1;
+            run1 += __popc(m2.x) + __popc(m2.y) + __popc(m2.z) + __popc(m2.w);
+        }
+        uint32_t inc1 = run1;                            // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t1 = __shfl_up(inc1, o, 64);
+            if (lane >= o) inc1 += t1;
+        }
+        if (lane == 63) wsum[wv] = inc1;
+        __syncthreads();
+        uint32_t base1 = inc1 - run1, tot1 = 0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const uint32_t t1 = wsum[q];
+            if (q < wv) base1 += t1;
+            tot1 += t1;
+        }
+#pragma unroll
+        for (int g = 0; g < GPT; g++) {
+            const uint32_t pv = base1 + e1[g];
+            pre1[tid * GPT + g] = (uint16_t)(pv < 65535u ? pv : 65535u);    // only ranks below d1cap <= 16384 are used
+        }
+        __syncthreads();
+        // the dictionary: ascending columns, as many as the LDS budget takes
+        {
+            int64_t p1 = a1 + base1;
+            for (int i = 0; i < GPT * 4 && p1 < d1cap; i++) {
+                const int wd = tid * GPT * 4 + i;
+                uint32_t bits = bm2[wd];
+                while (bits && p1 < d1cap) {
+                    const int b = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    dc[p1++] = (int32_t)(c0 + (int64_t)wd * 32 + b);
+                }
+            }
+        }
+        // the rows: dictionary entries to the front (index << 16 | count), the others to the back (count; column beside it)
+        for (int64_t row = ra + wv; row < rb; row += NW) {
+            const int64_t s = indptr[row];
+            const int len = (int)(indptr[row + 1] - s);
+            if (len > hub_len) continue;
+            uint32_t nf = nfront[row - ra], nb = nback[row - ra];
+            for (int base = 0; base < len; base += 256) {
+                int64_t c[4];
+                uint32_t cv[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int k = base + t * 64 + lane;
+                    c[t] = k < len ? (int64_t)indices[s + k] - c0 : -1;
+                    cv[t] = k < len ? counts[s + k] & 0xFFFFu : 0u;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const bool in = c[t] >= 0 && c[t] < ((int64_t)1 << TCD_CHUNK_LG);
+                    bool front = false;
+                    int64_t r = 0;
+                    if (in) {
+                        const int wd = (int)(c[t] >> 5), g = wd >> 2;
+                        if ((bm2[wd] >> (c[t] & 31)) & 1u) {
+                            r = a1 + pre1[g];
+                            for (int j = g * 4; j < wd; j++) r += __popc(bm2[j]);
+                            r += __popc(bm2[wd] & ((1u << (c[t] & 31)) - 1u));
+                            front = r < d1cap;
+                        }
+                    }
+                    const unsigned long long mf = __ballot(in && front), mb = __ballot(in && !front);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (in && front) packed[s + nf + __popcll(mf & below)] = ((uint32_t)r << 16) | cv[t];
+                    if (in && !front) {
+                        const int64_t at = s + len - 1 - (int64_t)(nb + __popcll(mb & below));
+                        packed[at] = cv[t];
+                        pcol[at] = (int32_t)(c[t] + c0);
+                    }
+                    nf += __popcll(mf);
+                    nb += __popcll(mb);
+                }
+            }
+            if (lane == 0) { nfront[row - ra] = nf; nback[row - ra] = nb; }
+        }
+        a1 += tot1;
+        __syncthreads();
     }
+    for (int i = tid; i < (int)(rb - ra); i += TCD_TB) n1_out[ra + i - r0] = (int32_t)nfront[i];
+    if (tid == 0) {
+        const int d1 = (int)(a1 < d1cap ? a1 : d1cap);
+        dict_cnt[tile] = d1;
+        atomicMax(&stats[0], (unsigned long long)d1);
+        atomicAdd(&stats[2], (unsigned long long)d1);
+    }
+    // entries left in the tails (statistics only)
+    if (tid < (int)(rb - ra) && nback[tid]) atomicAdd(&stats[3], (unsigned long long)nback[tid]);
 }
 
-template <int UN>
-__global__ void __launch_bounds__(BLK) kr_kb_sell(int64_t r0, int64_t r1, int64_t n, const KRState *__restrict__ sin,
-                                                   KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
-                                                   int PS, const int64_t *__restrict__ sptr,
-                                                   const int32_t *__restrict__ slen, const int32_t *__restrict__ cols,
-                                                   const double *__restrict__ vals, const double *__restrict__ dfix,
-                                                   const double *__restrict__ u, const double *__restrict__ x,
-                                                   const double *__restrict__ p, double *__restrict__ v,
-                                                   double *__restrict__ rk, double *__restrict__ w,
-                                                   double *__restrict__ part_out)
+template <int OP>
+__device__ void block_partial_at(double v, double *__restrict__ part, int64_t at, double *lds)
 {
-    __shared__ double lds[BLK];
+    const int t = threadIdx.x;
+    v = OP == 0 ? wave_sum(v) : (OP == 1 ? wave_min(v) : wave_max(v));
+    if ((t & 63) == 0) lds[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) {
+        double r = lds[0];
+#pragma unroll
+        for (int w = 1; w < BLK / 64; w++) r = OP == 0 ? r + lds[w] : (OP == 1 ? fmin(r, lds[w]) : fmax(r, lds[w]));
+        part[at] = r;
+    }
+    __syncthreads();
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// LPR lanes per row, UN 16-byte vectors of dictionary entries and TU tail entries per lane and pass
+template <int LPR, int UN, int TU>
+__global__ void __launch_bounds__(BLK) kr_kb_tcd(int64_t r0, int64_t r1, int64_t ncols, int R, int dlds, int dstride, int ntiles,
+                                                  int swz, const KRState *__restrict__ sin, KRState *__restrict__ sout,
+                                                  const double *__restrict__ partA, int PA, int PS,
+                                                  const int64_t *__restrict__ indptr, const uint32_t *__restrict__ packed,
+                                                  const int32_t *__restrict__ pcol, const int32_t *__restrict__ n1v,
+                                                  const int32_t *__restrict__ dict_cols, const int32_t *__restrict__ dict_cnt,
+                                                  const double *__restrict__ rs, const double *__restrict__ dfix,
+                                                  const double *__restrict__ u, const double *__restrict__ x,
+                                                  const double *__restrict__ p, double *__restrict__ v,
+                                                  double *__restrict__ rk, double *__restrict__ w,
+                                                  double *__restrict__ part_out, int hub_len, uint32_t probe_mask, int probe)
+{
+    extern __shared__ __attribute__((aligned(16))) double ksm[];
+    double *xl = ksm;                         // dlds operands of the tile's dictionary
+    double *tx = xl + dlds, *tp = tx + R, *tv = tp + R, *td = tv + R, *tr = td + R, *o0 = tr + R, *o1 = o0 + R;
+    int64_t *ipl = (int64_t *)(o1 + R);       // R + 1 row pointers
+    double *lds = (double *)(ipl + R + 1);    // BLK doubles for the reductions
+    int32_t *n1l = (int32_t *)(lds + BLK);    // R dictionary-entry counts
+    // blocks b and b + 8 share an XCD (and its L2): swz gives every XCD a contiguous eighth of the tiles, so that the
+    // operand windows its tiles gather overlap
+    int64_t tile = blockIdx.x;
+    if (swz) {
+        const int per = (ntiles + 7) / 8;
+        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    }
+    const bool live = tile < ntiles;          // padding blocks of the swizzled grid carry no tile
+    const int tid = threadIdx.x;
+    const int64_t ra = r0 + (live ? tile : 0) * R;
+    const int nrows = live ? (int)((ra + R < r1 ? ra + R : r1) - ra) : 0;
+    // everything that does not depend on the control state is requested first
+    const int D1 = live ? dict_cnt[tile] : 0;
+    for (int i = tid; i <= nrows && live; i += BLK) ipl[i] = indptr[ra + i];
+    for (int i = tid; i < nrows; i += BLK) {
+        tx[i] = x[ra + i];
+        td[i] = dfix[ra + i];
+        tr[i] = rs ? rs[ra + i] : 1.0;
+        tp[i] = p[ra + i];
+        tv[i] = v[ra + i];
+        n1l[i] = n1v[ra + i - r0];
+    }
+    {
+        const int32_t *__restrict__ dc1 = dict_cols + (live ? tile : 0) * (int64_t)dstride;
+        for (int base = 0; base < D1 && !(probe & 4); base += BLK * 4) {
+            int32_t cc[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = base + q * BLK + tid; cc[q] = i < D1 ? dc1[i] : 0; }
+            double gg[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) gg[q] = u[(uint32_t)cc[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = base + q * BLK + tid; if (i < D1) xl[i] = gg[q]; }
+        }
+    }
+    if (D1 == 0 && tid == 0) xl[0] = 0.0;     // masked lanes multiply a zero count with xl[0]: keep stale LDS (NaN) out
     KRState st = *sin;
     if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
     const bool inner = st.phase == A_INNER;
     if (st.phase == A_INNER) st.phase = B_INNER;
     else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase == P_DONE) return;
+    if (st.phase == P_DONE || !live) return;
+    __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
-    const int64_t s0 = r0 / 64, s1 = (r1 + 63) / 64;     // r0 is a multiple of 64
+    // the tile's entries and the operand vector as buffer resources (descriptors from wave-uniform values only): a lane
+    // that must not load passes offset ~0 and the range check drops it -- no branch, no look-up
+    const int64_t e0 = ipl[0];
+    const uint32_t ebytes = __builtin_amdgcn_readfirstlane((uint32_t)((ipl[nrows] - e0) * 4));
+    const uint64_t pa = (uint64_t)(packed + e0), ca = (uint64_t)(pcol + e0);
+    const uint32_t palo = __builtin_amdgcn_readfirstlane((uint32_t)pa), pahi = __builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
+    const uint32_t calo = __builtin_amdgcn_readfirstlane((uint32_t)ca), cahi = __builtin_amdgcn_readfirstlane((uint32_t)(ca >> 32));
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)pahi << 32) | palo), 0, (int)ebytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)cahi << 32) | calo), 0, (int)ebytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, (int)(ncols * 8), 0x00020000);
+    constexpr uint32_t NOLOAD = 0xFFFFFFFFu;
+
+    constexpr int RPW = 64 / LPR;
+    constexpr int RPP = RPW * (BLK / 64);     // rows per pass of the workgroup
+    constexpr int CH = LPR * UN * 4;
+    constexpr int TCH = LPR * TU * 4;
+    const int lane = tid & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
     double contrib = 0.0;
-    for (int64_t sl = s0 + wave; sl < s1; sl += nwave) {
-        const int64_t row = sl * 64 + lane;
-        const bool live = row < r1 && row < n;
-        const int L = slen[sl];
-        const int32_t *__restrict__ ci = cols + sptr[sl] + lane;
-        const double *__restrict__ av = vals + sptr[sl] + lane;
-        double xi = 0.0, pi = 0.0, vi = 0.0, di = 0.0;
-        if (live) {
-            xi = x[row];
-            di = dfix[row] * u[row];
-            if (inner) { pi = p[row]; vi = v[row]; }
+    int rl = (tid >> 6) * RPW + sub;
+    uint32_t so = 0;                          // byte offset of the row inside the tile's entries
+    int len = 0, n1 = 0;
+    if (rl < nrows) {
+        so = (uint32_t)((ipl[rl] - e0) * 4);
+        len = (int)(ipl[rl + 1] - ipl[rl]);
+        n1 = n1l[rl];
+        if (len > hub_len) { len = -1; n1 = 0; }
+    }
+    // TU 16-byte vectors of tail entries per lane: counts from the end of the row in `packed`, columns beside them
+    u32x4 c[UN], tc[TU], tcol[TU];
+#pragma unroll
+    for (int q = 0; q < UN; q++) {
+        const int i = (q * LPR + sl) * 4;
+        c[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1 ? so + (uint32_t)i * 4u : NOLOAD, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < TU; k++) {
+        const int t = n1 + (k * LPR + sl) * 4;
+        const uint32_t off = t < len && !(probe & 2) ? so + (uint32_t)t * 4u : NOLOAD;
+        tc[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0);
+        tcol[k] = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
+    }
+    while (rl < nrows) {
+        const int rln = rl + RPP;
+        uint32_t son = 0;
+        int lenn = 0, n1n = 0;
+        if (rln < nrows) {
+            son = (uint32_t)((ipl[rln] - e0) * 4);
+            lenn = (int)(ipl[rln + 1] - ipl[rln]);
+            n1n = n1l[rln];
+            if (lenn > hub_len) { lenn = -1; n1n = 0; }
         }
-        double acc0 = 0.0, acc1 = 0.0;
-        int j = 0;
-        for (; j + UN <= L; j += UN) {                  // L is wave-uniform: no predication in the main loop
-            int32_t c[UN];
-            double m[UN];
+        // tail operands of this row from global memory, then the entries of the next row
+        double tg[TU][4];
+#pragma unroll
+        for (int k = 0; k < TU; k++) {
+            const int t = n1 + (k * LPR + sl) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len && !(probe & 3) ? (tcol[k][j] & probe_mask) * 8u : NOLOAD, 0, 0);
+                tg[k][j] = __hiloint2double((int)gw.y, (int)gw.x);
+            }
+        }
+        u32x4 c2[UN], tc2[TU], tcol2[TU];
+#pragma unroll
+        for (int q = 0; q < UN; q++) {
+            const int i = (q * LPR + sl) * 4;
+            c2[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1n ? son + (uint32_t)i * 4u : NOLOAD, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < TU; k++) {
+            const int t = n1n + (k * LPR + sl) * 4;
+            const uint32_t off = t < lenn && !(probe & 2) ? son + (uint32_t)t * 4u : NOLOAD;
+            tc2[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0);
+            tcol2[k] = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < UN; q++) {
+            const int i = (q * LPR + sl) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t e = i + j < n1 ? c[q][j] : 0u;
+                acc += (double)(e & 0xFFFFu) * xl[e >> 16];
+            }
+        }
+        for (int base = CH; base < n1; base += CH) {          // more dictionary entries than one chunk
 #pragma unroll
             for (int q = 0; q < UN; q++) {
-                c[q] = ci[(j + q) * 64];
-                m[q] = av[(j + q) * 64];
-            }
-            double g[UN];
+                const int i = base + (q * LPR + sl) * 4;
+                const u32x4 cc = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1 ? so + (uint32_t)i * 4u : NOLOAD, 0, 0);
 #pragma unroll
-            for (int q = 0; q < UN; q++) g[q] = u[(uint32_t)c[q]];
-#pragma unroll
-            for (int q = 0; q < UN; q += 2) {
-                acc0 += m[q] * g[q];
-                acc1 += m[q + 1] * g[q + 1];
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t e = i + j < n1 ? cc[j] : 0u;
+                    acc += (double)(e & 0xFFFFu) * xl[e >> 16];
+                }
             }
         }
-        for (; j < L; j++) acc0 += av[j * 64] * u[(uint32_t)ci[j * 64]];
-        if (live) {
-            const double t = (acc0 + acc1) + di;
+#pragma unroll
+        for (int k = 0; k < TU; k++) {
+            const int t = n1 + (k * LPR + sl) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc += (t + j < len ? (double)(tc[k][j] & 0xFFFFu) : 0.0) * tg[k][j];
+        }
+        for (int base = n1 + TCH; base < len && !(probe & 2); base += TCH) {  // longer tails
+#pragma unroll
+            for (int k = 0; k < TU; k++) {
+                const int t = base + (k * LPR + sl) * 4;
+                const uint32_t off = t < len ? so + (uint32_t)t * 4u : NOLOAD;
+                const u32x4 cn = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0);
+                const u32x4 cl = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len ? (cl[j] & probe_mask) * 8u : NOLOAD, 0, 0);
+                    acc += (t + j < len ? (double)(cn[j] & 0xFFFFu) : 0.0) * __hiloint2double((int)gw.y, (int)gw.x);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
+        if (sl == 0 && len >= 0) {
+            const double xi = tx[rl];
+            const double pi = inner ? tp[rl] : 0.0;
+            const double t = acc * tr[rl] + td[rl] * (inner ? xi * pi : xi);
             if (inner) {
-                const double wi = xi * t + vi * pi;
-                w[row] = wi;
+                const double wi = xi * t + tv[rl] * pi;
+                o0[rl] = wi;
                 contrib += pi * wi;
             } else {
                 const double vn = xi * t;
                 const double r = 1.0 - vn;
-                v[row] = vn;
-                rk[row] = r;
+                o0[rl] = vn;
+                o1[rl] = r;
                 contrib += r * r;
             }
         }
+        rl = rln;
+        so = son;
+        len = lenn;
+        n1 = n1n;
+#pragma unroll
+        for (int q = 0; q < UN; q++) c[q] = c2[q];
+#pragma unroll
+        for (int k = 0; k < TU; k++) { tc[k] = tc2[k]; tcol[k] = tcol2[k]; }
     }
-    block_partial<0>(contrib, part_out, lds);
+    __syncthreads();
+    for (int i = tid; i < nrows; i += BLK) {
+        if (ipl[i + 1] - ipl[i] > hub_len) continue;       // written by kr_kb_hub
+        if (inner) w[ra + i] = o0[i];
+        else { v[ra + i] = o0[i]; rk[ra + i] = o1[i]; }
+    }
+    block_partial_at<0>(contrib, part_out, tile, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1335,25 +1343,6 @@ __global__ void kr_site_scale(int64_t n, double *__restrict__ sites, double *__r
     }
 }
 
-template <int LPR>
-void launch_kb(hipStream_t s, int grid, int64_t n, const KRState *sin, KRState *sout, const double *partA, int PA,
-               const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
-               double *rk, double *w, double *part_out)
-{
-    hipLaunchKernelGGL(kr_kb<LPR>, dim3(grid), dim3(BLK), 0, s, n, sin, sout, partA, PA, 1, m->indptr, m->indices,
-                       (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
-}
-
-template <int LPR>
-void launch_kb_stream(hipStream_t s, int grid, size_t shmem, int64_t n, int64_t nblk, int lds_cap, const KRState *sin,
-                      KRState *sout, const double *partA, int PA, const int64_t *rb, const b3c_mat *m,
-                      const double *dfix, const double *u, const double *x, const double *p, double *v, double *rk,
-                      double *w, double *part_out)
-{
-    hipLaunchKernelGGL(kr_kb_stream<LPR>, dim3(grid), dim3(BLK), shmem, s, n, nblk, lds_cap, sin, sout, partA, PA, 1, rb,
-                       m->indptr, m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
-}
-
 template <int LPR, int UN>
 void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
                     int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
@@ -1389,19 +1378,6 @@ void launch_kb_vec(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState
                            m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
 }
 
-template <int LPR, int UN>
-void launch_kb_rows(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
-                    int PA, int PS, const b3c_mat *m, const double *dfix, const double *u, const double *x, const double *p, double *v,
-                    double *rk, double *w, double *part_out)
-{
-    if (getenv("B3C_KR_NOGATHER"))   // wrong results by design: measures the kernel without its random gathers
-        hipLaunchKernelGGL((kr_kb_rows<LPR, UN, true>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
-    else
-        hipLaunchKernelGGL((kr_kb_rows<LPR, UN>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const double *)m->data, dfix, u, x, p, v, rk, w, part_out);
-}
-
 }  // namespace
 
 static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_in, double tol, double delta, double Delta,
@@ -1427,9 +1403,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // geometry: fixed for a given (n, nnz, world) so that reductions are reproducible
     const int G = grid_for(nloc, BLK * 2, 4 * ctx->n_cu);
     const double avg = (double)a->nnz / (double)n;
-    const int lpr = avg >= 96 ? 64 : avg >= 40 ? 32 : avg >= 18 ? 16 : avg >= 8 ? 8 : 4;
-    const int rows_per_block = (BLK / 64) * (64 / lpr);
-    // streaming SpMV unless some row is too long to park in LDS (then: wave-per-row kernel)
     unsigned long long maxdeg = 0;
     {
         DevBuf<unsigned long long> md(ctx, 1);
@@ -1442,41 +1415,27 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     int64_t n_hub = 0;
     DevBuf<int64_t> hub_flag(ctx, nloc + 2), hub_pos(ctx, nloc + 2);
     if (!hub_flag.p || !hub_pos.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
-    // SpMV form: "rows" (default), "stream" (LDS-staged CSR-stream) or "wave" (plain wave-per-row)
-    const char *kform = getenv("B3C_KR_KERNEL");
-    if (getenv("B3C_KR_ROWWAVE")) kform = "wave";
-    if (counts) kform = "pipe";                  // the count form exists for the pipelined kernel only
-    const bool stream_kb = !dist && kform && !strcmp(kform, "stream") && maxdeg <= 4096;
-    const bool rows_kb = dist || (!stream_kb && !(kform && !strcmp(kform, "wave")));
-    // default: sliced-ELL working layout when no row is extreme (a slice is as long as its longest row)
-    // sliced-ELL working layout: only on request (B3C_KR_KERNEL=sell).  Measured at C3: 1.41 ms per SpMV against
-    // 0.97 ms for the row-group form -- 64 rows per wave blow the gather working set out of the 32 KB L1.
-    const bool sell = rows_kb && kform && !strcmp(kform, "sell") && maxdeg <= 8192 && n >= 2048 && a->nnz >= (1 << 16);
-    const int64_t nsl = (n + 63) / 64;
-    const bool pipe_kb = rows_kb && !sell && !(kform && !strcmp(kform, "rows"));
+    // SpMV form: row groups of lpr_p lanes (kr_kb_pipe / kr_kb_vec), or -- 16-bit counts -- tiles with column dictionaries
     const int lpr_p = avg > 64 ? 16 : avg > 24 ? 8 : 4;   // lanes per row of the pipelined form
-    // rows form: lanes per row so that LPR*8 covers an average row
-    const int lpr_r = avg > 128 ? 32 : avg > 64 ? 16 : avg > 32 ? 8 : 4;
-    const int64_t nblk = a->nnz > 0 ? (a->nnz + KB_T - 1) / KB_T : 1;
-    const int lds_cap = (int)((KB_T + maxdeg + 15) & ~15ull);
-    const size_t kb_shmem = sizeof(double) * (size_t)(lds_cap + BLK);
-    // phase-2 group width: about two LDS reads per lane for an average row
-    const int lpr2 = avg >= 64 ? 32 : avg >= 24 ? 16 : avg >= 10 ? 8 : 4;
-    const int GS = stream_kb ? grid_for(nblk, 1, 8 * ctx->n_cu)
-                 : sell ? grid_for((nloc + 63) / 64, BLK / 64, 8 * ctx->n_cu)
-                 : pipe_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_p), (getenv("B3C_KR_GSMUL") ? atoi(getenv("B3C_KR_GSMUL")) : 16) * ctx->n_cu)
-                 : rows_kb ? grid_for(nloc, (BLK / 64) * (64 / lpr_r), 8 * ctx->n_cu)
-                           : grid_for(n, rows_per_block, 8 * ctx->n_cu);
-    // hub rows add one partial each behind the GS of the row-group kernel (at most nnz / HUB_LEN of them)
+    const int GS_rows = grid_for(nloc, (BLK / 64) * (64 / lpr_p), (getenv("B3C_KR_GSMUL") ? atoi(getenv("B3C_KR_GSMUL")) : 16) * ctx->n_cu);
+    // tile geometry of the dictionary form (used once the value width is known, below)
+    const int tcd_R = getenv("B3C_KR_TCD_R") ? std::min(256, std::max(8, atoi(getenv("B3C_KR_TCD_R")) & ~7)) : 128;
+    const int tcd_dcap = getenv("B3C_KR_TCD_DCAP") ? std::min(16384, std::max(16, atoi(getenv("B3C_KR_TCD_DCAP")))) : 2560;   // LDS budget of a dictionary
+    const int64_t tcd_tiles = (nloc + tcd_R - 1) / tcd_R;
+    const bool tcd_swz = getenv("B3C_KR_TCD_NOSWZ") == nullptr && tcd_tiles >= 64;
+    const int64_t tcd_grid = tcd_swz ? 8 * ((tcd_tiles + 7) / 8) : tcd_tiles;
+    // opt-in for now (B3C_KR_TCD=1): at C3 the SpMV runs at 0.44-0.46 ms against 0.50 ms for kr_kb_vec, which the 4 ms of
+    // kr_tcd_build (62 SpMVs per call) eats again; see DESIGN.md section 4
+    const bool tcd_may = counts && nloc > 0 && a->nnz > 0 && getenv("B3C_KR_TCD") != nullptr && getenv("B3C_KR_NO_TCD") == nullptr;
+    const int GS_max = (int)std::max<int64_t>(GS_rows, tcd_may ? tcd_tiles : 0);
+    // hub rows add one partial each behind the GS of the row kernel (at most nnz / HUB_LEN of them)
     // threshold: twice the pipelined chunk of the row-group kernel that will run, at least HUB_LEN (sweep on a power-law
     // map of 300k contigs / 28M entries, average row 93: 137 us per SpMV at 256, 151 at 512, 194 at 2048, 232 without)
     const int hub_thr = getenv("B3C_KR_HUB_LEN") ? std::max(64, atoi(getenv("B3C_KR_HUB_LEN"))) : (avg > 128 ? 2 * HUB_LEN : HUB_LEN);
-    const bool hub_kb = pipe_kb && maxdeg > (unsigned long long)hub_thr && getenv("B3C_KR_NO_HUB") == nullptr;
+    const bool hub_kb = maxdeg > (unsigned long long)hub_thr && getenv("B3C_KR_NO_HUB") == nullptr;
     const int64_t hub_cap = hub_kb ? a->nnz / hub_thr + 1 : 0;
     const int hub_len = hub_kb ? hub_thr : 0x7fffffff;
-    const int P = (int)std::max<int64_t>(G, (int64_t)GS + hub_cap);
-    DevBuf<int64_t> rb(ctx, nblk + 1);
-    if (!rb.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
+    const int P = (int)std::max<int64_t>(G, (int64_t)GS_max + hub_cap);
 
     DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z(ctx, n), rk(ctx, n), v(ctx, n), w(ctx, n), u_own(ctx, dist ? 1 : n), dfix(ctx, n);
     struct { double *p; } u{dist ? D.vec : u_own.p};   // the gathered operand lives in the exchange buffer when sharded
@@ -1555,7 +1514,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (n_hub > hub_cap) return ctx->fail(B3C_E_HIP, "b3c_kr_balance: hub row count out of bounds");
         if (n_hub) hipLaunchKernelGGL(kr_hub_fill, dim3(gh), dim3(256), 0, s, r0, r1, hub_flag.p, hub_pos.p, hub_rows.p);
     }
-    const int GSP = GS + (int)n_hub;          // partials the SpMV step leaves behind: row groups + hub rows
     // count form: 16-bit copy of the values when they all fit (built on the matrix the iteration runs on)
     DevBuf<uint16_t> v16buf(ctx, counts ? a->nnz + 16 : 1);     // slack: kr_kb_vec reads whole 4-entry vectors
     const uint16_t *v16 = nullptr;
@@ -1572,45 +1530,35 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             v16 = v16buf.p;
         }
     }
-    // ---- sliced-ELL working layout ----
-    DevBuf<int32_t> sperm(ctx, sell ? n : 1), sinv(ctx, sell ? n : 1), slen(ctx, sell ? nsl : 1);
-    DevBuf<int64_t> sptr(ctx, sell ? nsl + 1 : 1);
-    int32_t *scols = nullptr;
-    double *svals = nullptr;
-    struct SellGuard { b3c_ctx *c; int32_t **a; double **b; ~SellGuard() { c->release(*a); c->release(*b); } } sell_guard{ctx, &scols, &svals};
-    if (sell) {
-        DevBuf<int64_t> k_in(ctx, n), k_out(ctx, n), ssz(ctx, nsl + 1);
-        DevBuf<int32_t> v_in(ctx, n);
-        if (!sperm.p || !sinv.p || !slen.p || !sptr.p || !k_in.p || !k_out.p || !ssz.p || !v_in.p)
-            return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: SELL set-up");
-        const unsigned gn = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(sell_keys, dim3(gn), dim3(256), 0, s, n, a->indptr, k_in.p, v_in.p);
-        int wbits = 1;
-        while ((1ll << wbits) < (n + SELL_W - 1) / SELL_W + 1) wbits++;
-        size_t tb = 0;
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, sperm.p, (int64_t)n, 0, 32 + wbits, s));
-        {
-            DevBuf<char> tmp(ctx, tb);
-            if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: SELL sort workspace");
-            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, sperm.p, (int64_t)n, 0, 32 + wbits, s));
-        }
-        hipLaunchKernelGGL(sell_invert, dim3(gn), dim3(256), 0, s, n, sperm.p, sinv.p);
-        hipLaunchKernelGGL(sell_slice_sizes, dim3((unsigned)((nsl + 256) / 256)), dim3(256), 0, s, n, nsl, a->indptr, sperm.p,
-                           slen.p, ssz.p);
-        int rc = b3c_exclusive_scan_i64(ctx, ssz.p, sptr.p, nsl + 1);
-        if (rc) return rc;
-        int64_t tot = 0;
-        { const int rb_ = b3c_readback(ctx, &tot, sptr.p + nsl, sizeof(int64_t)); if (rb_) return rb_; }
-        scols = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(tot > 0 ? tot : 1));
-        svals = (double *)ctx->alloc(sizeof(double) * (size_t)(tot > 0 ? tot : 1));
-        if (!scols || !svals) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: SELL storage");
-        hipLaunchKernelGGL(sell_fill, dim3(grid_for(nsl, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, nsl, a->indptr, a->indices,
-                           (const double *)a->data, sperm.p, sinv.p, slen.p, sptr.p, scols, svals);
-        hipLaunchKernelGGL(kr_gather_f64, dim3(gn), dim3(256), 0, s, n, dfix.p, sperm.p, w.p);
-        HIP_TRY(ctx, hipMemcpyAsync(dfix.p, w.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    // ---- tile-local column dictionaries (16-bit counts only) ----
+    const bool tcd = tcd_may && v16 != nullptr;
+    DevBuf<uint32_t> packed(ctx, tcd ? a->nnz + 8 : 1);
+    DevBuf<int32_t> pcol(ctx, tcd ? a->nnz + 8 : 1), n1v(ctx, tcd ? nloc : 1);
+    DevBuf<int32_t> dict_cols(ctx, tcd ? (size_t)tcd_tiles * (size_t)tcd_dcap : 1), dict_cnt(ctx, tcd ? tcd_tiles : 1);
+    int tcd_lds_d = 0;                     // operands the SpMV kernel keeps in LDS: the largest dictionary, even
+    size_t tcd_shmem = 0;
+    if (tcd) {
+        DevBuf<unsigned long long> stt(ctx, 4);
+        if (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
+        HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 4, s));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS));
+        hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
+                           a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
+        unsigned long long hst[4];
+        { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
+        tcd_lds_d = (int)((hst[0] + 1) & ~1ull);
+        if (tcd_lds_d < 2) tcd_lds_d = 2;
+        tcd_shmem = sizeof(double) * ((size_t)tcd_lds_d + 7 * (size_t)tcd_R + (size_t)tcd_R + 1 + BLK) + sizeof(int32_t) * (size_t)tcd_R;
+        info->tcd_tiles = tcd_tiles;
+        info->tcd_dict_max = (int64_t)hst[0];
+        info->tcd_dict_total = (int64_t)hst[2];
+        info->tcd_tail_entries = (int64_t)hst[3];
+        if (getenv("B3C_KR_DEBUG"))
+            fprintf(stderr, "[b3c] dictionary layout: %lld tiles of %d rows, largest dictionary %llu (cap %d), mean %.0f, %.1f %% of the entries in tails, %zu B of LDS\n",
+                    (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles, 100.0 * (double)hst[3] / (double)a->nnz, tcd_shmem);
     }
-    if (stream_kb)
-        hipLaunchKernelGGL(kr_row_blocks, dim3((unsigned)((nblk + 256) / 256)), dim3(256), 0, s, n, nblk, a->indptr, rb.p);
+    const int GS = tcd ? (int)tcd_tiles : GS_rows;
+    const int GSP = GS + (int)n_hub;          // partials the SpMV step leaves behind: row groups / tiles + hub rows
 
     KRParams prm;
     prm.tol = tol; prm.delta = delta; prm.Delta = Delta; prm.rt = tol * tol; prm.stop_tol = tol * 0.5;
@@ -1639,6 +1587,15 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (D.allgather(D.user, buf) != 0) return ctx->fail(B3C_E_HIP, "b3c_kr_balance: all-gather callback failed");
         return B3C_OK;
     };
+#define KR_TCD(L, U, T)                                                                                                     \
+    do {                                                                                                                    \
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tcd_shmem)); \
+        hipLaunchKernelGGL((kr_kb_tcd<L, U, T>), dim3((unsigned)tcd_grid), dim3(BLK), tcd_shmem, s, r0, r1, n, tcd_R, tcd_lds_d,      \
+                           tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p,  \
+                           dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len,                 \
+                           getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu, \
+                           getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0);                                     \
+    } while (0)
     for (;;) {
         for (int b = 0; b < BATCH; b++) {
             KRState *s0 = states.p + (t & 1), *s1 = states.p + ((t + 1) & 1);
@@ -1664,44 +1621,28 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             // KB consumes part1 (from KA, G partials), produces part0 (GS partials)
             const double *kbp = dist ? D.scal : part1.p;
             const int kbP = dist ? D.world : G, kbS = dist ? 4 : 1;
-            if (stream_kb) {
-                switch (lpr2) {
-                case 32: launch_kb_stream<32>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                case 16: launch_kb_stream<16>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                case 8: launch_kb_stream<8>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                default: launch_kb_stream<4>(s, GS, kb_shmem, n, nblk, lds_cap, s0, s1, part1.p, G, rb.p, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                }
-            } else if (sell) {
-                hipLaunchKernelGGL(kr_kb_sell<8>, dim3(GS), dim3(BLK), 0, s, r0, r1, n, s0, s1, kbp, kbP, kbS, sptr.p, slen.p, scols,
-                                   svals, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p);
-            } else if (rows_kb && pipe_kb) {
+            if (tcd) {
+                // tiles with column dictionaries; shape by average row length (4 entries per lane and load)
+                const int shp = getenv("B3C_KR_TCD_SHAPE") ? atoi(getenv("B3C_KR_TCD_SHAPE")) : 0;   // LPR*100 + UN*10 + TU
+                if (shp == 1642) KR_TCD(16, 4, 2);
+                else if (shp == 882) KR_TCD(8, 8, 2);
+                else if (shp == 881) KR_TCD(8, 8, 1);
+                else if (shp == 3221) KR_TCD(32, 2, 1);
+                else if (shp == 1641) KR_TCD(16, 4, 1);
+                else if (avg > 128) KR_TCD(16, 4, 1);
+                else if (avg > 48) KR_TCD(8, 4, 1);
+                else if (avg > 20) KR_TCD(4, 4, 1);
+                else KR_TCD(4, 2, 1);
+            } else {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
                 if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-                else if (vec_shape == 88) launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
                 else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-                else if (vec_shape == 162) launch_kb_vec<16, 2>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-                else if (vec_shape == 48) launch_kb_vec<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-                else if (vec_shape == 324) launch_kb_vec<32, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
                 else if (avg > 128 && a->kind == B3C_U32 && vec_shape >= 0)    // 4 entries per lane and load: 0.505 vs 0.544 ms at C3
                     launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
                 else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
                 else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
                 else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
                 else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-            } else if (rows_kb) {
-                switch (lpr_r) {
-                case 32: launch_kb_rows<32, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                case 16: launch_kb_rows<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                case 8: launch_kb_rows<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                default: launch_kb_rows<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-                }
-            } else
-            switch (lpr) {
-            case 64: launch_kb<64>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-            case 32: launch_kb<32>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-            case 16: launch_kb<16>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-            case 8: launch_kb<8>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
-            default: launch_kb<4>(s, GS, n, s0, s1, part1.p, G, a, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p); break;
             }
             if (n_hub) {       // the rows the row-group kernel left out; same state slot, partials behind its GS
                 if (a->kind == B3C_U32 && v16)
@@ -1752,6 +1693,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (ticks > 200000 + 16 * (long long)max_iter)
             return ctx->fail(B3C_E_NOCONV, "b3c_kr_balance: inner iteration did not terminate after %lld SpMVs", ticks);
     }
+#undef KR_TCD
     HIP_TRY(ctx, hipGetLastError());
 
     unsigned long long hc[4];
@@ -1763,10 +1705,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         int rc = xchg(B3C_BUF_VEC);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(x.p, D.vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    }
-    if (sell) {
-        hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x.p, sinv.p, w.p);
-        HIP_TRY(ctx, hipMemcpyAsync(x.p, w.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     }
     if (reorder) {
         hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x.p, old2new.p, w.p);
