@@ -1,15 +1,20 @@
 // Knight-Ruiz balancing on gfx950 -- replaces kr_biostochastic (mzd/sparse_utils.py:90-224).
 //
 // Design (see DESIGN.md "KR"): the whole inexact-Newton / CG iteration runs from device-resident
-// state.  One "tick" is four launches
-//     KA (vector)  -> KB (CSR SpMV, fused epilogue) -> KC (vector) -> KD (vector)
+// state.  One "tick" is three launches
+//     KA (vector)  -> KB (CSR SpMV, fused epilogue) -> KCD (vector)
 // and corresponds to one SpMV of the reference (one inner CG step, or one outer update).  All
 // data-dependent control flow of the reference's two while-loops (:146, :154, the delta/Delta cuts
 // :171-183, the eta update :203-211) is evaluated ON DEVICE in the prologue of the kernel that needs
 // the result: every block reduces the previous kernel's per-block partials in a fixed order, runs
 // the scalar control step on an identical copy of the state, and block 0 publishes the new state in a
-// ping-pong slot.  The host enqueues ticks in batches and only reads the state back between batches,
+// ping-pong slot.  The host enqueues ticks in batches and looks at the state one batch behind,
 // so there is no host round trip inside the iteration; ticks issued after convergence are no-ops.
+//
+// KCD runs the CG update of :185-190 (rk, Z, rk.Z) SPECULATIVELY next to the min/max of ynew that decides
+// whether the step is taken (:171, :179): a bound cut needs neither rk nor Z again, and y is only advanced by
+// the next KA once the decision is known.  The vector kernels request their operands before they look at
+// the control state, so that a tick costs three memory latencies, not nine.
 //
 // Reductions are deterministic (fixed grid, fixed shuffle/LDS trees): the same input always gives
 // the same x, bit for bit.
@@ -31,17 +36,14 @@ constexpr int BLK = 256;
 enum Phase : int32_t {
     P_INIT = 0,          // KA: x = 1, u = 1
     P_INNER_FIRST,       // KA: begin inner iteration k = 1
-    P_INNER_PENDING,     // KA: rk.Z partials pending -> continue inner loop or leave it
+    C_PENDING,           // KA: min/max(ynew) and rk.Z partials pending -> take the step or cut it, continue or leave the inner loop
     P_CUT_PENDING,       // KA: gamma partials pending -> outer update with y += gamma*ap
-    P_CUT0,              // KA: delta == 0 break -> outer update, y unchanged
     P_SKIP_INNER,        // KA: inner loop had no iteration -> outer update with y = 1
     A_INNER,             // KB: inner SpMV (k == 1: rk.Z partials pending)
     A_OUTER,             // KB: outer SpMV
-    B_INNER,             // KC: p.w partials pending
-    B_OUTER,             // KC: rk.rk partials pending -> end of outer iteration
-    B_INIT,              // KC: rk.rk partials pending -> initial residual
-    C_INNER,             // KD: min/max(ynew) partials pending
-    C_PASS,              // KD: nothing to do, next phase already chosen in `next`
+    B_INNER,             // KCD: p.w partials pending
+    B_OUTER,             // KCD: rk.rk partials pending -> end of outer iteration
+    B_INIT,              // KCD: rk.rk partials pending -> initial residual
     P_DONE
 };
 
@@ -109,49 +111,119 @@ __device__ void block_partial(double v, double *__restrict__ part, double *lds)
     __syncthreads();
 }
 
+// min, max and sum of three partial arrays at once (one LDS tree): identical in every block
+__device__ void reduce_partials3(const double *__restrict__ pmin, const double *__restrict__ pmax,
+                                 const double *__restrict__ psum, int P, int stride, double *lds, double &rmin, double &rmax,
+                                 double &rsum)
+{
+    const int t = threadIdx.x;
+    double a = INFINITY, b = -INFINITY, c = 0.0;
+    constexpr int U = 8;
+    for (int base = 0; base < P; base += BLK * U) {
+        double qa[U], qb[U], qc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + t + u * BLK;
+            qa[u] = i < P ? pmin[(size_t)i * stride] : INFINITY;
+            qb[u] = i < P ? pmax[(size_t)i * stride] : -INFINITY;
+            qc[u] = i < P ? psum[(size_t)i * stride] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { a = fmin(a, qa[u]); b = fmax(b, qb[u]); c += qc[u]; }
+    }
+    lds[t] = a;
+    lds[BLK + t] = b;
+    lds[2 * BLK + t] = c;
+    __syncthreads();
+#pragma unroll
+    for (int s = BLK / 2; s > 0; s >>= 1) {
+        if (t < s) {
+            lds[t] = fmin(lds[t], lds[t + s]);
+            lds[BLK + t] = fmax(lds[BLK + t], lds[BLK + t + s]);
+            lds[2 * BLK + t] = lds[2 * BLK + t] + lds[2 * BLK + t + s];
+        }
+        __syncthreads();
+    }
+    rmin = lds[0];
+    rmax = lds[BLK];
+    rsum = lds[2 * BLK];
+    __syncthreads();
+}
+
+constexpr int KV_E = 4;      // elements per thread and pass of the vector kernels (requested before the control state is known)
+
 // ---------------------------------------------------------------------------------------------
-// KA: control after KD, then either p/u of the next CG step or the outer update x *= y
+// KA: control after KCD (take or cut the CG step), then p/u of the next CG step or the outer update x *= y
+//   consumes  pmin / pmax / psum (KCD) or pgam (its own gamma partials of the tick before)
+//   produces  pk1 (rk.Z of a first inner iteration, for KB) or pgam (a bound cut)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm, const KRState *__restrict__ sin,
-                                              KRState *__restrict__ sout, const double *__restrict__ partA, int PA, int PS,
+                                              KRState *__restrict__ sout, const double *__restrict__ pmin,
+                                              const double *__restrict__ pmax, const double *__restrict__ psum,
+                                              const double *__restrict__ pgam_in, int PA, int PS,
                                               double *__restrict__ x, double *__restrict__ y, double *__restrict__ p,
                                               double *__restrict__ Z, const double *__restrict__ rk,
                                               const double *__restrict__ v, double *__restrict__ u,
-                                              const double *__restrict__ rs, double *__restrict__ part_out,
-                                              int *__restrict__ flags)
+                                              const double *__restrict__ rs, double *__restrict__ pk1,
+                                              double *__restrict__ pgam_out, int *__restrict__ flags)
 {
     // rs != nullptr: the matrix is stored as raw counts C and A = diag(rs) C diag(rs); the SpMV operand is then
     // rs * (x*p) and the kernel that consumes it multiplies the row sum by rs again (see kr_kb_pipe)
-    __shared__ double lds[BLK];
+    __shared__ double lds[3 * BLK];
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    const int64_t i0 = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x;
+    // operands every mode needs, requested before the state: x, p, 1/s, and y / Z for the common inner step
+    double ex[KV_E], ep[KV_E], er[KV_E], ey[KV_E], eZ[KV_E];
+#pragma unroll
+    for (int e = 0; e < KV_E; e++) {
+        const int64_t i = i0 + e * stride;
+        const bool ok = i < n;
+        ex[e] = ok ? x[i] : 0.0;
+        ep[e] = ok ? p[i] : 0.0;
+        er[e] = ok ? (rs ? rs[i] : 1.0) : 0.0;
+        ey[e] = ok ? y[i] : 0.0;
+        eZ[e] = ok ? Z[i] : 0.0;
+    }
     KRState st = *sin;
-    int yone = 0;
-    if (st.phase == P_INNER_PENDING) {
-        // sparse_utils.py:187,190 then the loop test of :154
-        double s = reduce_partials<0>(partA, PA, PS, lds);
-        st.rho_km2 = st.rho_km1;
-        st.rho_km1 = s;
-        if (flags[0] & 1) {  // :192-193
-            st.rc = B3C_E_NAN;
-            st.phase = P_DONE;
-        } else if (st.rho_km1 > st.inner_tol) {
-            st.k += 1;
-            st.beta = st.rho_km1 / st.rho_km2;  // :162
-            st.phase = A_INNER;
+    const int32_t entered = st.phase;
+    bool adopt = false;          // the CG step of the tick before is taken: y += alpha p (:185)
+    int gmode = 0;               // 2 / 3: this launch computes the gamma partials of a delta / Delta cut
+    bool yone = false;           // y is still the implicit vector of ones
+    if (st.phase == C_PENDING) {
+        double mn, mx, sm;
+        reduce_partials3(pmin, pmax, psum, PA, PS, lds, mn, mx, sm);
+        yone = st.k == 1;
+        if (mn <= prm.delta) {                       // :171
+            st.hit_delta += 1;
+            if (prm.delta == 0.0) { st.gamma = 0.0; st.phase = A_OUTER; }       // :172-173, y unchanged
+            else { gmode = 2; st.phase = P_CUT_PENDING; }
+        } else if (mx >= prm.Delta) {                // :179
+            st.hit_Delta += 1;
+            gmode = 3;
+            st.phase = P_CUT_PENDING;
         } else {
-            st.gamma = 0.0;
-            st.phase = A_OUTER;
+            adopt = true;                            // :185-190 (rk, Z were advanced by KCD already)
+            st.rho_km2 = st.rho_km1;
+            st.rho_km1 = sm;
+            if (flags[0] & 1) {                      // :192-193
+                st.rc = B3C_E_NAN;
+                st.phase = P_DONE;
+            } else if (st.rho_km1 > st.inner_tol) {  // :154
+                st.k += 1;
+                st.beta = st.rho_km1 / st.rho_km2;   // :162
+                st.phase = A_INNER;
+            } else {
+                st.gamma = 0.0;
+                st.phase = A_OUTER;
+            }
         }
     } else if (st.phase == P_CUT_PENDING) {
-        st.gamma = reduce_partials<1>(PS > 1 ? partA + 3 : partA, PA, PS, lds);  // :175 / :181 (sharded: slot 3)
-        yone = st.k == 1;
-        st.phase = A_OUTER;
-    } else if (st.phase == P_CUT0) {
-        st.gamma = 0.0;
+        st.gamma = reduce_partials<1>(pgam_in, PA, PS, lds);  // :175 / :181
         yone = st.k == 1;
         st.phase = A_OUTER;
     } else if (st.phase == P_SKIP_INNER) {
         st.gamma = 0.0;
-        yone = 1;
+        yone = true;
         st.phase = A_OUTER;
     } else if (st.phase == P_INNER_FIRST) {
         st.k = 1;
@@ -159,49 +231,104 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
     } else if (st.phase == P_INIT) {
         st.phase = A_OUTER;
     }
-    const int32_t entered = sin->phase;
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
     if (st.phase == P_DONE) return;
 
     // rows [r0, n) of this rank (r0 = 0 and n = all rows on a single GPU)
-    const int64_t stride = (int64_t)gridDim.x * BLK;
-    int64_t i = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x;
     if (entered == P_INIT) {
-        for (; i < n; i += stride) { x[i] = 1.0; u[i] = rs ? rs[i] : 1.0; }  // :126-127,134
+        for (int64_t i = i0; i < n; i += stride) { x[i] = 1.0; u[i] = rs ? rs[i] : 1.0; }  // :126-127,134
+        return;
+    }
+    const double alpha = st.alpha;
+    if (gmode) {
+        // the step is cut at a bound: gamma = min over the offending elements, from the y BEFORE the step (:174-175, :180-181)
+        double g = INFINITY;
+        for (int64_t base = i0; base < n; base += KV_E * stride) {
+#pragma unroll
+            for (int e = 0; e < KV_E; e++) {
+                const int64_t i = base + e * stride;
+                if (i >= n) continue;
+                const bool first = base == i0;
+                const double yo = yone ? 1.0 : (first ? ey[e] : y[i]);
+                const double ap = alpha * (first ? ep[e] : p[i]);
+                if (gmode == 2) {
+                    if (ap < 0) g = fmin(g, (prm.delta - yo) / ap);
+                } else {
+                    if (yo + ap > prm.Delta) g = fmin(g, (prm.Delta - yo) / ap);
+                }
+            }
+        }
+        block_partial<1>(g, pgam_out, lds);
         return;
     }
     if (st.phase == A_INNER) {
-        double acc = 0.0;
         if (st.k == 1) {
-            for (; i < n; i += stride) {
-                double z = rk[i] / v[i];  // :158
-                Z[i] = z;
-                p[i] = z;                 // :159
-                u[i] = rs ? rs[i] * (x[i] * z) : x[i] * z;
-                acc += rk[i] * z;         // :160
+            double acc = 0.0;
+            for (int64_t base = i0; base < n; base += KV_E * stride) {
+                double erk[KV_E], ev[KV_E];
+#pragma unroll
+                for (int e = 0; e < KV_E; e++) {
+                    const int64_t i = base + e * stride;
+                    erk[e] = i < n ? rk[i] : 0.0;
+                    ev[e] = i < n ? v[i] : 1.0;
+                }
+#pragma unroll
+                for (int e = 0; e < KV_E; e++) {
+                    const int64_t i = base + e * stride;
+                    if (i >= n) continue;
+                    const bool first = base == i0;
+                    const double xi = first ? ex[e] : x[i];
+                    const double ri = first ? er[e] : (rs ? rs[i] : 1.0);
+                    const double z = erk[e] / ev[e];   // :158
+                    Z[i] = z;
+                    p[i] = z;                          // :159
+                    u[i] = rs ? ri * (xi * z) : xi * z;
+                    acc += erk[e] * z;                 // :160
+                }
             }
-            block_partial<0>(acc, part_out, lds);
+            block_partial<0>(acc, pk1, lds);
         } else {
             const double beta = st.beta;
-            for (; i < n; i += stride) {
-                double pn = Z[i] + beta * p[i];  // :163
-                p[i] = pn;
-                u[i] = rs ? rs[i] * (x[i] * pn) : x[i] * pn;
+            for (int64_t base = i0; base < n; base += KV_E * stride) {
+#pragma unroll
+                for (int e = 0; e < KV_E; e++) {
+                    const int64_t i = base + e * stride;
+                    if (i >= n) continue;
+                    const bool first = base == i0;
+                    const double po = first ? ep[e] : p[i];
+                    const double xi = first ? ex[e] : x[i];
+                    const double ri = first ? er[e] : (rs ? rs[i] : 1.0);
+                    const double zi = first ? eZ[e] : Z[i];
+                    if (adopt) y[i] = (yone ? 1.0 : (first ? ey[e] : y[i])) + alpha * po;   // :185
+                    const double pn = zi + beta * po;  // :163
+                    p[i] = pn;
+                    u[i] = rs ? ri * (xi * pn) : xi * pn;
+                }
             }
         }
         return;
     }
-    // A_OUTER: x *= y (:195) with the cut step y += gamma*ap (:176,:182) folded in
-    const double gamma = st.gamma, alpha = st.alpha;
+    // A_OUTER: x *= y (:195) with the last step y += alpha p (:185) or the cut step y += gamma*ap (:176,:182) folded in
+    const double gamma = st.gamma;
     const bool cut = st.gamma != 0.0;
     int bad = 0;
-    for (; i < n; i += stride) {
-        double yy = yone ? 1.0 : y[i];
-        if (cut) yy += gamma * (alpha * p[i]);
-        double xn = x[i] * yy;
-        x[i] = xn;
-        u[i] = rs ? rs[i] * xn : xn;
-        bad |= (xn != xn);
+    for (int64_t base = i0; base < n; base += KV_E * stride) {
+#pragma unroll
+        for (int e = 0; e < KV_E; e++) {
+            const int64_t i = base + e * stride;
+            if (i >= n) continue;
+            const bool first = base == i0;
+            const double po = first ? ep[e] : p[i];
+            const double xi = first ? ex[e] : x[i];
+            const double ri = first ? er[e] : (rs ? rs[i] : 1.0);
+            double yy = yone ? 1.0 : (first ? ey[e] : y[i]);
+            if (adopt) yy = yy + alpha * po;
+            if (cut) yy += gamma * (alpha * po);
+            const double xn = xi * yy;
+            x[i] = xn;
+            u[i] = rs ? ri * xn : xn;
+            bad |= (xn != xn);
+        }
     }
     if (bad) atomicOr(&flags[0], 1);
 }
@@ -250,7 +377,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
     if (st.phase == A_INNER) st.phase = B_INNER;
     else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase == P_DONE) return;
+    if (st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) return;   // no SpMV in this tick (done, or a bound cut pending)
 
     constexpr int RPW = 64 / LPR;
     constexpr int CH = LPR * UN;
@@ -385,7 +512,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
     if (st.phase == A_INNER) st.phase = B_INNER;
     else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase == P_DONE) return;
+    if (st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) return;   // no SpMV in this tick (done, or a bound cut pending)
 
     constexpr int RPW = 64 / LPR;
     constexpr int CH = LPR * UN * 4;
@@ -832,7 +959,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_tcd(int64_t r0, int64_t r1, int64_t
     if (st.phase == A_INNER) st.phase = B_INNER;
     else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase == P_DONE || !live) return;
+    if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
     __syncthreads();
 
     // the tile's entries and the operand vector as buffer resources (descriptors from wave-uniform values only): a lane
@@ -990,27 +1117,45 @@ __global__ void __launch_bounds__(BLK) kr_kb_tcd(int64_t r0, int64_t r1, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// KC: inner -> alpha, min/max of ynew = y + alpha p   (sparse_utils.py:166-171,179)
-//     outer -> end-of-outer-iteration control         (:199-211, loop tests :146,:154)
+// KCD: inner -> alpha (:166), min/max of ynew = y + alpha p (:167-171,179) and, speculatively, the CG update
+//               rk -= alpha w, Z = rk*v, partial rk.Z (:186-190); y itself is advanced by the next KA
+//      outer -> end-of-outer-iteration control         (:199-211, loop tests :146,:154)
+//   consumes pkb (KB), produces pmin / pmax / psum
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLK) kr_kc(int64_t r0, int64_t n, KRParams prm, const KRState *__restrict__ sin,
-                                              KRState *__restrict__ sout, const double *__restrict__ partA, int PA, int PS,
-                                              const double *__restrict__ y, const double *__restrict__ p,
-                                              double *__restrict__ part_min, double *__restrict__ part_max)
+__global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams prm, const KRState *__restrict__ sin,
+                                               KRState *__restrict__ sout, const double *__restrict__ pkb, int PA, int PS,
+                                               const double *__restrict__ y, const double *__restrict__ p,
+                                               double *__restrict__ rk, const double *__restrict__ w,
+                                               const double *__restrict__ v, double *__restrict__ Z,
+                                               double *__restrict__ pmin, double *__restrict__ pmax,
+                                               double *__restrict__ psum)
 {
     __shared__ double lds[BLK];
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    const int64_t i0 = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x;
+    // the operands of the inner step, requested before the state is known
+    double ey[KV_E], ep[KV_E], erk[KV_E], ew[KV_E], ev[KV_E];
+#pragma unroll
+    for (int e = 0; e < KV_E; e++) {
+        const int64_t i = i0 + e * stride;
+        const bool ok = i < n;
+        ey[e] = ok ? y[i] : 0.0;
+        ep[e] = ok ? p[i] : 0.0;
+        erk[e] = ok ? rk[i] : 0.0;
+        ew[e] = ok ? w[i] : 0.0;
+        ev[e] = ok ? v[i] : 0.0;
+    }
     KRState st = *sin;
     if (st.phase == B_INNER) {
-        double pw = reduce_partials<0>(partA, PA, PS, lds);
+        double pw = reduce_partials<0>(pkb, PA, PS, lds);
         st.alpha = st.rho_km1 / pw;  // :166
-        st.phase = C_INNER;
+        st.phase = C_PENDING;
     } else if (st.phase == B_OUTER || st.phase == B_INIT) {
-        double s = reduce_partials<0>(partA, PA, PS, lds);
+        double s = reduce_partials<0>(pkb, PA, PS, lds);
         st.rho_km1 = s;  // :139 / :199
         st.rout = s;
         if (st.phase == B_INIT) {
             st.rold = s;  // :141
-            st.next = P_DONE;  // any value but P_INIT: marks the initial SpMV as consumed
         } else {
             st.n_iter += st.k + 1;  // :201
             double rat = st.rout / st.rold;  // :203
@@ -1026,93 +1171,40 @@ __global__ void __launch_bounds__(BLK) kr_kc(int64_t r0, int64_t n, KRParams prm
             st.n_outer += 1;
             st.k = 0;
             st.inner_tol = fmax(st.rout * (st.eta * st.eta), prm.rt);  // :152
-            st.next = st.rho_km1 > st.inner_tol ? P_INNER_FIRST : P_SKIP_INNER;  // :154
+            st.phase = st.rho_km1 > st.inner_tol ? P_INNER_FIRST : P_SKIP_INNER;  // :154
         } else {
             if (st.n_iter > prm.max_iter) st.rc = B3C_E_NOCONV;  // :213-214
-            st.next = P_DONE;
+            st.phase = P_DONE;
         }
-        st.phase = C_PASS;
+        st.next = P_DONE;   // any value but P_INIT: marks the initial SpMV as consumed
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase != C_INNER) return;
+    if (st.phase != C_PENDING) return;
 
     const double alpha = st.alpha;
     const bool yone = st.k == 1;
-    double mn = INFINITY, mx = -INFINITY;
-    const int64_t stride = (int64_t)gridDim.x * BLK;
-    for (int64_t i = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
-        double yn = (yone ? 1.0 : y[i]) + alpha * p[i];  // :167,169
-        mn = fmin(mn, yn);
-        mx = fmax(mx, yn);
-    }
-    block_partial<1>(mn, part_min, lds);
-    block_partial<2>(mx, part_max, lds);
-}
-
-// ---------------------------------------------------------------------------------------------
-// KD: inner -> branch on min/max(ynew): bound cut (gamma partials) or the CG update
-//     (sparse_utils.py:171-190)
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLK) kr_kd(int64_t r0, int64_t n, KRParams prm, const KRState *__restrict__ sin,
-                                              KRState *__restrict__ sout, const double *__restrict__ part_min,
-                                              const double *__restrict__ part_max, int PA, int PS, double *__restrict__ y,
-                                              const double *__restrict__ p, double *__restrict__ rk,
-                                              const double *__restrict__ w, const double *__restrict__ v,
-                                              double *__restrict__ Z, double *__restrict__ part_out)
-{
-    __shared__ double lds[BLK];
-    KRState st = *sin;
-    int mode = 0;  // 1 normal update, 2 delta cut, 3 Delta cut
-    if (st.phase == C_INNER) {
-        double mn = reduce_partials<1>(part_min, PA, PS, lds);
-        double mx = reduce_partials<2>(part_max, PA, PS, lds);
-        if (mn <= prm.delta) {  // :171
-            st.hit_delta += 1;
-            if (prm.delta == 0.0) st.phase = P_CUT0;  // :172-173
-            else { st.phase = P_CUT_PENDING; mode = 2; }
-        } else if (mx >= prm.Delta) {  // :179
-            st.hit_Delta += 1;
-            st.phase = P_CUT_PENDING;
-            mode = 3;
-        } else {
-            st.phase = P_INNER_PENDING;
-            mode = 1;
-        }
-    } else if (st.phase == C_PASS) {
-        st.phase = st.next;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (mode == 0) return;
-
-    const double alpha = st.alpha;
-    const bool yone = st.k == 1;
-    const int64_t stride = (int64_t)gridDim.x * BLK;
-    int64_t i = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x;
-    if (mode == 1) {
-        double acc = 0.0;
-        for (; i < n; i += stride) {
-            double yo = yone ? 1.0 : y[i];
-            y[i] = yo + alpha * p[i];            // :185
-            double r = rk[i] - alpha * w[i];     // :186
+    double mn = INFINITY, mx = -INFINITY, acc = 0.0;
+    for (int64_t base = i0; base < n; base += KV_E * stride) {
+#pragma unroll
+        for (int e = 0; e < KV_E; e++) {
+            const int64_t i = base + e * stride;
+            if (i >= n) continue;
+            const bool first = base == i0;
+            const double yo = yone ? 1.0 : (first ? ey[e] : y[i]);
+            const double pi = first ? ep[e] : p[i];
+            const double yn = yo + alpha * pi;                 // :167,169
+            mn = fmin(mn, yn);
+            mx = fmax(mx, yn);
+            const double r = (first ? erk[e] : rk[i]) - alpha * (first ? ew[e] : w[i]);   // :186
             rk[i] = r;
-            double z = r * v[i];                 // :189 (multiply, sic)
+            const double z = r * (first ? ev[e] : v[i]);       // :189 (multiply, sic)
             Z[i] = z;
-            acc += r * z;                        // :190
+            acc += r * z;                                      // :190
         }
-        block_partial<0>(acc, part_out, lds);
-    } else {
-        double g = INFINITY;
-        for (; i < n; i += stride) {
-            double yo = yone ? 1.0 : y[i];
-            double ap = alpha * p[i];
-            if (mode == 2) {
-                if (ap < 0) g = fmin(g, (prm.delta - yo) / ap);           // :174-175
-            } else {
-                if (yo + ap > prm.Delta) g = fmin(g, (prm.Delta - yo) / ap);  // :180-181
-            }
-        }
-        block_partial<1>(g, part_out, lds);
     }
+    block_partial<1>(mn, pmin, lds);
+    block_partial<2>(mx, pmax, lds);
+    block_partial<0>(acc, psum, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1401,7 +1493,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int64_t r1 = dist ? std::min<int64_t>(n, r0 + D.chunk) : n;
     const int64_t nloc = r1 - r0;
     // geometry: fixed for a given (n, nnz, world) so that reductions are reproducible
-    const int G = grid_for(nloc, BLK * 2, 4 * ctx->n_cu);
+    const int G = grid_for(nloc, BLK * KV_E, 4 * ctx->n_cu);
     const double avg = (double)a->nnz / (double)n;
     unsigned long long maxdeg = 0;
     {
@@ -1439,10 +1531,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 
     DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z(ctx, n), rk(ctx, n), v(ctx, n), w(ctx, n), u_own(ctx, dist ? 1 : n), dfix(ctx, n);
     struct { double *p; } u{dist ? D.vec : u_own.p};   // the gathered operand lives in the exchange buffer when sharded
-    DevBuf<double> part0(ctx, P), part1(ctx, P), part2(ctx, P);
+    DevBuf<double> pmin(ctx, P), pmax(ctx, P), psum(ctx, P), pgam(ctx, P), pk1(ctx, P), pkb(ctx, P);   // block partials, see the kernels
     DevBuf<KRState> states(ctx, 2);
     DevBuf<unsigned long long> counters(ctx, 4);
-    if (!x.p || !y.p || !p.p || !Z.p || !rk.p || !v.p || !w.p || !u_own.p || !dfix.p || !part0.p || !part1.p || !part2.p ||
+    if (!x.p || !y.p || !p.p || !Z.p || !rk.p || !v.p || !w.p || !u_own.p || !dfix.p || !pmin.p || !pmax.p || !psum.p || !pgam.p || !pk1.p || !pkb.p ||
         !states.p || !counters.p)
         return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: out of device memory");
     int *flags = (int *)(counters.p + 2);
@@ -1580,34 +1672,51 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int BATCH = 8;
     const int vec_shape = getenv("B3C_KR_VEC") ? atoi(getenv("B3C_KR_VEC")) : 0;   // other kr_kb_vec<LPR, UN> shapes, e.g. 164; -1: scalar-load form
     long long ticks = 0;
-    // sharded: a kernel's block partials are folded into this rank's slot of the packed scalar buffer and
-    // all-gathered; the consumer then reduces `world` values (stride 4) in rank order instead of P block partials
+    // sharded: a kernel's block partials are folded into this rank's slot of the packed scalar buffer (slot 0 sum, 1 min,
+    // 2 max, 3 gamma) and all-gathered; the consumer then reduces `world` values (stride 4) in rank order instead of P block partials
     double *my_scal = dist ? D.scal + 4 * D.rank : nullptr;
     auto xchg = [&](int buf) -> int {
         if (D.allgather(D.user, buf) != 0) return ctx->fail(B3C_E_HIP, "b3c_kr_balance: all-gather callback failed");
         return B3C_OK;
     };
+    const int cP = dist ? D.world : 0, cS = dist ? 4 : 1;      // consumer view of gathered partials
+    if (tcd) {
+#define KR_TCD_ATTR(L, U, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tcd_shmem))
+        KR_TCD_ATTR(16, 4, 2); KR_TCD_ATTR(8, 8, 2); KR_TCD_ATTR(8, 8, 1); KR_TCD_ATTR(32, 2, 1); KR_TCD_ATTR(16, 4, 1);
+        KR_TCD_ATTR(8, 4, 1); KR_TCD_ATTR(4, 4, 1); KR_TCD_ATTR(4, 2, 1);
+#undef KR_TCD_ATTR
+    }
 #define KR_TCD(L, U, T)                                                                                                     \
-    do {                                                                                                                    \
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tcd_shmem)); \
-        hipLaunchKernelGGL((kr_kb_tcd<L, U, T>), dim3((unsigned)tcd_grid), dim3(BLK), tcd_shmem, s, r0, r1, n, tcd_R, tcd_lds_d,      \
-                           tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p,  \
-                           dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len,                 \
-                           getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu, \
-                           getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0);                                     \
-    } while (0)
-    for (;;) {
+    hipLaunchKernelGGL((kr_kb_tcd<L, U, T>), dim3((unsigned)tcd_grid), dim3(BLK), tcd_shmem, s, r0, r1, n, tcd_R, tcd_lds_d,          \
+                       tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p,      \
+                       dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len,                       \
+                       getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu, \
+                       getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0)
+    // The host looks at the state ONE BATCH BEHIND: the copy of batch b's final state is waited for after batch b + 1 has
+    // been enqueued, so the device never idles on the read-back (ticks after convergence are no-ops: at most two batches of them).
+    KRState *hstate = (KRState *)ctx->pin;               // two slots of the pinned staging buffer
+    hipEvent_t ev_state[2] = {ctx->ev0, ctx->ev1};
+    const bool pipelined = ctx->pin != nullptr && ctx->ev0 != nullptr && ctx->ev1 != nullptr && !dist;
+    long long batches = 0;
+    bool done = false;
+    const bool tick_timing = getenv("B3C_KR_TIMING") != nullptr;
+    std::vector<hipEvent_t> tev;
+    auto tmark = [&]() { if (tick_timing && batches == 1) { hipEvent_t e = ctx->ev_get(); if (e) { (void)hipEventRecord(e, s); tev.push_back(e); } } };
+    while (!done) {
         for (int b = 0; b < BATCH; b++) {
             KRState *s0 = states.p + (t & 1), *s1 = states.p + ((t + 1) & 1);
-            // KA consumes part0 (rk.Z or gamma), may produce part1 (rk.Z for k == 1)
-            hipLaunchKernelGGL(kr_ka, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : part0.p, dist ? D.world : G,
-                               dist ? 4 : 1, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, rs, part1.p, flags);
+            tmark();
+            hipLaunchKernelGGL(kr_ka, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal + 1 : pmin.p, dist ? D.scal + 2 : pmax.p,
+                               dist ? D.scal : psum.p, dist ? D.scal + 3 : pgam.p, dist ? cP : G, cS, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, rs,
+                               pk1.p, pgam.p, flags);
             if (dist) {
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part1.p, G, 0, my_scal);
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pk1.p, G, 0, my_scal);
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pgam.p, G, 1, my_scal + 3);
                 int rc;
                 if ((rc = xchg(B3C_BUF_SCAL_VEC))) return rc;
             }
             t++;
+            tmark();
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
             // every PROF_EVERY-th SpMV is bracketed by events (an event pair costs ~12 us of idle GPU and two driver calls)
             const bool timed = prof && ticks % PROF_EVERY == 0;
@@ -1618,9 +1727,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                 ev_tick.push_back(ticks);
                 HIP_TRY(ctx, hipEventRecord(e0, s));
             }
-            // KB consumes part1 (from KA, G partials), produces part0 (GS partials)
-            const double *kbp = dist ? D.scal : part1.p;
-            const int kbP = dist ? D.world : G, kbS = dist ? 4 : 1;
+            // KB consumes pk1 (from KA, G partials; first inner iteration only), produces pkb (GS partials)
+            const double *kbp = dist ? D.scal : pk1.p;
+            const int kbP = dist ? D.world : G, kbS = cS;
             if (tcd) {
                 // tiles with column dictionaries; shape by average row length (4 entries per lane and load)
                 const int shp = getenv("B3C_KR_TCD_SHAPE") ? atoi(getenv("B3C_KR_TCD_SHAPE")) : 0;   // LPR*100 + UN*10 + TU
@@ -1635,65 +1744,82 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                 else KR_TCD(4, 2, 1);
             } else {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
-                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
+                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
                 else if (avg > 128 && a->kind == B3C_U32 && vec_shape >= 0)    // 4 entries per lane and load: 0.505 vs 0.544 ms at C3
-                    launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-                else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
-                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p, hub_len);
+                    launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
+                else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
+                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
+                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
+                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
             }
             if (n_hub) {       // the rows the row-group kernel left out; same state slot, partials behind its GS
                 if (a->kind == B3C_U32 && v16)
                     hipLaunchKernelGGL(kr_kb_hub<uint16_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices, v16,
-                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p + GS);
+                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p + GS);
                 else if (a->kind == B3C_U32)
                     hipLaunchKernelGGL(kr_kb_hub<uint32_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p + GS);
+                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p + GS);
                 else
                     hipLaunchKernelGGL(kr_kb_hub<double>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, part0.p + GS);
+                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p + GS);
             }
             if (timed) HIP_TRY(ctx, hipEventRecord(evs.back(), s));
             if (dist) {
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part0.p, GSP, 0, my_scal);
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pkb.p, GSP, 0, my_scal);
                 int rc;
                 if ((rc = xchg(B3C_BUF_SCAL))) return rc;
             }
             t++;
+            tmark();
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
-            // KC consumes part0 (GSP), produces part1/part2 (min/max, G)
-            hipLaunchKernelGGL(kr_kc, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : part0.p, dist ? D.world : GSP,
-                               dist ? 4 : 1, y.p, p.p, part1.p, part2.p);
+            // KCD consumes pkb (GSP), produces pmin / pmax / psum (G)
+            hipLaunchKernelGGL(kr_kcd, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : pkb.p, dist ? cP : GSP, cS, y.p, p.p,
+                               rk.p, w.p, v.p, Z.p, pmin.p, pmax.p, psum.p);
             if (dist) {
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part1.p, G, 1, my_scal + 1);
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part2.p, G, 2, my_scal + 2);
-                int rc;
-                if ((rc = xchg(B3C_BUF_SCAL))) return rc;
-            }
-            t++;
-            s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
-            // KD consumes part1/part2 (G), produces part0 (G; a sum for the CG update, a minimum for a bound cut)
-            hipLaunchKernelGGL(kr_kd, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal + 1 : part1.p,
-                               dist ? D.scal + 2 : part2.p, dist ? D.world : G, dist ? 4 : 1, y.p, p.p, rk.p, w.p, v.p, Z.p,
-                               part0.p);
-            if (dist) {
-                // the consumer (KA) knows from the state whether slot 0 is a sum or slot 3 a minimum
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part0.p, G, 0, my_scal);
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, part0.p, G, 1, my_scal + 3);
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, psum.p, G, 0, my_scal);
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pmin.p, G, 1, my_scal + 1);
+                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pmax.p, G, 2, my_scal + 2);
                 int rc;
                 if ((rc = xchg(B3C_BUF_SCAL))) return rc;
             }
             t++;
             ticks++;
         }
-        { const int rb_ = b3c_readback(ctx, &h, states.p + (t & 1), sizeof(h)); if (rb_) return rb_; }
-        if (h.phase == P_DONE) break;
-        if (ticks > 200000 + 16 * (long long)max_iter)
+        tmark();
+        if (pipelined) {
+            const int slot = (int)(batches & 1);
+            HIP_TRY(ctx, hipMemcpyAsync(hstate + slot, states.p + (t & 1), sizeof(KRState), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipEventRecord(ev_state[slot], s));
+            if (batches > 0) {
+                HIP_TRY(ctx, hipEventSynchronize(ev_state[slot ^ 1]));
+                h = hstate[slot ^ 1];
+                done = h.phase == P_DONE;
+            }
+            batches++;
+        } else {
+            { const int rb_ = b3c_readback(ctx, &h, states.p + (t & 1), sizeof(h)); if (rb_) return rb_; }
+            done = h.phase == P_DONE;
+        }
+        if (!done && ticks > 200000 + 16 * (long long)max_iter)
             return ctx->fail(B3C_E_NOCONV, "b3c_kr_balance: inner iteration did not terminate after %lld SpMVs", ticks);
     }
 #undef KR_TCD
+    if (tick_timing && tev.size() == (size_t)(3 * BATCH + 1)) {
+        (void)hipStreamSynchronize(s);
+        double tka = 0, tkb = 0, tkcd = 0;
+        for (int b = 0; b < BATCH; b++) {
+            float f = 0;
+            (void)hipEventElapsedTime(&f, tev[3 * b], tev[3 * b + 1]); tka += f;
+            (void)hipEventElapsedTime(&f, tev[3 * b + 1], tev[3 * b + 2]); tkb += f;
+            (void)hipEventElapsedTime(&f, tev[3 * b + 2], tev[3 * b + 3]); tkcd += f;
+        }
+        float tot = 0;
+        (void)hipEventElapsedTime(&tot, tev.front(), tev.back());
+        fprintf(stderr, "[b3c] tick timing (second batch, us): KA %.1f  KB %.1f  KCD %.1f  tick %.1f\n", tka / BATCH * 1e3, tkb / BATCH * 1e3,
+                tkcd / BATCH * 1e3, tot / BATCH * 1e3);
+        for (auto e : tev) ctx->ev_put(e);
+    }
     HIP_TRY(ctx, hipGetLastError());
 
     unsigned long long hc[4];
@@ -1725,15 +1851,21 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     info->n_spmv = h.n_iter + 1;
     info->value_bits = counts ? (v16 ? 16 : 32) : 64;
     if (prof) {
-        double ms = 0.0;
-        long long cnt = 0;
+        // ticks after convergence and the tick that only prepares a bound cut launch the SpMV kernel as a no-op (a few us):
+        // the mean is taken over the launches that did work, told apart by their duration
+        std::vector<float> dur;
+        float longest = 0.f;
         for (size_t e = 0; e + 1 < evs.size(); e += 2) {
             float f = 0.f;
-            // launches after convergence are no-ops: only SpMV number < n_spmv did work
-            if (ev_tick[e / 2] < info->n_spmv && hipEventElapsedTime(&f, evs[e], evs[e + 1]) == hipSuccess) { ms += f; cnt++; }
+            if (hipEventElapsedTime(&f, evs[e], evs[e + 1]) == hipSuccess) { dur.push_back(f); longest = f > longest ? f : longest; }
+            if (getenv("B3C_KR_DEBUG")) fprintf(stderr, "[b3c] SpMV launch of tick %lld: %.1f us\n", ev_tick[e / 2], f * 1e3);
             ctx->ev_put(evs[e]);
             ctx->ev_put(evs[e + 1]);
         }
+        double ms = 0.0;
+        long long cnt = 0;
+        for (float f : dur)
+            if (f >= 0.25f * longest) { ms += f; cnt++; }
         // sampled mean x number of SpMVs that did work
         info->spmv_ms = cnt ? ms / (double)cnt * (double)info->n_spmv : 0.0;
     }
