@@ -71,35 +71,38 @@ def measured_copy_gbs():
     return 2.0 * (1 << 30) / (best * 1e-3) / 1e9
 
 
-def cpu_baseline(sample_n, sample_e, seed, threads=1):
-    """Oracle (scalar C port of the reference path) on a bounded sample of the same workload.  threads > 1: the SpMV, the
-    site normalisation and the final scaling run row-parallel (OpenMP); compress and the sequential Louvain stay serial,
-    as python-louvain's semantics are."""
+def cpu_baseline(ip, ix, cnt, sites, lengths, e_true, what, threads=1):
+    """Oracle (scalar C port of the reference path, kind "port") on the host cores, timed over the whole cluster step on
+    the given map: mask, site normalisation, KR, X A X, compress, graph weights, sequential Louvain.  threads > 1: the
+    row-parallel loops (SpMV, symmetry guard, site normalisation, scaling, max_offdiag, compress) run under OpenMP -- every
+    row is still processed by one thread, so the results are bit for bit those of one thread; the python-louvain-style
+    Louvain stays sequential, as its semantics are."""
     import oracle
-    from bin3c_amd.synth import make_synth
     oracle.build()
-    sm = make_synth(sample_n, sample_e, seed)
-    e_true = sm.n_edges
     oracle.set_threads(threads)
     try:
         t0 = time.perf_counter()
-        sig = oracle.max_offdiag_u32(sm.indptr, sm.indices, sm.counts)
-        mask = (sm.lengths >= 1000) & (sig >= 5)
-        nd = oracle.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
-        rc, x, st = oracle.kr_balance(sm.indptr, sm.indices, nd)
+        sig = oracle.max_offdiag_u32(ip, ix, cnt)
+        mask = (lengths >= 1000) & (sig >= 5)
+        nd = oracle.site_norm(ip, ix, cnt.astype(np.float64), sites)
+        rc, x, st = oracle.kr_balance(ip, ix, nd)
         t_kr = time.perf_counter() - t0
-        proc = oracle.scale_sym(sm.indptr, sm.indices, nd, x)
-        m, ip, ix, a = oracle.compress(sm.indptr, sm.indices, proc, mask)
-        scl = 1.0 / oracle.max_value(ip, a)
-        w = oracle.graph_weights(ip, ix, a, scl)
-        r = oracle.louvain_seq(ip, ix, w)
+        proc = oracle.scale_sym(ip, ix, nd, x)
+        del nd
+        m, sip, six, a = oracle.compress(ip, ix, proc, mask)
+        del proc
+        scl = 1.0 / oracle.max_value(sip, a)
+        w = oracle.graph_weights(sip, six, a, scl)
+        del a
+        r = oracle.louvain_seq(sip, six, w)
         dt = time.perf_counter() - t0
     finally:
         oracle.set_threads(1)
-    return {'value': e_true / dt, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
-            'sample': 'hic-synth-v1 n={} E={} seed={}: full mask+norm+KR({} SpMV)+compress+sequential Louvain '
-                      '({} sweeps) in {:.1f}s (mask+norm+KR {:.1f}s) on {} host thread{}'.format(
-                          sample_n, e_true, seed, st.n_iter + 1, r['n_sweeps'], dt, t_kr, threads, 's' if threads > 1 else '')}
+    return {'value': e_true / dt, 'unit': 'edges/s', 'cores': threads, 'kind': 'port', 'seconds': dt,
+            'kr_spmv': int(st.n_iter + 1), 'louvain_sweeps': int(r['n_sweeps']), 'communities': int(r['n_comm']),
+            'sample': '{}: full mask+norm+KR({} SpMV)+compress+sequential Louvain ({} sweeps) in {:.1f}s (mask+norm+KR '
+                      '{:.1f}s) on {} host thread{}'.format(what, st.n_iter + 1, r['n_sweeps'], dt, t_kr, threads,
+                                                            's' if threads > 1 else '')}
 
 
 def main():
@@ -109,6 +112,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='C3', choices=['C1', 'C2', 'C3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline', default='same', choices=['same', 'sample'],
+                    help="'same': the oracle on the very map the GPU ran (about two minutes at C3); 'sample': on a bounded "
+                         "sample of the same generator (n = 200k, E = 10M)")
     ap.add_argument('--mode', default='auto', choices=['auto', 'sharded', 'replicas'], help='N > 1 only')
     args = ap.parse_args()
 
@@ -234,12 +240,24 @@ def main():
             if world == 1:
                 out['roofline']['copy_gbs'] = measured_copy_gbs()     # what a plain copy reaches on this box, beside `peak`
             if world == 1 and not args.no_cpu_baseline:
-                sample = {'C1': (1000, 50000), 'C2': (100000, 5000000), 'C3': (200000, 10000000)}[args.config]
-                out['cpu_baseline'] = cpu_baseline(sample[0], sample[1], seed)
-                # SURVEY 8(d) iii: the same with the row-parallel loops on the host cores of this NUMA node (at most 64)
                 nthr = min(64, len(os.sched_getaffinity(0))) if hasattr(os, 'sched_getaffinity') else 1
+                if args.cpu_baseline == 'same' or args.config != 'C3':
+                    # like for like: the same map, downloaded from HBM (SURVEY 8(d) ii and iii)
+                    hip_, hix_, hcnt_ = counts.download()
+                    what = '{} (the map the GPU ran: n={} E={} nnz={})'.format(args.config, n, e_true, nnz)
+                    base_args = (hip_, hix_, hcnt_, sites_h, lengths_h, e_true, what)
+                else:
+                    from bin3c_amd.synth import make_synth
+                    sm = make_synth(200000, 10000000, seed)
+                    base_args = (sm.indptr, sm.indices, sm.counts, sm.sites, sm.lengths, sm.n_edges,
+                                 'hic-synth-v1 sample n=200000 E={} seed={}'.format(sm.n_edges, seed))
                 if nthr > 1:
-                    out['cpu_baseline_mt'] = cpu_baseline(sample[0], sample[1], seed, threads=nthr)
+                    # the multi-thread figure first: it also tells how long the one-thread run will take
+                    out['cpu_baseline_mt'] = cpu_baseline(*base_args, threads=nthr)
+                out['cpu_baseline'] = cpu_baseline(*base_args, threads=1)
+                out['cpu_baseline']['gpu_speedup'] = out['value'] / out['cpu_baseline']['value']
+                if nthr > 1:
+                    out['cpu_baseline_mt']['gpu_speedup'] = out['value'] / out['cpu_baseline_mt']['value']
             print(json.dumps(out), flush=True)
 
     want_replicas = world == 1 or args.mode in ('auto', 'replicas')

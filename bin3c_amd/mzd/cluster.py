@@ -91,15 +91,33 @@ def read_tree(pathname):
 
 def write_edges(graph, parent_dir, base_name, sep=' '):
     """``u v weight`` per undirected edge, the file every external solver reads (cluster.py:139-151).
-    ``graph`` is the (indptr, indices, weights) triple of :func:`to_graph`; each edge is written once
-    from its lower endpoint, self-loops included, like ``nx.write_edgelist`` on the reference's graph."""
+    ``graph`` is the (indptr, indices, weights) triple of :func:`to_graph`.  The file is byte for byte what
+    ``nx.write_edgelist(g, f, data=['weight'], delimiter=sep)`` writes for the graph cluster.py:316-321 builds from the
+    same map (entries added in row-major order): networkx walks the nodes in insertion order -- the order of first
+    appearance in the (row, col) stream -- and prints every edge once, from the endpoint inserted first, neighbours in
+    the order they were attached (ascending ids here); self-loops included; weights as ``str(float)``
+    (tests/golden/edges_nx.npz holds networkx's own bytes)."""
     edge_file = os.path.join(parent_dir, '{}.edges'.format(base_name))
     ip, ix, w = graph
-    rows = np.repeat(np.arange(ip.shape[0] - 1), np.diff(ip))
-    keep = rows <= ix
+    n = ip.shape[0] - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ip))
+    cols = np.asarray(ix, dtype=np.int64)
+    # node insertion order = first appearance in r0, c0, r1, c1, ...
+    stream = np.empty(2 * rows.shape[0], dtype=np.int64)
+    stream[0::2] = rows
+    stream[1::2] = cols
+    nodes, first = np.unique(stream, return_index=True)
+    rank = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+    rank[nodes[np.argsort(first, kind='stable')]] = np.arange(nodes.shape[0])
+    keep = rows <= cols                                    # every undirected edge once (the map is symmetric)
+    u, v, ww = rows[keep], cols[keep], np.asarray(w)[keep]
+    swap = rank[v] < rank[u]
+    a = np.where(swap, v, u)
+    b = np.where(swap, u, v)
+    order = np.lexsort((b, rank[a]))
     with open(edge_file, 'w') as out:
-        for u, v, ww in zip(rows[keep].tolist(), ix[keep].tolist(), w[keep].tolist()):
-            out.write('{}{}{}{}{}\n'.format(u, sep, v, sep, repr(ww)))
+        for x, y, z in zip(a[order].tolist(), b[order].tolist(), ww[order].tolist()):
+            out.write('{}{}{}{}{}\n'.format(x, sep, y, sep, repr(z)))
     return edge_file
 
 

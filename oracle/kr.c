@@ -20,6 +20,7 @@
  * with more, every row is still summed sequentially by one thread, so the SpMV result does not change. */
 static int g_threads = 1;
 void orc_set_threads(int n) { g_threads = n > 1 ? n : 1; }
+int orc_get_threads(void) { return g_threads; }
 
 /* y = A x, row-sequential accumulation like scipy's csr_matvec (the m.dot() calls at
  * mzd/sparse_utils.py:136,165,196). */
@@ -48,22 +49,29 @@ static double dot(int64_t n, const double *a, const double *b)
 static int64_t build_working(int64_t n, const int64_t *ip, const int32_t *ix, const double *a, int64_t **wip,
                              int32_t **wix, double **wa)
 {
-    int64_t n_zero = 0, extra = 0;
+    int64_t n_zero = 0;
+    *wip = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    /* pass 1 (row-parallel): is the diagonal stored, is it zero */
+    uint8_t *absent = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+#pragma omp parallel for schedule(static) num_threads(g_threads) reduction(+ : n_zero) if (g_threads > 1)
     for (int64_t i = 0; i < n; i++) {
         int found = 0;
         double d = 0.0;
         for (int64_t k = ip[i]; k < ip[i + 1]; k++)
             if (ix[k] == i) { found = 1; d = a[k]; break; }
-        if (!found) extra++;
+        absent[i] = !found;
         if (!found || d == 0.0) n_zero++;
     }
-    int64_t nnz = ip[n] + extra;
-    *wip = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    int64_t o = 0;
+    for (int64_t i = 0; i < n; i++) { (*wip)[i] = o; o += ip[i + 1] - ip[i] + absent[i]; }
+    (*wip)[n] = o;
+    const int64_t nnz = o;
     *wix = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
     *wa = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
-    int64_t o = 0;
+    /* pass 2 (row-parallel): copy the row, the unit diagonal overwriting a stored zero or inserted in sorted position */
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int64_t i = 0; i < n; i++) {
-        (*wip)[i] = o;
+        int64_t o = (*wip)[i];
         int placed = 0;
         for (int64_t k = ip[i]; k < ip[i + 1]; k++) {
             if (!placed && ix[k] >= i) {
@@ -85,7 +93,7 @@ static int64_t build_working(int64_t n, const int64_t *ip, const int32_t *ix, co
             (*wa)[o++] = 1.0;
         }
     }
-    (*wip)[n] = o;
+    free(absent);
     return n_zero;
 }
 
@@ -103,12 +111,16 @@ static double csr_get(const int64_t *ip, const int32_t *ix, const double *a, int
 /* Sparse restatement of is_hermitian (mzd/sparse_utils.py:10-18): any |m_ij - m_ji| >= tol ? */
 static int is_symmetric(int64_t n, const int64_t *ip, const int32_t *ix, const double *a, double tol)
 {
-    for (int64_t i = 0; i < n; i++)
+    int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(g_threads) reduction(| : bad) if (g_threads > 1)
+    for (int64_t i = 0; i < n; i++) {
+        if (bad) continue;
         for (int64_t k = ip[i]; k < ip[i + 1]; k++) {
             double t = csr_get(ip, ix, a, ix[k], (int32_t)i);
-            if (fabs(a[k] - t) >= tol) return 0;
+            if (fabs(a[k] - t) >= tol) { bad = 1; break; }
         }
-    return 1;
+    }
+    return !bad;
 }
 
 /*
@@ -247,9 +259,20 @@ void orc_site_norm(int64_t n, const int64_t *ip, const int32_t *ix, const double
 void orc_max_offdiag_u32(int64_t n, const int64_t *ip, const int32_t *ix, const uint32_t *a, uint32_t *out)
 {
     for (int64_t j = 0; j < n; j++) out[j] = 0;
+    if (g_threads <= 1) {
+        for (int64_t i = 0; i < n; i++)
+            for (int64_t k = ip[i]; k < ip[i + 1]; k++)
+                if (ix[k] != i && a[k] > out[ix[k]]) out[ix[k]] = a[k];
+        return;
+    }
+    /* threads: rows in parallel, the column maximum raised by compare-and-swap (a maximum does not depend on the order) */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int64_t i = 0; i < n; i++)
-        for (int64_t k = ip[i]; k < ip[i + 1]; k++)
-            if (ix[k] != i && a[k] > out[ix[k]]) out[ix[k]] = a[k];
+        for (int64_t k = ip[i]; k < ip[i + 1]; k++) {
+            if (ix[k] == i) continue;
+            uint32_t cur = __atomic_load_n(&out[ix[k]], __ATOMIC_RELAXED);
+            while (a[k] > cur && !__atomic_compare_exchange_n(&out[ix[k]], &cur, a[k], 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
 }
 
 /* compress, mzd/sparse_utils.py:284-314: keep (i,j) with mask[i] && mask[j], re-index by
@@ -258,24 +281,36 @@ int64_t orc_compress(int64_t n, const int64_t *ip, const int32_t *ix, const doub
                      int64_t *out_ip, int32_t *out_ix, double *out_a)
 {
     int64_t *newid = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    int64_t *kept = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
     int64_t shift = 0, m = 0;
     for (int64_t i = 0; i < n; i++) {
         if (!mask[i]) shift++;
         newid[i] = i - shift;                                                    /* :307,310-312 */
         if (mask[i]) m++;
     }
-    int64_t o = 0, r = 0;
+    /* kept entries per kept row (row-parallel), then the row pointers */
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int64_t i = 0; i < n; i++) {
-        if (!mask[i]) continue;
-        out_ip[r++] = o;
-        for (int64_t k = ip[i]; k < ip[i + 1]; k++)
-            if (mask[ix[k]]) {                                                   /* :302 */
-                if (out_ix) { out_ix[o] = (int32_t)newid[ix[k]]; out_a[o] = a[k]; }
-                o++;
-            }
+        int64_t c = 0;
+        if (mask[i])
+            for (int64_t k = ip[i]; k < ip[i + 1]; k++) c += mask[ix[k]] != 0;   /* :302 */
+        kept[i] = c;
     }
-    out_ip[r] = o;
+    int64_t o = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (mask[i]) { out_ip[newid[i]] = o; o += kept[i]; }
+    out_ip[m] = o;
+    if (out_ix) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+        for (int64_t i = 0; i < n; i++) {
+            if (!mask[i]) continue;
+            int64_t w = out_ip[newid[i]];
+            for (int64_t k = ip[i]; k < ip[i + 1]; k++)
+                if (mask[ix[k]]) { out_ix[w] = (int32_t)newid[ix[k]]; out_a[w] = a[k]; w++; }
+        }
+    }
     free(newid);
+    free(kept);
     return m;
 }
 

@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <omp.h>
+
 #include "oracle.h"
 
 typedef __int128 i128;
@@ -115,6 +117,15 @@ int orc_louvain_bsp(int64_t n, const int64_t *ip, const int32_t *ix, const int64
             free(kdeg); free(tot); free(com); free(nxt); free(csize); free(dnc); free(touched);
             break;
         }
+        /* per-thread scratch of the threaded decide loop (orc_set_threads; one thread: the arrays above) */
+        const int nthr = nn >= 4096 ? orc_get_threads() : 1;
+        int64_t *tdnc = NULL;
+        int32_t *ttouched = NULL;
+        if (nthr > 1) {
+            tdnc = malloc(sizeof(int64_t) * (size_t)nthr * (size_t)nn);
+            ttouched = malloc(sizeof(int32_t) * (size_t)nthr * (size_t)nn);
+            for (size_t c = 0; c < (size_t)nthr * (size_t)nn; c++) tdnc[c] = -1;
+        }
         double cur_mod, new_mod = exact_modularity(&g, com, tot, m2);
         int32_t sweep = 0;
         for (;;) {
@@ -122,7 +133,18 @@ int orc_louvain_bsp(int64_t n, const int64_t *ip, const int32_t *ix, const int64
             int64_t moved = 0;
             sweep++; (*n_sweeps)++;
             for (int32_t r = 0; r < n_sub; r++) {
-                /* decide from the snapshot */
+                /* decide from the snapshot: the decisions of a sub-round do not depend on one another, so the nodes may be
+                 * taken in any order -- with threads (orc_set_threads, the multi-thread CPU baseline) in parallel, each
+                 * thread with its own neighbour-community scratch; the result is the same bit for bit */
+#pragma omp parallel num_threads(nthr) if (nthr > 1)
+                {
+                int64_t *my_dnc = dnc;
+                int32_t *my_touched = touched;
+                if (nthr > 1) {
+                    my_dnc = tdnc + (size_t)omp_get_thread_num() * (size_t)nn;
+                    my_touched = ttouched + (size_t)omp_get_thread_num() * (size_t)nn;
+                }
+#pragma omp for schedule(dynamic, 1024)
                 for (int64_t i = 0; i < nn; i++) {
                     nxt[i] = com[i];
                     if (bucket(i, n_sub) != (uint32_t)r || kdeg[i] == 0) continue;
@@ -132,23 +154,24 @@ int orc_louvain_bsp(int64_t n, const int64_t *ip, const int32_t *ix, const int64
                         int64_t j = g.ix[k];
                         if (j == i) continue;
                         int32_t c = com[j];
-                        if (dnc[c] < 0) { dnc[c] = 0; touched[nt++] = c; }
-                        dnc[c] += g.q[k];
+                        if (my_dnc[c] < 0) { my_dnc[c] = 0; my_touched[nt++] = c; }
+                        my_dnc[c] += g.q[k];
                     }
                     int32_t best = a;
                     i128 best_gain = 0;
                     int have = 0;
                     for (int64_t t = 0; t < nt; t++) {
-                        int32_t c = touched[t];
+                        int32_t c = my_touched[t];
                         int64_t tc = tot[c] - (c == a ? kdeg[i] : 0);
-                        i128 gain = (i128)dnc[c] * m2 - (i128)tc * kdeg[i];
+                        i128 gain = (i128)my_dnc[c] * m2 - (i128)tc * kdeg[i];
                         if (gain > best_gain || (have && gain == best_gain && c < best)) {
                             best_gain = gain; best = c; have = 1;
                         }
-                        dnc[c] = -1;
+                        my_dnc[c] = -1;
                     }
                     if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
                     nxt[i] = best;
+                }
                 }
                 /* apply */
                 for (int64_t i = 0; i < nn; i++) {
@@ -164,6 +187,7 @@ int orc_louvain_bsp(int64_t n, const int64_t *ip, const int32_t *ix, const int64
             if (new_mod - cur_mod < PL_MIN) break;
             if (max_sweeps > 0 && sweep >= max_sweeps) break;
         }
+        free(tdnc); free(ttouched);
         if (!first && new_mod - mod < PL_MIN) {
             free(kdeg); free(tot); free(com); free(nxt); free(csize); free(dnc); free(touched);
             break;

@@ -28,6 +28,7 @@ typedef struct {
 
 /* threads of the row-parallel loops (SpMV, site normalisation, final scaling); 1 = sequential (default) */
 void orc_set_threads(int n);
+int orc_get_threads(void);
 
 int orc_kr_balance(int64_t n, const int64_t *ip, const int32_t *ix, const double *a, double tol, double delta,
                    double Delta, int64_t max_iter, double *x, orc_kr_stats *st);

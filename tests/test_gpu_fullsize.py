@@ -1,8 +1,15 @@
 """
-GPU suite: BASELINE.json's full sizes through size-independent properties (the oracle is too slow to run there):
-balanced rows sum to one, the planted genomes are recovered, results do not depend on the HBM layout, and two runs
-are bit-identical.  C2 = 100k contigs / 5M edges; C3 = 1M contigs / 100M edges (about 30 s including generation).
+GPU suite at BASELINE.json's full sizes.  C2 = 100k contigs / 5M edges; C3 = 1M contigs / 100M edges.
+
+* test_full_size_matches_the_oracle: the HIP path against the CPU oracle ON THE SAME MAP, stage by stage -- mask, KR
+  (same iteration count and branch counters, x within 1e-9; the contract of sparse_utils.py:90-224 is 1e-6), the masked
+  sub-map bit for bit, Louvain labels identical to the device schedule's scalar twin (orc_louvain_bsp) and the same
+  partition as the sequential python-louvain-style oracle (orc_louvain_seq).  C2 takes seconds; C3 about two minutes of
+  host time (the oracle's row-parallel loops run on the host cores, which leaves its results bit for bit unchanged).
+* test_full_size_properties: size-independent properties (balanced rows sum to one, planted genomes recovered, layout
+  independence, bit-identical repeat runs, block reduction conserves mass).
 """
+import os
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -12,14 +19,76 @@ import graphs
 pytestmark = pytest.mark.gpu
 
 
-def _run(ctx, cfg, reorder=True):
+def _run(ctx, cfg, reorder=True, keep=False):
     from bin3c_amd.pipeline import run_hot_path
     from bin3c_amd.synth import CONFIGS, make_edges
     n, e, seed, law = CONFIGS[cfg]
     lo, hi, c, diag, lengths, sites, genome = make_edges(n, e, seed, law)
     counts, n_edges = ctx.coo_symmetrise(n, lo, hi, c, diag)
-    res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, reorder=reorder)
+    res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, reorder=reorder, keep=keep)
     return counts, n_edges, sites, lengths, genome, res
+
+
+@pytest.mark.parametrize('cfg', ['C2', 'C3'])
+def test_full_size_matches_the_oracle(ctx, oracle_lib, cfg):
+    counts, n_edges, sites, lengths, genome, res = _run(ctx, cfg, keep=True)
+    n = counts.n
+    ip, ix, cnt = counts.download()
+    orc = oracle_lib
+    orc.set_threads(min(32, len(os.sched_getaffinity(0))) if hasattr(os, 'sched_getaffinity') else 1)
+    try:
+        # acceptance mask (contact_map.py:888-905 over sparse_utils.py:269-281)
+        sig = orc.max_offdiag_u32(ip, ix, cnt)
+        assert np.array_equal(res.signal, sig)
+        mask = (lengths >= 1000) & (sig >= 5)
+        assert np.array_equal(res.mask, mask)
+        # site normalisation + Knight-Ruiz (contact_map.py:100-113, sparse_utils.py:90-224)
+        nd = orc.site_norm(ip, ix, cnt.astype(np.float64), sites)
+        rc, xo, st = orc.kr_balance(ip, ix, nd)
+        assert rc == orc.OK
+        assert (res.kr_info.n_iter, res.kr_info.n_zero_diag, res.kr_info.hit_delta, res.kr_info.hit_Delta) == \
+               (st.n_iter, st.n_zero_diag, st.hit_delta, st.hit_Delta)
+        assert res.kr_info.is_symmetric == st.is_symmetric == 1
+        np.testing.assert_allclose(res.x, xo, rtol=1e-9, atol=0)
+        # get_subspace of the balanced map (sparse_utils.py:223-224, :284-314): bit for bit from the same x
+        proc = orc.scale_sym(ip, ix, nd, res.x)
+        del nd
+        m, sip, six, sa = orc.compress(ip, ix, proc, mask)
+        del proc
+        sub = res.sub if res.sub is not None else res.processed
+        dip, dix, da = sub.download()
+        ids = ctx.mat_ids(sub)                               # caller-side (gapless) id of every stored row
+        assert sub.n == m and da.shape[0] == sa.shape[0]
+        if ids is None:
+            assert np.array_equal(dip, sip) and np.array_equal(dix, six)
+            lower = np.repeat(np.arange(m), np.diff(sip)) >= six
+            assert np.array_equal(da[lower], sa[lower])      # graph form: both triangles hold the lower value
+        else:
+            # the device keeps the sub-map in its locality order: compare row by row through the ids
+            got = sp.csr_matrix((da, ids[dix], dip), shape=(m, m))[np.argsort(ids)]
+            got.sort_indices()
+            assert np.array_equal(got.indptr, sip) and np.array_equal(got.indices, six)
+            lower = np.repeat(np.arange(m), np.diff(sip)) >= six
+            assert np.array_equal(got.data[lower], sa[lower])
+            del got
+        # to_graph weights + Louvain (cluster.py:316-321, louvain.py:70)
+        # (the device takes the maximum over the graph form, whose upper triangle mirrors the lower one: an ulp at most)
+        np.testing.assert_allclose(res.scl, 1.0 / orc.max_value(sip, sa), rtol=4e-16, atol=0)
+        w = orc.graph_weights(sip, six, sa, res.scl)
+        del sa
+        q = orc.quantise(w, orc.quant_shift(sip, six, w))
+        ref = orc.louvain_bsp(sip, six, q)
+        del q
+        assert np.array_equal(res.labels, ref['labels'])
+        assert (res.lv_info.modularity, res.lv_info.n_sweeps, res.lv_info.n_levels, res.lv_info.n_comm) == \
+               (ref['Q'], ref['n_sweeps'], ref['n_levels'], ref['n_comm'])
+        seq = orc.louvain_seq(sip, six, w)
+        assert graphs.same_partition(res.labels, seq['labels'])
+        assert abs(seq['Q'] - ref['Q']) < 1e-9
+    finally:
+        orc.set_threads(1)
+        res.free()
+        counts.free()
 
 
 @pytest.mark.parametrize('cfg', ['C2', 'C3'])

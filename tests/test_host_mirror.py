@@ -97,6 +97,36 @@ def test_solver_wire_formats(tmp_path):
     assert open(f).read().split('\n')[:3] == ['0 0 0.5', '0 1 0.25', '1 2 1.0']
 
 
+def test_write_edges_is_byte_identical_to_networkx(tmp_path):
+    """cluster.py:139-151: the file networkx.write_edgelist wrote for the graph of cluster.py:316-321 (bytes captured by
+    tools/make_golden2.py), and -- where networkx is installed -- the same comparison live on a second map."""
+    from bin3c_amd.mzd import cluster
+    import scipy.sparse as sp
+    g = np.load(os.path.join(GOLDEN, 'edges_nx.npz'))
+    c = sp.csr_matrix((g['data'], g['indices'], g['indptr']))
+    # the graph triple as to_graph forms it: the lower triangle mirrored (the later add_edge(v, u) overwrites (u, v))
+    low = sp.tril(c, k=0, format='csr')
+    sym = (low + sp.tril(c, k=-1, format='csr').T).tocsr()
+    sym.sort_indices()
+    f = cluster.write_edges((sym.indptr.astype(np.int64), sym.indices.astype(np.int32), sym.data * float(g['scl'])),
+                            str(tmp_path), 'cm_graph')
+    assert open(f, 'rb').read() == g['edge_file'].tobytes()
+    nx = pytest.importorskip('networkx')
+    rs = np.random.RandomState(3)
+    a = sp.random(70, 70, density=0.08, random_state=rs, format='coo')
+    a = (a + a.T + sp.diags(rs.uniform(0, 1, 70) * (rs.uniform(0, 1, 70) < 0.5))).tocsr()
+    a.eliminate_zeros()
+    a.sort_indices()
+    coo = a.tocoo()
+    gr = nx.Graph()
+    for u, v, w in zip(coo.row, coo.col, coo.data):
+        gr.add_edge(u, v, weight=w)
+    ref = tmp_path / 'ref.edges'
+    nx.write_edgelist(gr, str(ref), data=['weight'], delimiter='\t')
+    f = cluster.write_edges((a.indptr.astype(np.int64), a.indices.astype(np.int32), a.data), str(tmp_path), 'mine', sep='\t')
+    assert open(f, 'rb').read() == ref.read_bytes()
+
+
 def test_object_io_roundtrip_and_suffixes(tmp_path):
     from bin3c_amd.mzd import io_utils
     obj = {'a': np.arange(5), 'b': 'x'}
