@@ -78,9 +78,11 @@ def _solve_draws(target_unique, pair_cap, share):
     return hi
 
 
-def make_edges(n, n_edges, seed, degree_law='flat'):
+def make_edges(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5):
     """
-    Draw the contact pair stream.
+    Draw the contact pair stream.  `noise`: share of the edges that join two random contigs (inter-genome); `intra_boost`:
+    multiplier of the intra-genome counts.  The defaults are hic-synth-v1; larger noise / boost 1 give a HARD clustering
+    problem (modularity ~0.4-0.6, several Louvain levels) for the tests.
 
     :return: (i, j, count) with i < j, possibly holding duplicates (the consumer sums them),
              diag counts (uint32[n]), lengths (int32[n]), sites (float64[n]), genome id (int32[n])
@@ -96,7 +98,7 @@ def make_edges(n, n_edges, seed, degree_law='flat'):
     lengths = np.maximum(500, rs.lognormal(np.log(8000.0), 1.0, n)).astype(np.int32)
     sites = np.maximum(1, rs.poisson(lengths / 256.0)).astype(np.float64)
 
-    n_intra = int(round(0.9 * n_edges))
+    n_intra = int(round((1.0 - noise) * n_edges))
     n_noise = n_edges - n_intra
     cap = sizes.astype(np.float64) * (sizes - 1) / 2.0
     share = sizes / float(sizes.sum())
@@ -122,7 +124,7 @@ def make_edges(n, n_edges, seed, degree_law='flat'):
     a = perm[starts[g_of] + a][keep]
     b = perm[starts[g_of] + b][keep]
     del g_of, sz
-    c_intra = (rs.geometric(0.2, a.shape[0]) * 5).astype(np.uint32)
+    c_intra = (rs.geometric(0.2, a.shape[0]) * intra_boost).astype(np.uint32)
 
     na = rs.randint(0, n, int(n_noise * 1.01) + 8).astype(np.int64)
     nb = rs.randint(0, n, na.shape[0]).astype(np.int64)
@@ -170,8 +172,8 @@ def symmetrise_to_csr(n, lo, hi, c, diag):
     return indptr, indices, counts
 
 
-def make_synth(n, n_edges, seed, degree_law='flat'):
+def make_synth(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5):
     """Full host-side generation -> :class:`SynthMap`."""
-    lo, hi, c, diag, lengths, sites, genome = make_edges(n, n_edges, seed, degree_law)
+    lo, hi, c, diag, lengths, sites, genome = make_edges(n, n_edges, seed, degree_law, noise, intra_boost)
     indptr, indices, counts = symmetrise_to_csr(n, lo, hi, c, diag)
     return SynthMap(n, indptr, indices, counts, lengths, sites, genome)

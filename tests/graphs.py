@@ -60,10 +60,10 @@ def same_partition(a, b):
     return len(pairs) == len(set(p[0] for p in pairs)) == len(set(p[1] for p in pairs))
 
 
-def synth_graph(oracle, n, n_edges, seed, min_len=1000, min_sig=5, degree_law='flat'):
+def synth_graph(oracle, n, n_edges, seed, min_len=1000, min_sig=5, degree_law='flat', noise=0.1, intra_boost=5):
     """Synthetic contact map pushed through the oracle's normalise/KR/compress steps -> graph CSR + weights."""
     from bin3c_amd.synth import make_synth
-    sm = make_synth(n, n_edges, seed, degree_law)
+    sm = make_synth(n, n_edges, seed, degree_law, noise, intra_boost)
     sig = oracle.max_offdiag_u32(sm.indptr, sm.indices, sm.counts)
     mask = (sm.lengths >= min_len) & (sig >= min_sig)
     nd = oracle.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
@@ -73,3 +73,22 @@ def synth_graph(oracle, n, n_edges, seed, min_len=1000, min_sig=5, degree_law='f
     scl = 1.0 / oracle.max_value(ip, a)
     return dict(sm=sm, mask=mask, n=m, indptr=ip, indices=ix, data=a, scl=scl,
                 w=oracle.graph_weights(ip, ix, a, scl))
+
+
+def adjusted_rand(a, b):
+    """Adjusted Rand index of two labelings (entries < 0 in either are left out)."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    keep = (a >= 0) & (b >= 0)
+    a, b = a[keep], b[keep]
+    _, ai = np.unique(a, return_inverse=True)
+    _, bi = np.unique(b, return_inverse=True)
+    m = sp.coo_matrix((np.ones(a.shape[0]), (ai, bi))).tocsr()
+    comb = lambda x: x * (x - 1.0) / 2.0
+    sum_ij = comb(m.data).sum()
+    sa = comb(np.asarray(m.sum(axis=1)).ravel()).sum()
+    sb = comb(np.asarray(m.sum(axis=0)).ravel()).sum()
+    tot = comb(float(a.shape[0]))
+    exp = sa * sb / tot
+    mx = 0.5 * (sa + sb)
+    return 1.0 if mx == exp else (sum_ij - exp) / (mx - exp)
