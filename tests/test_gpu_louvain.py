@@ -138,11 +138,12 @@ def test_internal_reorder_path_matches_oracle(ctx, oracle_lib):
 def test_hard_maps_multilevel(ctx, oracle_lib, n, e, seed, noise):
     """Maps on which Louvain has real work to do (40-50 % of the edges are inter-genome noise with the same counts as the
     intra-genome ones: Q ~ 0.5, several levels, dozens of sweeps, thousands of nodes moving back and forth): the device
-    must still reproduce its scalar twin bit for bit -- labels, sweep and level counts, exact modularity -- and ends within
-    0.03 of the sequential python-louvain-style optimum (tests/test_oracle_louvain.py reports the ARI between the two)."""
+    must still reproduce its scalar twin bit for bit -- labels, sweep and level counts, exact modularity -- and its optimum is
+    no more than 0.03 below the sequential python-louvain-style one (on the largest map it is 0.03 ABOVE;
+    tests/test_oracle_louvain.py reports the ARI between the two)."""
     gr = graphs.synth_graph(oracle_lib, n, e, seed, noise=noise, intra_boost=1)
     ref, labels, info = _run_both(ctx, oracle_lib, gr['indptr'], gr['indices'], gr['data'], gr['scl'])
     assert ref['n_levels'] >= 2 and ref['n_sweeps'] >= 12 and 0.3 < ref['Q'] < 0.7
     _assert_same(ref, labels, info)
     seq = oracle_lib.louvain_seq(gr['indptr'], gr['indices'], gr['w'])
-    assert abs(seq['Q'] - info.modularity) < 0.03
+    assert info.modularity > seq['Q'] - 0.03 and abs(seq['Q'] - info.modularity) < 0.06
