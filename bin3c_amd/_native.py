@@ -46,6 +46,10 @@ SYMBOLS = [
     ('b3c_ctx_sync', C.c_int, [_VP]),
     ('b3c_ctx_bytes', C.c_int64, [_VP]),
     ('b3c_ctx_set_dist', C.c_int, [_VP, _VP]),
+    ('b3c_dist_unique_id', C.c_int, [_VP]),
+    ('b3c_dist_comm_create', C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
+    ('b3c_dist_comm_destroy', C.c_int, [_VP, _VP]),
+    ('b3c_ctx_exchanges', C.c_int64, [_VP]),
     ('b3c_mat_upload', C.c_int, [_VP, C.c_int64, C.c_int64, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
     ('b3c_mat_free', C.c_int, [_VP, _VP]),
     ('b3c_mat_info', C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'libb3c.so')
-SOURCES = ['api.hip', 'csr_ops.hip', 'kr.hip', 'louvain.hip', 'reorder.hip', 'accumulate.hip', 'downsample.hip']
+SOURCES = ['api.hip', 'csr_ops.hip', 'kr.hip', 'louvain.hip', 'reorder.hip', 'accumulate.hip', 'downsample.hip', 'dist.hip']
 
 
 def _stale():
@@ -41,7 +41,7 @@ def build_lib(force=False, verbose=False):
             raise RuntimeError('hipcc failed on {}'.format(src))
         if verbose and out:
             sys.stdout.write(out.decode())
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
     subprocess.check_call(cmd)
     return LIB
 

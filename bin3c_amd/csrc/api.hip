@@ -62,7 +62,7 @@ extern "C" int b3c_ctx_set_dist(b3c_ctx *ctx, const b3c_dist *dist)
 {
     if (!ctx) return B3C_E_ARG;
     if (!dist) { ctx->has_dist = false; return B3C_OK; }
-    if (dist->world < 1 || dist->rank < 0 || dist->rank >= dist->world || dist->chunk < 1 || !dist->allgather ||
+    if (dist->world < 1 || dist->rank < 0 || dist->rank >= dist->world || dist->chunk < 1 || (!dist->allgather && !dist->comm) ||
         !dist->vec || !dist->scal || !dist->labels || !dist->isum)
         return ctx->fail(B3C_E_ARG, "b3c_ctx_set_dist: bad argument");
     ctx->dist = *dist;

@@ -37,6 +37,7 @@ struct b3c_ctx {
     void *pin = nullptr;      // pinned host staging for small read-backs (a pageable destination costs a staged copy)
     b3c_dist dist;            // row-sharded multi-GPU execution (b3c_ctx_set_dist); world <= 1: off
     bool has_dist = false;
+    int64_t n_exchanges = 0;  // collectives issued (b3c_dist_exchange)
 
     int fail(int code, const char *fmt, ...)
     {
@@ -163,6 +164,7 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 }
 
 // internal cross-file entry points
+int b3c_dist_exchange(b3c_ctx *ctx, int buf);   // in-place all-gather of an exchange buffer: RCCL or the caller's callback
 int b3c_mat_alloc(b3c_ctx *ctx, int64_t n, int64_t nnz, int kind, b3c_mat **out);
 int b3c_copy_in(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
 int b3c_copy_out(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);

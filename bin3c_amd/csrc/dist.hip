@@ -1,0 +1,144 @@
+// Multi-GPU exchanges of libb3c (include/b3c.h "multi-GPU"): one process per GPU, contig-row ranges of one map.
+//
+// Every exchange is an in-place all-gather of a buffer laid out as `world` equal slices.  With a communicator installed
+// (b3c_dist.comm, created by b3c_dist_comm_create from a unique id the caller broadcasts) the library issues the RCCL
+// collective itself on the context's stream -- no host round trip, no callback; the vector + scalar pair that follows
+// every KCD launch is one grouped launch.  Without one, the caller-supplied callback moves the data (the gloo path of the
+// CPU/one-GPU tests).  RCCL is bound at run time (dlopen): the copy already in the process (PyTorch ships one under the
+// same soname) is preferred, so that a process never holds two.
+#include "common.hpp"
+
+#include <dlfcn.h>
+
+namespace {
+
+// the few RCCL/NCCL 2.x entry points used; enum values from rccl.h (stable across 2.x)
+typedef int (*fn_get_unique_id)(void *);
+typedef int (*fn_comm_init_rank)(void **, int, unsigned char[128], int);   // ncclUniqueId is passed BY VALUE (128 bytes)
+typedef int (*fn_comm_destroy)(void *);
+typedef int (*fn_all_gather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*fn_group)(void);
+typedef const char *(*fn_err)(int);
+
+struct IdByValue { char bytes[128]; };
+typedef int (*fn_comm_init_rank_v)(void **, int, IdByValue, int);
+
+struct Rccl {
+    void *h = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank_v comm_init_rank = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_all_gather all_gather = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;
+    fn_err err = nullptr;
+    bool ok = false;
+};
+
+constexpr int NCCL_INT32 = 2, NCCL_INT64 = 4, NCCL_FLOAT64 = 8;
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return &r;
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    r.h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);                // already in the process (PyTorch)?
+    for (int i = 0; !r.h && i < 3; i++) r.h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!r.h) return &r;
+    r.get_unique_id = (fn_get_unique_id)dlsym(r.h, "ncclGetUniqueId");
+    r.comm_init_rank = (fn_comm_init_rank_v)dlsym(r.h, "ncclCommInitRank");
+    r.comm_destroy = (fn_comm_destroy)dlsym(r.h, "ncclCommDestroy");
+    r.all_gather = (fn_all_gather)dlsym(r.h, "ncclAllGather");
+    r.group_start = (fn_group)dlsym(r.h, "ncclGroupStart");
+    r.group_end = (fn_group)dlsym(r.h, "ncclGroupEnd");
+    r.err = (fn_err)dlsym(r.h, "ncclGetErrorString");
+    r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_gather && r.group_start && r.group_end;
+    return &r;
+}
+
+int rccl_fail(b3c_ctx *ctx, const char *what, int rc)
+{
+    Rccl *r = rccl();
+    return ctx->fail(B3C_E_RCCL, "%s failed: %s", what, r->err ? r->err(rc) : "RCCL error");
+}
+
+struct BufDesc { void *p; size_t count; int type; };
+
+bool describe(const b3c_dist &D, int buf, BufDesc *out)
+{
+    switch (buf) {
+    case B3C_BUF_VEC: *out = {D.vec, (size_t)D.chunk, NCCL_FLOAT64}; return true;
+    case B3C_BUF_SCAL: *out = {D.scal, 4, NCCL_FLOAT64}; return true;
+    case B3C_BUF_LABELS: *out = {D.labels, (size_t)D.chunk, NCCL_INT32}; return true;
+    case B3C_BUF_ISUM: *out = {D.isum, 2, NCCL_INT64}; return true;
+    default: return false;
+    }
+}
+
+}  // namespace
+
+extern "C" int b3c_dist_unique_id(void *id128)
+{
+    Rccl *r = rccl();
+    if (!id128 || !r->ok) return B3C_E_RCCL;
+    return r->get_unique_id(id128) == 0 ? B3C_OK : B3C_E_RCCL;
+}
+
+extern "C" int b3c_dist_comm_create(b3c_ctx *ctx, int world, int rank, const void *id128, void **comm_out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world) return ctx->fail(B3C_E_ARG, "b3c_dist_comm_create: bad argument");
+    Rccl *r = rccl();
+    if (!r->ok) return ctx->fail(B3C_E_RCCL, "b3c_dist_comm_create: librccl.so.1 could not be loaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    IdByValue id;
+    memcpy(id.bytes, id128, sizeof(id.bytes));
+    void *comm = nullptr;
+    const int rc = r->comm_init_rank(&comm, world, id, rank);
+    if (rc != 0) return rccl_fail(ctx, "ncclCommInitRank", rc);
+    *comm_out = comm;
+    return B3C_OK;
+}
+
+extern "C" int b3c_dist_comm_destroy(b3c_ctx *ctx, void *comm)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!comm) return B3C_OK;
+    Rccl *r = rccl();
+    if (!r->ok) return ctx->fail(B3C_E_RCCL, "b3c_dist_comm_destroy: librccl.so.1 could not be loaded");
+    (void)hipStreamSynchronize(ctx->stream);
+    const int rc = r->comm_destroy(comm);
+    return rc == 0 ? B3C_OK : rccl_fail(ctx, "ncclCommDestroy", rc);
+}
+
+// All-gather exchange buffer `buf` in place (B3C_BUF_SCAL_VEC: the scalar and the vector buffer, one grouped launch).
+int b3c_dist_exchange(b3c_ctx *ctx, int buf)
+{
+    const b3c_dist &D = ctx->dist;
+    ctx->n_exchanges++;
+    if (!D.comm) {
+        if (!D.allgather) return ctx->fail(B3C_E_ARG, "multi-GPU exchange without communicator or callback");
+        if (D.allgather(D.user, buf) != 0) return ctx->fail(B3C_E_RCCL, "all-gather callback failed (buffer %d)", buf);
+        return B3C_OK;
+    }
+    Rccl *r = rccl();
+    if (!r->ok) return ctx->fail(B3C_E_RCCL, "librccl.so.1 could not be loaded");
+    int ids[2] = {buf, -1};
+    if (buf == B3C_BUF_SCAL_VEC) { ids[0] = B3C_BUF_SCAL; ids[1] = B3C_BUF_VEC; }
+    int rc = 0;
+    const bool grouped = ids[1] >= 0;
+    if (grouped && (rc = r->group_start()) != 0) return rccl_fail(ctx, "ncclGroupStart", rc);
+    for (int k = 0; k < 2 && ids[k] >= 0; k++) {
+        BufDesc d;
+        if (!describe(D, ids[k], &d)) return ctx->fail(B3C_E_ARG, "unknown exchange buffer %d", ids[k]);
+        const size_t esz = d.type == NCCL_INT32 ? 4 : 8;
+        // in place: the send buffer is this rank's slice of the receive buffer (NCCL/RCCL define this case)
+        rc = r->all_gather((const char *)d.p + (size_t)D.rank * d.count * esz, d.p, d.count, d.type, D.comm, ctx->stream);
+        if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
+    }
+    if (grouped && (rc = r->group_end()) != 0) return rccl_fail(ctx, "ncclGroupEnd", rc);
+    return B3C_OK;
+}
+
+extern "C" int64_t b3c_ctx_exchanges(const b3c_ctx *ctx) { return ctx ? ctx->n_exchanges : 0; }

@@ -159,8 +159,8 @@ constexpr int KV_E = 4;      // elements per thread and pass of the vector kerne
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm, const KRState *__restrict__ sin,
                                               KRState *__restrict__ sout, const double *__restrict__ pmin,
-                                              const double *__restrict__ pmax, const double *__restrict__ psum,
-                                              const double *__restrict__ pgam_in, int PA, int PS,
+                                              const double *__restrict__ pmax, const double *__restrict__ psum, int PA, int PS,
+                                              const double *__restrict__ pgam_in, int PG, int z_given,
                                               double *__restrict__ x, double *__restrict__ y, double *__restrict__ p,
                                               double *__restrict__ Z, const double *__restrict__ rk,
                                               const double *__restrict__ v, double *__restrict__ u,
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
             }
         }
     } else if (st.phase == P_CUT_PENDING) {
-        st.gamma = reduce_partials<1>(pgam_in, PA, PS, lds);  // :175 / :181
+        st.gamma = reduce_partials<1>(pgam_in, PG, 1, lds);  // :175 / :181
         yone = st.k == 1;
         st.phase = A_OUTER;
     } else if (st.phase == P_SKIP_INNER) {
@@ -262,7 +262,22 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
         return;
     }
     if (st.phase == A_INNER) {
-        if (st.k == 1) {
+        if (st.k == 1 && z_given) {
+            // sharded: Z = rk / v (:158) and its partial rk.Z (:160) were formed by KCD on every rank's rows and gathered
+            for (int64_t base = i0; base < n; base += KV_E * stride) {
+#pragma unroll
+                for (int e = 0; e < KV_E; e++) {
+                    const int64_t i = base + e * stride;
+                    if (i >= n) continue;
+                    const bool first = base == i0;
+                    const double xi = first ? ex[e] : x[i];
+                    const double ri = first ? er[e] : (rs ? rs[i] : 1.0);
+                    const double z = first ? eZ[e] : Z[i];
+                    p[i] = z;                          // :159
+                    u[i] = rs ? ri * (xi * z) : xi * z;
+                }
+            }
+        } else if (st.k == 1) {
             double acc = 0.0;
             for (int64_t base = i0; base < n; base += KV_E * stride) {
                 double erk[KV_E], ev[KV_E];
@@ -1128,7 +1143,7 @@ __global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams pr
                                                double *__restrict__ rk, const double *__restrict__ w,
                                                const double *__restrict__ v, double *__restrict__ Z,
                                                double *__restrict__ pmin, double *__restrict__ pmax,
-                                               double *__restrict__ psum)
+                                               double *__restrict__ psum, int z_first)
 {
     __shared__ double lds[BLK];
     const int64_t stride = (int64_t)gridDim.x * BLK;
@@ -1179,6 +1194,25 @@ __global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams pr
         st.next = P_DONE;   // any value but P_INIT: marks the initial SpMV as consumed
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if (z_first && st.phase == P_INNER_FIRST) {
+        // sharded: the first inner iteration starts from Z = rk / v (:158) and rk.Z (:160); formed here, on this rank's rows,
+        // so that they travel with the exchange that follows this launch and KA needs none
+        double acc = 0.0;
+        for (int64_t base = i0; base < n; base += KV_E * stride) {
+#pragma unroll
+            for (int e = 0; e < KV_E; e++) {
+                const int64_t i = base + e * stride;
+                if (i >= n) continue;
+                const bool first = base == i0;
+                const double r = first ? erk[e] : rk[i];
+                const double z = r / (first ? ev[e] : v[i]);
+                Z[i] = z;
+                acc += r * z;
+            }
+        }
+        block_partial<0>(acc, psum, lds);
+        return;
+    }
     if (st.phase != C_PENDING) return;
 
     const double alpha = st.alpha;
@@ -1493,7 +1527,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int64_t r1 = dist ? std::min<int64_t>(n, r0 + D.chunk) : n;
     const int64_t nloc = r1 - r0;
     // geometry: fixed for a given (n, nnz, world) so that reductions are reproducible
-    const int G = grid_for(nloc, BLK * KV_E, 4 * ctx->n_cu);
+    const int G = grid_for(nloc, BLK * KV_E, 4 * ctx->n_cu);          // vector kernels over this rank's rows (KCD)
+    const int GA = grid_for(n, BLK * KV_E, 4 * ctx->n_cu);            // ... over all rows (KA: p, y, x and the operand are kept whole on every rank)
     const double avg = (double)a->nnz / (double)n;
     unsigned long long maxdeg = 0;
     {
@@ -1527,14 +1562,14 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const bool hub_kb = maxdeg > (unsigned long long)hub_thr && getenv("B3C_KR_NO_HUB") == nullptr;
     const int64_t hub_cap = hub_kb ? a->nnz / hub_thr + 1 : 0;
     const int hub_len = hub_kb ? hub_thr : 0x7fffffff;
-    const int P = (int)std::max<int64_t>(G, (int64_t)GS_max + hub_cap);
+    const int P = (int)std::max<int64_t>(GA, (int64_t)GS_max + hub_cap);
 
-    DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z(ctx, n), rk(ctx, n), v(ctx, n), w(ctx, n), u_own(ctx, dist ? 1 : n), dfix(ctx, n);
-    struct { double *p; } u{dist ? D.vec : u_own.p};   // the gathered operand lives in the exchange buffer when sharded
+    DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z_own(ctx, dist ? 1 : n), rk(ctx, n), v(ctx, n), w(ctx, n), u(ctx, n), dfix(ctx, n);
+    struct { double *p; } Z{dist ? D.vec : Z_own.p};   // sharded: Z lives in the exchange buffer (slices gathered after every KCD)
     DevBuf<double> pmin(ctx, P), pmax(ctx, P), psum(ctx, P), pgam(ctx, P), pk1(ctx, P), pkb(ctx, P);   // block partials, see the kernels
     DevBuf<KRState> states(ctx, 2);
     DevBuf<unsigned long long> counters(ctx, 4);
-    if (!x.p || !y.p || !p.p || !Z.p || !rk.p || !v.p || !w.p || !u_own.p || !dfix.p || !pmin.p || !pmax.p || !psum.p || !pgam.p || !pk1.p || !pkb.p ||
+    if (!x.p || !y.p || !p.p || !Z_own.p || !rk.p || !v.p || !w.p || !u.p || !dfix.p || !pmin.p || !pmax.p || !psum.p || !pgam.p || !pk1.p || !pkb.p ||
         !states.p || !counters.p)
         return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: out of device memory");
     int *flags = (int *)(counters.p + 2);
@@ -1675,10 +1710,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // sharded: a kernel's block partials are folded into this rank's slot of the packed scalar buffer (slot 0 sum, 1 min,
     // 2 max, 3 gamma) and all-gathered; the consumer then reduces `world` values (stride 4) in rank order instead of P block partials
     double *my_scal = dist ? D.scal + 4 * D.rank : nullptr;
-    auto xchg = [&](int buf) -> int {
-        if (D.allgather(D.user, buf) != 0) return ctx->fail(B3C_E_HIP, "b3c_kr_balance: all-gather callback failed");
-        return B3C_OK;
-    };
+    auto xchg = [&](int buf) -> int { return b3c_dist_exchange(ctx, buf); };
     const int cP = dist ? D.world : 0, cS = dist ? 4 : 1;      // consumer view of gathered partials
     if (tcd) {
 #define KR_TCD_ATTR(L, U, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tcd_shmem))
@@ -1706,15 +1738,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         for (int b = 0; b < BATCH; b++) {
             KRState *s0 = states.p + (t & 1), *s1 = states.p + ((t + 1) & 1);
             tmark();
-            hipLaunchKernelGGL(kr_ka, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal + 1 : pmin.p, dist ? D.scal + 2 : pmax.p,
-                               dist ? D.scal : psum.p, dist ? D.scal + 3 : pgam.p, dist ? cP : G, cS, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, rs,
+            // KA: all rows on every rank (sharded: no exchange needed before the SpMV)
+            hipLaunchKernelGGL(kr_ka, dim3(GA), dim3(BLK), 0, s, (int64_t)0, n, prm, s0, s1, dist ? D.scal + 1 : pmin.p, dist ? D.scal + 2 : pmax.p,
+                               dist ? D.scal : psum.p, dist ? cP : G, cS, pgam.p, GA, dist ? 1 : 0, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, rs,
                                pk1.p, pgam.p, flags);
-            if (dist) {
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pk1.p, G, 0, my_scal);
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pgam.p, G, 1, my_scal + 3);
-                int rc;
-                if ((rc = xchg(B3C_BUF_SCAL_VEC))) return rc;
-            }
             t++;
             tmark();
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
@@ -1775,13 +1802,14 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
             // KCD consumes pkb (GSP), produces pmin / pmax / psum (G)
             hipLaunchKernelGGL(kr_kcd, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : pkb.p, dist ? cP : GSP, cS, y.p, p.p,
-                               rk.p, w.p, v.p, Z.p, pmin.p, pmax.p, psum.p);
+                               rk.p, w.p, v.p, Z.p, pmin.p, pmax.p, psum.p, dist ? 1 : 0);
             if (dist) {
+                // second (and last) exchange of the tick: this rank's slice of Z with the partials of rk.Z, min and max
                 hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, psum.p, G, 0, my_scal);
                 hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pmin.p, G, 1, my_scal + 1);
                 hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pmax.p, G, 2, my_scal + 2);
                 int rc;
-                if ((rc = xchg(B3C_BUF_SCAL))) return rc;
+                if ((rc = xchg(B3C_BUF_SCAL_VEC))) return rc;
             }
             t++;
             ticks++;
@@ -1824,14 +1852,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 
     unsigned long long hc[4];
     HIP_TRY(ctx, hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
-    if (dist) {
-        // every rank holds only its slice of x: all-gather it through the operand buffer
-        if (nloc > 0)
-            HIP_TRY(ctx, hipMemcpyAsync(D.vec + r0, x.p + r0, sizeof(double) * (size_t)nloc, hipMemcpyDeviceToDevice, s));
-        int rc = xchg(B3C_BUF_VEC);
-        if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(x.p, D.vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    }
+    // (sharded: x was advanced for all rows by every rank, nothing to gather)
     if (reorder) {
         hipLaunchKernelGGL(kr_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x.p, old2new.p, w.p);
         HIP_TRY(ctx, hipMemcpyAsync(x_out, w.p, sizeof(double) * (size_t)n, hipMemcpyDefault, s));

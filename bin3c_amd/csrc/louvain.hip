@@ -1161,7 +1161,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             if (dist) {
                 // integer partial sums of the ranks: exact, so the order of the final addition is irrelevant
                 HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, ctr.p + 2, sizeof(u64), hipMemcpyDeviceToDevice, s));
-                if (D.allgather(D.user, B3C_BUF_ISUM) != 0) return ctx->fail(B3C_E_HIP, "b3c_louvain: all-gather callback failed");
+                { const int rx_ = b3c_dist_exchange(ctx, B3C_BUF_ISUM); if (rx_) return rx_; }
                 std::vector<int64_t> parts(2 * (size_t)D.world);
                 { const int rb_ = b3c_readback(ctx, parts.data(), D.isum, sizeof(int64_t) * parts.size()); if (rb_) return rb_; }
                 u64 tot_i2 = 0;
@@ -1225,8 +1225,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 #undef LV_DECIDE
                 }
                 evs.rec();
-                if (dist && D.allgather(D.user, B3C_BUF_LABELS) != 0)
-                    return ctx->fail(B3C_E_HIP, "b3c_louvain: all-gather callback failed");
+                if (dist) { const int rx_ = b3c_dist_exchange(ctx, B3C_BUF_LABELS); if (rx_) return rx_; }
                 info->n_move_launch++;
                 if (incr) {
                     const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;

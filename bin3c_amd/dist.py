@@ -1,19 +1,24 @@
 """
-Row-sharded multi-GPU execution of the hot path: one process per GPU (torch.distributed, backend "nccl" =
-RCCL over xGMI), every rank holds the whole locality-ordered map and works on the contig-row range
-[rank*chunk, (rank+1)*chunk).  libb3c calls back into :class:`DistSession` whenever the other ranks' slices
-are needed (include/b3c.h "multi-GPU"):
+Row-sharded multi-GPU execution of the hot path: one process per GPU (launched by torch.distributed.run), every rank
+holds the whole locality-ordered map and works on the contig-row range [rank*chunk, (rank+1)*chunk)
+(include/b3c.h "multi-GPU").
 
-    KR, per SpMV     all-gather of the operand slice x∘p (8·n bytes in total) + up to four all-gathers of
-                     four packed partial scalars (p·w | rk·rk, min/max of ynew, rk·Z | gamma), reduced by
-                     every rank in rank order -> identical control flow everywhere
-    Louvain level 0  all-gather of the decided labels per sub-round (4·n bytes), all-gather of one integer
-                     partial sum per modularity evaluation; moves are applied by every rank
+Transport.  On real multi-GPU runs (torch.distributed backend "nccl") the session creates an RCCL communicator INSIDE
+libb3c (b3c_dist_comm_create; the 128-byte unique id travels over torch.distributed once) and libb3c then issues every
+collective itself on its stream -- ncclAllGather over xGMI, no Python in the loop.  With any other backend (gloo: the
+CPU / one-GPU tests) libb3c calls back into :meth:`DistSession._allgather`, which moves the same buffers with
+torch.distributed.
 
-The reference has no counterpart (single process); this is north_star's "sharded by
-contig-row range with RCCL all-reduce over xGMI for the KR column sums and community-weight vectors".
-xGMI is point to point (7 links per GPU), the vector exchange is 1-8 MB per rank and the scalar ones are
-latency bound, so each exchange is ONE collective and nothing is exchanged that can be recomputed.
+    KR, per SpMV     two exchanges: the partial of p.w | rk.rk after the SpMV, and after the vector step the slice of
+                     Z = rk*v together with the partials of min/max(ynew) and rk.Z (one grouped launch); every rank then
+                     advances p, y, x and the operand for all rows itself, so the operand is never exchanged
+    Louvain level 0  all-gather of the decided labels per sub-round (4 n bytes), one integer partial sum per modularity
+                     evaluation; moves are applied by every rank
+
+The reference has no counterpart (single process); this is north_star's "sharded by contig-row
+range with RCCL all-reduce over xGMI for the KR column sums and community-weight vectors".  xGMI is point to point
+(7 links per GPU), the vector exchange is 1-8 MB per rank and the scalar ones are latency bound, so every exchange is
+ONE launch and nothing is exchanged that can be recomputed.
 """
 import ctypes as C
 import os
@@ -28,7 +33,7 @@ BUF_VEC, BUF_SCAL, BUF_LABELS, BUF_ISUM, BUF_SCAL_VEC = 0, 1, 2, 3, 4
 class B3CDist(C.Structure):
     _fields_ = [('rank', C.c_int32), ('world', C.c_int32), ('chunk', C.c_int64), ('vec', C.c_void_p),
                 ('scal', C.c_void_p), ('labels', C.c_void_p), ('isum', C.c_void_p), ('allgather', C.c_void_p),
-                ('user', C.c_void_p)]
+                ('user', C.c_void_p), ('comm', C.c_void_p)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
@@ -84,14 +89,39 @@ class DistSession(object):
         self.labels = torch.zeros(tot, dtype=torch.int32, device=dev)
         self.isum = torch.zeros(2 * self.world, dtype=torch.int64, device=dev)
         self._bufs = {BUF_VEC: self.vec, BUF_SCAL: self.scal, BUF_LABELS: self.labels, BUF_ISUM: self.isum}
-        self.n_exchanges = 0
         self._error = None
         self._cb = ALLGATHER_FN(self._allgather)          # keep a reference: ctypes callbacks are not owned by C
-        d = B3CDist(self.rank, self.world, self.chunk, self.vec.data_ptr(), self.scal.data_ptr(),
-                    self.labels.data_ptr(), self.isum.data_ptr(), C.cast(self._cb, C.c_void_p), None)
-        self._struct = d
         lib = ctx.lib
+        # RCCL inside libb3c when the job runs on the nccl backend (or on request); the callback transport otherwise
+        want = os.environ.get('B3C_DIST_TRANSPORT', 'auto')
+        use_rccl = want == 'rccl' or (want == 'auto' and dist.get_backend(group) == 'nccl')
+        self.comm = None
+        if use_rccl:
+            ident = np.zeros(128, dtype=np.uint8)
+            if self.rank == 0:
+                ctx._check(lib.b3c_dist_unique_id(ident.ctypes.data_as(C.c_void_p)))
+            t = torch.from_numpy(ident)
+            if dist.get_backend(group) == 'nccl':
+                t = t.to(dev)
+                dist.broadcast(t, 0, group=group)
+                ident = t.cpu().numpy()
+            else:
+                dist.broadcast(t, 0, group=group)
+            comm = C.c_void_p()
+            ctx._check(lib.b3c_dist_comm_create(ctx.h, self.world, self.rank, ident.ctypes.data_as(C.c_void_p), C.byref(comm)))
+            self.comm = comm
+        self.transport = 'rccl (in libb3c)' if self.comm else 'callback ({})'.format(dist.get_backend(group))
+        self._x0 = int(lib.b3c_ctx_exchanges(ctx.h))
+        d = B3CDist(self.rank, self.world, self.chunk, self.vec.data_ptr(), self.scal.data_ptr(),
+                    self.labels.data_ptr(), self.isum.data_ptr(), C.cast(self._cb, C.c_void_p), None,
+                    self.comm.value if self.comm else None)
+        self._struct = d
         ctx._check(lib.b3c_ctx_set_dist(ctx.h, C.byref(d)))
+
+    @property
+    def n_exchanges(self):
+        """collectives libb3c issued since this session was installed (either transport)"""
+        return int(self.ctx.lib.b3c_ctx_exchanges(self.ctx.h)) - self._x0
 
     def _allgather(self, user, buf_id):
         import torch
@@ -99,7 +129,6 @@ class DistSession(object):
             with torch.cuda.stream(self.ctx.torch_stream):    # the stream libb3c launches on: ordered with its kernels
                 for b in ((BUF_SCAL, BUF_VEC) if buf_id == BUF_SCAL_VEC else (buf_id,)):
                     allgather_inplace(self._bufs[b], self.rank, self.world, self.group)
-                    self.n_exchanges += 1
             return 0
         except Exception as ex:                                # never let an exception cross the C frame
             self._error = ex
@@ -107,7 +136,11 @@ class DistSession(object):
 
     def close(self):
         if self.ctx.h is not None:
+            self._final = self.n_exchanges
             self.ctx.lib.b3c_ctx_set_dist(self.ctx.h, None)
+            if self.comm:
+                self.ctx._check(self.ctx.lib.b3c_dist_comm_destroy(self.ctx.h, self.comm))
+                self.comm = None
 
     def check(self):
         if self._error is not None:

@@ -30,6 +30,7 @@ extern "C" {
 #define B3C_E_NAN (-3)    /* RuntimeError('scale vector has developed invalid values (NANs)!') sparse_utils.py:193 */
 #define B3C_E_NOCONV (-4) /* RuntimeError('matrix balancing failed to converge in {} iterations') sparse_utils.py:214 */
 #define B3C_E_NOMEM (-5)
+#define B3C_E_RCCL (-6)   /* a collective of the row-sharded multi-GPU path failed (no reference counterpart) */
 
 #define B3C_F64 0
 #define B3C_U32 1
@@ -84,19 +85,26 @@ int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
 
 /* ---- multi-GPU: contig-row ranges of ONE map across ranks ---------------------------------- */
 
-/* Every rank holds the whole (ordered) matrix and works on the rows [rank*chunk, (rank+1)*chunk); what
- * the other ranks need is exchanged through the four caller-owned device buffers below, each laid out
- * as `world` equal slices, by calling `allgather(user, buffer_id)`: "all-gather buffer_id in place, my
- * slice is already written".  The callback must enqueue the collective on the context's stream (RCCL via
- * torch.distributed in bin3c_amd/dist.py) and return 0.  KR exchanges the operand slice of x∘p once and
- * four packed scalars up to four times per SpMV; Louvain exchanges the decided labels once per
- * sub-round and one integer per modularity evaluation.  All ranks reduce the gathered partials in rank
- * order, so every rank takes identical decisions and results do not depend on timing. */
-#define B3C_BUF_VEC 0     /* double[world*chunk]  KR operand / final x            */
+/* One process per GPU.  Every rank holds the whole (ordered) matrix and WORKS on the rows [rank*chunk, (rank+1)*chunk);
+ * what the other ranks need is exchanged through four caller-owned device buffers, each laid out as `world` equal
+ * slices, by an in-place all-gather ("my slice is already written").  All ranks reduce the gathered partials in rank
+ * order, so every rank takes identical decisions and results do not depend on timing.
+ *
+ * Transport: with `comm` set (an RCCL communicator from b3c_dist_comm_create) libb3c issues ncclAllGather itself on the
+ * context's stream -- xGMI between the GPUs of a node, no host round trip.  With comm == NULL it calls
+ * `allgather(user, buffer_id)` instead, which must enqueue the same collective on the context's stream and return 0
+ * (torch.distributed with gloo in the CPU / one-GPU tests, bin3c_amd/dist.py).
+ *
+ * KR: two exchanges per SpMV -- the partial of p.w | rk.rk after the SpMV (B3C_BUF_SCAL), and after the vector step the
+ * slice of Z = rk*v together with the partials of min/max(ynew) and rk.Z (B3C_BUF_SCAL_VEC, one grouped launch); p, y, x
+ * and the operand x*p are then advanced for ALL rows by every rank, so the operand itself is never exchanged.
+ * Louvain level 0: the decided labels once per sub-round (B3C_BUF_LABELS), one integer per modularity evaluation
+ * (B3C_BUF_ISUM); moves are applied by every rank. */
+#define B3C_BUF_VEC 0     /* double[world*chunk]  KR: Z slices                     */
 #define B3C_BUF_SCAL 1    /* double[world*4]      KR partial sums / min / max      */
 #define B3C_BUF_LABELS 2  /* int32[world*chunk]   Louvain decided communities      */
 #define B3C_BUF_ISUM 3    /* int64[world*2]       Louvain integer partial sums     */
-#define B3C_BUF_SCAL_VEC 4 /* B3C_BUF_SCAL, then B3C_BUF_VEC, in one call (one host round trip per SpMV less) */
+#define B3C_BUF_SCAL_VEC 4 /* B3C_BUF_SCAL and B3C_BUF_VEC in one (grouped) exchange */
 typedef int (*b3c_allgather_fn)(void *user, int buffer_id);
 typedef struct {
     int32_t rank, world;
@@ -105,12 +113,21 @@ typedef struct {
     double *scal;
     int32_t *labels;
     int64_t *isum;
-    b3c_allgather_fn allgather;
+    b3c_allgather_fn allgather;   /* used when comm == NULL */
     void *user;
+    void *comm;           /* ncclComm_t of b3c_dist_comm_create, or NULL */
 } b3c_dist;
 /* Install (or with NULL remove) the sharding description; it applies to b3c_kr_balance and b3c_louvain
  * calls on matrices with n <= world*chunk rows.  No reference counterpart (bin3C is single process). */
 int b3c_ctx_set_dist(b3c_ctx *ctx, const b3c_dist *dist);
+/* RCCL communicator over the ranks' GPUs: rank 0 obtains a unique id (128 bytes, host memory), the caller hands it to
+ * every rank (any side channel: torch.distributed broadcast, MPI, a file), every rank creates its communicator on its
+ * context's device.  librccl.so.1 is bound at run time. */
+int b3c_dist_unique_id(void *id128);
+int b3c_dist_comm_create(b3c_ctx *ctx, int world, int rank, const void *id128, void **comm_out);
+int b3c_dist_comm_destroy(b3c_ctx *ctx, void *comm);
+/* Exchanges issued through this context since it was created (both transports). */
+int64_t b3c_ctx_exchanges(const b3c_ctx *ctx);
 
 /* ---- matrices ------------------------------------------------------------------------------ */
 

@@ -48,7 +48,7 @@ def test_kr_on_an_input_that_turns_nan_behaves_like_the_reference(ctx):
     (:146) is False and the outer loop ends before the inner loop could test x again.  The reference therefore RETURNS a
     NaN scale vector without raising or warning; so does the device (same iteration count, same NaN pattern), and
     B3C_E_NAN stays reserved for the check should it ever fire."""
-    g = np.load(os.path.join(GOLDEN, 'kr_nan_input.npz'))
+    g = np.load(os.path.join(GOLDEN, 'nan_input_kr.npz'))
     assert str(g['error']) == ''
     rc, x, info = ctx.kr_balance(ctx.upload(g['in_indptr'], g['in_indices'], g['in_data']), check=False)
     assert rc == 0 and info.n_iter == int(g['n_iter'])

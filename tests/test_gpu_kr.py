@@ -47,7 +47,7 @@ def test_kr_bound_branches_taken_on_device(ctx):
     g = np.load(os.path.join(GOLDEN, 'kr_delta_bound.npz'))
     _, _, info = ctx.kr_balance(ctx.upload(g['in_indptr'], g['in_indices'], g['in_data']))
     assert info.hit_delta > 0
-    g = np.load(os.path.join(GOLDEN, 'kr_Delta_bound.npz'))
+    g = np.load(os.path.join(GOLDEN, 'kr_bigDelta_bound.npz'))
     _, _, info = ctx.kr_balance(ctx.upload(g['in_indptr'], g['in_indices'], g['in_data']))
     assert info.hit_Delta > 0
 

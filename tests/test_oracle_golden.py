@@ -39,7 +39,7 @@ def test_kr_bound_cases_hit_their_branches(oracle_lib):
     g = np.load(os.path.join(GOLDEN, 'kr_delta_bound.npz'))
     _, _, st = oracle_lib.kr_balance(g['in_indptr'], g['in_indices'], g['in_data'])
     assert st.hit_delta > 0
-    g = np.load(os.path.join(GOLDEN, 'kr_Delta_bound.npz'))
+    g = np.load(os.path.join(GOLDEN, 'kr_bigDelta_bound.npz'))
     _, _, st = oracle_lib.kr_balance(g['in_indptr'], g['in_indices'], g['in_data'])
     assert st.hit_Delta > 0
 

@@ -168,7 +168,7 @@ def kr_cases():
     cases['delta_bound'] = (m, {})
     # Delta bound: tiny row sums need y to grow past Delta=3 in the first outer iteration
     m = (sym_random(300, 0.08, 31) * 1e-3).tocsr()
-    cases['Delta_bound'] = (m, {})
+    cases['bigDelta_bound'] = (m, {})
     # already bistochastic: permutation-like + identity mix
     n = 128
     p = np.roll(np.arange(n), 1)

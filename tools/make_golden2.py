@@ -6,7 +6,7 @@ Build container only (needs /root/reference).  Adds, without touching the round-
 
   accumulate.npz     Sparse2DAccumulator.get_coo (sparse_utils.py:227-266) on a random pair stream
   reorder_seq.npz    ContactMap._reorder_seq (contact_map.py:1066-1085): P A P^T for a gapless order
-  kr_nan_input.npz   kr_biostochastic on an input that drives the scale vector to NaN: what the reference RETURNS
+  nan_input_kr.npz   kr_biostochastic on an input that drives the scale vector to NaN: what the reference RETURNS
                      (sparse_utils.py:192-193 never fires: a NaN in x makes v, rk and rout NaN, and `rout > rt` is then
                      False, so the outer loop ends first)
   edges_nx.npz       the bytes networkx.write_edgelist(g, f, data=['weight'], delimiter=' ') writes (cluster.py:139-151)
@@ -101,8 +101,8 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         res = mg.run_kr(ns, cap, mm, {})
-    print('kr_nan_input: n_iter={} err={!r} nan in x: {}'.format(res['n_iter'], res['error'], int(np.isnan(res['x']).sum())))
-    mg.save('kr_nan_input', in_indptr=mm.indptr.astype(np.int64), in_indices=mm.indices.astype(np.int32), in_data=mm.data,
+    print('nan_input_kr: n_iter={} err={!r} nan in x: {}'.format(res['n_iter'], res['error'], int(np.isnan(res['x']).sum())))
+    mg.save('nan_input_kr', in_indptr=mm.indptr.astype(np.int64), in_indices=mm.indices.astype(np.int32), in_data=mm.data,
             x=res['x'], n_iter=res['n_iter'], error=res['error'])
 
     # ---------------- edge list as networkx writes it ----------------
