@@ -1131,6 +1131,293 @@ __global__ void __launch_bounds__(BLK) kr_kb_tcd(int64_t r0, int64_t r1, int64_t
     block_partial_at<0>(contrib, part_out, tile, lds);
 }
 
+// The same with the two kinds of entries on DIFFERENT waves of a 512-thread workgroup: waves 0-3 stream the dictionary
+// entries (LDS operands), waves 4-7 the row tails (operands gathered from global memory).  The two access patterns wait on
+// different things (the HBM stream / the L2 round trips of the gathers), so they overlap inside the workgroup, and a
+// workgroup brings twice the waves for the same LDS.  Row sums meet in LDS; the epilogue is one thread per row with
+// coalesced loads and stores.
+constexpr int TBK = 512;
+
+// sum of P partials by NT threads, identical in every block and to every thread (fixed order)
+template <int NT>
+__device__ double reduce_sum_n(const double *__restrict__ part, int P, int stride, double *lds)
+{
+    const int t = threadIdx.x;
+    double v = 0.0;
+    constexpr int U = 8;
+    for (int base = 0; base < P; base += NT * U) {
+        double q[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + t + u * NT;
+            q[u] = i < P ? part[(size_t)i * stride] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) v += q[u];
+    }
+    lds[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (t < s) lds[t] = lds[t] + lds[t + s];
+        __syncthreads();
+    }
+    const double r = lds[0];
+    __syncthreads();
+    return r;
+}
+
+template <int LPR, int UN, int TLPR, int TU>
+__global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_t ncols, int R, int dlds, int dstride, int ntiles,
+                                                   int swz, const KRState *__restrict__ sin, KRState *__restrict__ sout,
+                                                   const double *__restrict__ partA, int PA, int PS,
+                                                   const int64_t *__restrict__ indptr, const uint32_t *__restrict__ packed,
+                                                   const int32_t *__restrict__ pcol, const int32_t *__restrict__ n1v,
+                                                   const int32_t *__restrict__ dict_cols, const int32_t *__restrict__ dict_cnt,
+                                                   const double *__restrict__ rs, const double *__restrict__ dfix,
+                                                   const double *__restrict__ u, const double *__restrict__ x,
+                                                   const double *__restrict__ p, double *__restrict__ v,
+                                                   double *__restrict__ rk, double *__restrict__ w,
+                                                   double *__restrict__ part_out, int hub_len)
+{
+    extern __shared__ __attribute__((aligned(16))) double ksm[];
+    double *xl = ksm;                         // dlds operands of the tile's dictionary
+    double *od = xl + dlds, *ot = od + R;     // row sums over the dictionary entries / over the tails
+    int64_t *ipl = (int64_t *)(ot + R);       // R + 1 row pointers
+    double *lds = (double *)(ipl + R + 1);    // TBK doubles for the reductions
+    int32_t *n1l = (int32_t *)(lds + TBK);    // R dictionary-entry counts
+    int64_t tile = blockIdx.x;
+    if (swz) {
+        const int per = (ntiles + 7) / 8;
+        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    }
+    const bool live = tile < ntiles;          // padding blocks of the swizzled grid carry no tile
+    const int tid = threadIdx.x;
+    const int64_t ra = r0 + (live ? tile : 0) * R;
+    const int nrows = live ? (int)((ra + R < r1 ? ra + R : r1) - ra) : 0;
+    // everything that does not depend on the control state is requested first
+    const int D1 = live ? dict_cnt[tile] : 0;
+    for (int i = tid; i <= nrows && live; i += TBK) ipl[i] = indptr[ra + i];
+    for (int i = tid; i < nrows; i += TBK) n1l[i] = n1v[ra + i - r0];
+    // the epilogue operands of "my" row (thread i < nrows owns row ra + i at the end)
+    double ex = 0.0, ed = 0.0, er = 1.0, ep = 0.0, ev = 0.0;
+    if (tid < nrows) {
+        ex = x[ra + tid];
+        ed = dfix[ra + tid];
+        er = rs ? rs[ra + tid] : 1.0;
+        ep = p[ra + tid];
+        ev = v[ra + tid];
+    }
+    {
+        const int32_t *__restrict__ dc1 = dict_cols + (live ? tile : 0) * (int64_t)dstride;
+        for (int base = 0; base < D1; base += TBK * 4) {
+            int32_t cc[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = base + q * TBK + tid; cc[q] = i < D1 ? dc1[i] : 0; }
+            double gg[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) gg[q] = u[(uint32_t)cc[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = base + q * TBK + tid; if (i < D1) xl[i] = gg[q]; }
+        }
+    }
+    if (D1 == 0 && tid == 0) xl[0] = 0.0;     // masked lanes multiply a zero count with xl[0]: keep stale LDS (NaN) out
+    KRState st = *sin;
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_sum_n<TBK>(partA, PA, PS, lds);   // :160
+    const bool inner = st.phase == A_INNER;
+    if (st.phase == A_INNER) st.phase = B_INNER;
+    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
+    __syncthreads();
+
+    const int64_t e0 = ipl[0];
+    const uint32_t ebytes = __builtin_amdgcn_readfirstlane((uint32_t)((ipl[nrows] - e0) * 4));
+    const uint64_t pa = (uint64_t)(packed + e0), ca = (uint64_t)(pcol + e0);
+    const uint32_t palo = __builtin_amdgcn_readfirstlane((uint32_t)pa), pahi = __builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
+    const uint32_t calo = __builtin_amdgcn_readfirstlane((uint32_t)ca), cahi = __builtin_amdgcn_readfirstlane((uint32_t)(ca >> 32));
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)pahi << 32) | palo), 0, (int)ebytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)cahi << 32) | calo), 0, (int)ebytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, (int)(ncols * 8), 0x00020000);
+    constexpr uint32_t NOLOAD = 0xFFFFFFFFu;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wv < 4) {
+        // ---- dictionary entries: LPR lanes per row, UN 16-byte vectors per lane, next row prefetched ----
+        constexpr int RPW = 64 / LPR;
+        constexpr int RPP = RPW * 4;
+        constexpr int CH = LPR * UN * 4;
+        const int sub = lane / LPR, sl = lane % LPR;
+        int rl = wv * RPW + sub;
+        uint32_t so = 0;
+        int n1 = 0;
+        if (rl < nrows) {
+            so = (uint32_t)((ipl[rl] - e0) * 4);
+            n1 = ipl[rl + 1] - ipl[rl] > hub_len ? 0 : n1l[rl];
+        }
+        u32x4 c[UN];
+#pragma unroll
+        for (int q = 0; q < UN; q++) {
+            const int i = (q * LPR + sl) * 4;
+            c[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1 ? so + (uint32_t)i * 4u : NOLOAD, 0, 0);
+        }
+        while (rl < nrows) {
+            const int rln = rl + RPP;
+            uint32_t son = 0;
+            int n1n = 0;
+            if (rln < nrows) {
+                son = (uint32_t)((ipl[rln] - e0) * 4);
+                n1n = ipl[rln + 1] - ipl[rln] > hub_len ? 0 : n1l[rln];
+            }
+            u32x4 c2[UN];
+#pragma unroll
+            for (int q = 0; q < UN; q++) {
+                const int i = (q * LPR + sl) * 4;
+                c2[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1n ? son + (uint32_t)i * 4u : NOLOAD, 0, 0);
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < UN; q++) {
+                const int i = (q * LPR + sl) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t e = i + j < n1 ? c[q][j] : 0u;
+                    acc += (double)(e & 0xFFFFu) * xl[e >> 16];
+                }
+            }
+            for (int base = CH; base < n1; base += CH) {          // more dictionary entries than one chunk
+#pragma unroll
+                for (int q = 0; q < UN; q++) {
+                    const int i = base + (q * LPR + sl) * 4;
+                    const u32x4 cc = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1 ? so + (uint32_t)i * 4u : NOLOAD, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t e = i + j < n1 ? cc[j] : 0u;
+                        acc += (double)(e & 0xFFFFu) * xl[e >> 16];
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
+            if (sl == 0) od[rl] = acc;
+            rl = rln;
+            so = son;
+            n1 = n1n;
+#pragma unroll
+            for (int q = 0; q < UN; q++) c[q] = c2[q];
+        }
+    } else {
+        // ---- row tails: TLPR lanes per row, TU 16-byte vectors of (count, column) per lane, next row prefetched ----
+        constexpr int RPW = 64 / TLPR;
+        constexpr int RPP = RPW * 4;
+        constexpr int TCH = TLPR * TU * 4;
+        const int sub = lane / TLPR, sl = lane % TLPR;
+        int rl = (wv - 4) * RPW + sub;
+        uint32_t so = 0;
+        int t0 = 0, len = 0;                  // the tail is entries [t0, len) of the row
+        if (rl < nrows) {
+            so = (uint32_t)((ipl[rl] - e0) * 4);
+            len = (int)(ipl[rl + 1] - ipl[rl]);
+            t0 = n1l[rl];
+            if (len > hub_len) { len = 0; t0 = 0; }
+        }
+        u32x4 tc[TU], tcol[TU];
+#pragma unroll
+        for (int k = 0; k < TU; k++) {
+            const int t = t0 + (k * TLPR + sl) * 4;
+            const uint32_t off = t < len ? so + (uint32_t)t * 4u : NOLOAD;
+            tc[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0);
+            tcol[k] = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
+        }
+        while (rl < nrows) {
+            const int rln = rl + RPP;
+            uint32_t son = 0;
+            int t0n = 0, lenn = 0;
+            if (rln < nrows) {
+                son = (uint32_t)((ipl[rln] - e0) * 4);
+                lenn = (int)(ipl[rln + 1] - ipl[rln]);
+                t0n = n1l[rln];
+                if (lenn > hub_len) { lenn = 0; t0n = 0; }
+            }
+            double tg[TU][4];
+#pragma unroll
+            for (int k = 0; k < TU; k++) {
+                const int t = t0 + (k * TLPR + sl) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len ? tcol[k][j] * 8u : NOLOAD, 0, 0);
+                    tg[k][j] = __hiloint2double((int)gw.y, (int)gw.x);
+                }
+            }
+            u32x4 tc2[TU], tcol2[TU];
+#pragma unroll
+            for (int k = 0; k < TU; k++) {
+                const int t = t0n + (k * TLPR + sl) * 4;
+                const uint32_t off = t < lenn ? son + (uint32_t)t * 4u : NOLOAD;
+                tc2[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0);
+                tcol2[k] = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < TU; k++) {
+                const int t = t0 + (k * TLPR + sl) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc += (t + j < len ? (double)(tc[k][j] & 0xFFFFu) : 0.0) * tg[k][j];
+            }
+            for (int base = t0 + TCH; base < len; base += TCH) {  // longer tails
+#pragma unroll
+                for (int k = 0; k < TU; k++) {
+                    const int t = base + (k * TLPR + sl) * 4;
+                    const uint32_t off = t < len ? so + (uint32_t)t * 4u : NOLOAD;
+                    const u32x4 cn = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0);
+                    const u32x4 cl = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len ? cl[j] * 8u : NOLOAD, 0, 0);
+                        acc += (t + j < len ? (double)(cn[j] & 0xFFFFu) : 0.0) * __hiloint2double((int)gw.y, (int)gw.x);
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = TLPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, TLPR);
+            if (sl == 0) ot[rl] = acc;
+            rl = rln;
+            so = son;
+            t0 = t0n;
+            len = lenn;
+#pragma unroll
+            for (int k = 0; k < TU; k++) { tc[k] = tc2[k]; tcol[k] = tcol2[k]; }
+        }
+    }
+    __syncthreads();
+    // epilogue: one thread per row, coalesced
+    double contrib = 0.0;
+    if (tid < nrows && ipl[tid + 1] - ipl[tid] <= hub_len) {        // hub rows are written by kr_kb_hub
+        const double pi = inner ? ep : 0.0;
+        const double t = (od[tid] + ot[tid]) * er + ed * (inner ? ex * pi : ex);
+        if (inner) {
+            const double wi = ex * t + ev * pi;
+            w[ra + tid] = wi;
+            contrib = pi * wi;
+        } else {
+            const double vn = ex * t;
+            const double r = 1.0 - vn;
+            v[ra + tid] = vn;
+            rk[ra + tid] = r;
+            contrib = r * r;
+        }
+    }
+    contrib = wave_sum(contrib);
+    if (lane == 0) lds[wv] = contrib;
+    __syncthreads();
+    if (tid == 0) {
+        double r = lds[0];
+#pragma unroll
+        for (int q = 1; q < TBK / 64; q++) r += lds[q];
+        part_out[tile] = r;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // KCD: inner -> alpha (:166), min/max of ynew = y + alpha p (:167-171,179) and, speculatively, the CG update
 //               rk -= alpha w, Z = rk*v, partial rk.Z (:186-190); y itself is advanced by the next KA
@@ -1551,9 +1838,11 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int64_t tcd_tiles = (nloc + tcd_R - 1) / tcd_R;
     const bool tcd_swz = getenv("B3C_KR_TCD_NOSWZ") == nullptr && tcd_tiles >= 64;
     const int64_t tcd_grid = tcd_swz ? 8 * ((tcd_tiles + 7) / 8) : tcd_tiles;
-    // opt-in for now (B3C_KR_TCD=1): at C3 the SpMV runs at 0.44-0.46 ms against 0.50 ms for kr_kb_vec, which the 4 ms of
-    // kr_tcd_build (62 SpMVs per call) eats again; see DESIGN.md section 4
-    const bool tcd_may = counts && nloc > 0 && a->nnz > 0 && getenv("B3C_KR_TCD") != nullptr && getenv("B3C_KR_NO_TCD") == nullptr;
+    // On by default while the operand vector fits one XCD's L2 (n <= 2^19: C2 runs its SpMV in 28 instead of 39 us and the
+    // build is one bitmap pass); beyond that opt-in (B3C_KR_TCD=1): at C3 the SpMV reaches 0.42-0.46 ms against 0.50 ms for
+    // kr_kb_vec, which the 4 ms of kr_tcd_build (62 SpMVs per call) eat again -- see DESIGN.md section 4
+    const bool tcd_auto = n <= ((int64_t)1 << TCD_CHUNK_LG) && n >= 4096 && avg >= 16;
+    const bool tcd_may = counts && nloc > 0 && a->nnz > 0 && (tcd_auto || getenv("B3C_KR_TCD") != nullptr) && getenv("B3C_KR_NO_TCD") == nullptr;
     const int GS_max = (int)std::max<int64_t>(GS_rows, tcd_may ? tcd_tiles : 0);
     // hub rows add one partial each behind the GS of the row kernel (at most nnz / HUB_LEN of them)
     // threshold: twice the pipelined chunk of the row-group kernel that will run, at least HUB_LEN (sweep on a power-law
@@ -1712,7 +2001,12 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     double *my_scal = dist ? D.scal + 4 * D.rank : nullptr;
     auto xchg = [&](int buf) -> int { return b3c_dist_exchange(ctx, buf); };
     const int cP = dist ? D.world : 0, cS = dist ? 4 : 1;      // consumer view of gathered partials
+    const bool tcd_split = tcd && tcd_R <= TBK && getenv("B3C_KR_TCD_NOSPLIT") == nullptr;
+    const size_t tcd_shmem2 = sizeof(double) * ((size_t)tcd_lds_d + 2 * (size_t)tcd_R + (size_t)tcd_R + 1 + TBK) + sizeof(int32_t) * (size_t)tcd_R;
     if (tcd) {
+#define KR_TCD2_ATTR(L, U, TL, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tcd_shmem2))
+        KR_TCD2_ATTR(16, 4, 8, 1); KR_TCD2_ATTR(16, 4, 16, 1); KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 8, 4, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
+#undef KR_TCD2_ATTR
 #define KR_TCD_ATTR(L, U, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tcd_shmem))
         KR_TCD_ATTR(16, 4, 2); KR_TCD_ATTR(8, 8, 2); KR_TCD_ATTR(8, 8, 1); KR_TCD_ATTR(32, 2, 1); KR_TCD_ATTR(16, 4, 1);
         KR_TCD_ATTR(8, 4, 1); KR_TCD_ATTR(4, 4, 1); KR_TCD_ATTR(4, 2, 1);
@@ -1757,7 +2051,22 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             // KB consumes pk1 (from KA, G partials; first inner iteration only), produces pkb (GS partials)
             const double *kbp = dist ? D.scal : pk1.p;
             const int kbP = dist ? D.world : G, kbS = cS;
-            if (tcd) {
+            if (tcd && tcd_split) {
+                // dictionary waves and tail waves side by side (512-thread workgroups)
+#define KR_TCD2(L, U, TL, T)                                                                                                 \
+    hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T>), dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d,   \
+                       tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p,      \
+                       dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len)
+                const int shp2 = getenv("B3C_KR_TCD_SHAPE2") ? atoi(getenv("B3C_KR_TCD_SHAPE2")) : 0;
+                if (shp2 == 16481) KR_TCD2(16, 4, 8, 1);
+                else if (shp2 == 164161) KR_TCD2(16, 4, 16, 1);
+                else if (shp2 == 16482) KR_TCD2(16, 4, 8, 2);
+                else if (shp2 == 8841) KR_TCD2(8, 8, 4, 2);
+                else if (avg > 128) KR_TCD2(16, 4, 8, 2);
+                else if (avg > 48) KR_TCD2(8, 4, 4, 2);
+                else KR_TCD2(4, 4, 4, 1);
+#undef KR_TCD2
+            } else if (tcd) {
                 // tiles with column dictionaries; shape by average row length (4 entries per lane and load)
                 const int shp = getenv("B3C_KR_TCD_SHAPE") ? atoi(getenv("B3C_KR_TCD_SHAPE")) : 0;   // LPR*100 + UN*10 + TU
                 if (shp == 1642) KR_TCD(16, 4, 2);
