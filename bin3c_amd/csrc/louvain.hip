@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
                                                   const int32_t *__restrict__ ids, int64_t *__restrict__ kdeg,
                                                   int64_t *__restrict__ tot, int32_t *__restrict__ com,
                                                   int32_t *__restrict__ nxt, int32_t *__restrict__ csize,
-                                                  u64 *__restrict__ m2)
+                                                  u64 *__restrict__ m2, int64_t *__restrict__ wnl)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
     long long total = 0;
     for (int64_t row = wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
-        long long d = 0;
+        long long d = 0, lw = 0;
         for (int64_t base = s; base < e; base += 256) {
             int32_t j[4];
             long long w[4];
@@ -203,12 +203,17 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
                 w[t] = ok ? q[k] : 0;
             }
 #pragma unroll
-            for (int t = 0; t < 4; t++) d += j[t] == (int32_t)row ? 2 * w[t] : w[t];
+            for (int t = 0; t < 4; t++) {
+                d += j[t] == (int32_t)row ? 2 * w[t] : w[t];
+                lw += j[t] == (int32_t)row ? w[t] : 0;
+            }
         }
         d = wave_sum_ll(d);
+        lw = wave_sum_ll(lw);
         if (lane == 0) {
             const int32_t id = ids ? ids[row] : (int32_t)row;   // community ids live in the caller's numbering
             kdeg[row] = d;
+            wnl[row] = d - 2 * lw;                              // weight towards the OTHER nodes
             tot[id] = d;
             com[row] = id;
             nxt[row] = id;
@@ -436,7 +441,8 @@ __global__ void k_lv_list_fill(int64_t r0, int64_t r1, const int64_t *__restrict
 }
 
 template <int LPR, int UN>
-__global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt, const NodeRec *__restrict__ list, u64 m2,
+__global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int64_t *__restrict__ cnt_dev,
+                                                      const NodeRec *__restrict__ list, u64 m2,
                                                       const int32_t *__restrict__ indices,
                                                       const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
                                                       const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
@@ -445,6 +451,8 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt, const NodeRec 
     constexpr int CAP = 512;                       // >= 1.25 * LPR * UN + 1
     constexpr int LG = 9;
     static_assert(LPR * UN * 5 / 4 + 1 <= CAP, "table too small");
+    // the list may have been thinned on the device (k_lv_prune): its length then sits in device memory
+    const int64_t cnt = cnt_dev ? (*cnt_dev < cnt_max ? *cnt_dev : cnt_max) : cnt_max;
     __shared__ int32_t skeys[WPB][CAP];
     __shared__ u64 svals[WPB][CAP];
     constexpr int RPW = 64 / LPR;
@@ -601,6 +609,42 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt, const NodeRec 
     }
 }
 
+// Exact pruning of the neighbour scan.  With own_i = weight of node i towards the other members of its community a (kept
+// current by k_lv_internal / k_lv_delta_internal), every foreign community c has dnc(c) <= F_i = wnl_i - own_i, hence
+// gain(c) = dnc(c)*2m - tot(c)*k_i <= F_i*2m.  If that bound is below the (positive) gain of staying, or F_i == 0, no
+// neighbour community can win whatever the labels of the neighbours are: the node stays and its row is never read.
+// The others are appended to `out` (any order: decisions do not depend on one another inside a sub-round).
+__global__ void __launch_bounds__(BLK) k_lv_prune(int64_t cnt, const NodeRec *__restrict__ list, u64 m2,
+                                                   const int64_t *__restrict__ kdeg, const int64_t *__restrict__ wnl,
+                                                   const int64_t *__restrict__ own, const int64_t *__restrict__ tot,
+                                                   const int32_t *__restrict__ com, int32_t *__restrict__ nxt,
+                                                   NodeRec *__restrict__ out, unsigned long long *__restrict__ out_cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    for (int64_t base = (int64_t)blockIdx.x * BLK; base < cnt; base += stride) {
+        const int64_t t = base + threadIdx.x;
+        bool keep = false;
+        NodeRec rec;
+        rec.node = 0; rec.deg = 0; rec.start = 0;
+        if (t < cnt) {
+            rec = list[t];
+            const int32_t i = rec.node;
+            const int32_t a = com[i];
+            const long long ki = kdeg[i], o = own[i], f = wnl[i] - o;
+            const i128 stay = (i128)o * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            const bool stays = f <= 0 || (stay > 0 && (i128)f * (i128)m2 < stay);
+            if (stays) nxt[i] = a;
+            keep = !stays;
+        }
+        const unsigned long long m = __ballot(keep);
+        unsigned long long at = 0;
+        if (lane == 0 && m) at = atomicAdd(out_cnt, (unsigned long long)__popcll(m));
+        at = __shfl((long long)at, 0, 64);
+        if (keep) out[at + __popcll(m & ((1ull << lane) - 1ull))] = rec;
+    }
+}
+
 __global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int round, const int32_t *__restrict__ ids,
                                                    const int64_t *__restrict__ kdeg,
                                                    int64_t *__restrict__ tot, int32_t *__restrict__ com,
@@ -663,7 +707,7 @@ __global__ void __launch_bounds__(BLK) k_lv_apply_list(int64_t cnt, const NodeRe
 __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, const int64_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices,
                                                       const int64_t *__restrict__ q, const int32_t *__restrict__ com,
-                                                      u64 *__restrict__ i2)
+                                                      u64 *__restrict__ i2, int64_t *__restrict__ own)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -672,6 +716,7 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
     for (int64_t row = r0 + wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         const int32_t a = com[row];
+        long long mine = 0;                                   // weight towards the other members of the own community
         // four 64-entry slices in flight: index and weight loads first, then the label gathers (integer sums: any order)
         for (int64_t base = s; base < e; base += 256) {
             int32_t j[4];
@@ -689,8 +734,12 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 if (j[t] == (int32_t)row) acc += 2 * w[t];
-                else if (j[t] >= 0 && c[t] == a) acc += w[t];
+                else if (j[t] >= 0 && c[t] == a) { acc += w[t]; mine += w[t]; }
             }
+        }
+        if (own) {                                            // by-product for k_lv_prune (wave-uniform branch)
+            mine = wave_sum_ll(mine);
+            if (lane == 0) own[row] = mine;
         }
     }
     acc = wave_sum_ll(acc);
@@ -704,7 +753,7 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
 __global__ void __launch_bounds__(BLK) k_lv_delta_internal(int64_t cnt, const NodeRec *__restrict__ list,
                                                             const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
                                                             const int32_t *__restrict__ com, const int32_t *__restrict__ nxt,
-                                                            u64 *__restrict__ i2)
+                                                            u64 *__restrict__ i2, int64_t *__restrict__ own)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -714,12 +763,22 @@ __global__ void __launch_bounds__(BLK) k_lv_delta_internal(int64_t cnt, const No
         const NodeRec rec = list[t];
         const int32_t a = com[rec.node], b = nxt[rec.node];
         if (a == b) continue;
+        long long mine = 0;                                   // the mover's weight towards its NEW community, after all moves
         for (int64_t k = rec.start + lane; k < rec.start + rec.deg; k += 64) {
             const int32_t j = indices[k];
             if (j == rec.node) continue;
             const int32_t cj = com[j], nj = nxt[j];
             const int d = (int)(nj == b) - (int)(cj == a);
             if (d) acc += (long long)d * q[k] * (cj == nj ? 2 : 1);
+            if (own) {
+                if (nj == b) mine += q[k];
+                // a neighbour that stays: this mover leaves or joins its community (movers recompute theirs from scratch)
+                if (cj == nj && (cj == a || cj == b)) atomicAdd((u64 *)&own[j], (u64)(cj == a ? -q[k] : q[k]));
+            }
+        }
+        if (own) {
+            mine = wave_sum_ll(mine);
+            if (lane == 0) own[rec.node] = mine;
         }
     }
     acc = wave_sum_ll(acc);
@@ -856,6 +915,105 @@ __global__ void __launch_bounds__(BLK) k_pairs_fill(int64_t n, int64_t kc, const
             keys[pos[row]] = c1 * kc + c1;
             vals[pos[row]] = own;
         }
+    }
+}
+
+// Aggregation by DIRECT BINNING, for levels that end with few communities (kc <= AGG_BINS_KC, i.e. always at level 0 of
+// a metagenome): bins[c1*kc + c2] += q with 64-bit integer atomics (exact: any order gives the same sums), a presence
+// bitmap keeps pairs whose weights sum to zero (the sort path keeps them too).  Per node the entries that stay inside its
+// new community are summed in registers first (loops doubled, as in k_pairs_fill), so ~n + 10 % of nnz atomics reach L2.
+constexpr int64_t AGG_BINS_KC = 4096;
+
+__global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, const int64_t *__restrict__ indptr,
+                                                   const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
+                                                   const int32_t *__restrict__ cn, u64 *__restrict__ bins,
+                                                   uint32_t *__restrict__ present)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        if (e == s) continue;
+        const int64_t c1 = cn[row];
+        long long own = 0;
+        for (int64_t base = s; base < e; base += 256) {
+            int32_t j[4];
+            long long qv[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                const bool ok = k < e;
+                j[t] = ok ? indices[k] : -1;
+                qv[t] = ok ? q[k] : 0;
+            }
+            int32_t c2[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) c2[t] = j[t] >= 0 ? cn[j[t]] : (int32_t)c1;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (j[t] < 0) continue;
+                if (j[t] == (int32_t)row) own += 2 * qv[t];
+                else if (c2[t] == (int32_t)c1) own += qv[t];
+                else {
+                    const int64_t b = c1 * kc + c2[t];
+                    atomicAdd(&bins[b], (u64)qv[t]);
+                    atomicOr(&present[b >> 5], 1u << (b & 31));
+                }
+            }
+        }
+        own = wave_sum_ll(own);
+        if (lane == 0) {
+            const int64_t b = c1 * kc + c1;
+            atomicAdd(&bins[b], (u64)own);
+            atomicOr(&present[b >> 5], 1u << (b & 31));
+        }
+    }
+}
+
+// entries per row of the induced graph = present bits of the row (one wave per row)
+__global__ void __launch_bounds__(BLK) k_bins_count(int64_t kc, const uint32_t *__restrict__ present, int64_t *__restrict__ cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row > kc) return;
+    if (row == kc) { if (lane == 0) cnt[row] = 0; return; }
+    long long c = 0;
+    const int64_t b0 = row * kc, b1 = b0 + kc;
+    for (int64_t wd = (b0 >> 5) + lane; wd <= ((b1 - 1) >> 5); wd += 64) {
+        uint32_t m = present[wd];
+        const int64_t lo = wd << 5;
+        if (lo < b0) m &= ~0u << (b0 - lo);
+        if (lo + 32 > b1) m &= ~0u >> (lo + 32 - b1);
+        c += __popc(m);
+    }
+    c = wave_sum_ll(c);
+    if (lane == 0) cnt[row] = c;
+}
+
+__global__ void __launch_bounds__(BLK) k_bins_fill(int64_t kc, const uint32_t *__restrict__ present, const u64 *__restrict__ bins,
+                                                    const int64_t *__restrict__ indptr, int32_t *__restrict__ indices,
+                                                    int64_t *__restrict__ q)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (row >= kc) return;
+    int64_t o = indptr[row];
+    for (int64_t c0 = 0; c0 < kc; c0 += 64) {
+        const int64_t c = c0 + lane;
+        bool on = false;
+        if (c < kc) {
+            const int64_t b = row * kc + c;
+            on = (present[b >> 5] >> (b & 31)) & 1u;
+        }
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int64_t at = o + __popcll(m & ((1ull << lane) - 1ull));
+            const u64 sum = bins[row * kc + c];
+            indices[at] = (int32_t)c;
+            q[at] = c == row ? (int64_t)(sum / 2) : (int64_t)sum;
+        }
+        o += __popcll(m);
     }
 }
 
@@ -1064,7 +1222,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int64_t n = g.n;
         DevBuf<int64_t> kdeg(ctx, n), tot(ctx, n), goff(ctx, n + 1), gsz(ctx, n + 1);
         DevBuf<int32_t> com(ctx, n), nxt(ctx, n), csize(ctx, n);
-        if (!kdeg.p || !tot.p || !goff.p || !gsz.p || !com.p || !nxt.p || !csize.p) {
+        DevBuf<int64_t> wnl(ctx, n), own(ctx, n);            // weight towards the other nodes / towards the own community (k_lv_prune)
+        if (!kdeg.p || !tot.p || !goff.p || !gsz.p || !com.p || !nxt.p || !csize.p || !wnl.p || !own.p) {
             free_graph(ctx, g);
             return ctx->fail(B3C_E_NOMEM, "b3c_louvain: level buffers");
         }
@@ -1079,7 +1238,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int gv = grid_for(n, BLK, 8 * ctx->n_cu);      // thread-per-node kernels
         HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 8, s));
         hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p,
-                           nxt_p, csize.p, ctr.p);
+                           nxt_p, csize.p, ctr.p, wnl.p);
         hipLaunchKernelGGL(k_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
         u64 hc[8];
         { const int rb_ = b3c_readback(ctx, hc, ctr.p, sizeof(hc)); if (rb_) return rb_; }
@@ -1145,11 +1304,20 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // full: recount the internal weight; otherwise ctr[2] was kept up to date by k_lv_delta_internal.  The sums are
         // launched before the move count of the sweep is known and come back with it in ONE read-back (a host round
         // trip costs as much as k_lv_tot2); moved == 0 leaves *out alone.
+        // exact pruning of the neighbour scan (k_lv_prune): single GPU, grouped lists, during the sweeps that track the
+        // internal weight through the movers' rows (the same pass keeps own[] current)
+        const bool can_prune = grouped && !dist && getenv("B3C_LV_NO_PRUNE") == nullptr;
+        int64_t *own_p = can_prune ? own.p : nullptr;
+        int64_t max_list = 0;
+        for (int r = 0; r < n_sub; r++) max_list = std::max(max_list, loff[r + 1] - loff[r]);
+        DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1);
+        DevBuf<unsigned long long> pcnt(ctx, 1);
+        if (!plist.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
         auto modularity = [&](double *out, bool full, u64 *moved) -> int {
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
             if (full) {
                 HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64), s));
-                hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2);
+                hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2, own_p);
             }
             hipLaunchKernelGGL(k_lv_tot2, dim3(gv), dim3(BLK), 0, s, n, tot.p, ctr.p + 3);
             u64 h[8];
@@ -1193,8 +1361,17 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (grouped && loff[r + 1] > loff[r]) {
                     const int64_t cntr = loff[r + 1] - loff[r];
                     const NodeRec *lst = nlist.p + loff[r];
+                    const int64_t *cnt_dev = nullptr;
+                    if (incr && can_prune) {
+                        // nodes that provably stay are settled from four numbers each; the rest go through the scan
+                        HIP_TRY(ctx, hipMemsetAsync(pcnt.p, 0, sizeof(unsigned long long), s));
+                        hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(cntr, BLK, 8 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, m2, kdeg.p,
+                                           wnl.p, own.p, tot.p, com.p, nxt_p, plist.p, pcnt.p);
+                        lst = plist.p;
+                        cnt_dev = (const int64_t *)pcnt.p;
+                    }
 #define LV_DECIDE_G(L, U)                                                                                                \
-    hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, \
+    hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, cnt_dev, lst, \
                        m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p)
                     switch (short_max) {
                     case 256:      // C3 sweep of shapes, ms of delta-Q scan per step: 64x4 11.3, 32x8 12.2, 16x16 22.4
@@ -1230,9 +1407,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (incr) {
                     const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
                     if (c1) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c1, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c1,
-                                               nlist.p + loff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2);
+                                               nlist.p + loff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p);
                     if (c2) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c2, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c2,
-                                               hlist.p + hoff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2);
+                                               hlist.p + hoff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p);
                 }
                 if (grouped && !dist) {
                     // only the nodes that decided in this sub-round can have moved
@@ -1275,7 +1452,42 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         HIP_TRY(ctx, hipStreamSynchronize(s));
         info->n_comm = (int32_t)kc;
 
-        // ---- induced graph: sort (community pair) keys, sum weights ----
+        // ---- induced graph ----
+        LvGraph h;
+        if (kc <= AGG_BINS_KC && getenv("B3C_LV_AGG_SORT") == nullptr) {
+            // few communities: exact integer sums straight into kc x kc bins (see k_agg_bins)
+            const size_t nb = (size_t)kc * (size_t)kc;
+            DevBuf<u64> bins(ctx, nb);
+            DevBuf<uint32_t> present(ctx, nb / 32 + 2);
+            DevBuf<int64_t> rcnt(ctx, kc + 1);
+            h.n = kc; h.owned = true;
+            h.indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(kc + 1));
+            if (!bins.p || !present.p || !rcnt.p || !h.indptr) {
+                free_graph(ctx, h);
+                free_graph(ctx, g);
+                return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation bins");
+            }
+            HIP_TRY(ctx, hipMemsetAsync(bins.p, 0, sizeof(u64) * nb, s));
+            HIP_TRY(ctx, hipMemsetAsync(present.p, 0, sizeof(uint32_t) * (nb / 32 + 2), s));
+            hipLaunchKernelGGL(k_agg_bins, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, bins.p, present.p);
+            const unsigned gk = (unsigned)((kc + 1 + WPB - 1) / WPB);
+            hipLaunchKernelGGL(k_bins_count, dim3(gk), dim3(BLK), 0, s, kc, present.p, rcnt.p);
+            if ((rc = b3c_exclusive_scan_i64(ctx, rcnt.p, h.indptr, kc + 1))) { free_graph(ctx, h); free_graph(ctx, g); return rc; }
+            int64_t nu = 0;
+            { const int rb_ = b3c_readback(ctx, &nu, h.indptr + kc, sizeof(int64_t)); if (rb_) { free_graph(ctx, h); free_graph(ctx, g); return rb_; } }
+            h.nnz = nu;
+            h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu > 0 ? nu : 1));
+            h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu > 0 ? nu : 1));
+            if (!h.indices || !h.q) {
+                free_graph(ctx, h);
+                free_graph(ctx, g);
+                return ctx->fail(B3C_E_NOMEM, "b3c_louvain: next level");
+            }
+            hipLaunchKernelGGL(k_bins_fill, dim3(gk), dim3(BLK), 0, s, kc, present.p, bins.p, h.indptr, h.indices, h.q);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+        } else {
+        // many communities: sort (community pair) keys, sum weights
         DevBuf<int64_t> pcnt(ctx, n + 1), ppos(ctx, n + 1);
         if (!pcnt.p || !ppos.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation counts"); }
         hipLaunchKernelGGL(k_pairs_count, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, cn.p, pcnt.p);
@@ -1309,7 +1521,6 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         int64_t nu = 0;
         { const int rb_ = b3c_readback(ctx, &nu, nruns.p, sizeof(int64_t)); if (rb_) return rb_; }
 
-        LvGraph h;
         h.n = kc; h.nnz = nu; h.owned = true;
         h.indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(kc + 1));
         h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu > 0 ? nu : 1));
@@ -1325,6 +1536,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                                v_in.p, h.indices, h.q);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(s));
+        }
         free_graph(ctx, g);
         g = h;
         ids = nullptr;
