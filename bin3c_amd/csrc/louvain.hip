@@ -126,32 +126,10 @@ __global__ void __launch_bounds__(BLK) k_graph_w(int64_t n, const int64_t *__res
     }
 }
 
-// value-symmetric matrices: the entry already is the edge weight
-__global__ void __launch_bounds__(BLK) k_graph_w_sym(int64_t nnz, const double *__restrict__ a, double scl,
-                                                      double *__restrict__ w, double *__restrict__ part_max)
-{
-    __shared__ double lds[WPB];
-    double mx = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * BLK;
-    for (int64_t k = (int64_t)blockIdx.x * BLK + threadIdx.x; k < nnz; k += stride) {
-        const double ww = a[k] * scl;
-        w[k] = ww;
-        mx = fmax(mx, ww);
-    }
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double r = lds[0];
-        for (int i = 1; i < WPB; i++) r = fmax(r, lds[i]);
-        part_max[blockIdx.x] = r;
-    }
-}
-
 // sum of ceil(w * 2^(20-e)), diagonal twice: exact integer bound on 2m (oracle: orc_quant_shift)
 __global__ void __launch_bounds__(BLK) k_quant_total(int64_t n, const int64_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices,
-                                                      const double *__restrict__ w, int ex, u64 *__restrict__ total)
+                                                      const double *__restrict__ w, double scl, int ex, u64 *__restrict__ total)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -160,7 +138,7 @@ __global__ void __launch_bounds__(BLK) k_quant_total(int64_t n, const int64_t *_
     for (int64_t row = wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         for (int64_t k = s + lane; k < e; k += 64) {
-            u64 c = (u64)ceil(ldexp(w[k], ex));
+            u64 c = (u64)ceil(ldexp(w[k] * scl, ex));
             acc += indices[k] == (int32_t)row ? 2 * c : c;
         }
     }
@@ -168,11 +146,29 @@ __global__ void __launch_bounds__(BLK) k_quant_total(int64_t n, const int64_t *_
     if (lane == 0 && acc) atomicAdd(total, acc);
 }
 
-__global__ void k_quantise(int64_t nnz, const double *__restrict__ w, int shift, int64_t *__restrict__ q)
+__global__ void k_quantise(int64_t nnz, const double *__restrict__ w, double scl, int shift, int64_t *__restrict__ q)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride)
-        q[k] = __double2ll_rn(ldexp(w[k], shift));
+        q[k] = __double2ll_rn(ldexp(w[k] * scl, shift));
+}
+
+// value-symmetric matrices: only the largest weight is needed before the quantisation passes form a * scl themselves
+__global__ void __launch_bounds__(BLK) k_graph_wmax_sym(int64_t nnz, const double *__restrict__ a, double scl,
+                                                         double *__restrict__ part_max)
+{
+    __shared__ double lds[WPB];
+    double mx = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    for (int64_t k = (int64_t)blockIdx.x * BLK + threadIdx.x; k < nnz; k += stride) mx = fmax(mx, a[k] * scl);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = lds[0];
+        for (int i = 1; i < WPB; i++) r = fmax(r, lds[i]);
+        part_max[blockIdx.x] = r;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -919,15 +915,16 @@ __global__ void __launch_bounds__(BLK) k_pairs_fill(int64_t n, int64_t kc, const
 }
 
 // Aggregation by DIRECT BINNING, for levels that end with few communities (kc <= AGG_BINS_KC, i.e. always at level 0 of
-// a metagenome): bins[c1*kc + c2] += q with 64-bit integer atomics (exact: any order gives the same sums), a presence
-// bitmap keeps pairs whose weights sum to zero (the sort path keeps them too).  Per node the entries that stay inside its
-// new community are summed in registers first (loops doubled, as in k_pairs_fill), so ~n + 10 % of nnz atomics reach L2.
+// a metagenome): bins[c1*kc + c2] += q with 64-bit integer atomics (exact: any order gives the same sums).  Per node the
+// entries that stay inside its new community are summed in registers first (loops doubled, as in k_pairs_fill), so
+// ~n + 10 % of nnz atomics reach L2.  The induced graph holds the diagonal of every community and the off-diagonal pairs
+// of non-zero weight (a pair whose quantised weights sum to zero, which the sort path would keep as an entry of weight 0,
+// can neither attract a node nor change a degree, a total or the modularity: labels, sweeps and Q are unaffected).
 constexpr int64_t AGG_BINS_KC = 4096;
 
 __global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, const int64_t *__restrict__ indptr,
                                                    const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
-                                                   const int32_t *__restrict__ cn, u64 *__restrict__ bins,
-                                                   uint32_t *__restrict__ present)
+                                                   const int32_t *__restrict__ cn, u64 *__restrict__ bins)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -955,45 +952,29 @@ __global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, const i
                 if (j[t] < 0) continue;
                 if (j[t] == (int32_t)row) own += 2 * qv[t];
                 else if (c2[t] == (int32_t)c1) own += qv[t];
-                else {
-                    const int64_t b = c1 * kc + c2[t];
-                    atomicAdd(&bins[b], (u64)qv[t]);
-                    atomicOr(&present[b >> 5], 1u << (b & 31));
-                }
+                else if (qv[t]) atomicAdd(&bins[c1 * kc + c2[t]], (u64)qv[t]);
             }
         }
         own = wave_sum_ll(own);
-        if (lane == 0) {
-            const int64_t b = c1 * kc + c1;
-            atomicAdd(&bins[b], (u64)own);
-            atomicOr(&present[b >> 5], 1u << (b & 31));
-        }
+        if (lane == 0 && own) atomicAdd(&bins[c1 * kc + c1], (u64)own);
     }
 }
 
-// entries per row of the induced graph = present bits of the row (one wave per row)
-__global__ void __launch_bounds__(BLK) k_bins_count(int64_t kc, const uint32_t *__restrict__ present, int64_t *__restrict__ cnt)
+// entries per row of the induced graph: the diagonal and the non-zero bins (one wave per row)
+__global__ void __launch_bounds__(BLK) k_bins_count(int64_t kc, const u64 *__restrict__ bins, int64_t *__restrict__ cnt)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     if (row > kc) return;
     if (row == kc) { if (lane == 0) cnt[row] = 0; return; }
     long long c = 0;
-    const int64_t b0 = row * kc, b1 = b0 + kc;
-    for (int64_t wd = (b0 >> 5) + lane; wd <= ((b1 - 1) >> 5); wd += 64) {
-        uint32_t m = present[wd];
-        const int64_t lo = wd << 5;
-        if (lo < b0) m &= ~0u << (b0 - lo);
-        if (lo + 32 > b1) m &= ~0u >> (lo + 32 - b1);
-        c += __popc(m);
-    }
+    for (int64_t col = lane; col < kc; col += 64) c += (col == row || bins[row * kc + col] != 0) ? 1 : 0;
     c = wave_sum_ll(c);
     if (lane == 0) cnt[row] = c;
 }
 
-__global__ void __launch_bounds__(BLK) k_bins_fill(int64_t kc, const uint32_t *__restrict__ present, const u64 *__restrict__ bins,
-                                                    const int64_t *__restrict__ indptr, int32_t *__restrict__ indices,
-                                                    int64_t *__restrict__ q)
+__global__ void __launch_bounds__(BLK) k_bins_fill(int64_t kc, const u64 *__restrict__ bins, const int64_t *__restrict__ indptr,
+                                                    int32_t *__restrict__ indices, int64_t *__restrict__ q)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -1001,15 +982,15 @@ __global__ void __launch_bounds__(BLK) k_bins_fill(int64_t kc, const uint32_t *_
     int64_t o = indptr[row];
     for (int64_t c0 = 0; c0 < kc; c0 += 64) {
         const int64_t c = c0 + lane;
+        u64 sum = 0;
         bool on = false;
         if (c < kc) {
-            const int64_t b = row * kc + c;
-            on = (present[b >> 5] >> (b & 31)) & 1u;
+            sum = bins[row * kc + c];
+            on = c == row || sum != 0;
         }
         const unsigned long long m = __ballot(on);
         if (on) {
             const int64_t at = o + __popcll(m & ((1ull << lane) - 1ull));
-            const u64 sum = bins[row * kc + c];
             indices[at] = (int32_t)c;
             q[at] = c == row ? (int64_t)(sum / 2) : (int64_t)sum;
         }
@@ -1110,16 +1091,20 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
     const int64_t n = a->n, nnz = a->nnz;
     *shift_out = 0;
     if (nnz == 0) return B3C_OK;
-    DevBuf<double> w(ctx, nnz);
+    // value-symmetric matrices (the normal case: graph form) need no materialised weights: a * scl is formed on the fly
+    const bool direct = a->value_symmetric;
+    DevBuf<double> w(ctx, direct ? 1 : nnz);
     const int g = grid_for(n, WPB, 16 * ctx->n_cu);
     DevBuf<double> part(ctx, g);
     DevBuf<u64> total(ctx, 1);
     if (!w.p || !part.p || !total.p) return ctx->fail(B3C_E_NOMEM, "quantise_graph");
-    if (a->value_symmetric)
-        hipLaunchKernelGGL(k_graph_w_sym, dim3(g), dim3(BLK), 0, s, nnz, (const double *)a->data, scl, w.p, part.p);
+    if (direct)
+        hipLaunchKernelGGL(k_graph_wmax_sym, dim3(g), dim3(BLK), 0, s, nnz, (const double *)a->data, scl, part.p);
     else
         hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, ids,
                            a->sorted_cols ? 1 : 0, scl, w.p, part.p);
+    const double *wsrc = direct ? (const double *)a->data : w.p;
+    const double wscl = direct ? scl : 1.0;
     std::vector<double> hp(g);
     { const int rb_ = b3c_readback(ctx, hp.data(), part.p, sizeof(double) * g); if (rb_) return rb_; }
     double wmax = 0.0;
@@ -1129,14 +1114,14 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
         int e;
         frexp(wmax, &e);   // wmax < 2^e
         HIP_TRY(ctx, hipMemsetAsync(total.p, 0, sizeof(u64), s));
-        hipLaunchKernelGGL(k_quant_total, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, w.p, 20 - e, total.p);
+        hipLaunchKernelGGL(k_quant_total, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, wsrc, wscl, 20 - e, total.p);
         u64 tot = 0;
         { const int rb_ = b3c_readback(ctx, &tot, total.p, sizeof(u64)); if (rb_) return rb_; }
         int bits = 0;
         while (bits < 64 && (tot >> bits)) bits++;
         shift = 61 - (bits - 20 + e);
     }
-    hipLaunchKernelGGL(k_quantise, dim3(grid_for(nnz, BLK * 4, 8 * ctx->n_cu)), dim3(BLK), 0, s, nnz, w.p, shift, q);
+    hipLaunchKernelGGL(k_quantise, dim3(grid_for(nnz, BLK * 4, 8 * ctx->n_cu)), dim3(BLK), 0, s, nnz, wsrc, wscl, shift, q);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
     *shift_out = shift;
@@ -1458,20 +1443,18 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             // few communities: exact integer sums straight into kc x kc bins (see k_agg_bins)
             const size_t nb = (size_t)kc * (size_t)kc;
             DevBuf<u64> bins(ctx, nb);
-            DevBuf<uint32_t> present(ctx, nb / 32 + 2);
             DevBuf<int64_t> rcnt(ctx, kc + 1);
             h.n = kc; h.owned = true;
             h.indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(kc + 1));
-            if (!bins.p || !present.p || !rcnt.p || !h.indptr) {
+            if (!bins.p || !rcnt.p || !h.indptr) {
                 free_graph(ctx, h);
                 free_graph(ctx, g);
                 return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation bins");
             }
             HIP_TRY(ctx, hipMemsetAsync(bins.p, 0, sizeof(u64) * nb, s));
-            HIP_TRY(ctx, hipMemsetAsync(present.p, 0, sizeof(uint32_t) * (nb / 32 + 2), s));
-            hipLaunchKernelGGL(k_agg_bins, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, bins.p, present.p);
+            hipLaunchKernelGGL(k_agg_bins, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, bins.p);
             const unsigned gk = (unsigned)((kc + 1 + WPB - 1) / WPB);
-            hipLaunchKernelGGL(k_bins_count, dim3(gk), dim3(BLK), 0, s, kc, present.p, rcnt.p);
+            hipLaunchKernelGGL(k_bins_count, dim3(gk), dim3(BLK), 0, s, kc, bins.p, rcnt.p);
             if ((rc = b3c_exclusive_scan_i64(ctx, rcnt.p, h.indptr, kc + 1))) { free_graph(ctx, h); free_graph(ctx, g); return rc; }
             int64_t nu = 0;
             { const int rb_ = b3c_readback(ctx, &nu, h.indptr + kc, sizeof(int64_t)); if (rb_) { free_graph(ctx, h); free_graph(ctx, g); return rb_; } }
@@ -1483,7 +1466,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 free_graph(ctx, g);
                 return ctx->fail(B3C_E_NOMEM, "b3c_louvain: next level");
             }
-            hipLaunchKernelGGL(k_bins_fill, dim3(gk), dim3(BLK), 0, s, kc, present.p, bins.p, h.indptr, h.indices, h.q);
+            hipLaunchKernelGGL(k_bins_fill, dim3(gk), dim3(BLK), 0, s, kc, bins.p, h.indptr, h.indices, h.q);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipStreamSynchronize(s));
         } else {
