@@ -1993,7 +1993,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     constexpr long long PROF_EVERY = 4;
 
     int t = 0;  // state ping-pong index
-    const int BATCH = 8;
+    const int BATCH = getenv("B3C_KR_BATCH") ? std::max(1, atoi(getenv("B3C_KR_BATCH"))) : 4;   // ticks per state look (C3: 8 -> 4 saves 0.4 ms of no-op ticks after convergence)
     const int vec_shape = getenv("B3C_KR_VEC") ? atoi(getenv("B3C_KR_VEC")) : 0;   // other kr_kb_vec<LPR, UN> shapes, e.g. 164; -1: scalar-load form
     long long ticks = 0;
     // sharded: a kernel's block partials are folded into this rank's slot of the packed scalar buffer (slot 0 sum, 1 min,

@@ -95,7 +95,7 @@ template <typename T, int LPR>
 __global__ void __launch_bounds__(BLK) k_best_external(int64_t n, const int64_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices, const T *__restrict__ a,
                                                         const int32_t *__restrict__ label,
-                                                        unsigned long long *__restrict__ cbest)
+                                                        unsigned long long *__restrict__ cbest, int sample)
 {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
@@ -103,7 +103,9 @@ __global__ void __launch_bounds__(BLK) k_best_external(int64_t n, const int64_t 
     const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
     for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
-        const int64_t s = indptr[row], e = indptr[row + 1];
+        const int64_t s = indptr[row];
+        int64_t e = indptr[row + 1];
+        if (sample > 0 && e - s > sample) e = s + sample;     // the first entries of a row stand for all of them (B3C_ORDER_SAMPLE)
         const int32_t li = label[row];
         unsigned long long best = 0;
         // four masked slots per lane and pass: all index loads, then all label gathers are in flight together (a slot past
@@ -539,6 +541,7 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     if (n == 0) return B3C_OK;
     int ROUNDS = 3;
     if (const char *e = getenv("B3C_ORDER_ROUNDS")) ROUNDS = std::max(1, std::min(12, atoi(e)));
+    const int order_sample = getenv("B3C_ORDER_SAMPLE") ? atoi(getenv("B3C_ORDER_SAMPLE")) : 0;
     DevBuf<int32_t> p0(ctx, n), p1(ctx, n), lab(ctx, (size_t)n * ROUNDS), kin(ctx, n), kout(ctx, n), vout(ctx, n);
     DevBuf<unsigned long long> cbest(ctx, n);
     DevBuf<int> changed(ctx, 1);
@@ -566,11 +569,11 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
             const int32_t *prev = lab.p + (size_t)(r - 1) * n;
             HIP_TRY(ctx, hipMemsetAsync(cbest.p, 0, sizeof(unsigned long long) * (size_t)n, s));
             if (a->kind == B3C_F64) {
-                if (wide) hipLaunchKernelGGL((k_best_external<double, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, prev, cbest.p);
-                else hipLaunchKernelGGL((k_best_external<double, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, prev, cbest.p);
+                if (wide) hipLaunchKernelGGL((k_best_external<double, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, prev, cbest.p, order_sample);
+                else hipLaunchKernelGGL((k_best_external<double, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, prev, cbest.p, order_sample);
             } else {
-                if (wide) hipLaunchKernelGGL((k_best_external<uint32_t, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p);
-                else hipLaunchKernelGGL((k_best_external<uint32_t, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p);
+                if (wide) hipLaunchKernelGGL((k_best_external<uint32_t, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p, order_sample);
+                else hipLaunchKernelGGL((k_best_external<uint32_t, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p, order_sample);
             }
             hipLaunchKernelGGL(k_cluster_ptr, dim3(gn), dim3(256), 0, s, n, cbest.p, p0.p);
             if ((rc = forest_roots(ctx, n, p0.p, p1.p, changed.p, &roots))) return rc;
