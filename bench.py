@@ -9,8 +9,9 @@ mask compaction -> weight scaling -> Louvain labels on the host (bin3c_amd/pipel
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3]
 
 N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  `--mode`:
-  sharded   contig-row ranges of ONE map over all GPUs (BASELINE.json configs[3]; strong scaling; bin3c_amd/dist.py:
-            an all-gather per SpMV / Louvain sub-round plus packed scalar all-gathers)
+  sharded   contig-row blocks of ONE map over all GPUs (BASELINE.json configs[3]; strong scaling; bin3c_amd/dist.py:
+            every rank forms and works on its row block of the ordered map; RCCL collectives issued inside libb3c, two per
+            SpMV and one per Louvain sub-round)
   replicas  one map per GPU (weak scaling, no data-path collective)
   auto      (default) both, replicas first: `value` is the SHARDED figure ("scaling": "strong") and the replica
             throughput is reported beside it under "replicas".  The sharded leg runs under a watchdog: should the
@@ -220,7 +221,7 @@ def main():
             'config': {'workload': '{}: hic-synth-v1 n={} contigs, E={} undirected edges (nnz={}), seed={}'.format(
                            args.config, n, e_true, nnz, seed),
                        'parallelism': 'single GPU' if world == 1 else (
-                           'contig-row ranges of one map over {} GPUs, RCCL all-gather per SpMV / sub-round'.format(world)
+                           'one map over {} GPUs by contig-row blocks (each rank forms and works on its rows of the ordered map); RCCL: 2 exchanges per SpMV, 1 per Louvain sub-round'.format(world)
                            if sharded else 'replicas x{} (one map per GPU)'.format(world)),
                        'accepted_contigs': n_acc, 'kr_spmv_per_step': int(spmv_n // args.steps),
                        'louvain_sweeps_per_step': int(last.lv_info.n_sweeps), 'louvain_levels': int(last.lv_info.n_levels),

@@ -50,6 +50,9 @@ SYMBOLS = [
     ('b3c_dist_comm_create', C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
     ('b3c_dist_comm_destroy', C.c_int, [_VP, _VP]),
     ('b3c_ctx_exchanges', C.c_int64, [_VP]),
+    ('b3c_dist_max_f64', C.c_int, [_VP, C.POINTER(C.c_double)]),
+    ('b3c_dist_allgather_i32', C.c_int, [_VP, _VP, C.c_int64]),
+    ('b3c_mat_permute_rows', C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int64, C.c_int64, C.POINTER(_VP)]),
     ('b3c_mat_upload', C.c_int, [_VP, C.c_int64, C.c_int64, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
     ('b3c_mat_free', C.c_int, [_VP, _VP]),
     ('b3c_mat_info', C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
@@ -255,13 +258,30 @@ class Context(object):
         self._check(self.lib.b3c_locality_order(self.h, mat.h, _ptr(n2o), _ptr(o2n)))
         return n2o, o2n
 
-    def permute(self, mat, new2old, unsorted=False):
-        """P A P^T; unsorted=True skips re-sorting the columns inside each row (fast, not canonical CSR)."""
+    def permute(self, mat, new2old, unsorted=False, rows=None):
+        """P A P^T; unsorted=True skips re-sorting the columns inside each row (fast, not canonical CSR); rows=(r0, r1)
+        forms only that ROW BLOCK of the result (the other rows stay empty): the part a rank of the sharded path owns."""
         if isinstance(new2old, np.ndarray):
             new2old = np.ascontiguousarray(new2old, dtype=np.int32)
         h = _VP()
-        self._check(self.lib.b3c_mat_permute(self.h, mat.h, _ptr(new2old), 1 if unsorted else 0, C.byref(h)))
+        flags = 1 if unsorted else 0
+        if rows is None:
+            self._check(self.lib.b3c_mat_permute(self.h, mat.h, _ptr(new2old), flags, C.byref(h)))
+        else:
+            self._check(self.lib.b3c_mat_permute_rows(self.h, mat.h, _ptr(new2old), flags, int(rows[0]), int(rows[1]), C.byref(h)))
         return Mat(self, h)
+
+    def dist_max(self, value):
+        """maximum of a host float over the ranks of the installed sharding (identity without one)"""
+        out = C.c_double(float(value))
+        self._check(self.lib.b3c_dist_max_f64(self.h, C.byref(out)))
+        return out.value
+
+    def dist_allgather_i32(self, vec):
+        """all-gather of a per-contig int32 vector (every rank computed its row range) in place"""
+        n = vec.numel() if hasattr(vec, 'numel') else vec.shape[0]
+        self._check(self.lib.b3c_dist_allgather_i32(self.h, _ptr(vec), int(n)))
+        return vec
 
     def mat_ids(self, mat):
         """caller-side row ids of a permuted matrix, or None for identity"""

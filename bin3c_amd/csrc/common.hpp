@@ -106,6 +106,9 @@ struct b3c_mat {
     // column indices ascend inside every row (canonical CSR).  b3c_mat_permute with B3C_PERMUTE_UNSORTED clears it;
     // kernels that look an entry up then scan the row instead of bisecting it
     bool sorted_cols = true;
+    // rows [row0, row1) are the ones this matrix holds; the others are empty (row block of one rank of the sharded path).
+    // row1 < 0: all rows
+    int64_t row0 = 0, row1 = -1;
 };
 
 #define HIP_TRY(ctx, expr)                                                                          \
@@ -165,6 +168,8 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 
 // internal cross-file entry points
 int b3c_dist_exchange(b3c_ctx *ctx, int buf);   // in-place all-gather of an exchange buffer: RCCL or the caller's callback
+int b3c_dist_allreduce_u64(b3c_ctx *ctx, void *dev, int64_t count);
+int b3c_dist_allgather_rows(b3c_ctx *ctx, void *full, int esz, const int64_t *starts_host, const int64_t *starts_dev);
 int b3c_mat_alloc(b3c_ctx *ctx, int64_t n, int64_t nnz, int kind, b3c_mat **out);
 int b3c_copy_in(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
 int b3c_copy_out(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);

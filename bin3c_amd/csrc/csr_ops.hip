@@ -309,6 +309,8 @@ extern "C" int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *
                      (const uint32_t *)counts->data, ds.p, (double *)m->data);
     }
     m->ordered = counts->ordered;
+    m->row0 = counts->row0;
+    m->row1 = counts->row1;
     m->sorted_cols = counts->sorted_cols;
     if (counts->ids) {
         m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
@@ -383,6 +385,8 @@ extern "C" int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const do
                      (const uint32_t *)counts->data, ds.p, dx.p, counts->ids, graph_form ? 1 : 0, (double *)m->data);
     }
     m->ordered = counts->ordered;
+    m->row0 = counts->row0;
+    m->row1 = counts->row1;
     m->sorted_cols = counts->sorted_cols;
     m->value_symmetric = graph_form != 0;
     if (counts->ids) {
@@ -557,6 +561,14 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
     o->ordered = a->ordered;
     o->value_symmetric = ns ? ns->graph_form != 0 : a->value_symmetric;
     o->sorted_cols = a->sorted_cols;      // compaction keeps the relative order inside a row
+    if (a->row1 >= 0) {
+        // a row block stays a row block: its bounds in the compacted numbering
+        int64_t b[2] = {0, 0};
+        { const int rb_ = b3c_readback(ctx, &b[0], newid.p + a->row0, sizeof(int64_t)); if (rb_) { b3c_mat_free(ctx, o); return rb_; } }
+        { const int rb_ = b3c_readback(ctx, &b[1], newid.p + a->row1, sizeof(int64_t)); if (rb_) { b3c_mat_free(ctx, o); return rb_; } }
+        o->row0 = b[0];
+        o->row1 = b[1];
+    }
     if (a->ids && n) {
         DevBuf<int64_t> keep_o(ctx, n + 1), rank_o(ctx, n + 1);
         o->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1));

@@ -10,6 +10,8 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+
 namespace {
 
 // the few RCCL/NCCL 2.x entry points used; enum values from rccl.h (stable across 2.x)
@@ -17,6 +19,7 @@ typedef int (*fn_get_unique_id)(void *);
 typedef int (*fn_comm_init_rank)(void **, int, unsigned char[128], int);   // ncclUniqueId is passed BY VALUE (128 bytes)
 typedef int (*fn_comm_destroy)(void *);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_group)(void);
 typedef const char *(*fn_err)(int);
 
@@ -29,12 +32,14 @@ struct Rccl {
     fn_comm_init_rank_v comm_init_rank = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
     fn_all_gather all_gather = nullptr;
+    fn_all_reduce all_reduce = nullptr;
     fn_group group_start = nullptr, group_end = nullptr;
     fn_err err = nullptr;
     bool ok = false;
 };
 
-constexpr int NCCL_INT32 = 2, NCCL_INT64 = 4, NCCL_FLOAT64 = 8;
+constexpr int NCCL_INT32 = 2, NCCL_INT64 = 4, NCCL_UINT64 = 5, NCCL_FLOAT64 = 8;
+constexpr int NCCL_SUM = 0;
 
 Rccl *rccl()
 {
@@ -50,10 +55,11 @@ Rccl *rccl()
     r.comm_init_rank = (fn_comm_init_rank_v)dlsym(r.h, "ncclCommInitRank");
     r.comm_destroy = (fn_comm_destroy)dlsym(r.h, "ncclCommDestroy");
     r.all_gather = (fn_all_gather)dlsym(r.h, "ncclAllGather");
+    r.all_reduce = (fn_all_reduce)dlsym(r.h, "ncclAllReduce");
     r.group_start = (fn_group)dlsym(r.h, "ncclGroupStart");
     r.group_end = (fn_group)dlsym(r.h, "ncclGroupEnd");
     r.err = (fn_err)dlsym(r.h, "ncclGetErrorString");
-    r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_gather && r.group_start && r.group_end;
+    r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_gather && r.all_reduce && r.group_start && r.group_end;
     return &r;
 }
 
@@ -138,6 +144,96 @@ int b3c_dist_exchange(b3c_ctx *ctx, int buf)
         if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
     }
     if (grouped && (rc = r->group_end()) != 0) return rccl_fail(ctx, "ncclGroupEnd", rc);
+    return B3C_OK;
+}
+
+// Sum `count` unsigned 64-bit integers at `dev` over all ranks, in place (exact: integer sums do not depend on the order).
+int b3c_dist_allreduce_u64(b3c_ctx *ctx, void *dev, int64_t count)
+{
+    const b3c_dist &D = ctx->dist;
+    ctx->n_exchanges++;
+    if (!D.comm) {
+        if (!D.allreduce) return ctx->fail(B3C_E_ARG, "multi-GPU all-reduce without communicator or callback");
+        if (D.allreduce(D.user, dev, count) != 0) return ctx->fail(B3C_E_RCCL, "all-reduce callback failed");
+        return B3C_OK;
+    }
+    Rccl *r = rccl();
+    if (!r->ok) return ctx->fail(B3C_E_RCCL, "librccl.so.1 could not be loaded");
+    const int rc = r->all_reduce(dev, dev, (size_t)count, NCCL_UINT64, NCCL_SUM, D.comm, ctx->stream);
+    return rc == 0 ? B3C_OK : rccl_fail(ctx, "ncclAllReduce", rc);
+}
+
+namespace {
+// copy the gathered slots (slot r: len[r] elements at byte offset r * slot_bytes) to their places in the full vector
+__global__ void k_unpack_slots(int world, int skip, int64_t slot_bytes, int esz, const int64_t *__restrict__ starts,
+                               const char *__restrict__ slots, char *__restrict__ full)
+{
+    for (int r = 0; r < world; r++) {
+        if (r == skip) continue;
+        const int64_t bytes = (starts[r + 1] - starts[r]) * esz;
+        const char *src = slots + (int64_t)r * slot_bytes;
+        char *dst = full + starts[r] * esz;
+        // 4-byte granules (esz is 4 or 8, offsets are multiples of it)
+        for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < bytes; i += (int64_t)gridDim.x * blockDim.x * 4)
+            *(uint32_t *)(dst + i) = *(const uint32_t *)(src + i);
+    }
+}
+}  // namespace
+
+// Ragged all-gather of a row-indexed vector: rank r owns elements [starts[r], starts[r + 1]) of `full` (element size 4 or
+// 8 bytes); afterwards every rank holds all of it.  Staged through the vector exchange buffer (one slice of chunk doubles per
+// rank), so a rank's range must fit `chunk * 8` bytes.  `starts_dev`: the same world + 1 offsets in device memory.
+int b3c_dist_allgather_rows(b3c_ctx *ctx, void *full, int esz, const int64_t *starts_host, const int64_t *starts_dev)
+{
+    const b3c_dist &D = ctx->dist;
+    const int64_t slot_bytes = D.chunk * 8;
+    const int64_t mine = (starts_host[D.rank + 1] - starts_host[D.rank]) * esz;
+    for (int r = 0; r < D.world; r++)
+        if ((starts_host[r + 1] - starts_host[r]) * esz > slot_bytes) return ctx->fail(B3C_E_ARG, "b3c_dist_allgather_rows: a rank's range exceeds its exchange slice");
+    if (mine)
+        HIP_TRY(ctx, hipMemcpyAsync((char *)D.vec + (int64_t)D.rank * slot_bytes, (const char *)full + starts_host[D.rank] * esz, (size_t)mine,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = b3c_dist_exchange(ctx, B3C_BUF_VEC);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_unpack_slots, dim3(4 * ctx->n_cu), dim3(256), 0, ctx->stream, D.world, D.rank, slot_bytes, esz, starts_dev,
+                       (const char *)D.vec, (char *)full);
+    return B3C_OK;
+}
+
+// Maximum of one double over the ranks (host value in, host value out); identity when no sharding is installed.
+extern "C" int b3c_dist_max_f64(b3c_ctx *ctx, double *value)
+{
+    if (!ctx || !value) return B3C_E_ARG;
+    if (!ctx->has_dist) return B3C_OK;
+    const b3c_dist &D = ctx->dist;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4 * D.rank, value, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc = b3c_dist_exchange(ctx, B3C_BUF_SCAL);
+    if (rc) return rc;
+    std::vector<double> all(4 * (size_t)D.world);
+    if ((rc = b3c_readback(ctx, all.data(), D.scal, sizeof(double) * all.size()))) return rc;
+    double m = *value;
+    for (int r = 0; r < D.world; r++) m = all[4 * (size_t)r] > m ? all[4 * (size_t)r] : m;
+    *value = m;
+    return B3C_OK;
+}
+
+// All-gather of a row-indexed int32 vector whose rank r owns [rank*chunk, (rank+1)*chunk) (clipped to n): `vec` (device or
+// host, n elements) holds this rank's part on entry and everything on return.  Used for the per-contig signal of the mask.
+extern "C" int b3c_dist_allgather_i32(b3c_ctx *ctx, int32_t *vec, int64_t n)
+{
+    if (!ctx || !vec) return B3C_E_ARG;
+    if (!ctx->has_dist) return B3C_OK;
+    const b3c_dist &D = ctx->dist;
+    if ((int64_t)D.world * D.chunk < n) return ctx->fail(B3C_E_ARG, "b3c_dist_allgather_i32: vector longer than the exchange buffers");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t r0 = std::min<int64_t>(n, (int64_t)D.rank * D.chunk), r1 = std::min<int64_t>(n, r0 + D.chunk);
+    if (r1 > r0)
+        HIP_TRY(ctx, hipMemcpyAsync(D.labels + r0, vec + r0, sizeof(int32_t) * (size_t)(r1 - r0), hipMemcpyDefault, ctx->stream));
+    int rc = b3c_dist_exchange(ctx, B3C_BUF_LABELS);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(vec, D.labels, sizeof(int32_t) * (size_t)n, hipMemcpyDefault, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return B3C_OK;
 }
 

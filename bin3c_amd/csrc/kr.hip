@@ -1533,9 +1533,10 @@ __global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams pr
 // ---------------------------------------------------------------------------------------------
 // dfix[i] = 1 where the diagonal of row i is zero or absent (sparse_utils.py:110-115)
 template <typename VT>
-__global__ void kr_diag_fix(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+__global__ void kr_diag_fix(int64_t n, int64_t c0, int64_t c1, const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                             const VT *__restrict__ a, double *__restrict__ dfix, unsigned long long *n_zero)
 {
+    // rows [c0, c1) are counted (a row block holds only those; the others are empty there and belong to another rank)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int z = 0;
     if (i < n) {
@@ -1548,6 +1549,7 @@ __global__ void kr_diag_fix(int64_t n, const int64_t *__restrict__ indptr, const
         double d = (lo < e && indices[lo] == i) ? (double)a[lo] : 0.0;
         z = d == 0.0;
         dfix[i] = z ? 1.0 : 0.0;
+        z = z && i >= c0 && i < c1;
     }
     unsigned long long b = __ballot(z);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_zero, (unsigned long long)__popcll(b));
@@ -1555,7 +1557,7 @@ __global__ void kr_diag_fix(int64_t n, const int64_t *__restrict__ indptr, const
 
 // the same for rows whose columns are not ascending (B3C_PERMUTE_UNSORTED layouts): one wave scans the row
 template <typename VT>
-__global__ void __launch_bounds__(BLK) kr_diag_fix_scan(int64_t n, const int64_t *__restrict__ indptr,
+__global__ void __launch_bounds__(BLK) kr_diag_fix_scan(int64_t n, int64_t c0, int64_t c1, const int64_t *__restrict__ indptr,
                                                          const int32_t *__restrict__ indices,
                                                          const VT *__restrict__ a, double *__restrict__ dfix,
                                                          unsigned long long *n_zero)
@@ -1578,7 +1580,7 @@ __global__ void __launch_bounds__(BLK) kr_diag_fix_scan(int64_t n, const int64_t
         if (lane == 0) {
             const int z = d == 0.0;
             dfix[row] = z ? 1.0 : 0.0;
-            zeros += z;
+            zeros += (z && row >= c0 && row < c1) ? 1 : 0;
         }
     }
     if (lane == 0 && zeros) atomicAdd(n_zero, zeros);
@@ -1816,7 +1818,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // geometry: fixed for a given (n, nnz, world) so that reductions are reproducible
     const int G = grid_for(nloc, BLK * KV_E, 4 * ctx->n_cu);          // vector kernels over this rank's rows (KCD)
     const int GA = grid_for(n, BLK * KV_E, 4 * ctx->n_cu);            // ... over all rows (KA: p, y, x and the operand are kept whole on every rank)
-    const double avg = (double)a->nnz / (double)n;
+    // (a row block holds the entries of this rank's rows only)
+    const double avg = (double)a->nnz / (double)((a->row1 >= 0 && (a->row0 > 0 || a->row1 < n)) ? std::max<int64_t>(1, a->row1 - a->row0) : n);
     unsigned long long maxdeg = 0;
     {
         DevBuf<unsigned long long> md(ctx, 1);
@@ -1876,12 +1879,19 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     }
     const unsigned gn1 = (unsigned)((n + 255) / 256);
     const int gscan = grid_for(n, BLK / 64, 16 * ctx->n_cu);
+    // row block (a rank of the sharded path holds only its rows): zero diagonals are counted over its rows, the checksums
+    // cover its rows, and both are combined over the ranks below
+    const bool block = dist && a->row1 >= 0 && (a->row0 > 0 || a->row1 < n);
+    if (block && (a->row0 != r0 || a->row1 != r1))
+        return ctx->fail(B3C_E_ARG, "b3c_kr_balance: the row block of the matrix is not this rank's row range");
+    if (block && !a->ordered) return ctx->fail(B3C_E_ARG, "b3c_kr_balance: a row block must come from b3c_mat_permute_rows");
+    const int64_t zc0 = block ? r0 : 0, zc1 = block ? r1 : n;
     if (counts) {
-        if (a->sorted_cols) hipLaunchKernelGGL(kr_diag_fix<uint32_t>, dim3(gn1), dim3(256), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, counters.p);
-        else hipLaunchKernelGGL(kr_diag_fix_scan<uint32_t>, dim3(gscan), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, counters.p);
+        if (a->sorted_cols) hipLaunchKernelGGL(kr_diag_fix<uint32_t>, dim3(gn1), dim3(256), 0, s, n, zc0, zc1, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, counters.p);
+        else hipLaunchKernelGGL(kr_diag_fix_scan<uint32_t>, dim3(gscan), dim3(BLK), 0, s, n, zc0, zc1, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, counters.p);
     } else {
-        if (a->sorted_cols) hipLaunchKernelGGL(kr_diag_fix<double>, dim3(gn1), dim3(256), 0, s, n, a->indptr, a->indices, (const double *)a->data, dfix.p, counters.p);
-        else hipLaunchKernelGGL(kr_diag_fix_scan<double>, dim3(gscan), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, dfix.p, counters.p);
+        if (a->sorted_cols) hipLaunchKernelGGL(kr_diag_fix<double>, dim3(gn1), dim3(256), 0, s, n, zc0, zc1, a->indptr, a->indices, (const double *)a->data, dfix.p, counters.p);
+        else hipLaunchKernelGGL(kr_diag_fix_scan<double>, dim3(gscan), dim3(BLK), 0, s, n, zc0, zc1, a->indptr, a->indices, (const double *)a->data, dfix.p, counters.p);
     }
     {
         DevBuf<unsigned long long> hs(ctx, 4);
@@ -1891,9 +1901,21 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (counts) hipLaunchKernelGGL(kr_sym_hash<uint32_t>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, hs.p);
         else hipLaunchKernelGGL(kr_sym_hash<double>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, hs.p);
         unsigned long long hh[4];
-        { const int rb_ = b3c_readback(ctx, hh, hs.p, sizeof(hh)); if (rb_) return rb_; }
+        if (block) {
+            // checksums are sums modulo 2^64: add the ranks' parts (the scalar exchange buffer carries the 4 x 8 bytes)
+            HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4 * D.rank, hs.p, sizeof(hh), hipMemcpyDeviceToDevice, s));
+            { const int rx_ = b3c_dist_exchange(ctx, B3C_BUF_SCAL); if (rx_) return rx_; }
+            std::vector<unsigned long long> all(4 * (size_t)D.world);
+            { const int rb_ = b3c_readback(ctx, all.data(), D.scal, sizeof(unsigned long long) * all.size()); if (rb_) return rb_; }
+            for (int c = 0; c < 4; c++) { hh[c] = 0; for (int r = 0; r < D.world; r++) hh[c] += all[4 * (size_t)r + c]; }
+        } else {
+            const int rb_ = b3c_readback(ctx, hh, hs.p, sizeof(hh)); if (rb_) return rb_;
+        }
         info->bitwise_symmetric = hh[0] == hh[2] && hh[1] == hh[3];
-        if (!info->bitwise_symmetric || getenv("B3C_KR_EXACT_SYMCHECK")) {
+        // (a row block cannot look its mirror entries up: the exact tolerance search is left to unsharded calls, and an
+        // asymmetric map is reported from the checksums alone)
+        if (block && !info->bitwise_symmetric) HIP_TRY(ctx, hipMemsetAsync(counters.p + 1, 0xFF, sizeof(unsigned long long), s));
+        if (!block && (!info->bitwise_symmetric || getenv("B3C_KR_EXACT_SYMCHECK"))) {
             const int ga = grid_for(n, 4, 8 * ctx->n_cu);
             if (counts) hipLaunchKernelGGL(kr_asym_count<uint32_t>, dim3(ga), dim3(256), 0, s, n, a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const uint32_t *)a->data, (const double *)sd.p, tol, counters.p + 1);
             else hipLaunchKernelGGL(kr_asym_count<double>, dim3(ga), dim3(256), 0, s, n, a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const double *)a->data, (const double *)nullptr, tol, counters.p + 1);
@@ -2173,6 +2195,15 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     info->n_iter = h.n_iter;
     info->n_outer = h.n_outer;
     info->n_zero_diag = (int64_t)hc[0];
+    if (block) {
+        // every rank counted its rows: add them up (integer exchange buffer)
+        HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, counters.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+        { const int rx_ = b3c_dist_exchange(ctx, B3C_BUF_ISUM); if (rx_) return rx_; }
+        std::vector<int64_t> parts(2 * (size_t)D.world);
+        { const int rb_ = b3c_readback(ctx, parts.data(), D.isum, sizeof(int64_t) * parts.size()); if (rb_) return rb_; }
+        info->n_zero_diag = 0;
+        for (int r = 0; r < D.world; r++) info->n_zero_diag += parts[2 * (size_t)r];
+    }
     info->is_symmetric = hc[1] == 0;
     info->hit_max_iter = h.n_iter >= max_iter;  // :220-221
     info->hit_delta = h.hit_delta;

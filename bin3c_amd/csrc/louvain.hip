@@ -605,6 +605,43 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
     }
 }
 
+// Sharded level 0 on a ROW BLOCK (this rank's rows hold entries, the others are empty here): the weighted degrees are
+// gathered over the ranks with a "row is not empty" flag riding in bit 62 (degrees stay below 2^61), then totals, community
+// sizes, the initial labels and 2m are formed from the gathered vector by every rank.
+__global__ void k_lv_pack_flag(int64_t r0, int64_t r1, const int64_t *__restrict__ indptr, int64_t *__restrict__ kdeg)
+{
+    const int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < r1 && indptr[i + 1] > indptr[i]) kdeg[i] |= (int64_t)1 << 62;
+}
+
+__global__ void __launch_bounds__(BLK) k_lv_unpack_init(int64_t n, const int32_t *__restrict__ ids, int64_t *__restrict__ kdeg,
+                                                         int64_t *__restrict__ tot, int32_t *__restrict__ csize,
+                                                         int32_t *__restrict__ labels, u64 *__restrict__ m2)
+{
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    long long sum = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+        const int64_t kd = kdeg[i];
+        const int flag = (int)((kd >> 62) & 1);
+        const int64_t d = kd & ~((int64_t)1 << 62);
+        const int32_t id = ids ? ids[i] : (int32_t)i;
+        kdeg[i] = d;
+        tot[id] = d;
+        csize[id] = flag;
+        labels[i] = flag ? (int32_t)i : -1;
+        sum += d;
+    }
+    sum = wave_sum_ll(sum);
+    __shared__ long long red[WPB];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < WPB; w++) t += red[w];
+        if (t) atomicAdd(m2, (u64)t);
+    }
+}
+
 // Exact pruning of the neighbour scan.  With own_i = weight of node i towards the other members of its community a (kept
 // current by k_lv_internal / k_lv_delta_internal), every foreign community c has dnc(c) <= F_i = wnl_i - own_i, hence
 // gain(c) = dnc(c)*2m - tot(c)*k_i <= F_i*2m.  If that bound is below the (positive) gain of staying, or F_i == 0, no
@@ -1085,7 +1122,7 @@ struct Events {
     }
 };
 
-int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double scl, int64_t *q, int32_t *shift_out)
+int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double scl, int64_t *q, int32_t *shift_out, bool blockm = false)
 {
     hipStream_t s = ctx->stream;
     const int64_t n = a->n, nnz = a->nnz;
@@ -1109,6 +1146,15 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
     { const int rb_ = b3c_readback(ctx, hp.data(), part.p, sizeof(double) * g); if (rb_) return rb_; }
     double wmax = 0.0;
     for (int i = 0; i < g; i++) wmax = hp[i] > wmax ? hp[i] : wmax;
+    if (blockm) {
+        // a row block sees its rows only: the largest weight and (below) the integer total are taken over the ranks
+        const b3c_dist &D = ctx->dist;
+        HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4 * D.rank, &wmax, sizeof(double), hipMemcpyHostToDevice, s));
+        { const int rx_ = b3c_dist_exchange(ctx, B3C_BUF_SCAL); if (rx_) return rx_; }
+        std::vector<double> all(4 * (size_t)D.world);
+        { const int rb_ = b3c_readback(ctx, all.data(), D.scal, sizeof(double) * all.size()); if (rb_) return rb_; }
+        for (int r = 0; r < D.world; r++) wmax = all[4 * (size_t)r] > wmax ? all[4 * (size_t)r] : wmax;
+    }
     int shift = 0;
     if (wmax > 0.0) {
         int e;
@@ -1117,6 +1163,15 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
         hipLaunchKernelGGL(k_quant_total, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, wsrc, wscl, 20 - e, total.p);
         u64 tot = 0;
         { const int rb_ = b3c_readback(ctx, &tot, total.p, sizeof(u64)); if (rb_) return rb_; }
+        if (blockm) {
+            const b3c_dist &D = ctx->dist;
+            HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, total.p, sizeof(u64), hipMemcpyDeviceToDevice, s));
+            { const int rx_ = b3c_dist_exchange(ctx, B3C_BUF_ISUM); if (rx_) return rx_; }
+            std::vector<int64_t> parts(2 * (size_t)D.world);
+            { const int rb_ = b3c_readback(ctx, parts.data(), D.isum, sizeof(int64_t) * parts.size()); if (rb_) return rb_; }
+            tot = 0;
+            for (int r = 0; r < D.world; r++) tot += (u64)parts[2 * (size_t)r];
+        }
         int bits = 0;
         while (bits < 64 && (tot >> bits)) bits++;
         shift = 61 - (bits - 20 + e);
@@ -1189,7 +1244,10 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     DevBuf<int64_t> q0(ctx, a->nnz);
     if (!labels.p || !q0.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
     int32_t shift = 0;
-    rc = quantise_graph(ctx, a, ids0, scl, q0.p, &shift);
+    // sharded level 0 on a row block (b3c_mat_permute_rows + compress): this rank holds the entries of its rows only
+    const bool blockm = ctx->has_dist && a->row1 >= 0 && (a->row0 > 0 || a->row1 < n0);
+    if (blockm && reorder) return ctx->fail(B3C_E_ARG, "b3c_louvain: a row block must be ordered by the caller");
+    rc = quantise_graph(ctx, a, ids0, scl, q0.p, &shift, blockm);
     if (rc) return rc;
     info->quant_shift = shift;
     hipLaunchKernelGGL(k_init_labels, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, n0, a->indptr, labels.p);
@@ -1215,9 +1273,34 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // multi-GPU: level 0 is row-sharded (decide + internal-weight scan); induced graphs are tiny and replicated
         const bool dist = ctx->has_dist && first && (int64_t)ctx->dist.world * ctx->dist.chunk >= n;
         const b3c_dist &D = ctx->dist;
-        const int64_t r0 = dist ? std::min<int64_t>(n, (int64_t)D.rank * D.chunk) : 0;
-        const int64_t r1 = dist ? std::min<int64_t>(n, r0 + D.chunk) : n;
-        int32_t *nxt_p = dist ? D.labels : nxt.p;
+        if (first && blockm && !dist) { free_graph(ctx, g); return ctx->fail(B3C_E_ARG, "b3c_louvain: row block larger than the exchange buffers"); }
+        const bool blk0 = dist && blockm;             // level 0 on a row block
+        // rows of every rank: equal chunks of a whole matrix, or the row blocks the ranks hold (their bounds are exchanged)
+        std::vector<int64_t> starts(dist ? (size_t)D.world + 1 : 2, 0);
+        DevBuf<int64_t> starts_dev(ctx, dist ? D.world + 1 : 1);
+        if (dist) {
+            if (!starts_dev.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain"); }
+            if (blk0) {
+                const int64_t mine[2] = {a->row0, a->row1};
+                HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, mine, sizeof(mine), hipMemcpyHostToDevice, s));
+                { const int rx_ = b3c_dist_exchange(ctx, B3C_BUF_ISUM); if (rx_) return rx_; }
+                std::vector<int64_t> all(2 * (size_t)D.world);
+                { const int rb_ = b3c_readback(ctx, all.data(), D.isum, sizeof(int64_t) * all.size()); if (rb_) return rb_; }
+                for (int r = 0; r < D.world; r++) {
+                    starts[r] = all[2 * (size_t)r];
+                    if (r > 0 && all[2 * (size_t)r] != all[2 * (size_t)r - 1]) { free_graph(ctx, g); return ctx->fail(B3C_E_ARG, "b3c_louvain: the ranks' row blocks do not tile the matrix"); }
+                }
+                starts[D.world] = all[2 * (size_t)D.world - 1];
+                if (starts[0] != 0 || starts[D.world] != n) { free_graph(ctx, g); return ctx->fail(B3C_E_ARG, "b3c_louvain: the ranks' row blocks do not tile the matrix"); }
+            } else {
+                for (int r = 0; r <= D.world; r++) starts[r] = std::min<int64_t>(n, (int64_t)r * D.chunk);
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(starts_dev.p, starts.data(), sizeof(int64_t) * starts.size(), hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+        }
+        const int64_t r0 = dist ? starts[D.rank] : 0;
+        const int64_t r1 = dist ? starts[D.rank + 1] : n;
+        int32_t *nxt_p = nxt.p;
         const int gwl = grid_for(r1 - r0, WPB, 16 * ctx->n_cu);   // wave-per-row kernels over this rank's rows
         const int gw = grid_for(n, WPB, 16 * ctx->n_cu);     // wave-per-row kernels
         const int gv = grid_for(n, BLK, 8 * ctx->n_cu);      // thread-per-node kernels
@@ -1225,6 +1308,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p,
                            nxt_p, csize.p, ctr.p, wnl.p);
         hipLaunchKernelGGL(k_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
+        if (blk0) {
+            // degrees (and which rows exist) of the other ranks' rows, then totals / sizes / labels / 2m from the whole vector
+            if (r1 > r0) hipLaunchKernelGGL(k_lv_pack_flag, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, r0, r1, g.indptr, kdeg.p);
+            if ((rc = b3c_dist_allgather_rows(ctx, kdeg.p, 8, starts.data(), starts_dev.p))) { free_graph(ctx, g); return rc; }
+            HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64), s));
+            hipLaunchKernelGGL(k_lv_unpack_init, dim3(gv), dim3(BLK), 0, s, n, ids, kdeg.p, tot.p, csize.p, labels.p, ctr.p);
+        }
         u64 hc[8];
         { const int rb_ = b3c_readback(ctx, hc, ctr.p, sizeof(hc)); if (rb_) return rb_; }
         const u64 m2 = hc[0];
@@ -1387,7 +1477,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 #undef LV_DECIDE
                 }
                 evs.rec();
-                if (dist) { const int rx_ = b3c_dist_exchange(ctx, B3C_BUF_LABELS); if (rx_) return rx_; }
+                // every rank decided for its rows: gather the decisions
+                if (dist && (rc = b3c_dist_allgather_rows(ctx, nxt.p, 4, starts.data(), starts_dev.p))) { free_graph(ctx, g); return rc; }
                 info->n_move_launch++;
                 if (incr) {
                     const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
@@ -1453,6 +1544,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             }
             HIP_TRY(ctx, hipMemsetAsync(bins.p, 0, sizeof(u64) * nb, s));
             hipLaunchKernelGGL(k_agg_bins, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, bins.p);
+            if (blk0 && (rc = b3c_dist_allreduce_u64(ctx, bins.p, (int64_t)nb))) { free_graph(ctx, h); free_graph(ctx, g); return rc; }
             const unsigned gk = (unsigned)((kc + 1 + WPB - 1) / WPB);
             hipLaunchKernelGGL(k_bins_count, dim3(gk), dim3(BLK), 0, s, kc, bins.p, rcnt.p);
             if ((rc = b3c_exclusive_scan_i64(ctx, rcnt.p, h.indptr, kc + 1))) { free_graph(ctx, h); free_graph(ctx, g); return rc; }
@@ -1469,6 +1561,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             hipLaunchKernelGGL(k_bins_fill, dim3(gk), dim3(BLK), 0, s, kc, bins.p, h.indptr, h.indices, h.q);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipStreamSynchronize(s));
+        } else if (blk0) {
+            free_graph(ctx, g);
+            return ctx->fail(B3C_E_ARG, "b3c_louvain: a sharded level with more than %lld communities is not supported on row blocks", (long long)AGG_BINS_KC);
         } else {
         // many communities: sort (community pair) keys, sum weights
         DevBuf<int64_t> pcnt(ctx, n + 1), ppos(ctx, n + 1);

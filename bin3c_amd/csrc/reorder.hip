@@ -173,13 +173,13 @@ __global__ void k_invert_perm(int64_t n, const int32_t *__restrict__ new2old, in
     if (k < n) old2new[new2old[k]] = (int32_t)k;
 }
 
-__global__ void k_new_degrees(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ new2old,
-                              int64_t *__restrict__ deg)
+__global__ void k_new_degrees(int64_t n, int64_t row0, int64_t row1, const int64_t *__restrict__ indptr,
+                              const int32_t *__restrict__ new2old, int64_t *__restrict__ deg)
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) {
         const int32_t o = new2old[k];
-        deg[k] = indptr[o + 1] - indptr[o];
+        deg[k] = k >= row0 && k < row1 ? indptr[o + 1] - indptr[o] : 0;   // rows outside the block stay empty
     }
     if (k == n) deg[k] = 0;
 }
@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(BLK) k_permute_rows(int64_t n, const int64_t *
         const int64_t s = indptr[old];
         const int len = (int)(indptr[old + 1] - s);
         const int64_t o = out_indptr[k];
+        if (out_indptr[k + 1] == o) continue;             // empty in the output: an empty row, or a row of another rank's block
         for (int base = 0; base < len; base += 256) {
             int32_t c[4];
             T v[4];
@@ -260,6 +261,7 @@ __global__ void __launch_bounds__(BLK) k_permute_rows_sorted(int64_t n, const in
         const int64_t s = indptr[old];
         const int len = (int)(indptr[old + 1] - s);
         const int64_t o = out_indptr[k];
+        if (out_indptr[k + 1] == o) continue;             // empty in the output: an empty row, or a row of another rank's block
         int N = 64;
         while (N < len) N <<= 1;
         for (int e = lane; e < N; e += 64) {
@@ -321,6 +323,7 @@ __global__ void __launch_bounds__(BLK) k_permute_rows_packed(int64_t n, int pb, 
         const int64_t s = indptr[old];
         const int len = (int)(indptr[old + 1] - s);
         const int64_t o = out_indptr[k];
+        if (out_indptr[k + 1] == o) continue;             // empty in the output: an empty row, or a row of another rank's block
         int N = 64;
         while (N < len) N <<= 1;
         for (int e = lane; e < N; e += 64)
@@ -428,6 +431,7 @@ __global__ void __launch_bounds__(BLK) k_permute_rows_regs(int64_t n, int pb, in
         const int64_t s = indptr[old];
         const int len = (int)(indptr[old + 1] - s);
         const int64_t o = out_indptr[k];
+        if (out_indptr[k + 1] == o) continue;             // empty in the output: an empty row, or a row of another rank's block
         if (len > max_len) continue;                      // long rows: k_long_keys / k_long_scatter
         // wave-uniform choice of the network size
         if (len <= 64) permute_row_regs<T, 1>(lane, pb, len, indices + s, a + s, old2new, out_indices + o, out_a + o);
@@ -600,18 +604,23 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
 }
 
 // Symmetric permutation P A P^T into a new canonical CSR (columns sorted in the new numbering).
-int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out,
-                    bool sort_cols)
+// Rows outside [row0, row1) of the result stay empty (the row block of one rank of the sharded path).
+int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out,
+                         bool sort_cols, int64_t row0, int64_t row1)
 {
     hipStream_t s = ctx->stream;
-    const int64_t n = a->n, nnz = a->nnz;
+    const int64_t n = a->n;
+    const bool block = row0 > 0 || row1 < n;
+    DevBuf<int64_t> deg(ctx, n + 1), optr(ctx, n + 1);
+    if (!deg.p || !optr.p) return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr");
+    hipLaunchKernelGGL(k_new_degrees, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, row0, row1, a->indptr, new2old, deg.p);
+    int rc;
+    if ((rc = b3c_exclusive_scan_i64(ctx, deg.p, optr.p, n + 1))) return rc;
+    int64_t nnz = a->nnz;
+    if (block) { const int rb_ = b3c_readback(ctx, &nnz, optr.p + n, sizeof(int64_t)); if (rb_) return rb_; }
     b3c_mat *m = nullptr;
-    int rc = b3c_mat_alloc(ctx, n, nnz, a->kind, &m);
-    if (rc) return rc;
-    DevBuf<int64_t> deg(ctx, n + 1);
-    if (!deg.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr"); }
-    hipLaunchKernelGGL(k_new_degrees, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, a->indptr, new2old, deg.p);
-    if ((rc = b3c_exclusive_scan_i64(ctx, deg.p, m->indptr, n + 1))) { b3c_mat_free(ctx, m); return rc; }
+    if ((rc = b3c_mat_alloc(ctx, n, nnz, a->kind, &m))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(m->indptr, optr.p, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, s));
     m->sorted_cols = a->sorted_cols && sort_cols;
     // canonical output: per-row LDS sort when every row fits, else the global radix sort below
     unsigned long long maxlen = 0;
@@ -702,6 +711,9 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
         else
             hipLaunchKernelGGL(k_permute_rows<uint32_t>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
                                (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
+    } else if (nnz && block) {
+        b3c_mat_free(ctx, m);
+        return ctx->fail(B3C_E_ARG, "b3c_permute_csr: the global-sort path cannot produce a row block");
     } else if (nnz) {
         DevBuf<int64_t> k_in(ctx, nnz), k_out(ctx, nnz);
         if (!k_in.p || !k_out.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort keys"); }
@@ -731,6 +743,12 @@ int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, cons
     return B3C_OK;
 }
 
+int b3c_permute_csr(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, const int32_t *old2new, b3c_mat **out,
+                    bool sort_cols)
+{
+    return b3c_permute_csr_rows(ctx, a, new2old, old2new, out, sort_cols, 0, a->n);
+}
+
 // ---------------------------------------------------------------------------------------------
 // public entry points (include/b3c.h)
 // ---------------------------------------------------------------------------------------------
@@ -747,10 +765,11 @@ extern "C" int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2o
     return b3c_copy_out(ctx, old2new, o2n.p, sizeof(int32_t) * (size_t)a->n);
 }
 
-extern "C" int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, int flags, b3c_mat **out)
+extern "C" int b3c_mat_permute_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, int flags, int64_t row0, int64_t row1,
+                                    b3c_mat **out)
 {
     if (!ctx) return B3C_E_ARG;
-    if (!a || !new2old || !out) return ctx->fail(B3C_E_ARG, "b3c_mat_permute: bad argument");
+    if (!a || !new2old || !out || row0 < 0 || row1 < row0 || row1 > a->n) return ctx->fail(B3C_E_ARG, "b3c_mat_permute: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t n = a->n;
     DevBuf<int32_t> n2o(ctx, n), o2n(ctx, n);
@@ -760,7 +779,7 @@ extern "C" int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ne
     const unsigned gn = (unsigned)((n + 255) / 256);
     if (n) hipLaunchKernelGGL(k_invert_perm, dim3(gn), dim3(256), 0, ctx->stream, n, n2o.p, o2n.p);
     b3c_mat *m = nullptr;
-    if ((rc = b3c_permute_csr(ctx, a, n2o.p, o2n.p, &m, !(flags & B3C_PERMUTE_UNSORTED)))) return rc;
+    if ((rc = b3c_permute_csr_rows(ctx, a, n2o.p, o2n.p, &m, !(flags & B3C_PERMUTE_UNSORTED), row0, row1))) return rc;
     // caller-side id of every row: compose with the input's ids if it was permuted before
     m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
     if (!m->ids) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_mat_permute"); }
@@ -770,7 +789,16 @@ extern "C" int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ne
     }
     m->ordered = true;
     m->value_symmetric = a->value_symmetric;
+    m->row0 = row0;
+    m->row1 = row1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *out = m;
     return B3C_OK;
+}
+
+extern "C" int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old, int flags, b3c_mat **out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!a) return ctx->fail(B3C_E_ARG, "b3c_mat_permute: bad argument");
+    return b3c_mat_permute_rows(ctx, a, new2old, flags, 0, a->n, out);
 }

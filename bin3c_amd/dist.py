@@ -33,10 +33,11 @@ BUF_VEC, BUF_SCAL, BUF_LABELS, BUF_ISUM, BUF_SCAL_VEC = 0, 1, 2, 3, 4
 class B3CDist(C.Structure):
     _fields_ = [('rank', C.c_int32), ('world', C.c_int32), ('chunk', C.c_int64), ('vec', C.c_void_p),
                 ('scal', C.c_void_p), ('labels', C.c_void_p), ('isum', C.c_void_p), ('allgather', C.c_void_p),
-                ('user', C.c_void_p), ('comm', C.c_void_p)]
+                ('user', C.c_void_p), ('comm', C.c_void_p), ('allreduce', C.c_void_p)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 
 
 def shard_range(n, rank, world, align=64):
@@ -91,6 +92,7 @@ class DistSession(object):
         self._bufs = {BUF_VEC: self.vec, BUF_SCAL: self.scal, BUF_LABELS: self.labels, BUF_ISUM: self.isum}
         self._error = None
         self._cb = ALLGATHER_FN(self._allgather)          # keep a reference: ctypes callbacks are not owned by C
+        self._cb2 = ALLREDUCE_FN(self._allreduce)
         lib = ctx.lib
         # RCCL inside libb3c when the job runs on the nccl backend (or on request); the callback transport otherwise
         want = os.environ.get('B3C_DIST_TRANSPORT', 'auto')
@@ -114,9 +116,10 @@ class DistSession(object):
         self._x0 = int(lib.b3c_ctx_exchanges(ctx.h))
         d = B3CDist(self.rank, self.world, self.chunk, self.vec.data_ptr(), self.scal.data_ptr(),
                     self.labels.data_ptr(), self.isum.data_ptr(), C.cast(self._cb, C.c_void_p), None,
-                    self.comm.value if self.comm else None)
+                    self.comm.value if self.comm else None, C.cast(self._cb2, C.c_void_p))
         self._struct = d
         ctx._check(lib.b3c_ctx_set_dist(ctx.h, C.byref(d)))
+        ctx.dist_session = self                           # pipeline.run_hot_path shards the map over the ranks when set
 
     @property
     def n_exchanges(self):
@@ -134,7 +137,24 @@ class DistSession(object):
             self._error = ex
             return 1
 
+    def _allreduce(self, user, dev_ptr, count):
+        """callback transport: sum `count` uint64 at device pointer `dev_ptr` over the ranks (int64 view: same bits mod 2^64)"""
+        import torch
+        import torch.distributed as dist
+        try:
+            class _View(object):
+                __cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<i8', 'data': (int(dev_ptr), False), 'version': 2}
+            with torch.cuda.stream(self.ctx.torch_stream):
+                t = torch.as_tensor(_View(), device=torch.device('cuda', self.ctx.device))
+                dist.all_reduce(t, group=self.group)
+            return 0
+        except Exception as ex:
+            self._error = ex
+            return 1
+
     def close(self):
+        if getattr(self.ctx, 'dist_session', None) is self:
+            self.ctx.dist_session = None
         if self.ctx.h is not None:
             self._final = self.n_exchanges
             self.ctx.lib.b3c_ctx_set_dist(self.ctx.h, None)

@@ -81,6 +81,8 @@ class HotPathResult(object):
         self.timings = {}
         self._perm = None           # see `perm`
         self._n2o = self._o2n = None  # locality ordering on the device (int32 new2old, old2new), or None
+        self.row_block = None       # (r0, r1): rows of the ordered map this rank formed and worked on (sharded run), else None
+        self.work_nnz = None        # stored entries of the map this rank worked on
 
     @property
     def perm(self):
@@ -153,15 +155,23 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
         t0 = time.perf_counter()
         work = counts
         n2o = o2n = None
+        # row-sharded run (bin3c_amd.dist.DistSession installed on this context): every rank holds the caller's map, orders
+        # it, and then forms and works on ITS ROW BLOCK of the ordered map only -- mask, balancing, sub-map and Louvain touch
+        # 1/world of the entries per rank
+        sess = getattr(ctx, 'dist_session', None)
+        block = None
         if reorder and n >= REORDER_MIN_N and counts.nnz >= REORDER_MIN_NNZ:
             n2o = torch.empty(n, dtype=torch.int32, device=dev)
             o2n = torch.empty(n, dtype=torch.int32, device=dev)
             ctx._check(ctx.lib.b3c_locality_order(ctx.h, counts.h, _native._ptr(n2o), _native._ptr(o2n)))
+            if sess is not None and sess.world > 1 and sess.n == n:
+                block = (sess.r0, sess.r1)
             # canonical (columns re-sorted inside each row): unsorted rows cost the SpMV 12 % more than the sort saves
-            work = ctx.permute(counts, n2o)
+            work = ctx.permute(counts, n2o, rows=block)
             idx = n2o.long()
             sites_t, lengths_t = sites_t[idx], lengths_t[idx]
         res._n2o, res._o2n = n2o, o2n
+        res.row_block, res.work_nnz = block, work.nnz
         t['order'] = time.perf_counter() - t0
 
         try:
@@ -171,6 +181,8 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
             if mask is None:
                 signal_w = torch.empty(n, dtype=torch.int32, device=dev)          # uint32 bit pattern
                 ctx.max_offdiag_u32(work, assume_symmetric=True, out=signal_w)
+                if block is not None:
+                    ctx.dist_allgather_i32(signal_w)           # every rank scanned its rows
                 sig64 = signal_w.long() & 0xFFFFFFFF
                 mask_w = ((lengths_t >= int(min_len)) & (sig64 >= int(min_sig))).to(torch.uint8)
             else:
@@ -248,7 +260,7 @@ def _cluster_stage(ctx, res, mask_w, n_sub=0):
         t['compress'] = time.perf_counter() - t0
         t['louvain'] = 0.0
         return torch.full((sub.n,), -1, dtype=torch.int32, device=mask_w.device)
-    res.scl = 1.0 / ctx.max_value(sub)                                     # cluster.py:316
+    res.scl = 1.0 / ctx.dist_max(ctx.max_value(sub))                       # cluster.py:316 (row blocks: over the ranks)
     t['compress'] = time.perf_counter() - t0
 
     t0 = time.perf_counter()

@@ -106,6 +106,8 @@ int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
 #define B3C_BUF_ISUM 3    /* int64[world*2]       Louvain integer partial sums     */
 #define B3C_BUF_SCAL_VEC 4 /* B3C_BUF_SCAL and B3C_BUF_VEC in one (grouped) exchange */
 typedef int (*b3c_allgather_fn)(void *user, int buffer_id);
+/* comm == NULL only: sum `count` uint64 values at device pointer `dev` over all ranks, in place, on the context's stream */
+typedef int (*b3c_allreduce_fn)(void *user, void *dev, int64_t count);
 typedef struct {
     int32_t rank, world;
     int64_t chunk;        /* rows per rank, world*chunk >= n */
@@ -116,6 +118,7 @@ typedef struct {
     b3c_allgather_fn allgather;   /* used when comm == NULL */
     void *user;
     void *comm;           /* ncclComm_t of b3c_dist_comm_create, or NULL */
+    b3c_allreduce_fn allreduce;   /* used when comm == NULL (Louvain: community-pair bins of the sharded aggregation) */
 } b3c_dist;
 /* Install (or with NULL remove) the sharding description; it applies to b3c_kr_balance and b3c_louvain
  * calls on matrices with n <= world*chunk rows.  No reference counterpart (bin3C is single process). */
@@ -126,6 +129,11 @@ int b3c_ctx_set_dist(b3c_ctx *ctx, const b3c_dist *dist);
 int b3c_dist_unique_id(void *id128);
 int b3c_dist_comm_create(b3c_ctx *ctx, int world, int rank, const void *id128, void **comm_out);
 int b3c_dist_comm_destroy(b3c_ctx *ctx, void *comm);
+/* Row-sharded pipeline helpers (identity when no sharding is installed): the maximum of a host double over the ranks
+ * (1/max of the sub-map, cluster.py:316), and the all-gather of a per-contig int32 vector of which every rank computed
+ * the rows [rank*chunk, (rank+1)*chunk) (the off-diagonal signal of the acceptance mask, contact_map.py:899). */
+int b3c_dist_max_f64(b3c_ctx *ctx, double *value);
+int b3c_dist_allgather_i32(b3c_ctx *ctx, int32_t *vec /*host|dev*/, int64_t n);
 /* Exchanges issued through this context since it was created (both transports). */
 int64_t b3c_ctx_exchanges(const b3c_ctx *ctx);
 
@@ -167,6 +175,12 @@ int b3c_locality_order(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old /*host|d
                                 * longer ascend.  ~7x cheaper than the canonical form (no sort of the entries); every
                                 * libb3c entry point accepts such a matrix, but it is not canonical CSR on download. */
 int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old /*host|dev*/, int flags, b3c_mat **out);
+/* The same, but only the rows [row0, row1) of the result are formed; the others stay empty.  This is the ROW BLOCK a rank of
+ * the sharded path owns: site_norm / max_offdiag / b3c_kr_balance_counts / b3c_normalise_scale_compress / b3c_louvain then
+ * touch 1/world of the entries each, and combine what must be global (degrees, totals, checksums, community-pair sums)
+ * through the exchange buffers of b3c_ctx_set_dist.  row0 / row1 must be this rank's [rank*chunk, (rank+1)*chunk). */
+int b3c_mat_permute_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old /*host|dev*/, int flags, int64_t row0,
+                         int64_t row1, b3c_mat **out);
 
 /* Caller-side row ids of a permuted (and possibly compressed) matrix, int32[n] host|dev.
  * Returns 1 and writes nothing when the matrix carries no ids (identity). */

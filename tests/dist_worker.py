@@ -52,14 +52,23 @@ def gpu_mode(rank, world):
     from bin3c_amd.synth import make_synth
     ctx = make_context(0)
     total = 0
+    n_block = 0
     # a flat map, and a power-law one whose hub rows go through kr_kb_hub and the Louvain hub lists on both ranks
-    for args in ((40000, 1300000, 21), (30000, 900000, 9, 'powerlaw')):
+    # (the third is too small for the locality ordering: it runs the sharded kernels on a map every rank holds whole)
+    for args in ((40000, 1300000, 21), (70000, 4000000, 9, 'powerlaw'), (30000, 900000, 9, 'powerlaw')):
         sm = make_synth(*args)
         counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
         single = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)            # before sharding is installed
         sess = DistSession(ctx, sm.n)
         res = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)
         sess.check()
+        # the map was SHARDED, not replicated: this rank formed and touched only its row block of the ordered map
+        if sm.n >= 32768 and counts.nnz >= (1 << 21):
+            assert res.row_block == (sess.r0, sess.r1) and res.work_nnz < 0.7 * counts.nnz, (res.row_block, res.work_nnz, counts.nnz)
+            tot_nnz = torch.tensor([res.work_nnz], dtype=torch.int64)
+            dist.all_reduce(tot_nnz)
+            assert int(tot_nnz.item()) == counts.nnz
+            n_block += 1
         # two exchanges per KR tick (ticks are enqueued in batches of 8; a bound cut costs a tick without SpMV), per Louvain
         # sweep of level 0 one label exchange per sub-round and one integer sum per modularity evaluation
         n_spmv = res.kr_info.n_iter + 1
@@ -84,7 +93,8 @@ def gpu_mode(rank, world):
         assert np.array_equal(again.x, single.x) and np.array_equal(again.labels, single.labels)
         total += sess.n_exchanges
         counts.free()
-    print('rank %d gpu ok (%d exchanges)' % (rank, total))
+    assert n_block >= 2
+    print('rank %d gpu ok (%d exchanges, %d maps sharded by row blocks)' % (rank, total, n_block))
     ctx.close()
 
 

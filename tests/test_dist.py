@@ -67,7 +67,7 @@ def test_bench_two_ranks_one_gpu(mode):
         assert d['scaling'] == 'weak' and 'replicas x2' in d['config']['parallelism']
         return
     assert d['scaling'] == 'strong' and d['exchanges_per_step'] > 100
-    assert 'contig-row ranges of one map over 2 GPUs' in d['config']['parallelism']
+    assert 'one map over 2 GPUs by contig-row blocks' in d['config']['parallelism']
     if mode == 'auto':
         assert d['replicas']['value'] > 0 and d['replicas']['scaling'] == 'weak' and d['agrees_with_single_gpu'] is True
 
