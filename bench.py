@@ -143,7 +143,7 @@ def main():
     from bin3c_amd.synth import CONFIGS, make_edges
 
     n, n_edges, seed, law = CONFIGS[args.config]
-    ctx = make_context(local_rank)
+    ctx = make_context(local_rank, pin=True)       # one process per GPU: stay on the CPUs of its NUMA node
     # pair stream drawn on the host (numpy RandomState, deterministic), accumulated into the symmetric count matrix on
     # the device (b3c_coo_symmetrise: the ingest tail, bit-identical to synth.symmetrise_to_csr).  Every rank builds
     # the same map: the replica leg processes one copy per GPU, the sharded leg one copy over all GPUs.

@@ -83,6 +83,7 @@ def setup_logging(args):
 
 
 def main(argv=None):
+    os.environ.setdefault('B3C_PIN', '1')      # a command-line run owns its process: stay on the CPUs of the GPU's NUMA node
     parser = build_parser()
     args = parser.parse_args(argv)
     if getattr(args, 'version', False):

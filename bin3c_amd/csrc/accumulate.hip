@@ -96,7 +96,7 @@ extern "C" int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int6
     if (!ctx) return B3C_E_ARG;
     if (n < 0 || m < 0 || !out || (m > 0 && (!lo || !hi || !counts)) || n >= (int64_t)INT32_MAX)
         return ctx->fail(B3C_E_ARG, "b3c_coo_symmetrise: bad argument");
-    if (m >= (int64_t)INT32_MAX / 2) return ctx->fail(B3C_E_ARG, "b3c_coo_symmetrise: more than 2^30 pairs per call");
+    if (m >= ((int64_t)1 << 40)) return ctx->fail(B3C_E_ARG, "b3c_coo_symmetrise: more than 2^40 pairs per call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int gm = grid_for(m, 1024, 16 * ctx->n_cu);
@@ -148,7 +148,6 @@ extern "C" int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int6
     }
     int64_t nnz = 0;
     if (total) {
-        if (total >= (int64_t)INT32_MAX) return ctx->fail(B3C_E_ARG, "b3c_coo_symmetrise: more than 2^31 stored entries per call");
         size_t tb = 0;
         HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, e_in.p, e_out.p, w_in.p, w_out.p, (int64_t)total, 0, 64, s));
         DevBuf<char> tmp(ctx, tb);
@@ -160,9 +159,10 @@ extern "C" int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int6
         { const int rb_ = b3c_readback(ctx, &hc, cnt.p, sizeof(hc)); if (rb_) return rb_; }
         nnz = (int64_t)hc;
     }
-    b3c_mat *mat = nullptr;
-    int rc = b3c_mat_alloc(ctx, n, nnz, B3C_U32, &mat);
+    MatOwner own(ctx);            // freed on every early return below
+    int rc = b3c_mat_alloc(ctx, n, nnz, B3C_U32, &own.m);
     if (rc) return rc;
+    b3c_mat *mat = own.m;
     hipLaunchKernelGGL(k_indptr_from_sorted, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, nnz, e_out.p, mat->indptr);
     if (nnz) {
         hipLaunchKernelGGL(k_csr_from_sorted, dim3(grid_for(nnz, 1024, 16 * ctx->n_cu)), dim3(256), 0, s, nnz, n, e_out.p, mat->indices);
@@ -181,6 +181,6 @@ extern "C" int b3c_coo_symmetrise(b3c_ctx *ctx, int64_t n, int64_t m, const int6
         }
         *n_edges = (nnz - (int64_t)hd) / 2;
     }
-    *out = mat;
+    *out = own.release();
     return B3C_OK;
 }

@@ -133,20 +133,21 @@ extern "C" int b3c_mat_upload(b3c_ctx *ctx, int64_t n, int64_t nnz, const int64_
         return ctx->fail(B3C_E_ARG, "b3c_mat_upload: bad argument");
     if (n >= (int64_t)INT32_MAX) return ctx->fail(B3C_E_ARG, "b3c_mat_upload: n must fit int32 column ids");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    b3c_mat *m = nullptr;
-    int rc = b3c_mat_alloc(ctx, n, nnz, kind, &m);
+    MatOwner own(ctx);
+    int rc = b3c_mat_alloc(ctx, n, nnz, kind, &own.m);
     if (rc) return rc;
+    b3c_mat *m = own.m;
     size_t esz = kind == B3C_U32 ? 4 : 8;
     if ((rc = b3c_copy_in(ctx, m->indptr, indptr, sizeof(int64_t) * (size_t)(n + 1))) ||
         (rc = b3c_copy_in(ctx, m->indices, indices, sizeof(int32_t) * (size_t)nnz)) ||
-        (rc = b3c_copy_in(ctx, m->data, data, esz * (size_t)nnz))) {
-        b3c_mat_free(ctx, m);
+        (rc = b3c_copy_in(ctx, m->data, data, esz * (size_t)nnz)))
         return rc;
-    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *out = m;
+    *out = own.release();
     return B3C_OK;
 }
+
+int b3c_mat_free_internal(b3c_ctx *ctx, b3c_mat *m) { return b3c_mat_free(ctx, m); }
 
 extern "C" int b3c_mat_free(b3c_ctx *ctx, b3c_mat *m)
 {

@@ -60,6 +60,7 @@ struct b3c_ctx {
         if (it != pool.end() && it->first <= nbytes + nbytes / 4 + 4096) {
             void *p = it->second;
             pool.erase(it);
+            pooled[p] = false;
             return p;
         }
         void *p = nullptr;
@@ -72,11 +73,14 @@ struct b3c_ctx {
         bytes += (int64_t)nbytes;
         return p;
     }
+    std::map<void *, bool> pooled;          // blocks sitting in the pool (a second release of one must not hand it out twice)
     void release(void *p)
     {
         if (!p) return;
         auto it = live.find(p);
         if (it == live.end()) return;
+        if (pooled[p]) return;             // released already
+        pooled[p] = true;
         pool.insert({it->second, p});
     }
     void trim()
@@ -85,6 +89,7 @@ struct b3c_ctx {
             (void)hipFree(kv.second);
             bytes -= (int64_t)kv.first;
             live.erase(kv.second);
+            pooled.erase(kv.second);
         }
         pool.clear();
     }
@@ -117,6 +122,18 @@ struct b3c_mat {
         if (_e != hipSuccess)                                                                       \
             return (ctx)->fail(B3C_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
+
+// a matrix under construction: freed on every early return, handed over with release()
+int b3c_mat_free_internal(b3c_ctx *ctx, b3c_mat *m);
+struct MatOwner {
+    b3c_ctx *ctx;
+    b3c_mat *m = nullptr;
+    explicit MatOwner(b3c_ctx *c) : ctx(c) {}
+    ~MatOwner() { if (m) b3c_mat_free_internal(ctx, m); }
+    MatOwner(const MatOwner &) = delete;
+    MatOwner &operator=(const MatOwner &) = delete;
+    b3c_mat *release() { b3c_mat *t = m; m = nullptr; return t; }
+};
 
 // scoped pooled buffer
 template <typename T>

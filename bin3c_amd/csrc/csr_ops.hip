@@ -538,14 +538,15 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
     if ((rc = b3c_exclusive_scan_i64(ctx, cnt.p, optr.p, m + 1))) return rc;
     int64_t nnz = 0;
     { const int rb_ = b3c_readback(ctx, &nnz, optr.p + m, sizeof(int64_t)); if (rb_) return rb_; }
-    b3c_mat *o = nullptr;
-    if ((rc = b3c_mat_alloc(ctx, m, nnz, ns ? B3C_F64 : a->kind, &o))) return rc;
+    MatOwner own(ctx);            // freed on every early return below
+    if ((rc = b3c_mat_alloc(ctx, m, nnz, ns ? B3C_F64 : a->kind, &own.m))) return rc;
+    b3c_mat *o = own.m;
     HIP_TRY(ctx, hipMemcpyAsync(o->indptr, optr.p, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToDevice, s));
     if (n) {
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
         if (ns) {
             DevBuf<int2> ni(ctx, n + 1);
-            if (!ni.p) { b3c_mat_free(ctx, o); return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
+            if (!ni.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
             hipLaunchKernelGGL(k_pack_ni, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, newid.p, a->ids, ni.p);
             hipLaunchKernelGGL(k_compress_fill_ns, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data,
                                ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data);
@@ -564,23 +565,23 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
     if (a->row1 >= 0) {
         // a row block stays a row block: its bounds in the compacted numbering
         int64_t b[2] = {0, 0};
-        { const int rb_ = b3c_readback(ctx, &b[0], newid.p + a->row0, sizeof(int64_t)); if (rb_) { b3c_mat_free(ctx, o); return rb_; } }
-        { const int rb_ = b3c_readback(ctx, &b[1], newid.p + a->row1, sizeof(int64_t)); if (rb_) { b3c_mat_free(ctx, o); return rb_; } }
+        { const int rb_ = b3c_readback(ctx, &b[0], newid.p + a->row0, sizeof(int64_t)); if (rb_) { return rb_; } }
+        { const int rb_ = b3c_readback(ctx, &b[1], newid.p + a->row1, sizeof(int64_t)); if (rb_) { return rb_; } }
         o->row0 = b[0];
         o->row1 = b[1];
     }
     if (a->ids && n) {
         DevBuf<int64_t> keep_o(ctx, n + 1), rank_o(ctx, n + 1);
         o->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1));
-        if (!keep_o.p || !rank_o.p || !o->ids) { b3c_mat_free(ctx, o); return ctx->fail(B3C_E_NOMEM, "b3c_compress"); }
+        if (!keep_o.p || !rank_o.p || !o->ids) { return ctx->fail(B3C_E_NOMEM, "b3c_compress"); }
         HIP_TRY(ctx, hipMemsetAsync(keep_o.p, 0, sizeof(int64_t) * (size_t)(n + 1), s));
         hipLaunchKernelGGL(k_scatter_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, a->ids, keep_o.p);
-        if ((rc = b3c_exclusive_scan_i64(ctx, keep_o.p, rank_o.p, n + 1))) { b3c_mat_free(ctx, o); return rc; }
+        if ((rc = b3c_exclusive_scan_i64(ctx, keep_o.p, rank_o.p, n + 1))) { return rc; }
         hipLaunchKernelGGL(k_sub_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, a->ids, newid.p, rank_o.p, o->ids);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    *out = o;
+    *out = own.release();
     return B3C_OK;
 }
 

@@ -1255,6 +1255,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     LvGraph g;
     g.n = n0; g.nnz = a->nnz; g.indptr = a->indptr; g.indices = a->indices; g.q = q0.p; g.owned = false;
     const int32_t *ids = ids0;   // level 0 only; induced graphs are numbered by ascending community id
+    struct GraphGuard { b3c_ctx *c; LvGraph *g; ~GraphGuard() { free_graph(c, *g); } } graph_guard{ctx, &g};   // every exit path
 
     double mod = 0.0;
     bool first = true;

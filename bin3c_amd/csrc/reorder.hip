@@ -618,15 +618,16 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
     if ((rc = b3c_exclusive_scan_i64(ctx, deg.p, optr.p, n + 1))) return rc;
     int64_t nnz = a->nnz;
     if (block) { const int rb_ = b3c_readback(ctx, &nnz, optr.p + n, sizeof(int64_t)); if (rb_) return rb_; }
-    b3c_mat *m = nullptr;
-    if ((rc = b3c_mat_alloc(ctx, n, nnz, a->kind, &m))) return rc;
+    MatOwner own(ctx);            // freed on every early return below
+    if ((rc = b3c_mat_alloc(ctx, n, nnz, a->kind, &own.m))) return rc;
+    b3c_mat *m = own.m;
     HIP_TRY(ctx, hipMemcpyAsync(m->indptr, optr.p, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, s));
     m->sorted_cols = a->sorted_cols && sort_cols;
     // canonical output: per-row LDS sort when every row fits, else the global radix sort below
     unsigned long long maxlen = 0;
     if (nnz && sort_cols) {
         DevBuf<unsigned long long> ml(ctx, 1);
-        if (!ml.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr"); }
+        if (!ml.p) { return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr"); }
         HIP_TRY(ctx, hipMemsetAsync(ml.p, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_max_len, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, ml.p);
         { const int rb_ = b3c_readback(ctx, &maxlen, ml.p, sizeof(maxlen)); if (rb_) return rb_; }
@@ -651,32 +652,31 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
             // ... and the longer ones (hubs) through ONE radix sort of just their entries: a single long row no longer sends
             // the whole matrix down the global-sort path
             DevBuf<int64_t> rflag(ctx, n + 1), ecnt(ctx, n + 1), rpos(ctx, n + 2), epos(ctx, n + 2);
-            if (!rflag.p || !ecnt.p || !rpos.p || !epos.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: long rows"); }
+            if (!rflag.p || !ecnt.p || !rpos.p || !epos.p) { return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: long rows"); }
             hipLaunchKernelGGL(k_long_flags, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, CAPR, m->indptr, rflag.p, ecnt.p);
             if ((rc = b3c_exclusive_scan_i64(ctx, rflag.p, rpos.p, n + 1)) || (rc = b3c_exclusive_scan_i64(ctx, ecnt.p, epos.p, n + 1))) {
-                b3c_mat_free(ctx, m);
                 return rc;
             }
             int64_t tot[2] = {0, 0};
             { const int rb_ = b3c_readback(ctx, &tot[0], rpos.p + n, sizeof(int64_t)); if (rb_) return rb_; }
             { const int rb_ = b3c_readback(ctx, &tot[1], epos.p + n, sizeof(int64_t)); if (rb_) return rb_; }
             const int64_t n_long = tot[0], n_ent = tot[1];
-            if (n_ent >= (1ll << 31)) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_ARG, "b3c_permute_csr: more than 2^31 entries in long rows"); }
+            if (n_ent >= (1ll << 31)) { return ctx->fail(B3C_E_ARG, "b3c_permute_csr: more than 2^31 entries in long rows"); }
             DevBuf<int32_t> long_rows(ctx, n_long + 1);
             DevBuf<unsigned long long> k_in(ctx, n_ent + 1), k_out(ctx, n_ent + 1);
             DevBuf<uint32_t> v_in(ctx, n_ent + 1), v_out(ctx, n_ent + 1);
-            if (!long_rows.p || !k_in.p || !k_out.p || !v_in.p || !v_out.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: long rows"); }
+            if (!long_rows.p || !k_in.p || !k_out.p || !v_in.p || !v_out.p) { return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: long rows"); }
             hipLaunchKernelGGL(k_long_keys, dim3(grid_for(n, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr, a->indices, new2old,
                                old2new, rflag.p, rpos.p, epos.p, long_rows.p, k_in.p, v_in.p);
             int end_bit = 33;
             while (end_bit < 64 && (1ll << (end_bit - 32)) < n_long) end_bit++;
             size_t tb = 0;
             hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)n_ent, 0, end_bit, s);
-            if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort sizing failed"); }
+            if (e != hipSuccess) { return ctx->fail(B3C_E_HIP, "radix sort sizing failed"); }
             DevBuf<char> tmp(ctx, tb);
-            if (!tmp.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort workspace"); }
+            if (!tmp.p) { return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort workspace"); }
             e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)n_ent, 0, end_bit, s);
-            if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort failed"); }
+            if (e != hipSuccess) { return ctx->fail(B3C_E_HIP, "radix sort failed"); }
             const unsigned gs = (unsigned)((n_ent + 255) / 256);
             if (a->kind == B3C_F64)
                 hipLaunchKernelGGL(k_long_scatter<double>, dim3(gs), dim3(256), 0, s, n_ent, k_out.p, v_out.p, long_rows.p, epos.p, a->indptr,
@@ -712,11 +712,10 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
             hipLaunchKernelGGL(k_permute_rows<uint32_t>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
                                (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
     } else if (nnz && block) {
-        b3c_mat_free(ctx, m);
         return ctx->fail(B3C_E_ARG, "b3c_permute_csr: the global-sort path cannot produce a row block");
     } else if (nnz) {
         DevBuf<int64_t> k_in(ctx, nnz), k_out(ctx, nnz);
-        if (!k_in.p || !k_out.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort keys"); }
+        if (!k_in.p || !k_out.p) { return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort keys"); }
         hipLaunchKernelGGL(k_perm_keys, dim3(grid_for(n, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, a->indptr,
                            a->indices, old2new, k_in.p);
         int end_bit = 1;
@@ -727,19 +726,19 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
             e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, (const double *)a->data, (double *)m->data, (int64_t)nnz, 0, end_bit, s);
         else
             e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, (const uint32_t *)a->data, (uint32_t *)m->data, (int64_t)nnz, 0, end_bit, s);
-        if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort sizing failed"); }
+        if (e != hipSuccess) { return ctx->fail(B3C_E_HIP, "radix sort sizing failed"); }
         DevBuf<char> tmp(ctx, tb);
-        if (!tmp.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort workspace"); }
+        if (!tmp.p) { return ctx->fail(B3C_E_NOMEM, "b3c_permute_csr: sort workspace"); }
         if (a->kind == B3C_F64)
             e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, (const double *)a->data, (double *)m->data, (int64_t)nnz, 0, end_bit, s);
         else
             e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, (const uint32_t *)a->data, (uint32_t *)m->data, (int64_t)nnz, 0, end_bit, s);
-        if (e != hipSuccess) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_HIP, "radix sort failed"); }
+        if (e != hipSuccess) { return ctx->fail(B3C_E_HIP, "radix sort failed"); }
         hipLaunchKernelGGL(k_cols_from_keys, dim3(grid_for(nnz, 1024, 16 * ctx->n_cu)), dim3(256), 0, s, nnz, n, k_out.p, m->indices);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    *out = m;
+    *out = own.release();
     return B3C_OK;
 }
 
@@ -778,11 +777,12 @@ extern "C" int b3c_mat_permute_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_
     if (rc) return rc;
     const unsigned gn = (unsigned)((n + 255) / 256);
     if (n) hipLaunchKernelGGL(k_invert_perm, dim3(gn), dim3(256), 0, ctx->stream, n, n2o.p, o2n.p);
-    b3c_mat *m = nullptr;
-    if ((rc = b3c_permute_csr_rows(ctx, a, n2o.p, o2n.p, &m, !(flags & B3C_PERMUTE_UNSORTED), row0, row1))) return rc;
+    MatOwner own(ctx);
+    if ((rc = b3c_permute_csr_rows(ctx, a, n2o.p, o2n.p, &own.m, !(flags & B3C_PERMUTE_UNSORTED), row0, row1))) return rc;
+    b3c_mat *m = own.m;
     // caller-side id of every row: compose with the input's ids if it was permuted before
     m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
-    if (!m->ids) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_mat_permute"); }
+    if (!m->ids) return ctx->fail(B3C_E_NOMEM, "b3c_mat_permute");
     if (n) {
         if (a->ids) hipLaunchKernelGGL(k_gather_i32, dim3(gn), dim3(256), 0, ctx->stream, n, a->ids, n2o.p, m->ids);
         else HIP_TRY(ctx, hipMemcpyAsync(m->ids, n2o.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -792,7 +792,7 @@ extern "C" int b3c_mat_permute_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_
     m->row0 = row0;
     m->row1 = row1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *out = m;
+    *out = own.release();
     return B3C_OK;
 }
 

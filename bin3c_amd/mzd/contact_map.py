@@ -247,10 +247,12 @@ class ContactMap(object):
             self.order.order = self.order.order.astype(SeqOrder.STRUCT_TYPE)
 
     def __getstate__(self):
+        """The attribute dictionary the reference's ContactMap has (contact_map.py:488-529): the balanced map sits under its
+        reference name ``processed_map`` (materialised on the host before the device handles go away), nothing private."""
         d = self.__dict__.copy()
-        d['_processed_host'] = self.processed_map      # materialise before the device handles go away
-        d['_hot'] = None
-        d['_ctx'] = None
+        d['processed_map'] = self.processed_map
+        for k in ('_processed_host', '_hot', '_ctx'):
+            d.pop(k, None)
         return d
 
     # ---- device plumbing ----------------------------------------------------------------------
@@ -355,11 +357,8 @@ class ContactMap(object):
         if bisto:
             from ..pipeline import run_hot_path
             counts = ctx.upload(c.indptr, c.indices, c.data)
-            try:
-                res = run_hot_path(ctx, counts, self._get_sites(), self.order.lengths(), self.min_len, self.min_sig,
-                                   cluster=False, keep=True, mask=_mask)
-            finally:
-                counts.free()
+            res = run_hot_path(ctx, counts, self._get_sites(), self.order.lengths(), self.min_len, self.min_sig,
+                               cluster=False, keep=True, mask=_mask, adopt_counts=True)
             self._report_kr(res.kr_info)
             self.bisto_scale = res.x
             logger.debug('Map balanced')

@@ -51,13 +51,18 @@ def pin_to_device_cpus(device=0):
         return None
 
 
-def make_context(device=0):
-    """A libb3c context that launches on a torch stream of `device` (so torch ops and kernels interleave in order)."""
+def make_context(device=0, pin=None):
+    """A libb3c context that launches on a torch stream of `device` (so torch ops and kernels interleave in order).
+    pin=True restricts the PROCESS to the CPUs of the GPU's NUMA node (pin_to_device_cpus: worth 4-25 % of a step on
+    two-socket hosts) -- a process-wide side effect, so library callers get it only on request or with B3C_PIN=1;
+    bench.py and the bin3C.py command line ask for it."""
     import torch
     if not torch.cuda.is_available():
         raise _native.B3CError(_native.E_HIP, 'no MI355X visible: torch.cuda.is_available() is False and libb3c has '
                                               'no CPU fallback')
-    pin_to_device_cpus(device)
+    import os
+    if pin or (pin is None and os.environ.get('B3C_PIN')):
+        pin_to_device_cpus(device)
     stream = torch.cuda.Stream(device=device)
     ctx = _native.Context(device, stream=stream.cuda_stream)
     ctx.torch_stream = stream
@@ -128,7 +133,7 @@ def acceptance_mask(ctx, counts, lengths, min_len, min_sig):
 
 
 def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=0, cluster=True, keep=False,
-                 reorder=True, mask=None):
+                 reorder=True, mask=None, adopt_counts=False):
     """
     :param ctx: context from :func:`make_context`
     :param counts: _native.Mat (B3C_U32) raw symmetric contact counts, already in HBM
@@ -138,6 +143,8 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
                     returned vector is in the caller's numbering either way
     :param mask: bool[n] acceptance mask decided by the caller (ContactMap.primary_acceptance_mask); when
                  None it is computed here from lengths / min_len / min_sig
+    :param adopt_counts: the result takes `counts` over (frees it with res.free()); with keep=True the balanced map can then
+                         still be formed on demand when no ordered copy was made
     :return: HotPathResult (device matrices freed unless keep=True)
     """
     import torch
@@ -204,13 +211,18 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
         except Exception:
             if work is not counts:
                 work.free()
+            if adopt_counts:
+                counts.free()
             raise
         # the balanced map (normalisation exactly as the reference forms it, then X A X, sparse_utils.py:223-224; graph
         # form when A is bitwise symmetric so that Louvain needs no mirror lookups) is formed on demand from these
         graph_form = bool(res.kr_info.bitwise_symmetric)
-        res._lazy = (ctx, work, sites_t, x_w, graph_form, work is not counts)
-        if work is counts and keep:
+        res._lazy = (ctx, work, sites_t, x_w, graph_form, work is not counts or adopt_counts)
+        if adopt_counts and work is not counts:
+            counts.free()                      # the ordered copy is what the result works on
+        if work is counts and keep and not adopt_counts:
             res.processed                      # the caller owns `counts` and may free it: materialise now
+            res._lazy = None
 
         labels_t = None
         if cluster:
@@ -323,13 +335,26 @@ def device_subspace(ctx, res, mask, order=None):
 
 
 def processed_to_host(ctx, res):
-    """processed_map (contact_map.py:945) as host CSR arrays in the caller's numbering."""
-    m = res.processed
+    """processed_map (contact_map.py:945) as host CSR arrays in the caller's numbering, with the values scipy holds:
+    X.T * (A * X) entry by entry (sparse_utils.py:223-224).  The device copy used for clustering may be in graph form (both
+    triangles carry the lower-triangle value, an ulp or two off in the upper one), so the exported map is formed apart."""
+    import torch
     n2o, o2n = res.perm
-    if n2o is None:
-        return m.download()
-    back = ctx.permute(m, o2n)          # row k of the result = row o2n[k] of the ordered matrix = caller row k
+    own = None
+    if res._lazy is not None:
+        _c, work, sites_t, x_w, graph_form, _owned = res._lazy
+        if graph_form or res._processed is None:
+            with torch.cuda.stream(ctx.torch_stream):
+                own = ctx.normalise_scale(work, sites_t, x_w, graph_form=False)
+    m = own if own is not None else res.processed
     try:
-        return back.download()
+        if n2o is None:
+            return m.download()
+        back = ctx.permute(m, o2n)          # row k of the result = row o2n[k] of the ordered matrix = caller row k
+        try:
+            return back.download()
+        finally:
+            back.free()
     finally:
-        back.free()
+        if own is not None:
+            own.free()
