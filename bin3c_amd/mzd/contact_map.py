@@ -237,7 +237,11 @@ class ContactMap(object):
     def __setstate__(self, state):
         """Also accepts the attribute dictionary of a map pickled by the reference (old-style class, no private
         fields): its cached ``processed_map`` becomes the host copy, device handles start empty."""
+        from .io_utils import revive
         state = dict(state)
+        for k in ('seq_map', 'processed_map', 'extent_map'):          # scipy matrices of a reference-era (scipy < 1.8) pickle
+            if k in state:
+                state[k] = revive(state[k])
         if 'processed_map' in state:
             state['_processed_host'] = state.pop('processed_map')
         for k in ('_processed_host', '_hot', '_ctx'):

@@ -40,6 +40,43 @@ def save_object(file_name, obj):
         pickle.dump(obj, out_h, protocol=pickle.HIGHEST_PROTOCOL)
 
 
+class _LegacySparse(object):
+    """Stand-in for a scipy.sparse matrix pickled by scipy < 1.8 (the reference's era): such a pickle is the object's
+    attribute dictionary (``row`` / ``col`` / ``data`` / ``_shape`` for COO, ``indptr`` / ``indices`` / ``data`` for CSR), which a
+    current scipy class can no longer adopt as is (COO keeps ``coords`` now).  :meth:`to_scipy` rebuilds the real matrix."""
+
+    fmt = None
+
+    def __setstate__(self, state):
+        self.state = state
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        st = self.state
+        shape = tuple(st.get('_shape', st.get('shape')))
+        if self.fmt == 'coo':
+            return sp.coo_matrix((st['data'], (st['row'], st['col'])), shape=shape)
+        cls = sp.csr_matrix if self.fmt == 'csr' else sp.csc_matrix
+        return cls((st['data'], st['indices'], st['indptr']), shape=shape)
+
+
+class _LegacyCOO(_LegacySparse):
+    fmt = 'coo'
+
+
+class _LegacyCSR(_LegacySparse):
+    fmt = 'csr'
+
+
+class _LegacyCSC(_LegacySparse):
+    fmt = 'csc'
+
+
+def revive(obj):
+    """scipy matrices of a reference-era pickle -> current scipy objects (anything else is returned unchanged)"""
+    return obj.to_scipy() if isinstance(obj, _LegacySparse) else obj
+
+
 class _RefUnpickler(pickle.Unpickler):
     """Resolve the reference's module paths (``mzd.contact_map.ContactMap`` ...) and Python-2 names onto this package,
     so that a ``contact_map.p.gz`` written by bin3C itself loads here."""
@@ -48,7 +85,12 @@ class _RefUnpickler(pickle.Unpickler):
                 'mzd.exceptions': 'bin3c_amd.mzd.exceptions', 'mzd.io_utils': 'bin3c_amd.mzd.io_utils',
                 'mzd.utils': 'bin3c_amd.mzd.utils', '__builtin__': 'builtins', 'copy_reg': 'copyreg'}
 
+    _LEGACY = {('scipy.sparse.coo', 'coo_matrix'): _LegacyCOO, ('scipy.sparse.csr', 'csr_matrix'): _LegacyCSR,
+               ('scipy.sparse.csc', 'csc_matrix'): _LegacyCSC}
+
     def find_class(self, module, name):
+        if (module, name) in self._LEGACY:
+            return self._LEGACY[(module, name)]
         return pickle.Unpickler.find_class(self, self._MODULES.get(module, module), name)
 
 

@@ -193,3 +193,37 @@ def test_reference_module_paths_resolve_on_load(tmp_path):
     back = io_utils.load_object(str(tmp_path / 'ref_map.p.gz'))
     assert isinstance(back, ContactMap) and isinstance(back.order, SeqOrder)
     assert back.total_seq == 200 and (back.seq_map != cm.seq_map).nnz == 0
+
+
+def test_loads_a_python2_protocol0_contact_map(tmp_path):
+    """a ContactMap in the byte format the Python-2 reference writes (cPickle protocol 0: old-style class INST
+    records, S'...' strings with raw numpy buffers, copy_reg._reconstructor for the SeqInfo namedtuples and for the scipy
+    matrices of scipy < 1.8, numpy.random.__RandomState_ctor) -- assembled opcode by opcode by tools/make_py2_pickle.py
+    because no Python 2 exists here -- loads into the mirror classes with its content intact and round-trips."""
+    import warnings
+    import scipy.sparse as sp
+    from bin3c_amd.mzd import io_utils
+    from bin3c_amd.mzd.contact_map import ContactMap, SeqInfo, SeqOrder
+    import gzip
+    raw = gzip.open(os.path.join(GOLDEN, 'contact_map_py2.p.gz')).read()
+    assert raw.startswith(b'(imzd.contact_map\nContactMap\n') and raw.endswith(b'.')          # protocol 0, old-style instance
+    assert b'ccopy_reg\n_reconstructor\n' in raw and b'cnumpy.core.multiarray\n_reconstruct\n' in raw
+    exp = np.load(os.path.join(GOLDEN, 'contact_map_py2_expect.npz'))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')                    # numpy.core / scipy.sparse.coo shims announce their deprecation
+        cm = io_utils.load_object(os.path.join(GOLDEN, 'contact_map_py2.p.gz'))
+    assert isinstance(cm, ContactMap) and isinstance(cm.order, SeqOrder) and isinstance(cm.seq_info[0], SeqInfo)
+    n = exp['lengths'].shape[0]
+    assert (cm.total_seq, cm.min_len, cm.min_sig, cm.enzymes, cm.bam_file) == (n, 1000, 5, ['MluCI', 'Sau3AI'], 'hic2ctg.bam')
+    assert [s.length for s in cm.seq_info] == exp['lengths'].tolist() and [s.sites for s in cm.seq_info] == exp['sites'].astype(int).tolist()
+    assert sp.isspmatrix_coo(cm.seq_map) and cm.seq_map.dtype == np.uint32
+    c = cm.seq_map.tocsr()
+    c.sort_indices()
+    assert np.array_equal(c.indptr, exp['indptr']) and np.array_equal(c.indices, exp['indices']) and np.array_equal(c.data, exp['counts'])
+    assert cm.order.order.dtype == SeqOrder.STRUCT_TYPE and np.array_equal(cm.order.order['length'], exp['lengths'])
+    assert np.array_equal(cm.order.lengths(), exp['lengths']) and cm.order.count_accepted() == n
+    assert np.array_equal(cm.primary_acceptance_mask, exp['mask']) and cm.processed_map is None
+    assert np.array_equal(cm.random_state.randint(0, 1 << 30, 5), exp['rs_next'])        # the generator resumes where it was
+    io_utils.save_object(str(tmp_path / 'again.p'), cm)
+    back = io_utils.load_object(str(tmp_path / 'again.p.gz'))
+    assert back.total_seq == n and (back.seq_map != cm.seq_map).nnz == 0
