@@ -133,7 +133,7 @@ def acceptance_mask(ctx, counts, lengths, min_len, min_sig):
 
 
 def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=0, cluster=True, keep=False,
-                 reorder=True, mask=None, adopt_counts=False):
+                 reorder=True, mask=None, adopt_counts=False, max_iter=1000):
     """
     :param ctx: context from :func:`make_context`
     :param counts: _native.Mat (B3C_U32) raw symmetric contact counts, already in HBM
@@ -143,6 +143,7 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
                     returned vector is in the caller's numbering either way
     :param mask: bool[n] acceptance mask decided by the caller (ContactMap.primary_acceptance_mask); when
                  None it is computed here from lengths / min_len / min_sig
+    :param max_iter: iteration limit of the balancing (sparse_utils.py:90, default 1000 like the reference)
     :param adopt_counts: the result takes `counts` over (frees it with res.free()); with keep=True the balanced map can then
                          still be formed on demand when no ordered copy was made
     :return: HotPathResult (device matrices freed unless keep=True)
@@ -205,7 +206,7 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
             # mirror lookups; otherwise exactly as scipy does.
             t0 = time.perf_counter()
             x_w = torch.empty(n, dtype=torch.float64, device=dev)
-            rc, _, res.kr_info = ctx.kr_balance_counts(work, sites_t, tol=tol, x_out=x_w, check=False)
+            rc, _, res.kr_info = ctx.kr_balance_counts(work, sites_t, tol=tol, max_iter=max_iter, x_out=x_w, check=False)
             ctx._check(rc)
             t['kr'] = time.perf_counter() - t0
         except Exception:
