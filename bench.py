@@ -205,7 +205,9 @@ def main():
             vb = last.kr_info.value_bits / 8.0             # 2 when all counts fit 16 bits, else 4 (8: fp64 matrix)
             streamed = ((4.0 + vb) * nnz + 36.0 * n) * share   # what the SpMV kernel physically reads/writes
             avg_ms = spmv_ms / max(spmv_n, 1)
-            kname = 'kr_kb_vec (CSR SpMV on raw counts + fused KR epilogue)'
+            tcd = getattr(last.kr_info, 'tcd_tiles', 0) > 0    # tile-dictionary layout (automatic for n <= 2^19)
+            kname = ('kr_kb_tcd2 (tile-dictionary SpMV on raw counts + fused KR epilogue)' if tcd
+                     else 'kr_kb_vec (CSR SpMV on raw counts + fused KR epilogue)')
         else:
             per_launch = (16.0 * acc['move_nnz'] + 28.0 * acc['move_rows']) / max(move_n, 1)   # Louvain sweep / n_sub
             streamed = per_launch

@@ -748,9 +748,14 @@ constexpr int TCD_CHUNK_LG = 19;                      // columns per bitmap pass
 constexpr int TCD_WORDS = 1 << (TCD_CHUNK_LG - 5);    // 16384 words = 64 KB per bitmap
 constexpr int TCD_GROUPS = TCD_WORDS / 4;             // one 16-bit prefix per 128 columns
 constexpr int TCD_RMAX = 256;                         // rows per tile at most
-constexpr size_t TCD_BUILD_LDS = sizeof(uint32_t) * 2 * TCD_WORDS + sizeof(uint16_t) * TCD_GROUPS + sizeof(uint32_t) * (32 + 2 * TCD_RMAX);
+constexpr size_t TCD_BUILD_LDS = sizeof(uint32_t) * 2 * TCD_WORDS + sizeof(uint16_t) * TCD_GROUPS + sizeof(uint32_t) * (32 + 4 * TCD_RMAX) +
+                                 sizeof(int64_t) * (TCD_RMAX + 2);
 
-__global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap,
+// Columns ascend inside a row (`sorted` != 0), so the entries of one bitmap pass are a contiguous piece of the row: every
+// pass starts where the one before stopped (rdone) and stops at the first slice that leaves its column range -- each entry
+// is read once per sweep, whatever the number of passes.  The row pointers of the tile sit in LDS, and a wave has the first
+// slice of its NEXT row in flight while it works on the current one.
+__global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap, int sorted,
                                                         const int64_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices,
                                                         const uint32_t *__restrict__ counts, uint32_t *__restrict__ packed,
@@ -765,33 +770,64 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
     uint32_t *wsum = tsm + 2 * TCD_WORDS + TCD_GROUPS / 2;    // 16 wave sums
     uint32_t *nfront = wsum + 32;                     // per row: entries placed from the front / from the back so far
     uint32_t *nback = nfront + TCD_RMAX;
+    uint32_t *rdone = nback + TCD_RMAX;               // per row: entries consumed by the passes before
+    uint32_t *rcnt = rdone + TCD_RMAX;                // per row: entries of this pass
+    int64_t *ipl = (int64_t *)(rcnt + TCD_RMAX);      // row pointers of the tile
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t tile = blockIdx.x;
-    const int64_t ra = r0 + tile * R, rb = ra + R < r1 ? ra + R : r1;
+    const int64_t ra = r0 + tile * R;
+    const int nrows = (int)((ra + R < r1 ? ra + R : r1) - ra);
     uint4 *b14 = (uint4 *)bm1, *b24 = (uint4 *)bm2;
     constexpr int GPT = TCD_GROUPS / TCD_TB;          // groups per thread
     constexpr int NW = TCD_TB / 64;
-    for (int i = tid; i < 2 * TCD_RMAX; i += TCD_TB) nfront[i] = 0;
+    for (int i = tid; i < 4 * TCD_RMAX; i += TCD_TB) nfront[i] = 0;
+    for (int i = tid; i <= nrows; i += TCD_TB) ipl[i] = indptr[ra + i];
     int32_t *__restrict__ dc = dict_cols + tile * (int64_t)d1cap;
     int64_t a1 = 0;                                   // dictionary columns of the passes before (uncapped)
-    for (int64_t c0 = 0; c0 < ncols; c0 += (int64_t)1 << TCD_CHUNK_LG) {
+    const int64_t CHUNK = (int64_t)1 << TCD_CHUNK_LG;
+    for (int64_t c0 = 0; c0 < ncols; c0 += CHUNK) {
         for (int i = tid; i < TCD_WORDS / 4; i += TCD_TB) { b14[i] = make_uint4(0, 0, 0, 0); b24[i] = make_uint4(0, 0, 0, 0); }
         __syncthreads();
-        for (int64_t row = ra + wv; row < rb; row += NW) {
-            const int64_t s = indptr[row];
-            const int len = (int)(indptr[row + 1] - s);
-            if (len > hub_len) continue;                        // hub rows run on the CSR arrays (kr_kb_hub)
-            for (int base = 0; base < len; base += 256) {
-                int64_t c[4];
+        // ---- sweep 1: which columns does the tile use, which more than once ----
+        {
+            int rl = wv;
+            int32_t nx[4];                                 // first slice of the next row, in flight
+            auto first_slice = [&](int r, int32_t (&j)[4]) {
+                if (r < nrows) {
+                    const int64_t s = ipl[r] + (sorted ? rdone[r] : 0);
+                    const int64_t e = ipl[r + 1];
 #pragma unroll
-                for (int t = 0; t < 4; t++) { const int k = base + t * 64 + lane; c[t] = k < len ? (int64_t)indices[s + k] - c0 : -1; }
+                    for (int t = 0; t < 4; t++) { const int64_t k = s + t * 64 + lane; j[t] = k < e ? indices[k] : 0x7FFFFFFF; }
+                }
+            };
+            first_slice(rl, nx);
+            for (; rl < nrows; rl += NW) {
+                int32_t j[4] = {nx[0], nx[1], nx[2], nx[3]};
+                first_slice(rl + NW, nx);
+                const int64_t s0 = ipl[rl], e = ipl[rl + 1];
+                if (e - s0 > hub_len) { if (lane == 0) rcnt[rl] = 0; continue; }   // hub rows run on the CSR arrays (kr_kb_hub)
+                int64_t s = s0 + (sorted ? rdone[rl] : 0);
+                uint32_t got = 0;
+                for (;;) {
+                    bool beyond = false;
 #pragma unroll
-                for (int t = 0; t < 4; t++)
-                    if (c[t] >= 0 && c[t] < ((int64_t)1 << TCD_CHUNK_LG)) {
-                        const uint32_t bit = 1u << (c[t] & 31);
-                        const uint32_t old = atomicOr(&bm1[c[t] >> 5], bit);
-                        if (old & bit) atomicOr(&bm2[c[t] >> 5], bit);
+                    for (int t = 0; t < 4; t++) {
+                        const int64_t c = (int64_t)j[t] - c0;
+                        const bool in = j[t] != 0x7FFFFFFF && c >= 0 && c < CHUNK;
+                        if (in) {
+                            const uint32_t bit = 1u << (c & 31);
+                            const uint32_t old = atomicOr(&bm1[c >> 5], bit);
+                            if (old & bit) atomicOr(&bm2[c >> 5], bit);
+                        }
+                        got += (uint32_t)__popcll(__ballot(in));
+                        beyond |= j[t] != 0x7FFFFFFF && c >= CHUNK;
                     }
+                    s += 256;
+                    if (s >= e || (sorted && __ballot(beyond))) break;     // columns ascend: nothing of this pass further on
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { const int64_t k = s + t * 64 + lane; j[t] = k < e ? indices[k] : 0x7FFFFFFF; }
+                }
+                if (lane == 0) rcnt[rl] = got;
             }
         }
         __syncthreads();
@@ -837,53 +873,77 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
                 }
             }
         }
-        // the rows: dictionary entries to the front (index << 16 | count), the others to the back (count; column beside it)
-        for (int64_t row = ra + wv; row < rb; row += NW) {
-            const int64_t s = indptr[row];
-            const int len = (int)(indptr[row + 1] - s);
-            if (len > hub_len) continue;
-            uint32_t nf = nfront[row - ra], nb = nback[row - ra];
-            for (int base = 0; base < len; base += 256) {
-                int64_t c[4];
-                uint32_t cv[4];
+        // ---- sweep 2: the rows, dictionary entries to the front (index << 16 | count), the others to the back ----
+        {
+            int rl = wv;
+            int32_t nx[4];
+            uint32_t nv[4];
+            auto first_slice = [&](int r, int32_t (&j)[4], uint32_t (&cv)[4]) {
+                if (r < nrows) {
+                    const int64_t s = ipl[r] + (sorted ? rdone[r] : 0);
+                    const int64_t e = sorted ? s + rcnt[r] : ipl[r + 1];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int k = base + t * 64 + lane;
-                    c[t] = k < len ? (int64_t)indices[s + k] - c0 : -1;
-                    cv[t] = k < len ? counts[s + k] & 0xFFFFu : 0u;
+                    for (int t = 0; t < 4; t++) {
+                        const int64_t k = s + t * 64 + lane;
+                        j[t] = k < e ? indices[k] : 0x7FFFFFFF;
+                        cv[t] = k < e ? counts[k] & 0xFFFFu : 0u;
+                    }
                 }
+            };
+            first_slice(rl, nx, nv);
+            for (; rl < nrows; rl += NW) {
+                int32_t j[4] = {nx[0], nx[1], nx[2], nx[3]};
+                uint32_t cv[4] = {nv[0], nv[1], nv[2], nv[3]};
+                first_slice(rl + NW, nx, nv);
+                const int64_t s0 = ipl[rl];
+                const int len = (int)(ipl[rl + 1] - s0);
+                if (len > hub_len) continue;
+                const int64_t sb = s0 + (sorted ? rdone[rl] : 0);
+                const int64_t e = sorted ? sb + rcnt[rl] : ipl[rl + 1];
+                uint32_t nf = nfront[rl], nb = nback[rl];
+                for (int64_t s = sb; s < e; s += 256) {
+                    if (s > sb) {
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const bool in = c[t] >= 0 && c[t] < ((int64_t)1 << TCD_CHUNK_LG);
-                    bool front = false;
-                    int64_t r = 0;
-                    if (in) {
-                        const int wd = (int)(c[t] >> 5), g = wd >> 2;
-                        if ((bm2[wd] >> (c[t] & 31)) & 1u) {
-                            r = a1 + pre1[g];
-                            for (int j = g * 4; j < wd; j++) r += __popc(bm2[j]);
-                            r += __popc(bm2[wd] & ((1u << (c[t] & 31)) - 1u));
-                            front = r < d1cap;
+                        for (int t = 0; t < 4; t++) {
+                            const int64_t k = s + t * 64 + lane;
+                            j[t] = k < e ? indices[k] : 0x7FFFFFFF;
+                            cv[t] = k < e ? counts[k] & 0xFFFFu : 0u;
                         }
                     }
-                    const unsigned long long mf = __ballot(in && front), mb = __ballot(in && !front);
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    if (in && front) packed[s + nf + __popcll(mf & below)] = ((uint32_t)r << 16) | cv[t];
-                    if (in && !front) {
-                        const int64_t at = s + len - 1 - (int64_t)(nb + __popcll(mb & below));
-                        packed[at] = cv[t];
-                        pcol[at] = (int32_t)(c[t] + c0);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int64_t c = (int64_t)j[t] - c0;
+                        const bool in = j[t] != 0x7FFFFFFF && c >= 0 && c < CHUNK;
+                        bool front = false;
+                        int64_t r = 0;
+                        if (in) {
+                            const int wd = (int)(c >> 5), g = wd >> 2;
+                            if ((bm2[wd] >> (c & 31)) & 1u) {
+                                r = a1 + pre1[g];
+                                for (int q = g * 4; q < wd; q++) r += __popc(bm2[q]);
+                                r += __popc(bm2[wd] & ((1u << (c & 31)) - 1u));
+                                front = r < d1cap;
+                            }
+                        }
+                        const unsigned long long mf = __ballot(in && front), mb = __ballot(in && !front);
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        if (in && front) packed[s0 + nf + __popcll(mf & below)] = ((uint32_t)r << 16) | cv[t];
+                        if (in && !front) {
+                            const int64_t at = s0 + len - 1 - (int64_t)(nb + __popcll(mb & below));
+                            packed[at] = cv[t];
+                            pcol[at] = j[t];
+                        }
+                        nf += __popcll(mf);
+                        nb += __popcll(mb);
                     }
-                    nf += __popcll(mf);
-                    nb += __popcll(mb);
                 }
+                if (lane == 0) { nfront[rl] = nf; nback[rl] = nb; rdone[rl] += rcnt[rl]; }
             }
-            if (lane == 0) { nfront[row - ra] = nf; nback[row - ra] = nb; }
         }
         a1 += tot1;
         __syncthreads();
     }
-    for (int i = tid; i < (int)(rb - ra); i += TCD_TB) n1_out[ra + i - r0] = (int32_t)nfront[i];
+    for (int i = tid; i < nrows; i += TCD_TB) n1_out[ra + i - r0] = (int32_t)nfront[i];
     if (tid == 0) {
         const int d1 = (int)(a1 < d1cap ? a1 : d1cap);
         dict_cnt[tile] = d1;
@@ -891,7 +951,7 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
         atomicAdd(&stats[2], (unsigned long long)d1);
     }
     // entries left in the tails (statistics only)
-    if (tid < (int)(rb - ra) && nback[tid]) atomicAdd(&stats[3], (unsigned long long)nback[tid]);
+    if (tid < nrows && nback[tid]) atomicAdd(&stats[3], (unsigned long long)nback[tid]);
 }
 
 template <int OP>
@@ -954,6 +1014,13 @@ __global__ void __launch_bounds__(BLK) kr_kb_tcd(int64_t r0, int64_t r1, int64_t
         tv[i] = v[ra + i];
         n1l[i] = n1v[ra + i - r0];
     }
+    KRState st = *sin;
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
+    const bool inner = st.phase == A_INNER;
+    if (st.phase == A_INNER) st.phase = B_INNER;
+    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
     {
         const int32_t *__restrict__ dc1 = dict_cols + (live ? tile : 0) * (int64_t)dstride;
         for (int base = 0; base < D1 && !(probe & 4); base += BLK * 4) {
@@ -968,13 +1035,6 @@ __global__ void __launch_bounds__(BLK) kr_kb_tcd(int64_t r0, int64_t r1, int64_t
         }
     }
     if (D1 == 0 && tid == 0) xl[0] = 0.0;     // masked lanes multiply a zero count with xl[0]: keep stale LDS (NaN) out
-    KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
-    const bool inner = st.phase == A_INNER;
-    if (st.phase == A_INNER) st.phase = B_INNER;
-    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
     __syncthreads();
 
     // the tile's entries and the operand vector as buffer resources (descriptors from wave-uniform values only): a lane
@@ -1208,6 +1268,13 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
         ep = p[ra + tid];
         ev = v[ra + tid];
     }
+    KRState st = *sin;
+    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_sum_n<TBK>(partA, PA, PS, lds);   // :160
+    const bool inner = st.phase == A_INNER;
+    if (st.phase == A_INNER) st.phase = B_INNER;
+    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
     {
         const int32_t *__restrict__ dc1 = dict_cols + (live ? tile : 0) * (int64_t)dstride;
         for (int base = 0; base < D1; base += TBK * 4) {
@@ -1222,13 +1289,6 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
         }
     }
     if (D1 == 0 && tid == 0) xl[0] = 0.0;     // masked lanes multiply a zero count with xl[0]: keep stale LDS (NaN) out
-    KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_sum_n<TBK>(partA, PA, PS, lds);   // :160
-    const bool inner = st.phase == A_INNER;
-    if (st.phase == A_INNER) st.phase = B_INNER;
-    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
     __syncthreads();
 
     const int64_t e0 = ipl[0];
@@ -1979,9 +2039,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         DevBuf<unsigned long long> stt(ctx, 4);
         if (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
         HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 4, s));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS));
+        { static bool build_attr = false; if (!build_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS)); build_attr = true; } }
         hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
-                           a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
+                           a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
         unsigned long long hst[4];
         { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
         tcd_lds_d = (int)((hst[0] + 1) & ~1ull);
@@ -2026,13 +2086,20 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const bool tcd_split = tcd && tcd_R <= TBK && getenv("B3C_KR_TCD_NOSPLIT") == nullptr;
     const size_t tcd_shmem2 = sizeof(double) * ((size_t)tcd_lds_d + 2 * (size_t)tcd_R + (size_t)tcd_R + 1 + TBK) + sizeof(int32_t) * (size_t)tcd_R;
     if (tcd) {
-#define KR_TCD2_ATTR(L, U, TL, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tcd_shmem2))
-        KR_TCD2_ATTR(16, 4, 8, 1); KR_TCD2_ATTR(16, 4, 16, 1); KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 8, 4, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
+        // dynamic LDS beyond 64 KB needs the attribute; set once per process to the device limit (the call is not cheap:
+        // fourteen of them per balance call cost over 2 ms)
+        static bool attr_done = false;
+        if (!attr_done) {
+            constexpr int LDS_MAX = 160 * 1024;
+#define KR_TCD2_ATTR(L, U, TL, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
+            KR_TCD2_ATTR(16, 4, 8, 1); KR_TCD2_ATTR(16, 4, 16, 1); KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 8, 4, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
 #undef KR_TCD2_ATTR
-#define KR_TCD_ATTR(L, U, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tcd_shmem))
-        KR_TCD_ATTR(16, 4, 2); KR_TCD_ATTR(8, 8, 2); KR_TCD_ATTR(8, 8, 1); KR_TCD_ATTR(32, 2, 1); KR_TCD_ATTR(16, 4, 1);
-        KR_TCD_ATTR(8, 4, 1); KR_TCD_ATTR(4, 4, 1); KR_TCD_ATTR(4, 2, 1);
+#define KR_TCD_ATTR(L, U, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
+            KR_TCD_ATTR(16, 4, 2); KR_TCD_ATTR(8, 8, 2); KR_TCD_ATTR(8, 8, 1); KR_TCD_ATTR(32, 2, 1); KR_TCD_ATTR(16, 4, 1);
+            KR_TCD_ATTR(8, 4, 1); KR_TCD_ATTR(4, 4, 1); KR_TCD_ATTR(4, 2, 1);
 #undef KR_TCD_ATTR
+            attr_done = true;
+        }
     }
 #define KR_TCD(L, U, T)                                                                                                     \
     hipLaunchKernelGGL((kr_kb_tcd<L, U, T>), dim3((unsigned)tcd_grid), dim3(BLK), tcd_shmem, s, r0, r1, n, tcd_R, tcd_lds_d,          \
@@ -2212,7 +2279,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     info->n_spmv = h.n_iter + 1;
     info->value_bits = counts ? (v16 ? 16 : 32) : 64;
     if (prof) {
-        // ticks after convergence and the tick that only prepares a bound cut launch the SpMV kernel as a no-op (a few us):
+        // ticks after convergence and the tick that only prepares a bound cut launch the SpMV kernel as a no-op (a few us, well under half a pass):
         // the mean is taken over the launches that did work, told apart by their duration
         std::vector<float> dur;
         float longest = 0.f;
@@ -2226,7 +2293,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         double ms = 0.0;
         long long cnt = 0;
         for (float f : dur)
-            if (f >= 0.25f * longest) { ms += f; cnt++; }
+            if (f >= 0.5f * longest) { ms += f; cnt++; }
         // sampled mean x number of SpMVs that did work
         info->spmv_ms = cnt ? ms / (double)cnt * (double)info->n_spmv : 0.0;
     }
