@@ -194,6 +194,9 @@ extern "C" int b3c_mat_device_ptrs(const b3c_mat *m, void **indptr, void **indic
     if (!m) return B3C_E_ARG;
     if (indptr) *indptr = m->indptr;
     if (indices) *indices = m->indices;
-    if (data) *data = m->data;
+    if (data) {
+        *data = m->data;
+        const_cast<b3c_mat *>(m)->vmax_valid = false;      // the caller may write through this pointer
+    }
     return B3C_OK;
 }

@@ -114,6 +114,10 @@ struct b3c_mat {
     // rows [row0, row1) are the ones this matrix holds; the others are empty (row block of one rank of the sharded path).
     // row1 < 0: all rows
     int64_t row0 = 0, row1 = -1;
+    // largest stored value with fmax semantics (-inf: no entries), once a kernel or b3c_max_value has seen all of them.
+    // Matrices are immutable after creation; b3c_mat_device_ptrs hands out writable pointers and therefore drops it.
+    double vmax = 0.0;
+    bool vmax_valid = false;
 };
 
 #define HIP_TRY(ctx, expr)                                                                          \
@@ -176,6 +180,25 @@ __device__ __forceinline__ double wave_max(double v)
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
     return v;
 }
+// longest row of a CSR matrix into *out (zeroed by the caller).  The running maximum is read first: a wave whose rows
+// cannot raise it skips the atomic (a stale read only costs an atomic that changes nothing), so the 16k waves of a
+// million-row matrix do not queue up on one address.
+__device__ __forceinline__ void max_row_len_body(int64_t n, const int64_t *__restrict__ indptr, unsigned long long *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    long long d = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long long l = indptr[i + 1] - indptr[i];
+        d = l > d ? l : d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long t = __shfl_down(d, o, 64);
+        d = t > d ? t : d;
+    }
+    if ((threadIdx.x & 63) == 0 && (unsigned long long)d > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, (unsigned long long)d);
+}
+
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
 #pragma unroll

@@ -411,37 +411,66 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
                                                            const int2 *__restrict__ ni,         // (new id | -1, caller-side id)
                                                            int graph_form,
                                                            const int64_t *__restrict__ out_indptr,
-                                                           int32_t *__restrict__ out_indices, double *__restrict__ out_a)
+                                                           int32_t *__restrict__ out_indices, double *__restrict__ out_a,
+                                                           unsigned long long *__restrict__ vstat)   // [0] bits of the largest value, [1] a negative one was seen
 {
     constexpr int U = 4;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
-    for (int64_t row = wave; row < n; row += nwave) {
-        const int2 nr = ni[row];
-        if (nr.x < 0) continue;
-        const int64_t s = indptr[row], e = indptr[row + 1];
-        int64_t o = out_indptr[nr.x];
-        const double2 pr = sx[row];
+    double vmax = -INFINITY;
+    // software pipeline over the rows of this wave: while the gathers of row r are in flight, the header and the first
+    // 256 entries of the wave's next row are already being fetched (a dropped row passes through as an empty one)
+    int64_t row = wave;
+    int2 nr = make_int2(-1, 0);
+    int64_t s = 0, e = 0;
+    if (row < n) {
+        nr = ni[row];
+        if (nr.x >= 0) { s = indptr[row]; e = indptr[row + 1]; }
+    }
+    int32_t j[U];
+    uint32_t c[U];
+#pragma unroll
+    for (int t = 0; t < U; t++) {
+        const int64_t k = s + t * 64 + lane;
+        const bool ok = k < e;
+        j[t] = ok ? indices[k] : -1;
+        c[t] = ok ? counts[k] : 0u;
+    }
+    while (row < n) {
+        const int64_t rown = row + nwave;
+        int2 nrn = make_int2(-1, 0);
+        int64_t sn = 0, en = 0;
+        if (rown < n) {
+            nrn = ni[rown];
+            if (nrn.x >= 0) { sn = indptr[rown]; en = indptr[rown + 1]; }
+        }
+        int64_t o = 0;
+        double2 pr = make_double2(1.0, 0.0);
+        if (nr.x >= 0) { o = out_indptr[nr.x]; pr = sx[row]; }
         const double si = pr.x == 0.0 ? 1.0 : pr.x;
         const double xr = pr.y;
         const int32_t idr = nr.y;
         for (int64_t base = s; base < e; base += 64 * U) {
-            int32_t j[U];
-            uint32_t c[U];
-#pragma unroll
-            for (int t = 0; t < U; t++) {
-                const int64_t k = base + t * 64 + lane;
-                const bool ok = k < e;
-                j[t] = ok ? indices[k] : -1;
-                c[t] = ok ? counts[k] : 0u;
-            }
+            // both gathers are issued for every stored column: the second no longer waits for the first
             int2 nj[U];
-#pragma unroll
-            for (int t = 0; t < U; t++) nj[t] = j[t] >= 0 ? ni[j[t]] : make_int2(-1, 0);
             double2 pj[U];
 #pragma unroll
-            for (int t = 0; t < U; t++) pj[t] = nj[t].x >= 0 ? sx[j[t]] : make_double2(1.0, 0.0);
+            for (int t = 0; t < U; t++) nj[t] = j[t] >= 0 ? ni[j[t]] : make_int2(-1, 0);
+#pragma unroll
+            for (int t = 0; t < U; t++) pj[t] = j[t] >= 0 ? sx[j[t]] : make_double2(1.0, 0.0);
+            // the next 256 entries: of this row, or (after its last chunk) the first ones of the wave's next row
+            const bool last = base + 64 * U >= e;
+            const int64_t nb = last ? sn : base + 64 * U, ne = last ? en : e;
+            int32_t j2[U];
+            uint32_t c2[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                const int64_t k = nb + t * 64 + lane;
+                const bool ok = k < ne;
+                j2[t] = ok ? indices[k] : -1;
+                c2[t] = ok ? counts[k] : 0u;
+            }
 #pragma unroll
             for (int t = 0; t < U; t++) {
                 const bool keep = nj[t].x >= 0;
@@ -460,9 +489,37 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
                     }
                     out_indices[o + pos] = nj[t].x;
                     out_a[o + pos] = val;
+                    vmax = fmax(vmax, val);
                 }
                 o += __popcll(b);
             }
+#pragma unroll
+            for (int t = 0; t < U; t++) { j[t] = j2[t]; c[t] = c2[t]; }
+        }
+        if (e == s) {
+            // nothing of this row was processed: the prefetch of the next row has not been issued yet
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                const int64_t k = sn + t * 64 + lane;
+                const bool ok = k < en;
+                j[t] = ok ? indices[k] : -1;
+                c[t] = ok ? counts[k] : 0u;
+            }
+        }
+        row = rown;
+        nr = nrn;
+        s = sn;
+        e = en;
+    }
+    // the largest value written, for b3c_max_value (fmax semantics: NaNs are skipped); bit patterns of non-negative
+    // doubles order like the values, and the running maximum is read first so that few waves reach the atomic
+    vmax = wave_max(vmax);
+    if (lane == 0) {
+        if (vmax > 0.0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(vmax);
+            if (bits > __atomic_load_n(&vstat[0], __ATOMIC_RELAXED)) atomicMax(&vstat[0], bits);
+        } else if (vmax < 0.0 && vmax > -INFINITY) {
+            vstat[1] = 1ull;
         }
     }
 }
@@ -548,9 +605,21 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
             DevBuf<int2> ni(ctx, n + 1);
             if (!ni.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
             hipLaunchKernelGGL(k_pack_ni, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, newid.p, a->ids, ni.p);
+            DevBuf<unsigned long long> vstat(ctx, 2);
+            if (!vstat.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
+            HIP_TRY(ctx, hipMemsetAsync(vstat.p, 0, sizeof(unsigned long long) * 2, s));
             hipLaunchKernelGGL(k_compress_fill_ns, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data,
-                               ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data);
-            HIP_TRY(ctx, hipStreamSynchronize(s));       // `ni` goes back to the pool at the end of this scope
+                               ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data, vstat.p);
+            // (the read-back also ends the use of `ni`, which goes back to the pool at the end of this scope)
+            unsigned long long hv[2] = {0, 0};
+            { const int rb_ = b3c_readback(ctx, hv, vstat.p, sizeof(hv)); if (rb_) return rb_; }
+            if (hv[1] == 0 && nnz > 0) {
+                // all values non-negative: the largest one is known without another pass (b3c_max_value)
+                double vm;
+                memcpy(&vm, &hv[0], sizeof(double));
+                o->vmax = vm;
+                o->vmax_valid = true;
+            }
         }
         else if (a->kind == B3C_F64)
             hipLaunchKernelGGL(k_compress_fill<double>, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
@@ -590,14 +659,21 @@ extern "C" int b3c_max_value(b3c_ctx *ctx, const b3c_mat *a, double *out)
     if (!ctx) return B3C_E_ARG;
     if (!a || a->kind != B3C_F64 || !out) return ctx->fail(B3C_E_ARG, "b3c_max_value: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int g = grid_for(a->nnz, BLK * 4, 4 * ctx->n_cu);
-    DevBuf<double> part(ctx, g);
-    if (!part.p) return ctx->fail(B3C_E_NOMEM, "b3c_max_value");
-    hipLaunchKernelGGL(k_max_value, dim3(g), dim3(BLK), 0, ctx->stream, a->nnz, (const double *)a->data, part.p);
-    std::vector<double> h(g);
-    { const int rb_ = b3c_readback(ctx, h.data(), part.p, sizeof(double) * g); if (rb_) return rb_; }
     double m = -INFINITY;
-    for (int i = 0; i < g; i++) m = h[i] > m ? h[i] : m;
+    if (a->vmax_valid) {
+        m = a->vmax;              // left behind by the kernel that wrote the values (k_compress_fill_ns)
+    } else {
+        const int g = grid_for(a->nnz, BLK * 4, 4 * ctx->n_cu);
+        DevBuf<double> part(ctx, g);
+        if (!part.p) return ctx->fail(B3C_E_NOMEM, "b3c_max_value");
+        hipLaunchKernelGGL(k_max_value, dim3(g), dim3(BLK), 0, ctx->stream, a->nnz, (const double *)a->data, part.p);
+        std::vector<double> h(g);
+        { const int rb_ = b3c_readback(ctx, h.data(), part.p, sizeof(double) * g); if (rb_) return rb_; }
+        for (int i = 0; i < g; i++) m = h[i] > m ? h[i] : m;
+        b3c_mat *am = const_cast<b3c_mat *>(a);
+        am->vmax = m;
+        am->vmax_valid = true;
+    }
     // implicit zeros take part in scipy's max unless the matrix is completely dense
     if ((double)a->nnz < (double)a->n * (double)a->n && m < 0.0) m = 0.0;
     *out = m;

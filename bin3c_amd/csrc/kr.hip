@@ -358,14 +358,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
 // ---------------------------------------------------------------------------------------------
 __global__ void kr_max_degree(int64_t n, const int64_t *__restrict__ indptr, unsigned long long *__restrict__ out)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    long long d = i < n ? indptr[i + 1] - indptr[i] : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        long long t = __shfl_down(d, o, 64);
-        d = t > d ? t : d;
-    }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)d);
+    max_row_len_body(n, indptr, (unsigned long long *)out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1885,7 +1878,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         DevBuf<unsigned long long> md(ctx, 1);
         if (!md.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
         HIP_TRY(ctx, hipMemsetAsync(md.p, 0, sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(kr_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a->indptr, md.p);
+        hipLaunchKernelGGL(kr_max_degree, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, n, a->indptr, md.p);
         { const int rb_ = b3c_readback(ctx, &maxdeg, md.p, sizeof(maxdeg)); if (rb_) return rb_; }
     }
     // hub rows (kr_kb_hub): counted here (the count does not depend on the row order), listed once the working matrix is final

@@ -179,12 +179,13 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
                                                   const int32_t *__restrict__ ids, int64_t *__restrict__ kdeg,
                                                   int64_t *__restrict__ tot, int32_t *__restrict__ com,
                                                   int32_t *__restrict__ nxt, int32_t *__restrict__ csize,
-                                                  u64 *__restrict__ m2, int64_t *__restrict__ wnl)
+                                                  u64 *__restrict__ m2, int64_t *__restrict__ wnl, int64_t r0, int64_t r1,
+                                                  u64 *__restrict__ i2)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * WPB;
-    long long total = 0;
+    long long total = 0, loops = 0;
     for (int64_t row = wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         long long d = 0, lw = 0;
@@ -215,9 +216,11 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
             nxt[row] = id;
             csize[id] = e > s ? 1 : 0;   // empty rows are not graph nodes (cluster.py:321 never adds them)
             total += d;
+            if (row >= r0 && row < r1) loops += 2 * lw;         // every node alone: I2 is the self-loops (this rank's rows)
         }
     }
     if (lane == 0 && total) atomicAdd(m2, (u64)total);
+    if (lane == 0 && loops) atomicAdd(i2, (u64)loops);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1088,14 +1091,7 @@ __global__ void k_big_table_sizes(int64_t n, int cap, const int64_t *__restrict_
 
 __global__ void k_max_degree(int64_t n, const int64_t *__restrict__ indptr, u64 *__restrict__ out)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    long long d = i < n ? indptr[i + 1] - indptr[i] : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        long long t = __shfl_down(d, o, 64);
-        d = t > d ? t : d;
-    }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, (u64)d);
+    max_row_len_body(n, indptr, (unsigned long long *)out);
 }
 
 struct Events {
@@ -1135,17 +1131,23 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
     DevBuf<double> part(ctx, g);
     DevBuf<u64> total(ctx, 1);
     if (!w.p || !part.p || !total.p) return ctx->fail(B3C_E_NOMEM, "quantise_graph");
-    if (direct)
-        hipLaunchKernelGGL(k_graph_wmax_sym, dim3(g), dim3(BLK), 0, s, nnz, (const double *)a->data, scl, part.p);
-    else
-        hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, ids,
-                           a->sorted_cols ? 1 : 0, scl, w.p, part.p);
     const double *wsrc = direct ? (const double *)a->data : w.p;
     const double wscl = direct ? scl : 1.0;
-    std::vector<double> hp(g);
-    { const int rb_ = b3c_readback(ctx, hp.data(), part.p, sizeof(double) * g); if (rb_) return rb_; }
     double wmax = 0.0;
-    for (int i = 0; i < g; i++) wmax = hp[i] > wmax ? hp[i] : wmax;
+    if (direct && a->vmax_valid && scl > 0.0 && scl < INFINITY) {
+        // rounding is monotone: the largest a*scl is (largest a)*scl, and the largest a is on record
+        const double t = a->vmax * scl;
+        wmax = t > 0.0 ? t : 0.0;
+    } else {
+        if (direct)
+            hipLaunchKernelGGL(k_graph_wmax_sym, dim3(g), dim3(BLK), 0, s, nnz, (const double *)a->data, scl, part.p);
+        else
+            hipLaunchKernelGGL(k_graph_w, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, ids,
+                               a->sorted_cols ? 1 : 0, scl, w.p, part.p);
+        std::vector<double> hp(g);
+        { const int rb_ = b3c_readback(ctx, hp.data(), part.p, sizeof(double) * g); if (rb_) return rb_; }
+        for (int i = 0; i < g; i++) wmax = hp[i] > wmax ? hp[i] : wmax;
+    }
     if (blockm) {
         // a row block sees its rows only: the largest weight and (below) the integer total are taken over the ranks
         const b3c_dist &D = ctx->dist;
@@ -1307,8 +1309,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int gv = grid_for(n, BLK, 8 * ctx->n_cu);      // thread-per-node kernels
         HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 8, s));
         hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p,
-                           nxt_p, csize.p, ctr.p, wnl.p);
-        hipLaunchKernelGGL(k_max_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
+                           nxt_p, csize.p, ctr.p, wnl.p, r0, r1, ctr.p + 2);
+        hipLaunchKernelGGL(k_max_degree, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
         if (blk0) {
             // degrees (and which rows exist) of the other ranks' rows, then totals / sizes / labels / 2m from the whole vector
             if (r1 > r0) hipLaunchKernelGGL(k_lv_pack_flag, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, r0, r1, g.indptr, kdeg.p);
@@ -1420,7 +1422,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         };
 
         double cur_mod, new_mod;
-        if ((rc = modularity(&new_mod, true, nullptr))) { free_graph(ctx, g); return rc; }
+        // all nodes alone: k_lv_init has left the self-loop weight in ctr[2], no scan of the graph needed
+        if ((rc = modularity(&new_mod, false, nullptr))) { free_graph(ctx, g); return rc; }
         int sweep = 0;
         u64 prev_moved = ~0ull;
         const int incr_div = getenv("B3C_LV_INCR_DIV") ? atoi(getenv("B3C_LV_INCR_DIV")) : 4;
