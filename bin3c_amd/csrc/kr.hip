@@ -1231,8 +1231,9 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                                                    const double *__restrict__ u, const double *__restrict__ x,
                                                    const double *__restrict__ p, double *__restrict__ v,
                                                    double *__restrict__ rk, double *__restrict__ w,
-                                                   double *__restrict__ part_out, int hub_len)
+                                                   double *__restrict__ part_out, int hub_len, int probe)
 {
+    // probe (timing only, wrong results): 1 no tail gathers, 2 no tail work at all, 4 no dictionary staging, 8 no dictionary work
     extern __shared__ __attribute__((aligned(16))) double ksm[];
     double *xl = ksm;                         // dlds operands of the tile's dictionary
     double *od = xl + dlds, *ot = od + R;     // row sums over the dictionary entries / over the tails
@@ -1270,7 +1271,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
     {
         const int32_t *__restrict__ dc1 = dict_cols + (live ? tile : 0) * (int64_t)dstride;
-        for (int base = 0; base < D1; base += TBK * 4) {
+        for (int base = 0; base < D1 && !(probe & 4); base += TBK * 4) {
             int32_t cc[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) { const int i = base + q * TBK + tid; cc[q] = i < D1 ? dc1[i] : 0; }
@@ -1306,7 +1307,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
         int n1 = 0;
         if (rl < nrows) {
             so = (uint32_t)((ipl[rl] - e0) * 4);
-            n1 = ipl[rl + 1] - ipl[rl] > hub_len ? 0 : n1l[rl];
+            n1 = (ipl[rl + 1] - ipl[rl] > hub_len || (probe & 8)) ? 0 : n1l[rl];
         }
         u32x4 c[UN];
 #pragma unroll
@@ -1320,7 +1321,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
             int n1n = 0;
             if (rln < nrows) {
                 son = (uint32_t)((ipl[rln] - e0) * 4);
-                n1n = ipl[rln + 1] - ipl[rln] > hub_len ? 0 : n1l[rln];
+                n1n = (ipl[rln + 1] - ipl[rln] > hub_len || (probe & 8)) ? 0 : n1l[rln];
             }
             u32x4 c2[UN];
 #pragma unroll
@@ -1372,7 +1373,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
             so = (uint32_t)((ipl[rl] - e0) * 4);
             len = (int)(ipl[rl + 1] - ipl[rl]);
             t0 = n1l[rl];
-            if (len > hub_len) { len = 0; t0 = 0; }
+            if (len > hub_len || (probe & 2)) { len = 0; t0 = 0; }
         }
         u32x4 tc[TU], tcol[TU];
 #pragma unroll
@@ -1390,7 +1391,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                 son = (uint32_t)((ipl[rln] - e0) * 4);
                 lenn = (int)(ipl[rln + 1] - ipl[rln]);
                 t0n = n1l[rln];
-                if (lenn > hub_len) { lenn = 0; t0n = 0; }
+                if (lenn > hub_len || (probe & 2)) { lenn = 0; t0n = 0; }
             }
             double tg[TU][4];
 #pragma unroll
@@ -1398,7 +1399,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                 const int t = t0 + (k * TLPR + sl) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len ? tcol[k][j] * 8u : NOLOAD, 0, 0);
+                    const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len && !(probe & 1) ? tcol[k][j] * 8u : NOLOAD, 0, 0);
                     tg[k][j] = __hiloint2double((int)gw.y, (int)gw.x);
                 }
             }
@@ -1704,6 +1705,85 @@ __global__ void __launch_bounds__(BLK) kr_sym_hash(int64_t n, const int64_t *__r
     }
 }
 
+// Count matrices that are already in their working order: ONE pass over the entries does what kr_diag_fix, kr_sym_hash,
+// kr_max_u32 and kr_narrow_u16 do in four -- the two pairs of checksums, the zero-diagonal vector and count (:110-115),
+// the largest count, and (speculatively: used only if that maximum fits) the 16-bit copy of the values.
+__global__ void __launch_bounds__(BLK) kr_prep_counts(int64_t n, int64_t c0, int64_t c1, const int64_t *__restrict__ indptr,
+                                                       const int32_t *__restrict__ indices, const uint32_t *__restrict__ a,
+                                                       double *__restrict__ dfix, uint16_t *__restrict__ out16,
+                                                       unsigned long long *__restrict__ sums,      // [0..3] checksums, [4] largest count
+                                                       unsigned long long *__restrict__ n_zero)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    unsigned long long u1 = 0, u2 = 0, l1 = 0, l2 = 0;
+    uint32_t vmax = 0;
+    long long zeros = 0;
+    for (int64_t row = wave; row < n; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        bool found = false;                                   // this lane holds a non-zero diagonal entry
+        for (int64_t base = s; base < e; base += 256) {
+            int32_t j[4];
+            uint32_t c[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                const bool ok = k < e;
+                j[t] = ok ? indices[k] : -1;
+                c[t] = ok ? a[k] : 0u;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (j[t] < 0) continue;
+                out16[base + t * 64 + lane] = (uint16_t)c[t];
+                vmax = c[t] > vmax ? c[t] : vmax;
+                if (j[t] == (int32_t)row) { found = found || c[t] != 0u; continue; }
+                const bool up = j[t] > (int32_t)row;
+                const unsigned long long lo = up ? (unsigned long long)row : (unsigned long long)j[t];
+                const unsigned long long hi = up ? (unsigned long long)j[t] : (unsigned long long)row;
+                const unsigned long long key = lo * (unsigned long long)n + hi;
+                const unsigned long long b = (unsigned long long)c[t];
+                const unsigned long long h1 = mix64(key ^ mix64(b));
+                const unsigned long long h2 = mix64(key * 0x9E3779B97F4A7C15ull + b);
+                if (up) { u1 += h1; u2 += h2; } else { l1 += h1; l2 += h2; }
+            }
+        }
+        const bool z = __ballot(found) == 0ull;
+        if (lane == 0) {
+            dfix[row] = z ? 1.0 : 0.0;
+            zeros += (z && row >= c0 && row < c1) ? 1 : 0;
+        }
+    }
+    u1 = (unsigned long long)wave_sum_ll((long long)u1);
+    u2 = (unsigned long long)wave_sum_ll((long long)u2);
+    l1 = (unsigned long long)wave_sum_ll((long long)l1);
+    l2 = (unsigned long long)wave_sum_ll((long long)l2);
+    zeros = wave_sum_ll(zeros);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_down((int)vmax, o, 64);
+        vmax = t > vmax ? t : vmax;
+    }
+    __shared__ unsigned long long red[BLK / 64][6];
+    const int wib = threadIdx.x >> 6;
+    if (lane == 0) { red[wib][0] = u1; red[wib][1] = u2; red[wib][2] = l1; red[wib][3] = l2; red[wib][4] = vmax; red[wib][5] = (unsigned long long)zeros; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        unsigned long long t = 0;
+        for (int w = 0; w < BLK / 64; w++) t += red[w][threadIdx.x];
+        atomicAdd(&sums[threadIdx.x], t);
+    } else if (threadIdx.x == 4) {
+        unsigned long long t = 0;
+        for (int w = 0; w < BLK / 64; w++) t = red[w][4] > t ? red[w][4] : t;
+        if (t > __atomic_load_n(&sums[4], __ATOMIC_RELAXED)) atomicMax(&sums[4], t);
+    } else if (threadIdx.x == 5) {
+        unsigned long long t = 0;
+        for (int w = 0; w < BLK / 64; w++) t += red[w][5];
+        if (t) atomicAdd(n_zero, t);
+    }
+}
+
 // is_hermitian restated sparsely (sparse_utils.py:10-18): count entries with |a_ij - a_ji| >= tol
 // `sites` != nullptr: entries are raw counts and a_ij = c_ij * (1 / (s_i * s_j)) (contact_map.py:110-113)
 template <typename VT>
@@ -1939,7 +2019,17 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         return ctx->fail(B3C_E_ARG, "b3c_kr_balance: the row block of the matrix is not this rank's row range");
     if (block && !a->ordered) return ctx->fail(B3C_E_ARG, "b3c_kr_balance: a row block must come from b3c_mat_permute_rows");
     const int64_t zc0 = block ? r0 : 0, zc1 = block ? r1 : n;
-    if (counts) {
+    // the iteration reorders a map that is not in a locality order yet (below); a count map that needs no reordering gets
+    // its checks, its zero-diagonal vector and its 16-bit value copy from one fused pass (kr_prep_counts)
+    const bool reorder = !a->ordered && n >= 32768 && a->nnz >= (1 << 21) && getenv("B3C_NO_REORDER") == nullptr;
+    const bool want16 = counts && a->nnz && getenv("B3C_KR_NO_U16") == nullptr;
+    const bool fused_prep = want16 && !reorder && getenv("B3C_KR_NO_FUSED_PREP") == nullptr;
+    DevBuf<uint16_t> v16buf(ctx, counts ? a->nnz + 16 : 1);     // slack: kr_kb_vec reads whole 4-entry vectors
+    if (want16 && !v16buf.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts");
+    unsigned long long prep_max = 0;
+    if (fused_prep) {
+        // launched below, in place of kr_sym_hash
+    } else if (counts) {
         if (a->sorted_cols) hipLaunchKernelGGL(kr_diag_fix<uint32_t>, dim3(gn1), dim3(256), 0, s, n, zc0, zc1, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, counters.p);
         else hipLaunchKernelGGL(kr_diag_fix_scan<uint32_t>, dim3(gscan), dim3(BLK), 0, s, n, zc0, zc1, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, counters.p);
     } else {
@@ -1947,12 +2037,14 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         else hipLaunchKernelGGL(kr_diag_fix_scan<double>, dim3(gscan), dim3(BLK), 0, s, n, zc0, zc1, a->indptr, a->indices, (const double *)a->data, dfix.p, counters.p);
     }
     {
-        DevBuf<unsigned long long> hs(ctx, 4);
+        DevBuf<unsigned long long> hs(ctx, 5);
         if (!hs.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
-        HIP_TRY(ctx, hipMemsetAsync(hs.p, 0, sizeof(unsigned long long) * 4, s));
+        HIP_TRY(ctx, hipMemsetAsync(hs.p, 0, sizeof(unsigned long long) * 5, s));
         const int gh = grid_for(n, 4, 4 * ctx->n_cu);
-        if (counts) hipLaunchKernelGGL(kr_sym_hash<uint32_t>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, hs.p);
+        if (fused_prep) hipLaunchKernelGGL(kr_prep_counts, dim3(gh), dim3(BLK), 0, s, n, zc0, zc1, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, v16buf.p, hs.p, counters.p);
+        else if (counts) hipLaunchKernelGGL(kr_sym_hash<uint32_t>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, hs.p);
         else hipLaunchKernelGGL(kr_sym_hash<double>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, hs.p);
+        if (fused_prep) { const int rb_ = b3c_readback(ctx, &prep_max, hs.p + 4, sizeof(prep_max)); if (rb_) return rb_; }
         unsigned long long hh[4];
         if (block) {
             // checksums are sums modulo 2^64: add the ranks' parts (the scalar exchange buffer carries the 4 x 8 bytes)
@@ -1977,7 +2069,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 
     // locality-ordered working copy (see reorder.hip): the iteration runs in the new numbering,
     // x is returned in the caller's
-    const bool reorder = !a->ordered && n >= 32768 && a->nnz >= (1 << 21) && getenv("B3C_NO_REORDER") == nullptr;
     DevBuf<int32_t> new2old(ctx, reorder ? n : 1), old2new(ctx, reorder ? n : 1);
     MatGuard perm{ctx};
     if (reorder) {
@@ -2006,11 +2097,12 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (n_hub) hipLaunchKernelGGL(kr_hub_fill, dim3(gh), dim3(256), 0, s, r0, r1, hub_flag.p, hub_pos.p, hub_rows.p);
     }
     // count form: 16-bit copy of the values when they all fit (built on the matrix the iteration runs on)
-    DevBuf<uint16_t> v16buf(ctx, counts ? a->nnz + 16 : 1);     // slack: kr_kb_vec reads whole 4-entry vectors
     const uint16_t *v16 = nullptr;
-    if (counts && a->nnz && getenv("B3C_KR_NO_U16") == nullptr) {
+    if (fused_prep) {
+        if (prep_max <= 0xFFFFull) v16 = v16buf.p;               // written by kr_prep_counts
+    } else if (want16) {
         DevBuf<unsigned int> mx(ctx, 1);
-        if (!mx.p || !v16buf.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts");
+        if (!mx.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts");
         HIP_TRY(ctx, hipMemsetAsync(mx.p, 0, sizeof(unsigned int), s));
         const int gq = grid_for(a->nnz, 1024, 8 * ctx->n_cu);
         hipLaunchKernelGGL(kr_max_u32, dim3(gq), dim3(256), 0, s, a->nnz, (const uint32_t *)a->data, mx.p);
@@ -2138,7 +2230,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 #define KR_TCD2(L, U, TL, T)                                                                                                 \
     hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T>), dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d,   \
                        tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p,      \
-                       dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len)
+                       dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len,                      \
+                       getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0)
                 const int shp2 = getenv("B3C_KR_TCD_SHAPE2") ? atoi(getenv("B3C_KR_TCD_SHAPE2")) : 0;
                 if (shp2 == 16481) KR_TCD2(16, 4, 8, 1);
                 else if (shp2 == 164161) KR_TCD2(16, 4, 16, 1);

@@ -142,8 +142,8 @@ __global__ void __launch_bounds__(BLK) k_quant_total(int64_t n, const int64_t *_
             acc += indices[k] == (int32_t)row ? 2 * c : c;
         }
     }
-    acc = (u64)wave_sum_ll((long long)acc);
-    if (lane == 0 && acc) atomicAdd(total, acc);
+    __shared__ long long red[WPB];
+    block_atomic_add_u64((long long)acc, total, red);
 }
 
 __global__ void k_quantise(int64_t nnz, const double *__restrict__ w, double scl, int shift, int64_t *__restrict__ q)
@@ -219,8 +219,9 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
             if (row >= r0 && row < r1) loops += 2 * lw;         // every node alone: I2 is the self-loops (this rank's rows)
         }
     }
-    if (lane == 0 && total) atomicAdd(m2, (u64)total);
-    if (lane == 0 && loops) atomicAdd(i2, (u64)loops);
+    __shared__ long long red[WPB];
+    block_atomic_add_u64(lane == 0 ? total : 0, m2, red);
+    block_atomic_add_u64(lane == 0 ? loops : 0, i2, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -778,8 +779,8 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
             if (lane == 0) own[row] = mine;
         }
     }
-    acc = wave_sum_ll(acc);
-    if (lane == 0 && acc) atomicAdd(i2, (u64)acc);
+    __shared__ long long red[WPB];
+    block_atomic_add_u64(acc, i2, red);
 }
 
 // Change of I2 caused by the moves a sub-round is about to apply (com = labels before, nxt = labels after; nxt == com
