@@ -412,32 +412,49 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
 // summed in registers; only groups that saw a foreign community take turns on the wave's LDS table.
 // The node list of a sub-round is fixed for a level (the bucket depends on the id only), so it is built once.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, int round, int max_deg,
-                                const int64_t *__restrict__ indptr, const int32_t *__restrict__ ids,
-                                const int64_t *__restrict__ kdeg, int64_t *__restrict__ flag)
+// Node lists of one level, all at once.  Segment r < n_sub: the nodes of sub-round r with at most max_deg entries (grouped
+// kernel); segment n_sub + r: those with more (wave-per-node kernel).  A node sets the flag of its segment; ONE exclusive
+// scan over the n_seg * nloc flags gives every listed node its position in the common list and, at the segment starts,
+// the list boundaries.  Inside a segment the nodes ascend, as they did when every segment had its own scan.
+__device__ __forceinline__ int lv_list_segment(int64_t i, int n_sub, int max_deg, int with_hubs, const int64_t *__restrict__ indptr,
+                                               const int32_t *__restrict__ ids, const int64_t *__restrict__ kdeg)
 {
-    int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < r1) {
-        const int64_t deg = indptr[i + 1] - indptr[i];
-        const int32_t id = ids ? ids[i] : (int32_t)i;
-        // max_deg > 0: nodes with at most max_deg entries; max_deg < 0: nodes with MORE than -max_deg entries
-        const bool len_ok = max_deg >= 0 ? deg <= max_deg : deg > -max_deg;
-        flag[i - r0] = bucket_of(id, n_sub) == (uint32_t)round && kdeg[i] != 0 && len_ok;
-    }
-    if (i == r1) flag[i - r0] = 0;
+    if (kdeg[i] == 0) return -1;
+    const int64_t deg = indptr[i + 1] - indptr[i];
+    const int32_t id = ids ? ids[i] : (int32_t)i;
+    const int b = (int)bucket_of(id, n_sub);
+    if (deg <= max_deg) return b;
+    return with_hubs ? n_sub + b : -1;
 }
 
-__global__ void k_lv_list_fill(int64_t r0, int64_t r1, const int64_t *__restrict__ flag, const int64_t *__restrict__ pos,
-                               const int64_t *__restrict__ indptr, NodeRec *__restrict__ list)
+__global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, int max_deg, int with_hubs,
+                                const int64_t *__restrict__ indptr, const int32_t *__restrict__ ids,
+                                const int64_t *__restrict__ kdeg, int64_t *__restrict__ flag)     // zeroed by the caller
 {
-    int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < r1 && flag[i - r0]) {
-        NodeRec rec;
-        rec.node = (int32_t)i;
-        rec.start = indptr[i];
-        rec.deg = (int32_t)(indptr[i + 1] - rec.start);
-        list[pos[i - r0]] = rec;
-    }
+    const int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r1) return;
+    const int seg = lv_list_segment(i, n_sub, max_deg, with_hubs, indptr, ids, kdeg);
+    if (seg >= 0) flag[(int64_t)seg * (r1 - r0) + (i - r0)] = 1;
+}
+
+__global__ void k_lv_list_fill(int64_t r0, int64_t r1, int n_sub, int max_deg, int with_hubs,
+                               const int64_t *__restrict__ indptr, const int32_t *__restrict__ ids,
+                               const int64_t *__restrict__ kdeg, const int64_t *__restrict__ pos, NodeRec *__restrict__ list)
+{
+    const int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r1) return;
+    const int seg = lv_list_segment(i, n_sub, max_deg, with_hubs, indptr, ids, kdeg);
+    if (seg < 0) return;
+    NodeRec rec;
+    rec.node = (int32_t)i;
+    rec.start = indptr[i];
+    rec.deg = (int32_t)(indptr[i + 1] - rec.start);
+    list[pos[(int64_t)seg * (r1 - r0) + (i - r0)]] = rec;
+}
+
+__global__ void k_lv_list_bounds(int n_seg, int64_t nloc, const int64_t *__restrict__ pos, int64_t *__restrict__ bnd)
+{
+    for (int t = threadIdx.x; t <= n_seg; t += blockDim.x) bnd[t] = pos[(int64_t)t * nloc];
 }
 
 template <int LPR, int UN>
@@ -1345,39 +1362,30 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int short_max = avgdeg * 1.3 <= 32 ? 32 : avgdeg * 1.3 <= 64 ? 64 : avgdeg * 1.3 <= 128 ? 128 : 256;
         const bool grouped = n >= 4096 && getenv("B3C_LV_NO_GROUPED") == nullptr;
         const int64_t nloc = r1 - r0;
-        DevBuf<NodeRec> nlist(ctx, grouped ? nloc : 1);
-        std::vector<int64_t> loff(n_sub + 1, 0);
-        if (grouped) {
-            DevBuf<int64_t> lflag(ctx, nloc + 1), lpos(ctx, nloc + 1);
-            if (!nlist.p || !lflag.p || !lpos.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: node lists"); }
-            const unsigned gl = (unsigned)((nloc + 256) / 256);
-            for (int r = 0; r < n_sub; r++) {
-                hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, r, short_max, g.indptr, ids, kdeg.p, lflag.p);
-                if ((rc = b3c_exclusive_scan_i64(ctx, lflag.p, lpos.p, nloc + 1))) { free_graph(ctx, g); return rc; }
-                int64_t cntr = 0;
-                { const int rb_ = b3c_readback(ctx, &cntr, lpos.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
-                hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, lflag.p, lpos.p, g.indptr, nlist.p + loff[r]);
-                loff[r + 1] = loff[r] + cntr;
-            }
-            HIP_TRY(ctx, hipStreamSynchronize(s));
-        }
         const bool need_wave_kernel = !grouped || maxdeg > short_max;
-        // the hubs that the grouped kernel leaves out, per sub-round (usually a handful)
-        DevBuf<NodeRec> hlist(ctx, grouped && need_wave_kernel ? nloc : 1);
-        std::vector<int64_t> hoff(n_sub + 1, 0);
-        if (grouped && need_wave_kernel) {
-            DevBuf<int64_t> lflag(ctx, nloc + 1), lpos(ctx, nloc + 1);
-            if (!hlist.p || !lflag.p || !lpos.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hub lists"); }
-            const unsigned gl = (unsigned)((nloc + 256) / 256);
-            for (int r = 0; r < n_sub; r++) {
-                hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, r, -short_max, g.indptr, ids, kdeg.p, lflag.p);
-                if ((rc = b3c_exclusive_scan_i64(ctx, lflag.p, lpos.p, nloc + 1))) { free_graph(ctx, g); return rc; }
-                int64_t cntr = 0;
-                { const int rb_ = b3c_readback(ctx, &cntr, lpos.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
-                hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, lflag.p, lpos.p, g.indptr, hlist.p + hoff[r]);
-                hoff[r + 1] = hoff[r] + cntr;
+        // grouped lists and, behind them, the hubs the grouped kernel leaves out (usually a handful): one flag pass, one
+        // scan, one fill, one read-back of the boundaries for all sub-rounds
+        DevBuf<NodeRec> lists(ctx, grouped ? nloc + 1 : 1);
+        const NodeRec *nlist_p = lists.p, *hlist_p = lists.p;
+        std::vector<int64_t> loff(n_sub + 1, 0), hoff(n_sub + 1, 0);
+        if (grouped) {
+            const int n_seg = need_wave_kernel ? 2 * n_sub : n_sub;
+            const int64_t tot = (int64_t)n_seg * nloc + 1;
+            DevBuf<int64_t> lflag(ctx, tot), lpos(ctx, tot), bnd(ctx, n_seg + 1);
+            if (!lists.p || !lflag.p || !lpos.p || !bnd.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: node lists"); }
+            const unsigned gl = (unsigned)((nloc + 255) / 256);
+            HIP_TRY(ctx, hipMemsetAsync(lflag.p, 0, sizeof(int64_t) * (size_t)tot, s));
+            if (nloc) hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, short_max, need_wave_kernel ? 1 : 0, g.indptr, ids, kdeg.p, lflag.p);
+            if ((rc = b3c_exclusive_scan_i64(ctx, lflag.p, lpos.p, tot))) { free_graph(ctx, g); return rc; }
+            if (nloc) hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, short_max, need_wave_kernel ? 1 : 0, g.indptr, ids, kdeg.p, lpos.p, lists.p);
+            hipLaunchKernelGGL(k_lv_list_bounds, dim3(1), dim3(64), 0, s, n_seg, nloc, lpos.p, bnd.p);
+            std::vector<int64_t> hb(n_seg + 1, 0);
+            { const int rb_ = b3c_readback(ctx, hb.data(), bnd.p, sizeof(int64_t) * hb.size()); if (rb_) return rb_; }
+            for (int r = 0; r <= n_sub; r++) loff[r] = hb[r];
+            if (need_wave_kernel) {
+                hlist_p = lists.p + hb[n_sub];
+                for (int r = 0; r <= n_sub; r++) hoff[r] = hb[n_sub + r] - hb[n_sub];
             }
-            HIP_TRY(ctx, hipStreamSynchronize(s));
         }
 
         // full: recount the internal weight; otherwise ctr[2] was kept up to date by k_lv_delta_internal.  The sums are
@@ -1440,7 +1448,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 evs.rec();
                 if (grouped && loff[r + 1] > loff[r]) {
                     const int64_t cntr = loff[r + 1] - loff[r];
-                    const NodeRec *lst = nlist.p + loff[r];
+                    const NodeRec *lst = nlist_p + loff[r];
                     const int64_t *cnt_dev = nullptr;
                     if (incr && can_prune) {
                         // nodes that provably stay are settled from four numbers each; the rest go through the scan
@@ -1466,7 +1474,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 }
                 if (need_wave_kernel && (!grouped || hoff[r + 1] > hoff[r])) {
                     // all rows of this rank (small levels), or just the hubs the grouped kernel left out
-                    const NodeRec *hubs = grouped ? hlist.p + hoff[r] : nullptr;
+                    const NodeRec *hubs = grouped ? hlist_p + hoff[r] : nullptr;
                     const int64_t w0 = grouped ? 0 : r0, w1 = grouped ? hoff[r + 1] - hoff[r] : r1;
                     const int gwh = grid_for(w1 - w0, WPB, 16 * ctx->n_cu);
 #define LV_DECIDE(C)                                                                                                     \
@@ -1488,17 +1496,17 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (incr) {
                     const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
                     if (c1) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c1, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c1,
-                                               nlist.p + loff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p);
+                                               nlist_p + loff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p);
                     if (c2) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c2, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c2,
-                                               hlist.p + hoff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p);
+                                               hlist_p + hoff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p);
                 }
                 if (grouped && !dist) {
                     // only the nodes that decided in this sub-round can have moved
                     const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
                     if (c1) hipLaunchKernelGGL(k_lv_apply_list, dim3(grid_for(c1, BLK, 4 * ctx->n_cu)), dim3(BLK), 0, s, c1,
-                                               nlist.p + loff[r], kdeg.p, tot.p, com.p, nxt_p, csize.p, ctr.p + 1);
+                                               nlist_p + loff[r], kdeg.p, tot.p, com.p, nxt_p, csize.p, ctr.p + 1);
                     if (c2) hipLaunchKernelGGL(k_lv_apply_list, dim3(grid_for(c2, BLK, 4 * ctx->n_cu)), dim3(BLK), 0, s, c2,
-                                               hlist.p + hoff[r], kdeg.p, tot.p, com.p, nxt_p, csize.p, ctr.p + 1);
+                                               hlist_p + hoff[r], kdeg.p, tot.p, com.p, nxt_p, csize.p, ctr.p + 1);
                 } else {
                     hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt_p,
                                        csize.p, ctr.p + 1);

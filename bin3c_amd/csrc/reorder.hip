@@ -516,7 +516,7 @@ static int forest_roots(b3c_ctx *ctx, int64_t n, int32_t *p0, int32_t *p1, int *
     for (int round = 0; round < 64; round++) {
         HIP_TRY(ctx, hipMemsetAsync(changed, 0, sizeof(int), s));
         hipLaunchKernelGGL(k_jump, dim3(gn), dim3(256), 0, s, n, cur, nxt, changed);
-        if (n < 300000) {     // small forests: a second jump (idempotent once converged) is cheaper than a host round trip
+        {                     // a second jump (idempotent once converged) is cheaper than a host round trip
             hipLaunchKernelGGL(k_jump, dim3(gn), dim3(256), 0, s, n, nxt, cur, changed);
             int32_t *t2 = cur; cur = nxt; nxt = t2;
         }
