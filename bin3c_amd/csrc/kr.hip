@@ -1231,7 +1231,8 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                                                    const double *__restrict__ u, const double *__restrict__ x,
                                                    const double *__restrict__ p, double *__restrict__ v,
                                                    double *__restrict__ rk, double *__restrict__ w,
-                                                   double *__restrict__ part_out, int hub_len, int probe)
+                                                   double *__restrict__ part_out, int hub_len, int probe, uint32_t probe_mask,
+                                                   unsigned long long *__restrict__ tlog)
 {
     // probe (timing only, wrong results): 1 no tail gathers, 2 no tail work at all, 4 no dictionary staging, 8 no dictionary work
     extern __shared__ __attribute__((aligned(16))) double ksm[];
@@ -1247,6 +1248,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     }
     const bool live = tile < ntiles;          // padding blocks of the swizzled grid carry no tile
     const int tid = threadIdx.x;
+    const long long tl0 = tlog ? wall_clock64() : 0;      // B3C_KR_TCD_TLOG: phase timeline of every tile (100 MHz ticks)
     const int64_t ra = r0 + (live ? tile : 0) * R;
     const int nrows = live ? (int)((ra + R < r1 ? ra + R : r1) - ra) : 0;
     // everything that does not depend on the control state is requested first
@@ -1269,6 +1271,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
     if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
+    const long long tl1 = tlog ? wall_clock64() : 0;
     {
         const int32_t *__restrict__ dc1 = dict_cols + (live ? tile : 0) * (int64_t)dstride;
         for (int base = 0; base < D1 && !(probe & 4); base += TBK * 4) {
@@ -1284,6 +1287,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     }
     if (D1 == 0 && tid == 0) xl[0] = 0.0;     // masked lanes multiply a zero count with xl[0]: keep stale LDS (NaN) out
     __syncthreads();
+    const long long tl2 = tlog ? wall_clock64() : 0;
 
     const int64_t e0 = ipl[0];
     const uint32_t ebytes = __builtin_amdgcn_readfirstlane((uint32_t)((ipl[nrows] - e0) * 4));
@@ -1360,6 +1364,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
 #pragma unroll
             for (int q = 0; q < UN; q++) c[q] = c2[q];
         }
+        if (tlog && tid == 0) tlog[tile * 8 + 3] = (unsigned long long)wall_clock64();
     } else {
         // ---- row tails: TLPR lanes per row, TU 16-byte vectors of (count, column) per lane, next row prefetched ----
         constexpr int RPW = 64 / TLPR;
@@ -1399,7 +1404,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                 const int t = t0 + (k * TLPR + sl) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len && !(probe & 1) ? tcol[k][j] * 8u : NOLOAD, 0, 0);
+                    const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len && !(probe & 1) ? (tcol[k][j] & probe_mask) * 8u : NOLOAD, 0, 0);
                     tg[k][j] = __hiloint2double((int)gw.y, (int)gw.x);
                 }
             }
@@ -1442,8 +1447,10 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
 #pragma unroll
             for (int k = 0; k < TU; k++) { tc[k] = tc2[k]; tcol[k] = tcol2[k]; }
         }
+        if (tlog && tid == 256) tlog[tile * 8 + 4] = (unsigned long long)wall_clock64();
     }
     __syncthreads();
+    const long long tl5 = tlog ? wall_clock64() : 0;
     // epilogue: one thread per row, coalesced
     double contrib = 0.0;
     if (tid < nrows && ipl[tid + 1] - ipl[tid] <= hub_len) {        // hub rows are written by kr_kb_hub
@@ -1469,6 +1476,13 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
 #pragma unroll
         for (int q = 1; q < TBK / 64; q++) r += lds[q];
         part_out[tile] = r;
+        if (tlog) {
+            tlog[tile * 8 + 0] = (unsigned long long)tl0;
+            tlog[tile * 8 + 1] = (unsigned long long)tl1;
+            tlog[tile * 8 + 2] = (unsigned long long)tl2;
+            tlog[tile * 8 + 5] = (unsigned long long)tl5;
+            tlog[tile * 8 + 6] = (unsigned long long)wall_clock64();
+        }
     }
 }
 
@@ -2115,6 +2129,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     }
     // ---- tile-local column dictionaries (16-bit counts only) ----
     const bool tcd = tcd_may && v16 != nullptr;
+    const bool want_tlog = tcd && getenv("B3C_KR_TCD_TLOG") != nullptr;
+    DevBuf<unsigned long long> tlog(ctx, want_tlog ? (size_t)tcd_tiles * 8 : 0);
+    if (want_tlog && tlog.p) HIP_TRY(ctx, hipMemsetAsync(tlog.p, 0, sizeof(unsigned long long) * (size_t)tcd_tiles * 8, s));
     DevBuf<uint32_t> packed(ctx, tcd ? a->nnz + 8 : 1);
     DevBuf<int32_t> pcol(ctx, tcd ? a->nnz + 8 : 1), n1v(ctx, tcd ? nloc : 1);
     DevBuf<int32_t> dict_cols(ctx, tcd ? (size_t)tcd_tiles * (size_t)tcd_dcap : 1), dict_cnt(ctx, tcd ? tcd_tiles : 1);
@@ -2178,6 +2195,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             constexpr int LDS_MAX = 160 * 1024;
 #define KR_TCD2_ATTR(L, U, TL, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
             KR_TCD2_ATTR(16, 4, 8, 1); KR_TCD2_ATTR(16, 4, 16, 1); KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 8, 4, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
+            KR_TCD2_ATTR(16, 4, 4, 2); KR_TCD2_ATTR(16, 4, 4, 4); KR_TCD2_ATTR(16, 4, 2, 4);
 #undef KR_TCD2_ATTR
 #define KR_TCD_ATTR(L, U, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
             KR_TCD_ATTR(16, 4, 2); KR_TCD_ATTR(8, 8, 2); KR_TCD_ATTR(8, 8, 1); KR_TCD_ATTR(32, 2, 1); KR_TCD_ATTR(16, 4, 1);
@@ -2231,12 +2249,16 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T>), dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d,   \
                        tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p,      \
                        dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len,                      \
-                       getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0)
+                       getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0,                                       \
+                       getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu, tlog.p)
                 const int shp2 = getenv("B3C_KR_TCD_SHAPE2") ? atoi(getenv("B3C_KR_TCD_SHAPE2")) : 0;
                 if (shp2 == 16481) KR_TCD2(16, 4, 8, 1);
                 else if (shp2 == 164161) KR_TCD2(16, 4, 16, 1);
                 else if (shp2 == 16482) KR_TCD2(16, 4, 8, 2);
                 else if (shp2 == 8841) KR_TCD2(8, 8, 4, 2);
+                else if (shp2 == 16442) KR_TCD2(16, 4, 4, 2);
+                else if (shp2 == 16444) KR_TCD2(16, 4, 4, 4);
+                else if (shp2 == 16424) KR_TCD2(16, 4, 2, 4);
                 else if (avg > 128) KR_TCD2(16, 4, 8, 2);
                 else if (avg > 48) KR_TCD2(8, 4, 4, 2);
                 else KR_TCD2(4, 4, 4, 1);
@@ -2382,6 +2404,26 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             if (f >= 0.5f * longest) { ms += f; cnt++; }
         // sampled mean x number of SpMVs that did work
         info->spmv_ms = cnt ? ms / (double)cnt * (double)info->n_spmv : 0.0;
+    }
+    if (want_tlog && tlog.p) {
+        std::vector<unsigned long long> tl((size_t)tcd_tiles * 8);
+        if (hipMemcpy(tl.data(), tlog.p, sizeof(unsigned long long) * tl.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long first = ~0ull, last = 0;
+            double ph[6] = {0, 0, 0, 0, 0, 0};
+            long long cnt = 0;
+            for (int64_t t = 0; t < tcd_tiles; t++) {
+                const unsigned long long *e = &tl[(size_t)t * 8];
+                if (!e[6]) continue;
+                first = std::min(first, e[0]); last = std::max(last, e[6]);
+                ph[0] += (double)(e[1] - e[0]); ph[1] += (double)(e[2] - e[1]); ph[2] += (double)(e[3] - e[2]);
+                ph[3] += (double)(e[4] - e[2]); ph[4] += (double)(e[5] - e[2]); ph[5] += (double)(e[6] - e[5]);
+                cnt++;
+            }
+            if (cnt)
+                fprintf(stderr, "[b3c] tile timeline (us, mean over %lld tiles; kernel span %.1f): prologue %.2f, staging %.2f, dictionary rows %.2f, "
+                        "tails %.2f, both+barrier %.2f, epilogue %.2f\n", cnt, (double)(last - first) * 0.01, ph[0] / cnt * 0.01, ph[1] / cnt * 0.01,
+                        ph[2] / cnt * 0.01, ph[3] / cnt * 0.01, ph[4] / cnt * 0.01, ph[5] / cnt * 0.01);
+        }
     }
     if (h.rc == B3C_E_NAN) return ctx->fail(B3C_E_NAN, "scale vector has developed invalid values (NANs)!");
     if (h.rc == B3C_E_NOCONV)

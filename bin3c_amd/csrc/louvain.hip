@@ -228,6 +228,7 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
 // delta-Q neighbour scan
 // ---------------------------------------------------------------------------------------------
 constexpr int32_t EMPTY = -1;
+constexpr int LV_DIRECT_CAP = 2048;     // levels of at most this many nodes: k_lv_decide_direct
 
 __device__ __forceinline__ uint32_t hash_slot(int32_t c, int lg) { return ((uint32_t)c * 0x9E3779B1u) >> (32 - lg); }
 
@@ -401,6 +402,80 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
         }
         if (use_lds) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    }
+}
+
+// Small levels (the induced graphs: n <= CAPD nodes, often dense rows): the weight towards every community goes into a
+// DIRECT table indexed by the community id in the wave's LDS -- no hashing, no compare-and-swap, and no global-memory
+// tables for rows of more than CAP/2 entries.  Same gains, same arg-max (ties to the lowest id) as k_lv_decide.
+template <int CAPD>
+__global__ void __launch_bounds__(BLK) k_lv_decide_direct(int64_t n, int n_sub, int round, u64 m2,
+                                                           const int64_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices,
+                                                           const int64_t *__restrict__ q, const int32_t *__restrict__ ids,
+                                                           const int64_t *__restrict__ kdeg,
+                                                           const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
+                                                           const int32_t *__restrict__ csize, int32_t *__restrict__ nxt)
+{
+    __shared__ u64 svals[WPB][CAPD];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + wib;
+    const int64_t nwave = (int64_t)gridDim.x * WPB;
+    u64 *lv = svals[wib];
+    for (int t = lane; t < CAPD; t += 64) lv[t] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (int64_t i = wave; i < n; i += nwave) {
+        const int32_t id = ids ? ids[i] : (int32_t)i;
+        if (bucket_of(id, n_sub) != (uint32_t)round) continue;
+        const long long ki = kdeg[i];
+        if (ki == 0) continue;
+        const int64_t s = indptr[i], e = indptr[i + 1];
+        const int32_t a = com[i];
+        long long own = 0;
+        for (int64_t base = s; base < e; base += 256) {
+            int32_t j[4];
+            u64 qv[4];
+            int32_t c[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t k = base + t * 64 + lane;
+                const bool ok = k < e;
+                j[t] = ok ? indices[k] : (int32_t)i;
+                qv[t] = ok ? (u64)q[k] : 0;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) c[t] = j[t] != (int32_t)i ? com[j[t]] : EMPTY;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (c[t] == EMPTY) continue;
+                if (c[t] == a) own += (long long)qv[t];
+                else atomicAdd(&lv[c[t]], qv[t]);
+            }
+        }
+        own = wave_sum_ll(own);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        Best b;
+        b.gain = 0; b.com = a; b.have = 0;
+        for (int32_t c = lane; c < (int32_t)n; c += 64) {
+            const u64 d = lv[c];
+            if (d) {
+                lv[c] = 0;
+                const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
+                best_take(b, g, c);
+            }
+        }
+        if (lane == 0) {
+            const i128 g = (i128)own * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            best_take(b, g, a);
+        }
+        b = best_wave_reduce(b);
+        if (lane == 0) {
+            int32_t best = b.have ? b.com : a;
+            if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
+            nxt[i] = best;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
 
@@ -980,17 +1055,37 @@ __global__ void __launch_bounds__(BLK) k_pairs_fill(int64_t n, int64_t kc, const
 // can neither attract a node nor change a degree, a total or the modularity: labels, sweeps and Q are unaffected).
 constexpr int64_t AGG_BINS_KC = 4096;
 
-__global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, const int64_t *__restrict__ indptr,
+constexpr int AGG_SLOTS = 4;
+
+// A block takes `rpb` CONSECUTIVE rows: in a locality-ordered map they belong to one or two communities, whose bin rows
+// are kept in LDS (the first `nslot` communities the block meets claim a slot; rows of any further community go straight
+// to the global bins) and flushed once at the end -- a tenth of the global atomics on the bench maps.
+__global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, int64_t rpb, int nslot, const int64_t *__restrict__ indptr,
                                                    const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
                                                    const int32_t *__restrict__ cn, u64 *__restrict__ bins)
 {
+    extern __shared__ u64 agg_lds[];                    // nslot * kc
+    __shared__ int32_t slot_com[AGG_SLOTS];
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * WPB;
-    for (int64_t row = wave; row < n; row += nwave) {
+    const int wib = threadIdx.x >> 6;
+    const int64_t ra = (int64_t)blockIdx.x * rpb, rb = ra + rpb < n ? ra + rpb : n;
+    for (int64_t t = threadIdx.x; t < (int64_t)nslot * kc; t += BLK) agg_lds[t] = 0;
+    if (threadIdx.x < AGG_SLOTS) slot_com[threadIdx.x] = -1;
+    __syncthreads();
+    for (int64_t row = ra + wib; row < rb; row += WPB) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         if (e == s) continue;
         const int64_t c1 = cn[row];
+        int sl = -1;
+        if (lane == 0) {
+            for (int k = 0; k < nslot; k++) {
+                const int32_t prev = atomicCAS(&slot_com[k], -1, (int32_t)c1);
+                if (prev == -1 || prev == (int32_t)c1) { sl = k; break; }
+            }
+        }
+        sl = __shfl(sl, 0, 64);
+        u64 *lrow = sl >= 0 ? agg_lds + (int64_t)sl * kc : nullptr;
+        u64 *grow = bins + c1 * kc;
         long long own = 0;
         for (int64_t base = s; base < e; base += 256) {
             int32_t j[4];
@@ -1010,11 +1105,26 @@ __global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, const i
                 if (j[t] < 0) continue;
                 if (j[t] == (int32_t)row) own += 2 * qv[t];
                 else if (c2[t] == (int32_t)c1) own += qv[t];
-                else if (qv[t]) atomicAdd(&bins[c1 * kc + c2[t]], (u64)qv[t]);
+                else if (qv[t]) {
+                    if (lrow) atomicAdd(&lrow[c2[t]], (u64)qv[t]);
+                    else atomicAdd(&grow[c2[t]], (u64)qv[t]);
+                }
             }
         }
         own = wave_sum_ll(own);
-        if (lane == 0 && own) atomicAdd(&bins[c1 * kc + c1], (u64)own);
+        if (lane == 0 && own) {
+            if (lrow) atomicAdd(&lrow[c1], (u64)own);
+            else atomicAdd(&grow[c1], (u64)own);
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < nslot; k++) {
+        const int32_t c = slot_com[k];
+        if (c < 0) continue;
+        for (int64_t t = threadIdx.x; t < kc; t += BLK) {
+            const u64 v = agg_lds[(int64_t)k * kc + t];
+            if (v) atomicAdd(&bins[(int64_t)c * kc + t], v);
+        }
     }
 }
 
@@ -1472,6 +1582,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     }
 #undef LV_DECIDE_G
                 }
+                if (!grouped && !dist && n <= LV_DIRECT_CAP && getenv("B3C_LV_NO_DIRECT") == nullptr) {
+                    // small level: direct community table in LDS
+                    hipLaunchKernelGGL(k_lv_decide_direct<LV_DIRECT_CAP>, dim3(grid_for(n, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, n_sub, r, m2,
+                                       g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p, csize.p, nxt_p);
+                } else
                 if (need_wave_kernel && (!grouped || hoff[r + 1] > hoff[r])) {
                     // all rows of this rank (small levels), or just the hubs the grouped kernel left out
                     const NodeRec *hubs = grouped ? hlist_p + hoff[r] : nullptr;
@@ -1556,7 +1671,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation bins");
             }
             HIP_TRY(ctx, hipMemsetAsync(bins.p, 0, sizeof(u64) * nb, s));
-            hipLaunchKernelGGL(k_agg_bins, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, bins.p);
+            {
+                const int nslot = kc <= 512 ? AGG_SLOTS : kc <= 2048 ? 2 : 1;
+                const int64_t rpb = std::max<int64_t>(64, std::min<int64_t>(512, n / (4 * (int64_t)ctx->n_cu)));   // at least four blocks per CU
+                const size_t lds = sizeof(u64) * (size_t)nslot * (size_t)kc;       // at most 32 KB
+                hipLaunchKernelGGL(k_agg_bins, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(BLK), lds, s, n, kc, rpb, nslot, g.indptr, g.indices,
+                                   g.q, cn.p, bins.p);
+            }
             if (blk0 && (rc = b3c_dist_allreduce_u64(ctx, bins.p, (int64_t)nb))) { free_graph(ctx, h); free_graph(ctx, g); return rc; }
             const unsigned gk = (unsigned)((kc + 1 + WPB - 1) / WPB);
             hipLaunchKernelGGL(k_bins_count, dim3(gk), dim3(BLK), 0, s, kc, bins.p, rcnt.p);
