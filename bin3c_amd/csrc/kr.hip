@@ -2130,8 +2130,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // ---- tile-local column dictionaries (16-bit counts only) ----
     const bool tcd = tcd_may && v16 != nullptr;
     const bool want_tlog = tcd && getenv("B3C_KR_TCD_TLOG") != nullptr;
-    DevBuf<unsigned long long> tlog(ctx, want_tlog ? (size_t)tcd_tiles * 8 : 0);
-    if (want_tlog && tlog.p) HIP_TRY(ctx, hipMemsetAsync(tlog.p, 0, sizeof(unsigned long long) * (size_t)tcd_tiles * 8, s));
+    DevBuf<unsigned long long> tlog(ctx, want_tlog ? (size_t)tcd_tiles * 8 : 1);     // (a pooled block even when unused: the kernel gets nullptr then)
+    if (want_tlog && !tlog.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: timeline log");
+    if (want_tlog) HIP_TRY(ctx, hipMemsetAsync(tlog.p, 0, sizeof(unsigned long long) * (size_t)tcd_tiles * 8, s));
     DevBuf<uint32_t> packed(ctx, tcd ? a->nnz + 8 : 1);
     DevBuf<int32_t> pcol(ctx, tcd ? a->nnz + 8 : 1), n1v(ctx, tcd ? nloc : 1);
     DevBuf<int32_t> dict_cols(ctx, tcd ? (size_t)tcd_tiles * (size_t)tcd_dcap : 1), dict_cnt(ctx, tcd ? tcd_tiles : 1);
@@ -2250,7 +2251,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                        tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p,      \
                        dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len,                      \
                        getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0,                                       \
-                       getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu, tlog.p)
+                       getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu, want_tlog ? tlog.p : nullptr)
                 const int shp2 = getenv("B3C_KR_TCD_SHAPE2") ? atoi(getenv("B3C_KR_TCD_SHAPE2")) : 0;
                 if (shp2 == 16481) KR_TCD2(16, 4, 8, 1);
                 else if (shp2 == 164161) KR_TCD2(16, 4, 16, 1);

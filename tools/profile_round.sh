@@ -1,14 +1,19 @@
 #!/bin/bash
-# GPU box: bench line + rocprofv3 kernel-trace stats + HBM traffic counters for the dominant kernel.
+# GPU box: the measurements behind profiles/ for one round -- bench lines, rocprofv3 kernel-trace stats (C3 and C2), HBM
+# traffic counters of the dominant kernel (separate --pmc passes, with two pure streaming kernels of known byte counts in
+# the same passes as calibration), and the per-tile timeline of the dictionary SpMV.
+# Every command runs under its own timeout: a profiler that hangs after a fault would otherwise eat the GPU budget.
 # usage: tools/profile_round.sh <tag>   (outputs under gpurun_out/<tag>/)
 tag=$1
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python bench.py --config C3 --steps 3 --warmup 1 > $out/bench_c3.json 2> $out/bench_c3.err
-python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_c2.json 2> $out/bench_c2.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --config C3 --steps 2 --warmup 1 --no-cpu-baseline > $out/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "kr_kb_vec" --output-format csv -d $out/pmc_fetch -- python bench.py --config C3 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "kr_kb_vec" --output-format csv -d $out/pmc_write -- python bench.py --config C3 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_write.log 2>&1
+timeout 600 python bench.py --config C3 --steps 5 --warmup 2 > $out/bench_c3.json 2> $out/bench_c3.err
+timeout 300 python bench.py --config C2 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_c2.json 2> $out/bench_c2.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c3 -- python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_c3.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2 -- python bench.py --config C2 --steps 10 --warmup 3 --no-cpu-baseline > $out/trace_c2.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "kr_kb_vec|kr_prep_counts|k_quantise" --output-format csv -d $out/pmc_fetch -- python bench.py --config C3 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "kr_kb_vec|kr_prep_counts|k_quantise" --output-format csv -d $out/pmc_write -- python bench.py --config C3 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_write.log 2>&1
+B3C_KR_TCD_TLOG=1 B3C_KR_TCD_DCAP=4096 timeout 300 python tools/tcd_probe.py C3 "" "B3C_KR_TCD_PROBE=2" "B3C_KR_TCD_PROBE=8" "B3C_KR_NO_TCD=1" > $out/tcd_timeline.txt 2>&1
 tail -1 $out/bench_c3.json | python tools/bsum.py
 tail -1 $out/bench_c2.json | python tools/bsum.py
