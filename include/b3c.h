@@ -85,7 +85,8 @@ int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
 
 /* ---- multi-GPU: contig-row ranges of ONE map across ranks ---------------------------------- */
 
-/* One process per GPU.  Every rank holds the whole (ordered) matrix and WORKS on the rows [rank*chunk, (rank+1)*chunk);
+/* One process per GPU.  Every rank WORKS on the rows [rank*chunk, (rank+1)*chunk) of the ordered matrix -- either of a
+ * whole matrix, or of a row block that holds only those rows (b3c_mat_permute_rows; the other rows are empty);
  * what the other ranks need is exchanged through four caller-owned device buffers, each laid out as `world` equal
  * slices, by an in-place all-gather ("my slice is already written").  All ranks reduce the gathered partials in rank
  * order, so every rank takes identical decisions and results do not depend on timing.
@@ -146,7 +147,9 @@ int b3c_mat_free(b3c_ctx *ctx, b3c_mat *m);
 int b3c_mat_info(const b3c_mat *m, int64_t *n, int64_t *nnz, int *kind);
 /* Copy back; any of the three output pointers may be NULL. */
 int b3c_mat_download(b3c_ctx *ctx, const b3c_mat *m, int64_t *indptr, int32_t *indices, void *data);
-/* Raw device pointers of a matrix (for zero-copy consumers such as torch tensors). */
+/* Raw device pointers of a matrix (for zero-copy consumers such as torch tensors).  Matrices are immutable once created;
+ * a caller that nevertheless writes through `data` must ask for the pointer again afterwards (the call drops the maximum
+ * that b3c_max_value / b3c_normalise_scale_compress keep with the matrix). */
 int b3c_mat_device_ptrs(const b3c_mat *m, void **indptr, void **indices, void **data);
 
 /* ---- ingest tail: pair stream -> symmetric count matrix ------------------------------------- */
