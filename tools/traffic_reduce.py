@@ -1,0 +1,55 @@
+"""Reduce the --pmc passes of tools/profile_round.sh to profiles/: the counter rows without the mangled signatures
+(profiles/<round>_c3_FETCH_SIZE.csv, ..._WRITE_SIZE.csv) and profiles/traffic.json (bytes per launch of the dominant
+kernel, corrected as MI355X_MICROARCH.md's HBM section prescribes, with the check on two streaming kernels of known size).
+usage: python tools/traffic_reduce.py gpurun_out/<tag> <round, e.g. r02>"""
+import csv, glob, json, sys
+
+src, rnd = sys.argv[1], sys.argv[2]
+NNZ, N = 200903927, 1000000            # C3 (bench.py prints them in config.workload)
+
+for tag, c in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+    f = glob.glob('%s/pmc_%s/*/*counter_collection.csv' % (src, tag))[0]
+    with open('profiles/%s_c3_%s.csv' % (rnd, c), 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['Dispatch_Id', 'Kernel', 'Grid_Size', 'Workgroup_Size', 'LDS_Block_Size', 'Scratch_Size', 'VGPR_Count',
+                    'SGPR_Count', 'Counter_Name', 'Counter_Value', 'Duration_ns'])
+        for r in csv.DictReader(open(f)):
+            nm = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
+            w.writerow([r['Dispatch_Id'], nm, r['Grid_Size'], r['Workgroup_Size'], r['LDS_Block_Size'], r['Scratch_Size'],
+                        r['VGPR_Count'], r['SGPR_Count'], r['Counter_Name'], r['Counter_Value'],
+                        int(r['End_Timestamp']) - int(r['Start_Timestamp'])])
+
+
+def active(counter, kern):
+    """mean counter value (bytes; the counters are in KB) over the launches that did work (>= half the longest)"""
+    rows = [r for r in csv.DictReader(open('profiles/%s_c3_%s.csv' % (rnd, counter))) if r['Kernel'].startswith(kern)]
+    mx = max(int(r['Duration_ns']) for r in rows)
+    a = [float(r['Counter_Value']) for r in rows if int(r['Duration_ns']) >= 0.5 * mx]
+    return sum(a) / len(a) * 1024.0, len(a), len(rows)
+
+
+fv, na, nt = active('FETCH_SIZE', 'kr_kb_vec')
+wv, _, _ = active('WRITE_SIZE', 'kr_kb_vec')
+fp, _, _ = active('FETCH_SIZE', 'kr_prep_counts')
+wp, _, _ = active('WRITE_SIZE', 'kr_prep_counts')
+fq, _, _ = active('FETCH_SIZE', 'k_quantise')
+wq, _, _ = active('WRITE_SIZE', 'k_quantise')
+out = {'C3': {
+    'kernel': 'kr_kb_vec<8,8,uint16> (CSR SpMV on raw 16-bit counts, 4 entries per lane and load, fused KR epilogue)',
+    'FETCH_SIZE_raw_bytes_per_launch': fv, 'WRITE_SIZE_raw_bytes_per_launch': wv,
+    'hbm_bytes_per_launch': 2.0 * fv + wv,
+    'launches_counted': na, 'launches_total': nt,
+    'correction': 'MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies the 128-byte fabric requests of coalesced reads at 64 '
+                  'bytes, so it is doubled; WRITE_SIZE is exact. Checked in the same two passes on two pure streaming kernels of '
+                  'known size: kr_prep_counts reads 8*nnz+8*n = %.0f MB and reports %.0f MB (x%.3f), writes 2*nnz+8*n = %.0f MB '
+                  'and reports %.0f MB; k_quantise reads and writes 8 bytes per sub-map entry and reports %.0f MB fetched / '
+                  '%.0f MB written (x%.3f).' % ((8 * NNZ + 8 * N) / 1e6, fp / 1e6, fp / (8 * NNZ + 8 * N), (2 * NNZ + 8 * N) / 1e6,
+                                                wp / 1e6, fq / 1e6, wq / 1e6, fq / wq),
+    'reading': 'streams by construction 6*nnz + 36*n = %.0f MB; the rest of the corrected %.0f MB are 128-byte operand lines '
+               'fetched for gathers that miss the XCD L2 (the 8 MB operand vector against 4 MB of L2): %.1f M line fetches for '
+               '%.0f M gathered operands' % ((6 * NNZ + 36 * N) / 1e6, (2 * fv + wv) / 1e6,
+                                             (2 * fv - (6 * NNZ + 28 * N)) / 128 / 1e6, NNZ / 1e6),
+    'source': 'profiles/%s_c3_FETCH_SIZE.csv, profiles/%s_c3_WRITE_SIZE.csv (rocprofv3 --pmc, one counter per pass, '
+              'bench.py --config C3 --steps 1 --warmup 0)' % (rnd, rnd)}}
+json.dump(out, open('profiles/traffic.json', 'w'), indent=1)
+print(json.dumps(out, indent=1))
