@@ -28,16 +28,17 @@ constexpr int BLK = 256;
 
 // heaviest off-diagonal neighbour of every row (ties -> lowest column); rows without one point at themselves
 template <typename T, int LPR>
-__global__ void __launch_bounds__(BLK) k_heaviest(int64_t n, const int64_t *__restrict__ indptr,
+__global__ void __launch_bounds__(BLK) k_heaviest(int64_t r0, int64_t n, const int64_t *__restrict__ indptr,
                                                    const int32_t *__restrict__ indices, const T *__restrict__ a,
                                                    int32_t *__restrict__ parent)
 {
+    // rows [r0, n): all rows, or the rows of one rank of the sharded path
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, sl = lane % LPR;
     const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
-    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
+    for (int64_t row = r0 + wave * RPW + sub; row < n; row += nwave * RPW) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         double best = -1.0;
         int32_t bj = (int32_t)row;
@@ -93,17 +94,20 @@ __global__ void k_jump(int64_t n, const int32_t *__restrict__ in, int32_t *__res
 // Boruvka round: heaviest edge leaving the cluster of every node, folded per cluster with a 64-bit
 // atomicMax on (float bits of the weight, ~target cluster) -- order independent, ties to the lowest target.
 template <typename T, int LPR>
-__global__ void __launch_bounds__(BLK) k_best_external(int64_t n, const int64_t *__restrict__ indptr,
+__global__ void __launch_bounds__(BLK) k_best_external(int64_t r0, int64_t n, const int64_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices, const T *__restrict__ a,
                                                         const int32_t *__restrict__ label,
-                                                        unsigned long long *__restrict__ cbest, int sample)
+                                                        unsigned long long *__restrict__ cbest,
+                                                        unsigned long long *__restrict__ rowbest, int sample)
 {
+    // rows [r0, n).  rowbest != nullptr (sharded path): the best key of every row is stored per ROW instead of being
+    // folded into its cluster here -- the rows of a cluster live on several ranks; k_fold_rowbest folds the gathered keys
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, sl = lane % LPR;
     const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
-    for (int64_t row = wave * RPW + sub; row < n; row += nwave * RPW) {
+    for (int64_t row = r0 + wave * RPW + sub; row < n; row += nwave * RPW) {
         const int64_t s = indptr[row];
         int64_t e = indptr[row + 1];
         if (sample > 0 && e - s > sample) e = s + sample;     // the first entries of a row stand for all of them (B3C_ORDER_SAMPLE)
@@ -136,8 +140,20 @@ __global__ void __launch_bounds__(BLK) k_best_external(int64_t n, const int64_t 
             unsigned long long ob = (unsigned long long)__shfl_down((long long)best, o, LPR);
             best = ob > best ? ob : best;
         }
-        if (sl == 0 && best) atomicMax(&cbest[li], best);
+        if (sl == 0) {
+            if (rowbest) rowbest[row] = best;
+            else if (best) atomicMax(&cbest[li], best);
+        }
     }
+}
+
+__global__ void k_fold_rowbest(int64_t n, const unsigned long long *__restrict__ rowbest, const int32_t *__restrict__ label,
+                               unsigned long long *__restrict__ cbest)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long b = rowbest[i];
+    if (b) atomicMax(&cbest[label[i]], b);
 }
 
 __global__ void k_cluster_ptr(int64_t n, const unsigned long long *__restrict__ cbest, int32_t *__restrict__ cptr)
@@ -546,7 +562,16 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     if (!p0.p || !p1.p || !lab.p || !kin.p || !kout.p || !vout.p || !cbest.p || !changed.p)
         return ctx->fail(B3C_E_NOMEM, "b3c_locality_order");
     const double avg = (double)a->nnz / (double)n;
-    const int g16 = grid_for(n, (BLK / 64) * 4, 16 * ctx->n_cu), g64 = grid_for(n, BLK / 64, 16 * ctx->n_cu);
+    // Sharded path (b3c_ctx_set_dist): the two passes over the matrix -- heaviest neighbour of every row, heaviest edge
+    // leaving its cluster -- run on this rank's rows only; their per-row results are all-gathered (4 and 8 bytes per row
+    // through the label and vector exchange buffers) and everything after them (cluster folds, pointer jumping, the
+    // sorts) is n-vector work every rank repeats.  Per-row results and max-folds do not depend on who computed them: the
+    // order is bit for bit the single-GPU one.
+    const b3c_dist &D = ctx->dist;
+    const bool dist = ctx->has_dist && D.world > 1 && (int64_t)D.world * D.chunk >= n && getenv("B3C_ORDER_REPLICATED") == nullptr;
+    const int64_t r0 = dist ? std::min<int64_t>(n, (int64_t)D.rank * D.chunk) : 0;
+    const int64_t r1 = dist ? std::min<int64_t>(n, (int64_t)(D.rank + 1) * D.chunk) : n;
+    const int g16 = grid_for(r1 - r0, (BLK / 64) * 4, 16 * ctx->n_cu), g64 = grid_for(r1 - r0, BLK / 64, 16 * ctx->n_cu);
     const unsigned gn = (unsigned)((n + 255) / 256);
     const bool wide = avg >= 48;
     int32_t *roots = nullptr;
@@ -554,24 +579,34 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     for (int r = 0; r < ROUNDS; r++) {
         int32_t *cur = lab.p + (size_t)r * n;
         if (r == 0) {
+            int32_t *par = dist ? D.labels : p0.p;         // sharded: straight into this rank's slice of the exchange buffer
             if (a->kind == B3C_F64) {
-                if (wide) hipLaunchKernelGGL((k_heaviest<double, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, p0.p);
-                else hipLaunchKernelGGL((k_heaviest<double, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, p0.p);
+                if (wide) hipLaunchKernelGGL((k_heaviest<double, 64>), dim3(g64), dim3(BLK), 0, s, r0, r1, a->indptr, a->indices, (const double *)a->data, par);
+                else hipLaunchKernelGGL((k_heaviest<double, 16>), dim3(g16), dim3(BLK), 0, s, r0, r1, a->indptr, a->indices, (const double *)a->data, par);
             } else {
-                if (wide) hipLaunchKernelGGL((k_heaviest<uint32_t, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, p0.p);
-                else hipLaunchKernelGGL((k_heaviest<uint32_t, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, p0.p);
+                if (wide) hipLaunchKernelGGL((k_heaviest<uint32_t, 64>), dim3(g64), dim3(BLK), 0, s, r0, r1, a->indptr, a->indices, (const uint32_t *)a->data, par);
+                else hipLaunchKernelGGL((k_heaviest<uint32_t, 16>), dim3(g16), dim3(BLK), 0, s, r0, r1, a->indptr, a->indices, (const uint32_t *)a->data, par);
+            }
+            if (dist) {
+                if ((rc = b3c_dist_exchange(ctx, B3C_BUF_LABELS))) return rc;
+                HIP_TRY(ctx, hipMemcpyAsync(p0.p, D.labels, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
             }
             if ((rc = forest_roots(ctx, n, p0.p, p1.p, changed.p, &roots))) return rc;
             HIP_TRY(ctx, hipMemcpyAsync(cur, roots, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
         } else {
             const int32_t *prev = lab.p + (size_t)(r - 1) * n;
             HIP_TRY(ctx, hipMemsetAsync(cbest.p, 0, sizeof(unsigned long long) * (size_t)n, s));
+            unsigned long long *rowbest = dist ? (unsigned long long *)D.vec : nullptr;   // 8-byte slots, one per row
             if (a->kind == B3C_F64) {
-                if (wide) hipLaunchKernelGGL((k_best_external<double, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, prev, cbest.p, order_sample);
-                else hipLaunchKernelGGL((k_best_external<double, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, prev, cbest.p, order_sample);
+                if (wide) hipLaunchKernelGGL((k_best_external<double, 64>), dim3(g64), dim3(BLK), 0, s, r0, r1, a->indptr, a->indices, (const double *)a->data, prev, cbest.p, rowbest, order_sample);
+                else hipLaunchKernelGGL((k_best_external<double, 16>), dim3(g16), dim3(BLK), 0, s, r0, r1, a->indptr, a->indices, (const double *)a->data, prev, cbest.p, rowbest, order_sample);
             } else {
-                if (wide) hipLaunchKernelGGL((k_best_external<uint32_t, 64>), dim3(g64), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p, order_sample);
-                else hipLaunchKernelGGL((k_best_external<uint32_t, 16>), dim3(g16), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p, order_sample);
+                if (wide) hipLaunchKernelGGL((k_best_external<uint32_t, 64>), dim3(g64), dim3(BLK), 0, s, r0, r1, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p, rowbest, order_sample);
+                else hipLaunchKernelGGL((k_best_external<uint32_t, 16>), dim3(g16), dim3(BLK), 0, s, r0, r1, a->indptr, a->indices, (const uint32_t *)a->data, prev, cbest.p, rowbest, order_sample);
+            }
+            if (dist) {
+                if ((rc = b3c_dist_exchange(ctx, B3C_BUF_VEC))) return rc;
+                hipLaunchKernelGGL(k_fold_rowbest, dim3(gn), dim3(256), 0, s, n, rowbest, prev, cbest.p);
             }
             hipLaunchKernelGGL(k_cluster_ptr, dim3(gn), dim3(256), 0, s, n, cbest.p, p0.p);
             if ((rc = forest_roots(ctx, n, p0.p, p1.p, changed.p, &roots))) return rc;

@@ -100,7 +100,9 @@ int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
  * slice of Z = rk*v together with the partials of min/max(ynew) and rk.Z (B3C_BUF_SCAL_VEC, one grouped launch); p, y, x
  * and the operand x*p are then advanced for ALL rows by every rank, so the operand itself is never exchanged.
  * Louvain level 0: the decided labels once per sub-round (B3C_BUF_LABELS), one integer per modularity evaluation
- * (B3C_BUF_ISUM); moves are applied by every rank. */
+ * (B3C_BUF_ISUM); moves are applied by every rank.
+ * b3c_locality_order: the two passes over the (whole, un-ordered) matrix run on this rank's rows; their per-row results
+ * travel through B3C_BUF_LABELS (once) and B3C_BUF_VEC (twice).  All of these calls are collective over the ranks. */
 #define B3C_BUF_VEC 0     /* double[world*chunk]  KR: Z slices                     */
 #define B3C_BUF_SCAL 1    /* double[world*4]      KR partial sums / min / max      */
 #define B3C_BUF_LABELS 2  /* int32[world*chunk]   Louvain decided communities      */

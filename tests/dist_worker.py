@@ -73,7 +73,11 @@ def gpu_mode(rank, world):
         # sweep of level 0 one label exchange per sub-round and one integer sum per modularity evaluation
         n_spmv = res.kr_info.n_iter + 1
         cuts = res.kr_info.hit_delta + res.kr_info.hit_Delta
-        assert 2 * n_spmv <= sess.n_exchanges <= 2 * (n_spmv + cuts + 8) + 5 * (res.lv_info.n_sweeps + 1), sess.n_exchanges
+        # (+ 3 for the locality ordering: the heaviest neighbours once, the per-row cluster-leaving edges twice)
+        assert 2 * n_spmv <= sess.n_exchanges <= 2 * (n_spmv + cuts + 8) + 5 * (res.lv_info.n_sweeps + 1) + 3, sess.n_exchanges
+        # the ordering computed from per-rank row ranges is the single-GPU ordering, bit for bit
+        if res._n2o is not None:
+            assert single._n2o is not None and torch.equal(res._n2o, single._n2o)
         assert res.kr_info.n_iter == single.kr_info.n_iter
         assert np.array_equal(res.mask, single.mask) and np.array_equal(res.signal, single.signal)
         np.testing.assert_allclose(res.x, single.x, rtol=1e-10)
