@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
                                               double *__restrict__ Z, const double *__restrict__ rk,
                                               const double *__restrict__ v, double *__restrict__ u,
                                               const double *__restrict__ rs, double *__restrict__ pk1,
-                                              double *__restrict__ pgam_out, int *__restrict__ flags)
+                                              double *__restrict__ pgam_out, int *__restrict__ flags, double *__restrict__ pumax)
 {
     // rs != nullptr: the matrix is stored as raw counts C and A = diag(rs) C diag(rs); the SpMV operand is then
     // rs * (x*p) and the kernel that consumes it multiplies the row sum by rs again (see kr_kb_pipe)
@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
         ey[e] = ok ? y[i] : 0.0;
         eZ[e] = ok ? Z[i] : 0.0;
     }
+    double um = 0.0;             // largest |operand| this block writes (pumax != nullptr: the fixed-point scale of kr_kb_tails)
     KRState st = *sin;
     const int32_t entered = st.phase;
     bool adopt = false;          // the CG step of the tick before is taken: y += alpha p (:185)
@@ -236,7 +237,8 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
 
     // rows [r0, n) of this rank (r0 = 0 and n = all rows on a single GPU)
     if (entered == P_INIT) {
-        for (int64_t i = i0; i < n; i += stride) { x[i] = 1.0; u[i] = rs ? rs[i] : 1.0; }  // :126-127,134
+        for (int64_t i = i0; i < n; i += stride) { const double ui = rs ? rs[i] : 1.0; x[i] = 1.0; u[i] = ui; um = fmax(um, fabs(ui)); }  // :126-127,134
+        if (pumax) block_partial<2>(um, pumax, lds);
         return;
     }
     const double alpha = st.alpha;
@@ -274,7 +276,9 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
                     const double ri = first ? er[e] : (rs ? rs[i] : 1.0);
                     const double z = first ? eZ[e] : Z[i];
                     p[i] = z;                          // :159
-                    u[i] = rs ? ri * (xi * z) : xi * z;
+                    const double ui = rs ? ri * (xi * z) : xi * z;
+                    u[i] = ui;
+                    um = fmax(um, fabs(ui));
                 }
             }
         } else if (st.k == 1) {
@@ -297,7 +301,9 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
                     const double z = erk[e] / ev[e];   // :158
                     Z[i] = z;
                     p[i] = z;                          // :159
-                    u[i] = rs ? ri * (xi * z) : xi * z;
+                    const double ui = rs ? ri * (xi * z) : xi * z;
+                    u[i] = ui;
+                    um = fmax(um, fabs(ui));
                     acc += erk[e] * z;                 // :160
                 }
             }
@@ -317,10 +323,13 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
                     if (adopt) y[i] = (yone ? 1.0 : (first ? ey[e] : y[i])) + alpha * po;   // :185
                     const double pn = zi + beta * po;  // :163
                     p[i] = pn;
-                    u[i] = rs ? ri * (xi * pn) : xi * pn;
+                    const double ui = rs ? ri * (xi * pn) : xi * pn;
+                    u[i] = ui;
+                    um = fmax(um, fabs(ui));
                 }
             }
         }
+        if (pumax) block_partial<2>(um, pumax, lds);
         return;
     }
     // A_OUTER: x *= y (:195) with the last step y += alpha p (:185) or the cut step y += gamma*ap (:176,:182) folded in
@@ -341,11 +350,14 @@ __global__ void __launch_bounds__(BLK) kr_ka(int64_t r0, int64_t n, KRParams prm
             if (cut) yy += gamma * (alpha * po);
             const double xn = xi * yy;
             x[i] = xn;
-            u[i] = rs ? ri * xn : xn;
+            const double ui = rs ? ri * xn : xn;
+            u[i] = ui;
+            um = fmax(um, fabs(ui));
             bad |= (xn != xn);
         }
     }
     if (bad) atomicOr(&flags[0], 1);
+    if (pumax) block_partial<2>(um, pumax, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1192,6 +1204,141 @@ __global__ void __launch_bounds__(BLK) kr_kb_tcd(int64_t r0, int64_t r1, int64_t
 constexpr int TBK = 512;
 
 // sum of P partials by NT threads, identical in every block and to every thread (fixed order)
+// ---------------------------------------------------------------------------------------------
+// Tails as their own pass (B3C_KR_TCD_XT).  What bounds the row kernels at C3 is the number of L1 misses, and three
+// quarters of them are the tails: ~26 M gathers of single-occurrence columns (the inter-genome noise), each pulling its own
+// 128-byte line.  Here the tails of a SUPER-TILE of S = 8192 rows are kept in COLUMN order (one radix sort at set-up), so
+// that neighbouring lanes gather neighbouring columns and a line serves three of them on average; the products are
+// accumulated per row in LDS in FIXED POINT with integer atomics -- a sum of integers does not depend on the order in
+// which lanes, waves or workgroups add, so the result is bit for bit reproducible.  Two accumulators per row: a 64-bit one
+// on a grid of 2^-E (E from the largest |operand| of this SpMV, the largest tail count and the longest tail, so that no row
+// can overflow) and a 32-bit one that takes what every product leaves below that grid, on a grid 2^20 times finer: the sum
+// is exact to 2^-(E+20), about 2^-70 of the largest term, i.e. more accurate than the fp64 sum it replaces.
+// Stand-alone measurement (tools/probes/tails_probe.hip): 26 M gathers in row order 273 us, this way 100 us.
+// ---------------------------------------------------------------------------------------------
+constexpr int XT_S = 8192;           // rows per super-tile (13 bits of a tail word)
+constexpr int XT_NT = 1024;          // threads of kr_kb_tails
+constexpr int XT_CHUNKS = 2;         // workgroups per super-tile
+
+// tail word: super-tile << 53 | column << 29 | row inside the super-tile << 16 | count
+__global__ void __launch_bounds__(256) kr_tails_count(int64_t r0, int64_t r1, int hub_len, const int64_t *__restrict__ indptr,
+                                                       const int32_t *__restrict__ n1v, int64_t *__restrict__ tcnt)
+{
+    const int64_t row = r0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row > r1) return;
+    int64_t c = 0;
+    if (row < r1) {
+        const int64_t len = indptr[row + 1] - indptr[row];
+        c = len > hub_len ? 0 : len - n1v[row - r0];
+    }
+    tcnt[row - r0] = c;
+}
+
+__global__ void __launch_bounds__(256) kr_tails_emit(int64_t r0, int64_t r1, int hub_len, const int64_t *__restrict__ indptr,
+                                                      const uint32_t *__restrict__ packed, const int32_t *__restrict__ pcol,
+                                                      const int32_t *__restrict__ n1v, const int64_t *__restrict__ toff,
+                                                      unsigned long long *__restrict__ words, unsigned long long *__restrict__ stats)
+{
+    // eight lanes per row
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = r0 + (g >> 3);
+    const int sl = (int)(g & 7);
+    unsigned long long cmax = 0, tmax = 0;
+    if (row < r1) {
+        const int64_t base = indptr[row];
+        const int64_t len = indptr[row + 1] - base;
+        if (len <= hub_len) {
+            const int n1 = n1v[row - r0];
+            const int64_t o = toff[row - r0];
+            const unsigned long long hi = ((unsigned long long)(row / XT_S) << 53) | ((unsigned long long)(row % XT_S) << 16);
+            for (int64_t t = n1 + sl; t < len; t += 8) {
+                const unsigned long long c = packed[base + t] & 0xFFFFu;
+                words[o + (t - n1)] = hi | ((unsigned long long)(uint32_t)pcol[base + t] << 29) | c;
+                cmax = c > cmax ? c : cmax;
+            }
+            tmax = (unsigned long long)(len - n1);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = (unsigned long long)__shfl_down((long long)cmax, o, 64), b = (unsigned long long)__shfl_down((long long)tmax, o, 64);
+        cmax = a > cmax ? a : cmax;
+        tmax = b > tmax ? b : tmax;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cmax > __atomic_load_n(&stats[0], __ATOMIC_RELAXED)) atomicMax(&stats[0], cmax);
+        if (tmax > __atomic_load_n(&stats[1], __ATOMIC_RELAXED)) atomicMax(&stats[1], tmax);
+    }
+}
+
+template <int NT>
+__device__ double reduce_max_n(const double *__restrict__ part, int P, double *lds)
+{
+    const int t = threadIdx.x;
+    double v = 0.0;
+    for (int i = t; i < P; i += NT) v = fmax(v, part[i]);
+    lds[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (t < s) lds[t] = fmax(lds[t], lds[t + s]);
+        __syncthreads();
+    }
+    const double r = lds[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__ sin, const double *__restrict__ pumax, int PU,
+                                                      int lg_bound, int64_t n_tails, const int64_t *__restrict__ toff, int64_t r0, int64_t n,
+                                                      const unsigned long long *__restrict__ words, const double *__restrict__ u,
+                                                      unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long xt_lds[];
+    unsigned long long *acc = xt_lds;                 // XT_S 64-bit sums
+    int *lo = (int *)(acc + XT_S);                    // XT_S 32-bit sums of the remainders
+    double *red = (double *)(lo + XT_S);              // XT_NT doubles
+    const KRState st = *sin;
+    if (st.phase != A_INNER && st.phase != A_OUTER) return;     // no SpMV in this tick (the row kernel decides the same way)
+    const double umax = reduce_max_n<XT_NT>(pumax, PU, red);
+    int E = 0;
+    const bool live = umax > 0.0 && umax < INFINITY;
+    if (live) E = 61 - lg_bound - (ilogb(umax) + 1);            // count * |operand| * 2^E < 2^(61 - lg(longest tail))
+    if (blockIdx.x == 0 && threadIdx.x == 0) tex[0] = E;
+    if (!live) return;
+    const double scale = ldexp(1.0, E);
+    const int stile = blockIdx.x / XT_CHUNKS, ch = blockIdx.x % XT_CHUNKS;
+    for (int i = threadIdx.x; i < XT_S; i += XT_NT) { acc[i] = 0; lo[i] = 0; }
+    __syncthreads();
+    const int64_t ra = r0 + (int64_t)stile * XT_S, rb = ra + XT_S < n ? ra + XT_S : n;
+    const int64_t a = toff[ra - r0], b = rb >= n ? n_tails : toff[rb - r0];
+    const int64_t len = (b - a + XT_CHUNKS - 1) / XT_CHUNKS;
+    const int64_t s0 = a + ch * len, e0 = s0 + len < b ? s0 + len : b;
+    for (int64_t k0 = s0 + threadIdx.x; k0 < e0; k0 += 4 * XT_NT) {
+        unsigned long long w[4];
+        double g[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = k0 + q * XT_NT < e0 ? words[k0 + q * XT_NT] : 0ull;
+#pragma unroll
+        for (int q = 0; q < 4; q++) g[q] = u[(uint32_t)(w[q] >> 29) & 0xFFFFFFu];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (k0 + q * XT_NT < e0) {
+                const double ps = (g[q] * (double)(uint32_t)(w[q] & 0xFFFFu)) * scale;
+                const long long f = __double2ll_rn(ps);
+                const int l = __double2int_rn((ps - (double)f) * 1048576.0);
+                const uint32_t r = (uint32_t)(w[q] >> 16) & (XT_S - 1);
+                atomicAdd(&acc[r], (unsigned long long)f);
+                if (l) atomicAdd(&lo[r], l);
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < XT_S && ra + i < n; i += XT_NT) {
+        if (acc[i]) atomicAdd(&yhi[ra - r0 + i], acc[i]);
+        if (lo[i]) atomicAdd(&ylo[ra - r0 + i], lo[i]);
+    }
+}
+
 template <int NT>
 __device__ double reduce_sum_n(const double *__restrict__ part, int P, int stride, double *lds)
 {
@@ -1220,7 +1367,7 @@ __device__ double reduce_sum_n(const double *__restrict__ part, int P, int strid
     return r;
 }
 
-template <int LPR, int UN, int TLPR, int TU>
+template <int LPR, int UN, int TLPR, int TU, bool XT>
 __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_t ncols, int R, int dlds, int dstride, int ntiles,
                                                    int swz, const KRState *__restrict__ sin, KRState *__restrict__ sout,
                                                    const double *__restrict__ partA, int PA, int PS,
@@ -1232,8 +1379,11 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                                                    const double *__restrict__ p, double *__restrict__ v,
                                                    double *__restrict__ rk, double *__restrict__ w,
                                                    double *__restrict__ part_out, int hub_len, int probe, uint32_t probe_mask,
-                                                   unsigned long long *__restrict__ tlog)
+                                                   unsigned long long *__restrict__ tlog,
+                                                   unsigned long long *__restrict__ yhi, int *__restrict__ ylo, const int *__restrict__ tex)
 {
+    // XT: the tails are summed by kr_kb_tails beforehand (fixed point in yhi / ylo, exponent tex[0]); all eight waves run
+    // dictionary rows here and the epilogue converts the row's tail sum and clears it for the next SpMV
     // probe (timing only, wrong results): 1 no tail gathers, 2 no tail work at all, 4 no dictionary staging, 8 no dictionary work
     extern __shared__ __attribute__((aligned(16))) double ksm[];
     double *xl = ksm;                         // dlds operands of the tile's dictionary
@@ -1264,6 +1414,9 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
         ep = p[ra + tid];
         ev = v[ra + tid];
     }
+    long long xt_h = 0;
+    int xt_l = 0, xt_e = 0;
+    if (XT && tid < nrows) { xt_h = (long long)yhi[ra - r0 + tid]; xt_l = ylo[ra - r0 + tid]; xt_e = tex[0]; }
     KRState st = *sin;
     if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_sum_n<TBK>(partA, PA, PS, lds);   // :160
     const bool inner = st.phase == A_INNER;
@@ -1300,10 +1453,11 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     constexpr uint32_t NOLOAD = 0xFFFFFFFFu;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (wv < 4) {
+    constexpr int DW = XT ? 8 : 4;            // waves on dictionary rows
+    if (wv < DW) {
         // ---- dictionary entries: LPR lanes per row, UN 16-byte vectors per lane, next row prefetched ----
         constexpr int RPW = 64 / LPR;
-        constexpr int RPP = RPW * 4;
+        constexpr int RPP = RPW * DW;
         constexpr int CH = LPR * UN * 4;
         const int sub = lane / LPR, sl = lane % LPR;
         int rl = wv * RPW + sub;
@@ -1365,7 +1519,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
             for (int q = 0; q < UN; q++) c[q] = c2[q];
         }
         if (tlog && tid == 0) tlog[tile * 8 + 3] = (unsigned long long)wall_clock64();
-    } else {
+    } else if constexpr (!XT) {
         // ---- row tails: TLPR lanes per row, TU 16-byte vectors of (count, column) per lane, next row prefetched ----
         constexpr int RPW = 64 / TLPR;
         constexpr int RPP = RPW * 4;
@@ -1455,7 +1609,15 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     double contrib = 0.0;
     if (tid < nrows && ipl[tid + 1] - ipl[tid] <= hub_len) {        // hub rows are written by kr_kb_hub
         const double pi = inner ? ep : 0.0;
-        const double t = (od[tid] + ot[tid]) * er + ed * (inner ? ex * pi : ex);
+        double tails = 0.0;
+        if (XT) {
+            tails = ldexp((double)xt_h, -xt_e) + ldexp((double)xt_l, -(xt_e + 20));
+            if (xt_h) yhi[ra - r0 + tid] = 0ull;
+            if (xt_l) ylo[ra - r0 + tid] = 0;
+        } else {
+            tails = ot[tid];
+        }
+        const double t = (od[tid] + tails) * er + ed * (inner ? ex * pi : ex);
         if (inner) {
             const double wi = ex * t + ev * pi;
             w[ra + tid] = wi;
@@ -1982,16 +2144,22 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // SpMV form: row groups of lpr_p lanes (kr_kb_pipe / kr_kb_vec), or -- 16-bit counts -- tiles with column dictionaries
     const int lpr_p = avg > 64 ? 16 : avg > 24 ? 8 : 4;   // lanes per row of the pipelined form
     const int GS_rows = grid_for(nloc, (BLK / 64) * (64 / lpr_p), (getenv("B3C_KR_GSMUL") ? atoi(getenv("B3C_KR_GSMUL")) : 16) * ctx->n_cu);
+    // The dictionary form is the default while the operand vector fits one XCD's L2 (n <= 2^19); beyond it, on a single GPU,
+    // it runs together with the tail pass (kr_kb_tails: the tails, whose gathers miss L2 there, are summed in
+    // column order by their own kernel): C3 0.32 ms per SpMV against 0.50 for kr_kb_vec, which pays for the 5 ms of set-up
+    // (62 SpMVs per call).  B3C_KR_TCD_XT=1 / =0 force the tail pass on (where eligible) / off.
+    const char *xt_env = getenv("B3C_KR_TCD_XT");
+    const bool xt_ok = counts && !dist && n < ((int64_t)1 << 24) && !(xt_env && atoi(xt_env) <= 0);
+    const bool xt_want = xt_ok && (n > ((int64_t)1 << TCD_CHUNK_LG) || (xt_env && atoi(xt_env) > 0));
     // tile geometry of the dictionary form (used once the value width is known, below)
     const int tcd_R = getenv("B3C_KR_TCD_R") ? std::min(256, std::max(8, atoi(getenv("B3C_KR_TCD_R")) & ~7)) : 128;
-    const int tcd_dcap = getenv("B3C_KR_TCD_DCAP") ? std::min(16384, std::max(16, atoi(getenv("B3C_KR_TCD_DCAP")))) : 2560;   // LDS budget of a dictionary
+    const int tcd_dcap = getenv("B3C_KR_TCD_DCAP") ? std::min(16384, std::max(16, atoi(getenv("B3C_KR_TCD_DCAP")))) : (xt_want ? 4096 : 2560);   // LDS budget of a dictionary (sweeps at C2 / C3)
     const int64_t tcd_tiles = (nloc + tcd_R - 1) / tcd_R;
     const bool tcd_swz = getenv("B3C_KR_TCD_NOSWZ") == nullptr && tcd_tiles >= 64;
     const int64_t tcd_grid = tcd_swz ? 8 * ((tcd_tiles + 7) / 8) : tcd_tiles;
-    // On by default while the operand vector fits one XCD's L2 (n <= 2^19: C2 runs its SpMV in 28 instead of 39 us and the
-    // build is one bitmap pass); beyond that opt-in (B3C_KR_TCD=1): at C3 the SpMV reaches 0.42-0.46 ms against 0.50 ms for
-    // kr_kb_vec, which the 4 ms of kr_tcd_build (62 SpMVs per call) eat again -- see DESIGN.md section 4
-    const bool tcd_auto = n <= ((int64_t)1 << TCD_CHUNK_LG) && n >= 4096 && avg >= 16;
+    // (n <= 2^19: C2 runs its SpMV in 32 instead of 39 us and the build is one bitmap pass; without the tail pass the form
+    // does not pay at C3: 0.455 ms per SpMV against 0.50, less than its build costs)
+    const bool tcd_auto = n >= 4096 && avg >= 16 && (n <= ((int64_t)1 << TCD_CHUNK_LG) || xt_want);
     const bool tcd_may = counts && nloc > 0 && a->nnz > 0 && (tcd_auto || getenv("B3C_KR_TCD") != nullptr) && getenv("B3C_KR_NO_TCD") == nullptr;
     const int GS_max = (int)std::max<int64_t>(GS_rows, tcd_may ? tcd_tiles : 0);
     // hub rows add one partial each behind the GS of the row kernel (at most nnz / HUB_LEN of them)
@@ -2158,6 +2326,57 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             fprintf(stderr, "[b3c] dictionary layout: %lld tiles of %d rows, largest dictionary %llu (cap %d), mean %.0f, %.1f %% of the entries in tails, %zu B of LDS\n",
                     (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles, 100.0 * (double)hst[3] / (double)a->nnz, tcd_shmem);
     }
+    // ---- tails as their own pass (kr_kb_tails): column-ordered tail words per super-tile, fixed-point row sums ----
+    // single GPU, n < 2^24 (24-bit columns in a tail word), 512-thread dictionary kernel; automatic for n > 2^19
+    const bool tails_xt = tcd && xt_want && tcd_R <= TBK && getenv("B3C_KR_TCD_NOSPLIT") == nullptr && info->tcd_tail_entries > 0;
+    int64_t n_tails = 0;                 // tails outside hub rows (counted below)
+    const int64_t xt_super = (nloc + XT_S - 1) / XT_S;
+    DevBuf<double> pumax(ctx, tails_xt ? GA : 1);
+    DevBuf<unsigned long long> yhi(ctx, tails_xt ? nloc : 1), xt_words(ctx, tails_xt ? info->tcd_tail_entries + 4 : 1);
+    DevBuf<int> ylo(ctx, tails_xt ? nloc : 1), tex(ctx, 1);
+    DevBuf<int64_t> xt_off(ctx, tails_xt ? nloc + 2 : 1);
+    int xt_lg_bound = 0;
+    const size_t xt_shmem = sizeof(unsigned long long) * XT_S + sizeof(int) * XT_S + sizeof(double) * XT_NT;
+    if (tails_xt) {
+        DevBuf<int64_t> tcnt(ctx, nloc + 2);
+        DevBuf<unsigned long long> words_in(ctx, info->tcd_tail_entries + 4), xst(ctx, 2);
+        if (!pumax.p || !yhi.p || !xt_words.p || !ylo.p || !tex.p || !xt_off.p || !tcnt.p || !words_in.p || !xst.p)
+            return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: tail pass");
+        HIP_TRY(ctx, hipMemsetAsync(yhi.p, 0, sizeof(unsigned long long) * (size_t)nloc, s));
+        HIP_TRY(ctx, hipMemsetAsync(ylo.p, 0, sizeof(int) * (size_t)nloc, s));
+        HIP_TRY(ctx, hipMemsetAsync(xst.p, 0, sizeof(unsigned long long) * 2, s));
+        HIP_TRY(ctx, hipMemsetAsync(tex.p, 0, sizeof(int), s));
+        hipLaunchKernelGGL(kr_tails_count, dim3((unsigned)((nloc + 256) / 256)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, n1v.p, tcnt.p);
+        int rct;
+        if ((rct = b3c_exclusive_scan_i64(ctx, tcnt.p, xt_off.p, nloc + 1))) return rct;
+        hipLaunchKernelGGL(kr_tails_emit, dim3((unsigned)((nloc * 8 + 255) / 256)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, packed.p, pcol.p,
+                           n1v.p, xt_off.p, words_in.p, xst.p);
+        { const int rb_ = b3c_readback(ctx, &n_tails, xt_off.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
+        if (n_tails < 0 || n_tails > info->tcd_tail_entries)
+            return ctx->fail(B3C_E_HIP, "b3c_kr_balance: tail count out of bounds (%lld of %lld)", (long long)n_tails, (long long)info->tcd_tail_entries);
+        unsigned long long hx[2];
+        { const int rb_ = b3c_readback(ctx, hx, xst.p, sizeof(hx)); if (rb_) return rb_; }
+        // the largest |count * operand * 2^E| summed over the longest tail must stay below 2^61
+        int lgc = 0, lgt = 0;
+        while ((1ull << lgc) < hx[0] + 1) lgc++;
+        while ((1ull << lgt) < hx[1] + 1) lgt++;
+        xt_lg_bound = lgc + lgt;
+        // column order inside every super-tile: sort on (super-tile, column) = bits [29, 53 + bits of the super-tile index)
+        int st_bits = 1;
+        while ((1ll << st_bits) < xt_super) st_bits++;
+        size_t tb = 0;
+        hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tb, words_in.p, xt_words.p, (int64_t)n_tails, 29, 53 + st_bits, s);
+        if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort sizing failed");
+        DevBuf<char> tmp(ctx, tb);
+        if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: tail sort workspace");
+        e = hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, words_in.p, xt_words.p, (int64_t)n_tails, 29, 53 + st_bits, s);
+        if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort of the tails failed");
+        { static bool xt_attr = false; if (!xt_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xt_shmem)); xt_attr = true; } }
+        HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch above goes back to the pool here
+        if (getenv("B3C_KR_DEBUG"))
+            fprintf(stderr, "[b3c] tail pass: %lld tails in %lld super-tiles of %d rows, largest count %llu, longest tail %llu\n",
+                    (long long)n_tails, (long long)xt_super, XT_S, hx[0], hx[1]);
+    }
     const int GS = tcd ? (int)tcd_tiles : GS_rows;
     const int GSP = GS + (int)n_hub;          // partials the SpMV step leaves behind: row groups / tiles + hub rows
 
@@ -2194,7 +2413,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         static bool attr_done = false;
         if (!attr_done) {
             constexpr int LDS_MAX = 160 * 1024;
-#define KR_TCD2_ATTR(L, U, TL, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
+#define KR_TCD2_ATTR(L, U, TL, T)                                                                                                             \
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX)); \
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
             KR_TCD2_ATTR(16, 4, 8, 1); KR_TCD2_ATTR(16, 4, 16, 1); KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 8, 4, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
             KR_TCD2_ATTR(16, 4, 4, 2); KR_TCD2_ATTR(16, 4, 4, 4); KR_TCD2_ATTR(16, 4, 2, 4);
 #undef KR_TCD2_ATTR
@@ -2228,7 +2449,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             // KA: all rows on every rank (sharded: no exchange needed before the SpMV)
             hipLaunchKernelGGL(kr_ka, dim3(GA), dim3(BLK), 0, s, (int64_t)0, n, prm, s0, s1, dist ? D.scal + 1 : pmin.p, dist ? D.scal + 2 : pmax.p,
                                dist ? D.scal : psum.p, dist ? cP : G, cS, pgam.p, GA, dist ? 1 : 0, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, rs,
-                               pk1.p, pgam.p, flags);
+                               pk1.p, pgam.p, flags, tails_xt ? pumax.p : nullptr);
             t++;
             tmark();
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
@@ -2245,13 +2466,21 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             const double *kbp = dist ? D.scal : pk1.p;
             const int kbP = dist ? D.world : G, kbS = cS;
             if (tcd && tcd_split) {
+                if (tails_xt)
+                    hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * XT_CHUNKS)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, n_tails,
+                                       xt_off.p, r0, r1, xt_words.p, u.p, yhi.p, ylo.p, tex.p);
                 // dictionary waves and tail waves side by side (512-thread workgroups)
+#define KR_TCD2_ARGS                                                                                                         \
+    dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \
+        kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len,     \
+        getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0,                                                                   \
+        getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu,                     \
+        want_tlog ? tlog.p : nullptr, tails_xt ? yhi.p : nullptr, tails_xt ? ylo.p : nullptr, tails_xt ? tex.p : nullptr
 #define KR_TCD2(L, U, TL, T)                                                                                                 \
-    hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T>), dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d,   \
-                       tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p,      \
-                       dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len,                      \
-                       getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0,                                       \
-                       getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu, want_tlog ? tlog.p : nullptr)
+    do {                                                                                                                     \
+        if (tails_xt) hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, true>), KR_TCD2_ARGS);                                    \
+        else hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, false>), KR_TCD2_ARGS);                                            \
+    } while (0)
                 const int shp2 = getenv("B3C_KR_TCD_SHAPE2") ? atoi(getenv("B3C_KR_TCD_SHAPE2")) : 0;
                 if (shp2 == 16481) KR_TCD2(16, 4, 8, 1);
                 else if (shp2 == 164161) KR_TCD2(16, 4, 16, 1);

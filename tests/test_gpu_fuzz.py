@@ -12,9 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('seed', [7, 8])
-def test_random_maps_against_the_oracle(seed):
+@pytest.mark.parametrize('seed,env', [(7, {}), (8, {}), (9, {'B3C_KR_TCD_XT': '1'}), (10, {'B3C_KR_NO_TCD': '1'})])
+def test_random_maps_against_the_oracle(seed, env):
+    """env: the tail pass of the dictionary SpMV forced on for every map that takes the dictionary form (it is automatic only
+    beyond 2^19 contigs) / the CSR row kernels for all maps."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_parity.py'), '80', str(seed)],
-                         env=dict(os.environ, PYTHONPATH=ROOT), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+                         env=dict(os.environ, PYTHONPATH=ROOT, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     text = out.stdout.decode()
     assert out.returncode == 0 and 'fuzz: 80 cases, 0 failures' in text, text[-3000:]

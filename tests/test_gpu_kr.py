@@ -113,9 +113,24 @@ def test_kr_locality_reordered_path_matches_oracle(ctx, oracle_lib, monkeypatch)
     _, x2, info2 = ctx.kr_balance(mat)
     assert info2.n_iter == info.n_iter
     np.testing.assert_allclose(x2, x1, rtol=1e-11)
-    monkeypatch.setenv('B3C_KR_ROWWAVE', '1')
-    _, x3, _ = ctx.kr_balance(mat)
-    np.testing.assert_allclose(x3, x1, rtol=1e-11)
+    # count form of the same map through the three SpMV forms: dictionary tiles (default at this size), dictionary tiles with
+    # the tails summed in fixed point by their own pass (automatic beyond 2^19 contigs, forced here), CSR row groups
+    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    monkeypatch.delenv('B3C_NO_REORDER')
+    _, xc, ic = ctx.kr_balance_counts(cm, sm.sites)
+    assert ic.n_iter == st.n_iter and ic.tcd_tiles > 0
+    np.testing.assert_allclose(xc, xo, rtol=1e-9)
+    monkeypatch.setenv('B3C_KR_TCD_XT', '1')
+    _, xt, it = ctx.kr_balance_counts(cm, sm.sites)
+    assert it.n_iter == st.n_iter and it.tcd_tiles > 0
+    np.testing.assert_allclose(xt, xc, rtol=1e-11)
+    _, xt2, _ = ctx.kr_balance_counts(cm, sm.sites)
+    assert np.array_equal(xt, xt2)                          # integer accumulation: bit-identical repeats
+    monkeypatch.delenv('B3C_KR_TCD_XT')
+    monkeypatch.setenv('B3C_KR_NO_TCD', '1')
+    _, xv, iv = ctx.kr_balance_counts(cm, sm.sites)
+    assert iv.n_iter == st.n_iter and iv.tcd_tiles == 0
+    np.testing.assert_allclose(xv, xc, rtol=1e-11)
 
 
 def test_symmetry_guard_fast_and_exact_paths(ctx):

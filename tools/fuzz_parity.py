@@ -19,7 +19,7 @@ fails = 0
 
 
 def random_map(rs):
-    n = int(rs.choice([3, 17, 64, 65, 200, 513, 1500, 4000]))
+    n = int(rs.choice([3, 17, 64, 65, 200, 513, 1500, 4000, 6000, 9000]))    # from 4096 rows on (and 16 entries per row) KR takes the dictionary form
     deg = float(rs.choice([1.5, 6, 30, 150, 400]))
     deg = min(deg, n - 1)
     m = int(n * deg / 2)
