@@ -205,8 +205,16 @@ def main():
             vb = last.kr_info.value_bits / 8.0             # 2 when all counts fit 16 bits, else 4 (8: fp64 matrix)
             streamed = ((4.0 + vb) * nnz + 36.0 * n) * share   # what the SpMV kernel physically reads/writes
             avg_ms = spmv_ms / max(spmv_n, 1)
-            tcd = getattr(last.kr_info, 'tcd_tiles', 0) > 0    # tile-dictionary layout (automatic for n <= 2^19)
-            kname = ('kr_kb_tcd2 (tile-dictionary SpMV on raw counts + fused KR epilogue)' if tcd
+            ki = last.kr_info
+            tcd = getattr(ki, 'tcd_tiles', 0) > 0              # tile-dictionary layout (automatic from 4096 contigs on)
+            xt = getattr(ki, 'tcd_xt_tails', 0) > 0            # ... with the tails summed by their own pass (beyond 2^19 contigs)
+            if tcd:
+                # what the dictionary form physically moves: 4 B per dictionary entry, 8 B per tail entry (word, or count +
+                # column), the dictionaries (ids in, operands gathered), row tables and the n-vectors of the epilogue
+                streamed = (4.0 * (nnz - ki.tcd_tail_entries) + 8.0 * ki.tcd_tail_entries + 12.0 * ki.tcd_dict_total + 52.0 * n) * share
+            kname = ('kr_kb_tails + kr_kb_tcd2 (ONE SpMV as two launches: tails summed in column order in fixed point, then dictionary '
+                     'rows + fused KR epilogue; times and bytes are those of the pair)' if xt
+                     else 'kr_kb_tcd2 (tile-dictionary SpMV on raw counts + fused KR epilogue)' if tcd
                      else 'kr_kb_vec (CSR SpMV on raw counts + fused KR epilogue)')
         else:
             per_launch = (16.0 * acc['move_nnz'] + 28.0 * acc['move_rows']) / max(move_n, 1)   # Louvain sweep / n_sub

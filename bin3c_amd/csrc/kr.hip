@@ -2152,8 +2152,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const bool xt_ok = counts && !dist && n < ((int64_t)1 << 24) && !(xt_env && atoi(xt_env) <= 0);
     const bool xt_want = xt_ok && (n > ((int64_t)1 << TCD_CHUNK_LG) || (xt_env && atoi(xt_env) > 0));
     // tile geometry of the dictionary form (used once the value width is known, below)
-    const int tcd_R = getenv("B3C_KR_TCD_R") ? std::min(256, std::max(8, atoi(getenv("B3C_KR_TCD_R")) & ~7)) : 128;
-    const int tcd_dcap = getenv("B3C_KR_TCD_DCAP") ? std::min(16384, std::max(16, atoi(getenv("B3C_KR_TCD_DCAP")))) : (xt_want ? 4096 : 2560);   // LDS budget of a dictionary (sweeps at C2 / C3)
+    const int tcd_R = getenv("B3C_KR_TCD_R") ? std::min(256, std::max(8, atoi(getenv("B3C_KR_TCD_R")) & ~7)) : (xt_want ? 192 : 128);
+    const int tcd_dcap = getenv("B3C_KR_TCD_DCAP") ? std::min(16384, std::max(16, atoi(getenv("B3C_KR_TCD_DCAP")))) : (xt_want ? 5120 : 2560);   // LDS budget of a dictionary (sweeps at C2 / C3)
     const int64_t tcd_tiles = (nloc + tcd_R - 1) / tcd_R;
     const bool tcd_swz = getenv("B3C_KR_TCD_NOSWZ") == nullptr && tcd_tiles >= 64;
     const int64_t tcd_grid = tcd_swz ? 8 * ((tcd_tiles + 7) / 8) : tcd_tiles;
@@ -2373,6 +2373,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort of the tails failed");
         { static bool xt_attr = false; if (!xt_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xt_shmem)); xt_attr = true; } }
         HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch above goes back to the pool here
+        info->tcd_xt_tails = n_tails;
         if (getenv("B3C_KR_DEBUG"))
             fprintf(stderr, "[b3c] tail pass: %lld tails in %lld super-tiles of %d rows, largest count %llu, longest tail %llu\n",
                     (long long)n_tails, (long long)xt_super, XT_S, hx[0], hx[1]);
@@ -2418,6 +2419,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
             KR_TCD2_ATTR(16, 4, 8, 1); KR_TCD2_ATTR(16, 4, 16, 1); KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 8, 4, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
             KR_TCD2_ATTR(16, 4, 4, 2); KR_TCD2_ATTR(16, 4, 4, 4); KR_TCD2_ATTR(16, 4, 2, 4);
+            KR_TCD2_ATTR(16, 8, 8, 2); KR_TCD2_ATTR(32, 2, 8, 2); KR_TCD2_ATTR(32, 4, 8, 2); KR_TCD2_ATTR(16, 2, 8, 2);
 #undef KR_TCD2_ATTR
 #define KR_TCD_ATTR(L, U, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
             KR_TCD_ATTR(16, 4, 2); KR_TCD_ATTR(8, 8, 2); KR_TCD_ATTR(8, 8, 1); KR_TCD_ATTR(32, 2, 1); KR_TCD_ATTR(16, 4, 1);
@@ -2489,6 +2491,11 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                 else if (shp2 == 16442) KR_TCD2(16, 4, 4, 2);
                 else if (shp2 == 16444) KR_TCD2(16, 4, 4, 4);
                 else if (shp2 == 16424) KR_TCD2(16, 4, 2, 4);
+                else if (shp2 == 8442) KR_TCD2(8, 4, 4, 2);
+                else if (shp2 == 16882) KR_TCD2(16, 8, 8, 2);
+                else if (shp2 == 32282) KR_TCD2(32, 2, 8, 2);
+                else if (shp2 == 32482) KR_TCD2(32, 4, 8, 2);
+                else if (shp2 == 16282) KR_TCD2(16, 2, 8, 2);
                 else if (avg > 128) KR_TCD2(16, 4, 8, 2);
                 else if (avg > 48) KR_TCD2(8, 4, 4, 2);
                 else KR_TCD2(4, 4, 4, 1);
@@ -2646,7 +2653,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                 if (!e[6]) continue;
                 first = std::min(first, e[0]); last = std::max(last, e[6]);
                 ph[0] += (double)(e[1] - e[0]); ph[1] += (double)(e[2] - e[1]); ph[2] += (double)(e[3] - e[2]);
-                ph[3] += (double)(e[4] - e[2]); ph[4] += (double)(e[5] - e[2]); ph[5] += (double)(e[6] - e[5]);
+                ph[3] += e[4] ? (double)(e[4] - e[2]) : 0.0;      // (no tail waves when kr_kb_tails sums the tails)
+                ph[4] += (double)(e[5] - e[2]); ph[5] += (double)(e[6] - e[5]);
                 cnt++;
             }
             if (cnt)

@@ -53,9 +53,11 @@ typedef struct {
     int64_t n_spmv;       /* SpMV launches that did work */
     int32_t bitwise_symmetric; /* 1: a_ij == a_ji exactly (checksum path); precondition of b3c_scale_sym_graph */
     int32_t value_bits;   /* width of the matrix values the SpMV streamed: 64 (fp64), 32 (counts) or 16 (counts <= 65535) */
-    /* tile-local column dictionaries (16-bit counts): tiles of the SpMV, tiles whose dictionary did not fit LDS and
-     * run on the CSR arrays, the largest dictionary and the sum of all dictionary sizes; all 0 for the other forms */
+    /* tile-local column dictionaries (16-bit counts): tiles of the SpMV, the largest dictionary, the sum of all
+     * dictionary sizes and the entries outside the dictionaries (tails); all 0 for the other forms */
     int64_t tcd_tiles, tcd_dict_max, tcd_dict_total, tcd_tail_entries;
+    /* tails summed by their own pass (kr_kb_tails, maps beyond 2^19 contigs on one GPU); 0: by the row kernel */
+    int64_t tcd_xt_tails;
 } b3c_kr_info;
 
 typedef struct {

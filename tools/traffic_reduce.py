@@ -28,6 +28,41 @@ def active(counter, kern):
     return sum(a) / len(a) * 1024.0, len(a), len(rows)
 
 
+import os
+prev = {}
+if os.path.exists('profiles/traffic.json'):
+    prev = json.load(open('profiles/traffic.json'))
+kernels = sorted({r['Kernel'].split('<')[0] for r in csv.DictReader(open('profiles/%s_c3_FETCH_SIZE.csv' % rnd))})
+fp, _, _ = active('FETCH_SIZE', 'kr_prep_counts')
+wp, _, _ = active('WRITE_SIZE', 'kr_prep_counts')
+fq, _, _ = active('FETCH_SIZE', 'k_quantise')
+wq, _, _ = active('WRITE_SIZE', 'k_quantise')
+correction = ('MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies the 128-byte fabric requests of coalesced reads at 64 '
+              'bytes, so it is doubled; WRITE_SIZE is exact. Checked in the same two passes on two pure streaming kernels of '
+              'known size: kr_prep_counts reads 8*nnz+8*n = %.0f MB and reports %.0f MB (x%.3f), writes 2*nnz+8*n = %.0f MB '
+              'and reports %.0f MB; k_quantise reads and writes 8 bytes per sub-map entry and reports %.0f MB fetched / '
+              '%.0f MB written (x%.3f).' % ((8 * NNZ + 8 * N) / 1e6, fp / 1e6, fp / (8 * NNZ + 8 * N), (2 * NNZ + 8 * N) / 1e6,
+                                            wp / 1e6, fq / 1e6, wq / 1e6, fq / wq))
+source = ('profiles/%s_c3_FETCH_SIZE.csv, profiles/%s_c3_WRITE_SIZE.csv (rocprofv3 --pmc, one counter per pass, '
+          'bench.py --config C3 --steps 1 --warmup 0)' % (rnd, rnd))
+out = dict(prev)
+if 'kr_kb_tails' in kernels:
+    # one SpMV = kr_kb_tails + kr_kb_tcd2: the sum of the two launches
+    ft, na, nt = active('FETCH_SIZE', 'kr_kb_tails')
+    wt, _, _ = active('WRITE_SIZE', 'kr_kb_tails')
+    fd, _, _ = active('FETCH_SIZE', 'kr_kb_tcd2')
+    wd, _, _ = active('WRITE_SIZE', 'kr_kb_tcd2')
+    if 'C3' in prev and prev['C3'].get('kernel', '').startswith('kr_kb_vec'):
+        out['C3_kr_kb_vec'] = prev['C3']            # the CSR row kernel's record (earlier passes), cited by DESIGN.md
+    out['C3'] = {
+        'kernel': 'kr_kb_tails + kr_kb_tcd2 (one SpMV: tails in column order in fixed point, dictionary rows + fused KR epilogue)',
+        'kr_kb_tails': {'FETCH_SIZE_raw_bytes_per_launch': ft, 'WRITE_SIZE_raw_bytes_per_launch': wt},
+        'kr_kb_tcd2': {'FETCH_SIZE_raw_bytes_per_launch': fd, 'WRITE_SIZE_raw_bytes_per_launch': wd},
+        'hbm_bytes_per_launch': 2.0 * (ft + fd) + wt + wd,
+        'launches_counted': na, 'launches_total': nt, 'correction': correction, 'source': source}
+    json.dump(out, open('profiles/traffic.json', 'w'), indent=1)
+    print(json.dumps(out['C3'], indent=1))
+    sys.exit(0)
 fv, na, nt = active('FETCH_SIZE', 'kr_kb_vec')
 wv, _, _ = active('WRITE_SIZE', 'kr_kb_vec')
 fp, _, _ = active('FETCH_SIZE', 'kr_prep_counts')
