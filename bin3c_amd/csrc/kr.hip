@@ -1250,7 +1250,8 @@ __global__ void __launch_bounds__(256) kr_tails_emit(int64_t r0, int64_t r1, int
         if (len <= hub_len) {
             const int n1 = n1v[row - r0];
             const int64_t o = toff[row - r0];
-            const unsigned long long hi = ((unsigned long long)(row / XT_S) << 53) | ((unsigned long long)(row % XT_S) << 16);
+            const int64_t rr = row - r0;               // super-tiles count from the first row of this rank
+            const unsigned long long hi = ((unsigned long long)(rr / XT_S) << 53) | ((unsigned long long)(rr % XT_S) << 16);
             for (int64_t t = n1 + sl; t < len; t += 8) {
                 const unsigned long long c = packed[base + t] & 0xFFFFu;
                 words[o + (t - n1)] = hi | ((unsigned long long)(uint32_t)pcol[base + t] << 29) | c;
@@ -2144,12 +2145,12 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // SpMV form: row groups of lpr_p lanes (kr_kb_pipe / kr_kb_vec), or -- 16-bit counts -- tiles with column dictionaries
     const int lpr_p = avg > 64 ? 16 : avg > 24 ? 8 : 4;   // lanes per row of the pipelined form
     const int GS_rows = grid_for(nloc, (BLK / 64) * (64 / lpr_p), (getenv("B3C_KR_GSMUL") ? atoi(getenv("B3C_KR_GSMUL")) : 16) * ctx->n_cu);
-    // The dictionary form is the default while the operand vector fits one XCD's L2 (n <= 2^19); beyond it, on a single GPU,
+    // The dictionary form is the default while the operand vector fits one XCD's L2 (n <= 2^19); beyond it
     // it runs together with the tail pass (kr_kb_tails: the tails, whose gathers miss L2 there, are summed in
     // column order by their own kernel): C3 0.32 ms per SpMV against 0.50 for kr_kb_vec, which pays for the 5 ms of set-up
     // (62 SpMVs per call).  B3C_KR_TCD_XT=1 / =0 force the tail pass on (where eligible) / off.
     const char *xt_env = getenv("B3C_KR_TCD_XT");
-    const bool xt_ok = counts && !dist && n < ((int64_t)1 << 24) && !(xt_env && atoi(xt_env) <= 0);
+    const bool xt_ok = counts && n < ((int64_t)1 << 24) && !(xt_env && atoi(xt_env) <= 0);
     const bool xt_want = xt_ok && (n > ((int64_t)1 << TCD_CHUNK_LG) || (xt_env && atoi(xt_env) > 0));
     // tile geometry of the dictionary form (used once the value width is known, below)
     const int tcd_R = getenv("B3C_KR_TCD_R") ? std::min(256, std::max(8, atoi(getenv("B3C_KR_TCD_R")) & ~7)) : (xt_want ? 192 : 128);
@@ -2327,7 +2328,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                     (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles, 100.0 * (double)hst[3] / (double)a->nnz, tcd_shmem);
     }
     // ---- tails as their own pass (kr_kb_tails): column-ordered tail words per super-tile, fixed-point row sums ----
-    // single GPU, n < 2^24 (24-bit columns in a tail word), 512-thread dictionary kernel; automatic for n > 2^19
+    // n < 2^24 (24-bit columns in a tail word), 512-thread dictionary kernel; automatic for n > 2^19.  Sharded path: every
+    // rank has the tails of ITS rows (the operand vector and its maximum are complete on every rank after KA)
     const bool tails_xt = tcd && xt_want && tcd_R <= TBK && getenv("B3C_KR_TCD_NOSPLIT") == nullptr && info->tcd_tail_entries > 0;
     int64_t n_tails = 0;                 // tails outside hub rows (counted below)
     const int64_t xt_super = (nloc + XT_S - 1) / XT_S;

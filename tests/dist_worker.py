@@ -55,7 +55,12 @@ def gpu_mode(rank, world):
     n_block = 0
     # a flat map, and a power-law one whose hub rows go through kr_kb_hub and the Louvain hub lists on both ranks
     # (the third is too small for the locality ordering: it runs the sharded kernels on a map every rank holds whole)
-    for args in ((40000, 1300000, 21), (70000, 4000000, 9, 'powerlaw'), (30000, 900000, 9, 'powerlaw')):
+    for k, args in enumerate(((40000, 1300000, 21), (70000, 4000000, 9, 'powerlaw'), (30000, 900000, 9, 'powerlaw'))):
+        # the second map also takes the tail pass of the KR SpMV (automatic only beyond 2^19 contigs) on both row blocks
+        if k == 1:
+            os.environ['B3C_KR_TCD_XT'] = '1'
+        else:
+            os.environ.pop('B3C_KR_TCD_XT', None)
         sm = make_synth(*args)
         counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
         single = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)            # before sharding is installed
@@ -79,6 +84,8 @@ def gpu_mode(rank, world):
         if res._n2o is not None:
             assert single._n2o is not None and torch.equal(res._n2o, single._n2o)
         assert res.kr_info.n_iter == single.kr_info.n_iter
+        if k == 1:
+            assert res.kr_info.tcd_xt_tails > 0 and single.kr_info.tcd_xt_tails > res.kr_info.tcd_xt_tails, (res.kr_info.tcd_xt_tails, single.kr_info.tcd_xt_tails)
         assert np.array_equal(res.mask, single.mask) and np.array_equal(res.signal, single.signal)
         np.testing.assert_allclose(res.x, single.x, rtol=1e-10)
         assert graphs.same_partition(res.labels, single.labels)
