@@ -749,7 +749,8 @@ __global__ void __launch_bounds__(BLK) kr_kb_hub(const int64_t *__restrict__ hub
 //                  masked lanes), results leave through LDS as coalesced stores.
 // ---------------------------------------------------------------------------------------------
 constexpr int TCD_TB = 1024;                          // threads of the build kernel (one workgroup per CU: 140 KB of LDS)
-constexpr int TCD_CHUNK_LG = 19;                      // columns per bitmap pass
+constexpr int TCD_CHUNK_LG = 19;                      // columns per bitmap pass (2^18 with two workgroups per CU: 4.0 instead of 2.9 ms at C3)
+constexpr int TCD_L2_LG = 19;                         // operand vectors up to 2^19 doubles sit in one XCD's L2
 constexpr int TCD_WORDS = 1 << (TCD_CHUNK_LG - 5);    // 16384 words = 64 KB per bitmap
 constexpr int TCD_GROUPS = TCD_WORDS / 4;             // one 16-bit prefix per 128 columns
 constexpr int TCD_RMAX = 256;                         // rows per tile at most
@@ -2151,7 +2152,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // (62 SpMVs per call).  B3C_KR_TCD_XT=1 / =0 force the tail pass on (where eligible) / off.
     const char *xt_env = getenv("B3C_KR_TCD_XT");
     const bool xt_ok = counts && n < ((int64_t)1 << 24) && !(xt_env && atoi(xt_env) <= 0);
-    const bool xt_want = xt_ok && (n > ((int64_t)1 << TCD_CHUNK_LG) || (xt_env && atoi(xt_env) > 0));
+    const bool xt_want = xt_ok && (n > ((int64_t)1 << TCD_L2_LG) || (xt_env && atoi(xt_env) > 0));
     // tile geometry of the dictionary form (used once the value width is known, below)
     const int tcd_R = getenv("B3C_KR_TCD_R") ? std::min(256, std::max(8, atoi(getenv("B3C_KR_TCD_R")) & ~7)) : (xt_want ? 192 : 128);
     const int tcd_dcap = getenv("B3C_KR_TCD_DCAP") ? std::min(16384, std::max(16, atoi(getenv("B3C_KR_TCD_DCAP")))) : (xt_want ? 5120 : 2560);   // LDS budget of a dictionary (sweeps at C2 / C3)
@@ -2160,7 +2161,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int64_t tcd_grid = tcd_swz ? 8 * ((tcd_tiles + 7) / 8) : tcd_tiles;
     // (n <= 2^19: C2 runs its SpMV in 32 instead of 39 us and the build is one bitmap pass; without the tail pass the form
     // does not pay at C3: 0.455 ms per SpMV against 0.50, less than its build costs)
-    const bool tcd_auto = n >= 4096 && avg >= 16 && (n <= ((int64_t)1 << TCD_CHUNK_LG) || xt_want);
+    const bool tcd_auto = n >= 4096 && avg >= 16 && (n <= ((int64_t)1 << TCD_L2_LG) || xt_want);
     const bool tcd_may = counts && nloc > 0 && a->nnz > 0 && (tcd_auto || getenv("B3C_KR_TCD") != nullptr) && getenv("B3C_KR_NO_TCD") == nullptr;
     const int GS_max = (int)std::max<int64_t>(GS_rows, tcd_may ? tcd_tiles : 0);
     // hub rows add one partial each behind the GS of the row kernel (at most nnz / HUB_LEN of them)
