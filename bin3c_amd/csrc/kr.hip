@@ -1219,7 +1219,7 @@ constexpr int TBK = 512;
 // ---------------------------------------------------------------------------------------------
 constexpr int XT_S = 8192;           // rows per super-tile (13 bits of a tail word)
 constexpr int XT_NT = 1024;          // threads of kr_kb_tails
-constexpr int XT_CHUNKS = 2;         // workgroups per super-tile
+constexpr int XT_CHUNKS = 2;         // workgroups per super-tile at least (more when a rank has few super-tiles)
 
 // tail word: super-tile << 53 | column << 29 | row inside the super-tile << 16 | count
 __global__ void __launch_bounds__(256) kr_tails_count(int64_t r0, int64_t r1, int hub_len, const int64_t *__restrict__ indptr,
@@ -1292,7 +1292,7 @@ __device__ double reduce_max_n(const double *__restrict__ part, int P, double *l
 }
 
 __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__ sin, const double *__restrict__ pumax, int PU,
-                                                      int lg_bound, int64_t n_tails, const int64_t *__restrict__ toff, int64_t r0, int64_t n,
+                                                      int lg_bound, int chunks, int64_t n_tails, const int64_t *__restrict__ toff, int64_t r0, int64_t n,
                                                       const unsigned long long *__restrict__ words, const double *__restrict__ u,
                                                       unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex)
 {
@@ -1309,12 +1309,12 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) tex[0] = E;
     if (!live) return;
     const double scale = ldexp(1.0, E);
-    const int stile = blockIdx.x / XT_CHUNKS, ch = blockIdx.x % XT_CHUNKS;
+    const int stile = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     for (int i = threadIdx.x; i < XT_S; i += XT_NT) { acc[i] = 0; lo[i] = 0; }
     __syncthreads();
     const int64_t ra = r0 + (int64_t)stile * XT_S, rb = ra + XT_S < n ? ra + XT_S : n;
     const int64_t a = toff[ra - r0], b = rb >= n ? n_tails : toff[rb - r0];
-    const int64_t len = (b - a + XT_CHUNKS - 1) / XT_CHUNKS;
+    const int64_t len = (b - a + chunks - 1) / chunks;
     const int64_t s0 = a + ch * len, e0 = s0 + len < b ? s0 + len : b;
     for (int64_t k0 = s0 + threadIdx.x; k0 < e0; k0 += 4 * XT_NT) {
         unsigned long long w[4];
@@ -2334,6 +2334,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const bool tails_xt = tcd && xt_want && tcd_R <= TBK && getenv("B3C_KR_TCD_NOSPLIT") == nullptr && info->tcd_tail_entries > 0;
     int64_t n_tails = 0;                 // tails outside hub rows (counted below)
     const int64_t xt_super = (nloc + XT_S - 1) / XT_S;
+    // two workgroups per super-tile fill the chip from ~110 super-tiles on (C3); a rank of the sharded path with fewer of them
+    // splits each over more workgroups (each clears and flushes all 8192 row sums, so not more than 16)
+    const int xt_chunks = 4 * XT_CHUNKS * xt_super >= 3 * (int64_t)ctx->n_cu || xt_super == 0
+                              ? XT_CHUNKS : (int)std::min<int64_t>(16, (ctx->n_cu + xt_super - 1) / xt_super);   // (3 at C3 costs 20 us per SpMV)
     DevBuf<double> pumax(ctx, tails_xt ? GA : 1);
     DevBuf<unsigned long long> yhi(ctx, tails_xt ? nloc : 1), xt_words(ctx, tails_xt ? info->tcd_tail_entries + 4 : 1);
     DevBuf<int> ylo(ctx, tails_xt ? nloc : 1), tex(ctx, 1);
@@ -2472,7 +2476,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             const int kbP = dist ? D.world : G, kbS = cS;
             if (tcd && tcd_split) {
                 if (tails_xt)
-                    hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * XT_CHUNKS)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, n_tails,
+                    hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_chunks, n_tails,
                                        xt_off.p, r0, r1, xt_words.p, u.p, yhi.p, ylo.p, tex.p);
                 // dictionary waves and tail waves side by side (512-thread workgroups)
 #define KR_TCD2_ARGS                                                                                                         \
