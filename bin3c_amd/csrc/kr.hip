@@ -978,224 +978,6 @@ __device__ void block_partial_at(double v, double *__restrict__ part, int64_t at
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// LPR lanes per row, UN 16-byte vectors of dictionary entries and TU tail entries per lane and pass
-template <int LPR, int UN, int TU>
-__global__ void __launch_bounds__(BLK) kr_kb_tcd(int64_t r0, int64_t r1, int64_t ncols, int R, int dlds, int dstride, int ntiles,
-                                                  int swz, const KRState *__restrict__ sin, KRState *__restrict__ sout,
-                                                  const double *__restrict__ partA, int PA, int PS,
-                                                  const int64_t *__restrict__ indptr, const uint32_t *__restrict__ packed,
-                                                  const int32_t *__restrict__ pcol, const int32_t *__restrict__ n1v,
-                                                  const int32_t *__restrict__ dict_cols, const int32_t *__restrict__ dict_cnt,
-                                                  const double *__restrict__ rs, const double *__restrict__ dfix,
-                                                  const double *__restrict__ u, const double *__restrict__ x,
-                                                  const double *__restrict__ p, double *__restrict__ v,
-                                                  double *__restrict__ rk, double *__restrict__ w,
-                                                  double *__restrict__ part_out, int hub_len, uint32_t probe_mask, int probe)
-{
-    extern __shared__ __attribute__((aligned(16))) double ksm[];
-    double *xl = ksm;                         // dlds operands of the tile's dictionary
-    double *tx = xl + dlds, *tp = tx + R, *tv = tp + R, *td = tv + R, *tr = td + R, *o0 = tr + R, *o1 = o0 + R;
-    int64_t *ipl = (int64_t *)(o1 + R);       // R + 1 row pointers
-    double *lds = (double *)(ipl + R + 1);    // BLK doubles for the reductions
-    int32_t *n1l = (int32_t *)(lds + BLK);    // R dictionary-entry counts
-    // blocks b and b + 8 share an XCD (and its L2): swz gives every XCD a contiguous eighth of the tiles, so that the
-    // operand windows its tiles gather overlap
-    int64_t tile = blockIdx.x;
-    if (swz) {
-        const int per = (ntiles + 7) / 8;
-        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    }
-    const bool live = tile < ntiles;          // padding blocks of the swizzled grid carry no tile
-    const int tid = threadIdx.x;
-    const int64_t ra = r0 + (live ? tile : 0) * R;
-    const int nrows = live ? (int)((ra + R < r1 ? ra + R : r1) - ra) : 0;
-    // everything that does not depend on the control state is requested first
-    const int D1 = live ? dict_cnt[tile] : 0;
-    for (int i = tid; i <= nrows && live; i += BLK) ipl[i] = indptr[ra + i];
-    for (int i = tid; i < nrows; i += BLK) {
-        tx[i] = x[ra + i];
-        td[i] = dfix[ra + i];
-        tr[i] = rs ? rs[ra + i] : 1.0;
-        tp[i] = p[ra + i];
-        tv[i] = v[ra + i];
-        n1l[i] = n1v[ra + i - r0];
-    }
-    KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
-    const bool inner = st.phase == A_INNER;
-    if (st.phase == A_INNER) st.phase = B_INNER;
-    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
-    {
-        const int32_t *__restrict__ dc1 = dict_cols + (live ? tile : 0) * (int64_t)dstride;
-        for (int base = 0; base < D1 && !(probe & 4); base += BLK * 4) {
-            int32_t cc[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const int i = base + q * BLK + tid; cc[q] = i < D1 ? dc1[i] : 0; }
-            double gg[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) gg[q] = u[(uint32_t)cc[q]];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const int i = base + q * BLK + tid; if (i < D1) xl[i] = gg[q]; }
-        }
-    }
-    if (D1 == 0 && tid == 0) xl[0] = 0.0;     // masked lanes multiply a zero count with xl[0]: keep stale LDS (NaN) out
-    __syncthreads();
-
-    // the tile's entries and the operand vector as buffer resources (descriptors from wave-uniform values only): a lane
-    // that must not load passes offset ~0 and the range check drops it -- no branch, no look-up
-    const int64_t e0 = ipl[0];
-    const uint32_t ebytes = __builtin_amdgcn_readfirstlane((uint32_t)((ipl[nrows] - e0) * 4));
-    const uint64_t pa = (uint64_t)(packed + e0), ca = (uint64_t)(pcol + e0);
-    const uint32_t palo = __builtin_amdgcn_readfirstlane((uint32_t)pa), pahi = __builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
-    const uint32_t calo = __builtin_amdgcn_readfirstlane((uint32_t)ca), cahi = __builtin_amdgcn_readfirstlane((uint32_t)(ca >> 32));
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)pahi << 32) | palo), 0, (int)ebytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)cahi << 32) | calo), 0, (int)ebytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, (int)(ncols * 8), 0x00020000);
-    constexpr uint32_t NOLOAD = 0xFFFFFFFFu;
-
-    constexpr int RPW = 64 / LPR;
-    constexpr int RPP = RPW * (BLK / 64);     // rows per pass of the workgroup
-    constexpr int CH = LPR * UN * 4;
-    constexpr int TCH = LPR * TU * 4;
-    const int lane = tid & 63;
-    const int sub = lane / LPR, sl = lane % LPR;
-    double contrib = 0.0;
-    int rl = (tid >> 6) * RPW + sub;
-    uint32_t so = 0;                          // byte offset of the row inside the tile's entries
-    int len = 0, n1 = 0;
-    if (rl < nrows) {
-        so = (uint32_t)((ipl[rl] - e0) * 4);
-        len = (int)(ipl[rl + 1] - ipl[rl]);
-        n1 = n1l[rl];
-        if (len > hub_len) { len = -1; n1 = 0; }
-    }
-    // TU 16-byte vectors of tail entries per lane: counts from the end of the row in `packed`, columns beside them
-    u32x4 c[UN], tc[TU], tcol[TU];
-#pragma unroll
-    for (int q = 0; q < UN; q++) {
-        const int i = (q * LPR + sl) * 4;
-        c[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1 ? so + (uint32_t)i * 4u : NOLOAD, 0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < TU; k++) {
-        const int t = n1 + (k * LPR + sl) * 4;
-        const uint32_t off = t < len && !(probe & 2) ? so + (uint32_t)t * 4u : NOLOAD;
-        tc[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0);
-        tcol[k] = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
-    }
-    while (rl < nrows) {
-        const int rln = rl + RPP;
-        uint32_t son = 0;
-        int lenn = 0, n1n = 0;
-        if (rln < nrows) {
-            son = (uint32_t)((ipl[rln] - e0) * 4);
-            lenn = (int)(ipl[rln + 1] - ipl[rln]);
-            n1n = n1l[rln];
-            if (lenn > hub_len) { lenn = -1; n1n = 0; }
-        }
-        // tail operands of this row from global memory, then the entries of the next row
-        double tg[TU][4];
-#pragma unroll
-        for (int k = 0; k < TU; k++) {
-            const int t = n1 + (k * LPR + sl) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len && !(probe & 3) ? (tcol[k][j] & probe_mask) * 8u : NOLOAD, 0, 0);
-                tg[k][j] = __hiloint2double((int)gw.y, (int)gw.x);
-            }
-        }
-        u32x4 c2[UN], tc2[TU], tcol2[TU];
-#pragma unroll
-        for (int q = 0; q < UN; q++) {
-            const int i = (q * LPR + sl) * 4;
-            c2[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1n ? son + (uint32_t)i * 4u : NOLOAD, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < TU; k++) {
-            const int t = n1n + (k * LPR + sl) * 4;
-            const uint32_t off = t < lenn && !(probe & 2) ? son + (uint32_t)t * 4u : NOLOAD;
-            tc2[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0);
-            tcol2[k] = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
-        }
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < UN; q++) {
-            const int i = (q * LPR + sl) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t e = i + j < n1 ? c[q][j] : 0u;
-                acc += (double)(e & 0xFFFFu) * xl[e >> 16];
-            }
-        }
-        for (int base = CH; base < n1; base += CH) {          // more dictionary entries than one chunk
-#pragma unroll
-            for (int q = 0; q < UN; q++) {
-                const int i = base + (q * LPR + sl) * 4;
-                const u32x4 cc = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1 ? so + (uint32_t)i * 4u : NOLOAD, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t e = i + j < n1 ? cc[j] : 0u;
-                    acc += (double)(e & 0xFFFFu) * xl[e >> 16];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < TU; k++) {
-            const int t = n1 + (k * LPR + sl) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc += (t + j < len ? (double)(tc[k][j] & 0xFFFFu) : 0.0) * tg[k][j];
-        }
-        for (int base = n1 + TCH; base < len && !(probe & 2); base += TCH) {  // longer tails
-#pragma unroll
-            for (int k = 0; k < TU; k++) {
-                const int t = base + (k * LPR + sl) * 4;
-                const uint32_t off = t < len ? so + (uint32_t)t * 4u : NOLOAD;
-                const u32x4 cn = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0);
-                const u32x4 cl = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len ? (cl[j] & probe_mask) * 8u : NOLOAD, 0, 0);
-                    acc += (t + j < len ? (double)(cn[j] & 0xFFFFu) : 0.0) * __hiloint2double((int)gw.y, (int)gw.x);
-                }
-            }
-        }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
-        if (sl == 0 && len >= 0) {
-            const double xi = tx[rl];
-            const double pi = inner ? tp[rl] : 0.0;
-            const double t = acc * tr[rl] + td[rl] * (inner ? xi * pi : xi);
-            if (inner) {
-                const double wi = xi * t + tv[rl] * pi;
-                o0[rl] = wi;
-                contrib += pi * wi;
-            } else {
-                const double vn = xi * t;
-                const double r = 1.0 - vn;
-                o0[rl] = vn;
-                o1[rl] = r;
-                contrib += r * r;
-            }
-        }
-        rl = rln;
-        so = son;
-        len = lenn;
-        n1 = n1n;
-#pragma unroll
-        for (int q = 0; q < UN; q++) c[q] = c2[q];
-#pragma unroll
-        for (int k = 0; k < TU; k++) { tc[k] = tc2[k]; tcol[k] = tcol2[k]; }
-    }
-    __syncthreads();
-    for (int i = tid; i < nrows; i += BLK) {
-        if (ipl[i + 1] - ipl[i] > hub_len) continue;       // written by kr_kb_hub
-        if (inner) w[ra + i] = o0[i];
-        else { v[ra + i] = o0[i]; rk[ra + i] = o1[i]; }
-    }
-    block_partial_at<0>(contrib, part_out, tile, lds);
-}
 
 // The same with the two kinds of entries on DIFFERENT waves of a 512-thread workgroup: waves 0-3 stream the dictionary
 // entries (LDS operands), waves 4-7 the row tails (operands gathered from global memory).  The two access patterns wait on
@@ -2307,7 +2089,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     DevBuf<int32_t> pcol(ctx, tcd ? a->nnz + 8 : 1), n1v(ctx, tcd ? nloc : 1);
     DevBuf<int32_t> dict_cols(ctx, tcd ? (size_t)tcd_tiles * (size_t)tcd_dcap : 1), dict_cnt(ctx, tcd ? tcd_tiles : 1);
     int tcd_lds_d = 0;                     // operands the SpMV kernel keeps in LDS: the largest dictionary, even
-    size_t tcd_shmem = 0;
     if (tcd) {
         DevBuf<unsigned long long> stt(ctx, 4);
         if (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
@@ -2319,19 +2100,18 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
         tcd_lds_d = (int)((hst[0] + 1) & ~1ull);
         if (tcd_lds_d < 2) tcd_lds_d = 2;
-        tcd_shmem = sizeof(double) * ((size_t)tcd_lds_d + 7 * (size_t)tcd_R + (size_t)tcd_R + 1 + BLK) + sizeof(int32_t) * (size_t)tcd_R;
         info->tcd_tiles = tcd_tiles;
         info->tcd_dict_max = (int64_t)hst[0];
         info->tcd_dict_total = (int64_t)hst[2];
         info->tcd_tail_entries = (int64_t)hst[3];
         if (getenv("B3C_KR_DEBUG"))
-            fprintf(stderr, "[b3c] dictionary layout: %lld tiles of %d rows, largest dictionary %llu (cap %d), mean %.0f, %.1f %% of the entries in tails, %zu B of LDS\n",
-                    (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles, 100.0 * (double)hst[3] / (double)a->nnz, tcd_shmem);
+            fprintf(stderr, "[b3c] dictionary layout: %lld tiles of %d rows, largest dictionary %llu (cap %d), mean %.0f, %.1f %% of the entries in tails\n",
+                    (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles, 100.0 * (double)hst[3] / (double)a->nnz);
     }
     // ---- tails as their own pass (kr_kb_tails): column-ordered tail words per super-tile, fixed-point row sums ----
     // n < 2^24 (24-bit columns in a tail word), 512-thread dictionary kernel; automatic for n > 2^19.  Sharded path: every
     // rank has the tails of ITS rows (the operand vector and its maximum are complete on every rank after KA)
-    const bool tails_xt = tcd && xt_want && tcd_R <= TBK && getenv("B3C_KR_TCD_NOSPLIT") == nullptr && info->tcd_tail_entries > 0;
+    const bool tails_xt = tcd && xt_want && info->tcd_tail_entries > 0;
     int64_t n_tails = 0;                 // tails outside hub rows (counted below)
     const int64_t xt_super = (nloc + XT_S - 1) / XT_S;
     // two workgroups per super-tile fill the chip from ~110 super-tiles on (C3); a rank of the sharded path with fewer of them
@@ -2413,7 +2193,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     double *my_scal = dist ? D.scal + 4 * D.rank : nullptr;
     auto xchg = [&](int buf) -> int { return b3c_dist_exchange(ctx, buf); };
     const int cP = dist ? D.world : 0, cS = dist ? 4 : 1;      // consumer view of gathered partials
-    const bool tcd_split = tcd && tcd_R <= TBK && getenv("B3C_KR_TCD_NOSPLIT") == nullptr;
     const size_t tcd_shmem2 = sizeof(double) * ((size_t)tcd_lds_d + 2 * (size_t)tcd_R + (size_t)tcd_R + 1 + TBK) + sizeof(int32_t) * (size_t)tcd_R;
     if (tcd) {
         // dynamic LDS beyond 64 KB needs the attribute; set once per process to the device limit (the call is not cheap:
@@ -2424,23 +2203,11 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 #define KR_TCD2_ATTR(L, U, TL, T)                                                                                                             \
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX)); \
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
-            KR_TCD2_ATTR(16, 4, 8, 1); KR_TCD2_ATTR(16, 4, 16, 1); KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 8, 4, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
-            KR_TCD2_ATTR(16, 4, 4, 2); KR_TCD2_ATTR(16, 4, 4, 4); KR_TCD2_ATTR(16, 4, 2, 4);
-            KR_TCD2_ATTR(16, 8, 8, 2); KR_TCD2_ATTR(32, 2, 8, 2); KR_TCD2_ATTR(32, 4, 8, 2); KR_TCD2_ATTR(16, 2, 8, 2);
+            KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
 #undef KR_TCD2_ATTR
-#define KR_TCD_ATTR(L, U, T) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd<L, U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
-            KR_TCD_ATTR(16, 4, 2); KR_TCD_ATTR(8, 8, 2); KR_TCD_ATTR(8, 8, 1); KR_TCD_ATTR(32, 2, 1); KR_TCD_ATTR(16, 4, 1);
-            KR_TCD_ATTR(8, 4, 1); KR_TCD_ATTR(4, 4, 1); KR_TCD_ATTR(4, 2, 1);
-#undef KR_TCD_ATTR
             attr_done = true;
         }
     }
-#define KR_TCD(L, U, T)                                                                                                     \
-    hipLaunchKernelGGL((kr_kb_tcd<L, U, T>), dim3((unsigned)tcd_grid), dim3(BLK), tcd_shmem, s, r0, r1, n, tcd_R, tcd_lds_d,          \
-                       tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p,      \
-                       dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len,                       \
-                       getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu, \
-                       getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0)
     // The host looks at the state ONE BATCH BEHIND: the copy of batch b's final state is waited for after batch b + 1 has
     // been enqueued, so the device never idles on the read-back (ticks after convergence are no-ops: at most two batches of them).
     KRState *hstate = (KRState *)ctx->pin;               // two slots of the pinned staging buffer
@@ -2474,7 +2241,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             // KB consumes pk1 (from KA, G partials; first inner iteration only), produces pkb (GS partials)
             const double *kbp = dist ? D.scal : pk1.p;
             const int kbP = dist ? D.world : G, kbS = cS;
-            if (tcd && tcd_split) {
+            if (tcd) {
                 if (tails_xt)
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_chunks, n_tails,
                                        xt_off.p, r0, r1, xt_words.p, u.p, yhi.p, ylo.p, tex.p);
@@ -2490,35 +2257,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (tails_xt) hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, true>), KR_TCD2_ARGS);                                    \
         else hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, false>), KR_TCD2_ARGS);                                            \
     } while (0)
-                const int shp2 = getenv("B3C_KR_TCD_SHAPE2") ? atoi(getenv("B3C_KR_TCD_SHAPE2")) : 0;
-                if (shp2 == 16481) KR_TCD2(16, 4, 8, 1);
-                else if (shp2 == 164161) KR_TCD2(16, 4, 16, 1);
-                else if (shp2 == 16482) KR_TCD2(16, 4, 8, 2);
-                else if (shp2 == 8841) KR_TCD2(8, 8, 4, 2);
-                else if (shp2 == 16442) KR_TCD2(16, 4, 4, 2);
-                else if (shp2 == 16444) KR_TCD2(16, 4, 4, 4);
-                else if (shp2 == 16424) KR_TCD2(16, 4, 2, 4);
-                else if (shp2 == 8442) KR_TCD2(8, 4, 4, 2);
-                else if (shp2 == 16882) KR_TCD2(16, 8, 8, 2);
-                else if (shp2 == 32282) KR_TCD2(32, 2, 8, 2);
-                else if (shp2 == 32482) KR_TCD2(32, 4, 8, 2);
-                else if (shp2 == 16282) KR_TCD2(16, 2, 8, 2);
-                else if (avg > 128) KR_TCD2(16, 4, 8, 2);
+                if (avg > 128) KR_TCD2(16, 4, 8, 2);       // (tail shapes 8x1, 4x2, 4x4 within 5 % of this one at C3, 2x4 17 % slower)
                 else if (avg > 48) KR_TCD2(8, 4, 4, 2);
                 else KR_TCD2(4, 4, 4, 1);
 #undef KR_TCD2
-            } else if (tcd) {
-                // tiles with column dictionaries; shape by average row length (4 entries per lane and load)
-                const int shp = getenv("B3C_KR_TCD_SHAPE") ? atoi(getenv("B3C_KR_TCD_SHAPE")) : 0;   // LPR*100 + UN*10 + TU
-                if (shp == 1642) KR_TCD(16, 4, 2);
-                else if (shp == 882) KR_TCD(8, 8, 2);
-                else if (shp == 881) KR_TCD(8, 8, 1);
-                else if (shp == 3221) KR_TCD(32, 2, 1);
-                else if (shp == 1641) KR_TCD(16, 4, 1);
-                else if (avg > 128) KR_TCD(16, 4, 1);
-                else if (avg > 48) KR_TCD(8, 4, 1);
-                else if (avg > 20) KR_TCD(4, 4, 1);
-                else KR_TCD(4, 2, 1);
             } else {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
                 if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
