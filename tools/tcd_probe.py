@@ -8,7 +8,7 @@ import torch
 from bin3c_amd.pipeline import make_context
 from bin3c_amd.synth import CONFIGS, make_edges
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'C3'
-variants = sys.argv[2:] or ['B3C_KR_NO_TCD=1', '', 'B3C_KR_TCD_R=64', 'B3C_KR_TCD_R=256', 'B3C_KR_TCD_NOSWZ=1']
+variants = sys.argv[2:] or ['B3C_KR_NO_TCD=1', '', 'B3C_KR_TCD_XT=0', 'B3C_KR_TCD_R=128,B3C_KR_TCD_DCAP=4096', 'B3C_KR_TCD_NOSWZ=1']
 os.environ['B3C_KR_TCD'] = '1'
 n, E, seed, law = CONFIGS[cfg]
 ctx = make_context(0)
