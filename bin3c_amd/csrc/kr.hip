@@ -995,8 +995,9 @@ constexpr int TBK = 512;
 // accumulated per row in LDS in FIXED POINT with integer atomics -- a sum of integers does not depend on the order in
 // which lanes, waves or workgroups add, so the result is bit for bit reproducible.  Two accumulators per row: a 64-bit one
 // on a grid of 2^-E (E from the largest |operand| of this SpMV, the largest tail count and the longest tail, so that no row
-// can overflow) and a 32-bit one that takes what every product leaves below that grid, on a grid 2^20 times finer: the sum
-// is exact to 2^-(E+20), about 2^-70 of the largest term, i.e. more accurate than the fp64 sum it replaces.
+// can overflow) and a 32-bit one that takes what every product leaves below that grid, on a grid 2^20 times finer (fewer bits for
+// tails of more than 2048 entries, so that the 32-bit sums cannot overflow either): the sum is exact to 2^-(E+20), about
+// 2^-70 of the largest term, i.e. more accurate than the fp64 sum it replaces.
 // Stand-alone measurement (tools/probes/tails_probe.hip): 26 M gathers in row order 273 us, this way 100 us.
 // ---------------------------------------------------------------------------------------------
 constexpr int XT_S = 8192;           // rows per super-tile (13 bits of a tail word)
@@ -1074,7 +1075,7 @@ __device__ double reduce_max_n(const double *__restrict__ part, int P, double *l
 }
 
 __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__ sin, const double *__restrict__ pumax, int PU,
-                                                      int lg_bound, int chunks, int64_t n_tails, const int64_t *__restrict__ toff, int64_t r0, int64_t n,
+                                                      int lg_bound, int lo_bits, int chunks, int64_t n_tails, const int64_t *__restrict__ toff, int64_t r0, int64_t n,
                                                       const unsigned long long *__restrict__ words, const double *__restrict__ u,
                                                       unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex)
 {
@@ -1088,9 +1089,10 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
     int E = 0;
     const bool live = umax > 0.0 && umax < INFINITY;
     if (live) E = 61 - lg_bound - (ilogb(umax) + 1);            // count * |operand| * 2^E < 2^(61 - lg(longest tail))
-    if (blockIdx.x == 0 && threadIdx.x == 0) tex[0] = E;
+    if (E > 900) E = 900;                                       // (operands below 2^-860: keep 2^E finite)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { tex[0] = E; tex[1] = lo_bits; }
     if (!live) return;
-    const double scale = ldexp(1.0, E);
+    const double scale = ldexp(1.0, E), lo_scale = ldexp(1.0, lo_bits);
     const int stile = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     for (int i = threadIdx.x; i < XT_S; i += XT_NT) { acc[i] = 0; lo[i] = 0; }
     __syncthreads();
@@ -1110,7 +1112,7 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
             if (k0 + q * XT_NT < e0) {
                 const double ps = (g[q] * (double)(uint32_t)(w[q] & 0xFFFFu)) * scale;
                 const long long f = __double2ll_rn(ps);
-                const int l = __double2int_rn((ps - (double)f) * 1048576.0);
+                const int l = __double2int_rn((ps - (double)f) * lo_scale);       // |.| <= 2^(lo_bits - 1)
                 const uint32_t r = (uint32_t)(w[q] >> 16) & (XT_S - 1);
                 atomicAdd(&acc[r], (unsigned long long)f);
                 if (l) atomicAdd(&lo[r], l);
@@ -1200,7 +1202,8 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     }
     long long xt_h = 0;
     int xt_l = 0, xt_e = 0;
-    if (XT && tid < nrows) { xt_h = (long long)yhi[ra - r0 + tid]; xt_l = ylo[ra - r0 + tid]; xt_e = tex[0]; }
+    int xt_lb = 20;
+    if (XT && tid < nrows) { xt_h = (long long)yhi[ra - r0 + tid]; xt_l = ylo[ra - r0 + tid]; xt_e = tex[0]; xt_lb = tex[1]; }
     KRState st = *sin;
     if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_sum_n<TBK>(partA, PA, PS, lds);   // :160
     const bool inner = st.phase == A_INNER;
@@ -1395,7 +1398,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
         const double pi = inner ? ep : 0.0;
         double tails = 0.0;
         if (XT) {
-            tails = ldexp((double)xt_h, -xt_e) + ldexp((double)xt_l, -(xt_e + 20));
+            tails = ldexp((double)xt_h, -xt_e) + ldexp((double)xt_l, -(xt_e + xt_lb));
             if (xt_h) yhi[ra - r0 + tid] = 0ull;
             if (xt_l) ylo[ra - r0 + tid] = 0;
         } else {
@@ -2120,9 +2123,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                               ? XT_CHUNKS : (int)std::min<int64_t>(16, (ctx->n_cu + xt_super - 1) / xt_super);   // (3 at C3 costs 20 us per SpMV)
     DevBuf<double> pumax(ctx, tails_xt ? GA : 1);
     DevBuf<unsigned long long> yhi(ctx, tails_xt ? nloc : 1), xt_words(ctx, tails_xt ? info->tcd_tail_entries + 4 : 1);
-    DevBuf<int> ylo(ctx, tails_xt ? nloc : 1), tex(ctx, 1);
+    DevBuf<int> ylo(ctx, tails_xt ? nloc : 1), tex(ctx, 2);
     DevBuf<int64_t> xt_off(ctx, tails_xt ? nloc + 2 : 1);
-    int xt_lg_bound = 0;
+    int xt_lg_bound = 0, xt_lo_bits = 20;
     const size_t xt_shmem = sizeof(unsigned long long) * XT_S + sizeof(int) * XT_S + sizeof(double) * XT_NT;
     if (tails_xt) {
         DevBuf<int64_t> tcnt(ctx, nloc + 2);
@@ -2132,7 +2135,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         HIP_TRY(ctx, hipMemsetAsync(yhi.p, 0, sizeof(unsigned long long) * (size_t)nloc, s));
         HIP_TRY(ctx, hipMemsetAsync(ylo.p, 0, sizeof(int) * (size_t)nloc, s));
         HIP_TRY(ctx, hipMemsetAsync(xst.p, 0, sizeof(unsigned long long) * 2, s));
-        HIP_TRY(ctx, hipMemsetAsync(tex.p, 0, sizeof(int), s));
+        HIP_TRY(ctx, hipMemsetAsync(tex.p, 0, sizeof(int) * 2, s));
         hipLaunchKernelGGL(kr_tails_count, dim3((unsigned)((nloc + 256) / 256)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, n1v.p, tcnt.p);
         int rct;
         if ((rct = b3c_exclusive_scan_i64(ctx, tcnt.p, xt_off.p, nloc + 1))) return rct;
@@ -2148,6 +2151,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         while ((1ull << lgc) < hx[0] + 1) lgc++;
         while ((1ull << lgt) < hx[1] + 1) lgt++;
         xt_lg_bound = lgc + lgt;
+        // the 32-bit remainder sums: a tail of T terms of at most 2^(lo_bits - 1) each must stay below 2^31
+        xt_lo_bits = std::max(4, std::min(20, 31 - lgt));
         // column order inside every super-tile: sort on (super-tile, column) = bits [29, 53 + bits of the super-tile index)
         int st_bits = 1;
         while ((1ll << st_bits) < xt_super) st_bits++;
@@ -2243,7 +2248,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             const int kbP = dist ? D.world : G, kbS = cS;
             if (tcd) {
                 if (tails_xt)
-                    hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_chunks, n_tails,
+                    hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
                                        xt_off.p, r0, r1, xt_words.p, u.p, yhi.p, ylo.p, tex.p);
                 // dictionary waves and tail waves side by side (512-thread workgroups)
 #define KR_TCD2_ARGS                                                                                                         \

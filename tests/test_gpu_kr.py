@@ -133,6 +133,30 @@ def test_kr_locality_reordered_path_matches_oracle(ctx, oracle_lib, monkeypatch)
     np.testing.assert_allclose(xv, xc, rtol=1e-11)
 
 
+def test_tail_pass_with_long_tails(ctx, monkeypatch):
+    """Tail pass of the dictionary SpMV on a power-law map whose hub rows stay in the tiles (B3C_KR_NO_HUB): tails of
+    thousands of entries narrow the 32-bit remainder sums of the fixed-point accumulation; x must agree with the CSR
+    row kernels and repeat bit for bit."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(30000, 900000, 9, 'powerlaw')
+    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    assert int(np.diff(sm.indptr).max()) > 2048
+    monkeypatch.setenv('B3C_KR_NO_TCD', '1')
+    _, xv, iv = ctx.kr_balance_counts(cm, sm.sites)
+    monkeypatch.delenv('B3C_KR_NO_TCD')
+    monkeypatch.setenv('B3C_KR_TCD_XT', '1')
+    for hub in (False, True):
+        if not hub:
+            monkeypatch.setenv('B3C_KR_NO_HUB', '1')
+        else:
+            monkeypatch.delenv('B3C_KR_NO_HUB')
+        _, xt, it = ctx.kr_balance_counts(cm, sm.sites)
+        assert it.tcd_xt_tails > 0 and it.n_iter == iv.n_iter
+        np.testing.assert_allclose(xt, xv, rtol=1e-10)
+        _, xt2, _ = ctx.kr_balance_counts(cm, sm.sites)
+        assert np.array_equal(xt, xt2)
+
+
 def test_symmetry_guard_fast_and_exact_paths(ctx):
     """Checksum path (bitwise symmetric), exact path (asymmetric beyond tol, and within tol but not bitwise)."""
     g = np.load(os.path.join(GOLDEN, 'kr_random1000.npz'))
