@@ -27,7 +27,7 @@ class KRInfo(C.Structure):
                 ('hit_Delta', C.c_int64), ('rout', C.c_double), ('spmv_ms', C.c_double), ('n_spmv', C.c_int64),
                 ('bitwise_symmetric', C.c_int32), ('value_bits', C.c_int32),
                 ('tcd_tiles', C.c_int64), ('tcd_dict_max', C.c_int64), ('tcd_dict_total', C.c_int64),
-                ('tcd_tail_entries', C.c_int64), ('tcd_xt_tails', C.c_int64)]
+                ('tcd_tail_entries', C.c_int64), ('tcd_xt_tails', C.c_int64), ('big_counts', C.c_int64)]
 
 
 class LouvainInfo(C.Structure):

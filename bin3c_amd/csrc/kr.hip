@@ -388,7 +388,8 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
                                                    const double *__restrict__ dfix, const double *__restrict__ u,
                                                    const double *__restrict__ x, const double *__restrict__ p,
                                                    double *__restrict__ v, double *__restrict__ rk,
-                                                   double *__restrict__ w, double *__restrict__ part_out, int hub_len)
+                                                   double *__restrict__ w, double *__restrict__ part_out, int hub_len,
+                                                  const double *__restrict__ corr)
 {
     __shared__ double lds[BLK];
     KRState st = *sin;
@@ -478,7 +479,8 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
         if (sl == 0 && len >= 0) {
-            const double t = acc * ri + di;
+            // corr: what the 16-bit value copy leaves out of the few counts beyond 65535 (kr_big_fix), else nullptr
+            const double t = (corr ? acc + corr[row] : acc) * ri + di;
             if (inner) {
                 const double wi = xi * t + vi * pi;
                 w[row] = wi;
@@ -523,7 +525,8 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
                                                   const double *__restrict__ dfix, const double *__restrict__ u,
                                                   const double *__restrict__ x, const double *__restrict__ p,
                                                   double *__restrict__ v, double *__restrict__ rk,
-                                                  double *__restrict__ w, double *__restrict__ part_out, int hub_len)
+                                                  double *__restrict__ w, double *__restrict__ part_out, int hub_len,
+                                                  const double *__restrict__ corr)
 {
     __shared__ double lds[BLK];
     KRState st = *sin;
@@ -626,7 +629,8 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
         if (sl == 0 && len >= 0) {
-            const double t = acc * ri + di;
+            // corr: what the 16-bit value copy leaves out of the few counts beyond 65535 (kr_big_fix), else nullptr
+            const double t = (corr ? acc + corr[row] : acc) * ri + di;
             if (inner) {
                 const double wi = xi * t + vi * pi;
                 w[row] = wi;
@@ -988,6 +992,50 @@ constexpr int TBK = 512;
 
 // sum of P partials by NT threads, identical in every block and to every thread (fixed order)
 // ---------------------------------------------------------------------------------------------
+// A FEW counts beyond 65535 (hub-to-hub contacts of a power-law map) no longer push the whole map onto the 32-bit paths:
+// the 16-bit forms run on the low halves of all counts, and the high halves of the few large ones are a short sorted list
+// whose products kr_big_fix sums per row -- sequentially, in list order: deterministic -- into a correction vector that the
+// row kernels add to the row sum before their epilogue.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLK) kr_big_collect(int64_t r0, int64_t r1, const int64_t *__restrict__ indptr,
+                                                       const int32_t *__restrict__ indices, const uint32_t *__restrict__ a,
+                                                       int64_t cap, unsigned long long *__restrict__ keys, uint32_t *__restrict__ hi,
+                                                       unsigned long long *__restrict__ count)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
+    for (int64_t row = r0 + wave; row < r1; row += nwave) {
+        const int64_t s = indptr[row], e = indptr[row + 1];
+        for (int64_t k = s + lane; k < e; k += 64) {
+            const uint32_t c = a[k];
+            if (c > 0xFFFFu) {
+                const unsigned long long at = atomicAdd(count, 1ull);
+                if ((int64_t)at < cap) {
+                    keys[at] = ((unsigned long long)row << 32) | (uint32_t)indices[k];
+                    hi[at] = c >> 16;
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) kr_big_fix(const KRState *__restrict__ sin, int64_t nbig, const unsigned long long *__restrict__ keys,
+                                                   const uint32_t *__restrict__ hi, const double *__restrict__ u, double *__restrict__ corr)
+{
+    const int32_t phase = sin->phase;
+    if (phase != A_INNER && phase != A_OUTER) return;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nbig) return;
+    const unsigned long long row = keys[t] >> 32;
+    if (t > 0 && (keys[t - 1] >> 32) == row) return;        // the first entry of a row sums the whole row
+    double sum = 0.0;
+    for (int64_t k = t; k < nbig && (keys[k] >> 32) == row; k++)
+        sum += (double)((unsigned long long)hi[k] << 16) * u[(uint32_t)(keys[k] & 0xFFFFFFFFull)];
+    corr[row] = sum;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tails as their own pass (B3C_KR_TCD_XT).  What bounds the row kernels at C3 is the number of L1 misses, and three
 // quarters of them are the tails: ~26 M gathers of single-occurrence columns (the inter-genome noise), each pulling its own
 // 128-byte line.  Here the tails of a SUPER-TILE of S = 8192 rows are kept in COLUMN order (one radix sort at set-up), so
@@ -1166,7 +1214,8 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                                                    double *__restrict__ rk, double *__restrict__ w,
                                                    double *__restrict__ part_out, int hub_len, int probe, uint32_t probe_mask,
                                                    unsigned long long *__restrict__ tlog,
-                                                   unsigned long long *__restrict__ yhi, int *__restrict__ ylo, const int *__restrict__ tex)
+                                                   unsigned long long *__restrict__ yhi, int *__restrict__ ylo, const int *__restrict__ tex,
+                                                   const double *__restrict__ corr)
 {
     // XT: the tails are summed by kr_kb_tails beforehand (fixed point in yhi / ylo, exponent tex[0]); all eight waves run
     // dictionary rows here and the epilogue converts the row's tail sum and clears it for the next SpMV
@@ -1404,6 +1453,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
         } else {
             tails = ot[tid];
         }
+        if (corr) tails += corr[ra + tid];                 // the part of counts beyond 65535 the packed words leave out
         const double t = (od[tid] + tails) * er + ed * (inner ? ex * pi : ex);
         if (inner) {
             const double wi = ex * t + ev * pi;
@@ -1857,36 +1907,38 @@ __global__ void kr_site_scale(int64_t n, double *__restrict__ sites, double *__r
 template <int LPR, int UN>
 void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
                     int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
-                    const double *x, const double *p, double *v, double *rk, double *w, double *part_out, int hub_len)
+                    const double *x, const double *p, double *v, double *rk, double *w, double *part_out, int hub_len,
+                    const double *corr = nullptr)
 {
     if (m->kind == B3C_U32 && getenv("B3C_KR_NOGATHER"))   // wrong results by design: the kernel without its random gathers
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t, true>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
+                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
     else if (m->kind == B3C_U32 && v16)
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint16_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
+                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
     else if (m->kind == B3C_U32)
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
+                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
     else
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, double>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
+                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
 }
 
 template <int LPR, int UN>
 void launch_kb_vec(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
                    int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
-                   const double *x, const double *p, double *v, double *rk, double *w, double *part_out, int hub_len)
+                   const double *x, const double *p, double *v, double *rk, double *w, double *part_out, int hub_len,
+                    const double *corr = nullptr)
 {
     if (m->kind == B3C_U32 && v16)
         hipLaunchKernelGGL((kr_kb_vec<LPR, UN, uint16_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
+                           m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
     else if (m->kind == B3C_U32)
         hipLaunchKernelGGL((kr_kb_vec<LPR, UN, uint32_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
+                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
     else
         hipLaunchKernelGGL((kr_kb_vec<LPR, UN, double>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len);
+                           m->indices, (const double *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
 }
 
 }  // namespace
@@ -2067,8 +2119,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     }
     // count form: 16-bit copy of the values when they all fit (built on the matrix the iteration runs on)
     const uint16_t *v16 = nullptr;
+    unsigned long long vmax_counts = 0;
     if (fused_prep) {
-        if (prep_max <= 0xFFFFull) v16 = v16buf.p;               // written by kr_prep_counts
+        vmax_counts = prep_max;
+        v16 = v16buf.p;                                          // written by kr_prep_counts (low halves), kept if usable below
     } else if (want16) {
         DevBuf<unsigned int> mx(ctx, 1);
         if (!mx.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts");
@@ -2077,11 +2131,47 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         hipLaunchKernelGGL(kr_max_u32, dim3(gq), dim3(256), 0, s, a->nnz, (const uint32_t *)a->data, mx.p);
         unsigned int hmx = 0;
         { const int rb_ = b3c_readback(ctx, &hmx, mx.p, sizeof(hmx)); if (rb_) return rb_; }
-        if (hmx <= 0xFFFFu) {
-            hipLaunchKernelGGL(kr_narrow_u16, dim3(gq), dim3(256), 0, s, a->nnz, (const uint32_t *)a->data, v16buf.p);
-            v16 = v16buf.p;
+        vmax_counts = hmx;
+        hipLaunchKernelGGL(kr_narrow_u16, dim3(gq), dim3(256), 0, s, a->nnz, (const uint32_t *)a->data, v16buf.p);
+        v16 = v16buf.p;
+    }
+    // counts beyond 16 bits: a short list of them (at most BIG_CAP and 1/64 of the entries) keeps the 16-bit forms usable
+    constexpr int64_t BIG_CAP = (int64_t)1 << 22;
+    int64_t n_big = 0;
+    DevBuf<unsigned long long> big_keys(ctx, v16 && vmax_counts > 0xFFFFull ? BIG_CAP : 1), big_keys2(ctx, v16 && vmax_counts > 0xFFFFull ? BIG_CAP : 1);
+    DevBuf<uint32_t> big_hi(ctx, v16 && vmax_counts > 0xFFFFull ? BIG_CAP : 1), big_hi2(ctx, v16 && vmax_counts > 0xFFFFull ? BIG_CAP : 1);
+    DevBuf<double> corr(ctx, v16 && vmax_counts > 0xFFFFull ? n : 1);
+    const double *corr_p = nullptr;
+    const unsigned long long *bk = nullptr;
+    const uint32_t *bh = nullptr;
+    if (v16 && vmax_counts > 0xFFFFull) {
+        DevBuf<unsigned long long> bc(ctx, 1);
+        if (!big_keys.p || !big_keys2.p || !big_hi.p || !big_hi2.p || !corr.p || !bc.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts: large counts");
+        HIP_TRY(ctx, hipMemsetAsync(bc.p, 0, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(kr_big_collect, dim3(grid_for(nloc, BLK / 64, 16 * ctx->n_cu)), dim3(BLK), 0, s, r0, r1, a->indptr, a->indices,
+                           (const uint32_t *)a->data, BIG_CAP, big_keys.p, big_hi.p, bc.p);
+        unsigned long long hb = 0;
+        { const int rb_ = b3c_readback(ctx, &hb, bc.p, sizeof(hb)); if (rb_) return rb_; }
+        if ((int64_t)hb <= BIG_CAP && (int64_t)hb * 64 <= a->nnz && getenv("B3C_KR_NO_BIGFIX") == nullptr) {
+            n_big = (int64_t)hb;
+            size_t tb = 0;
+            hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, big_keys.p, big_keys2.p, big_hi.p, big_hi2.p, n_big, 0, 64, s);
+            if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort sizing failed");
+            DevBuf<char> tmp(ctx, tb);
+            if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts: sort workspace");
+            e = hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, big_keys.p, big_keys2.p, big_hi.p, big_hi2.p, n_big, 0, 64, s);
+            if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort of the large counts failed");
+            HIP_TRY(ctx, hipMemsetAsync(corr.p, 0, sizeof(double) * (size_t)n, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            corr_p = corr.p;
+            bk = big_keys2.p;
+            bh = big_hi2.p;
+            if (getenv("B3C_KR_DEBUG")) fprintf(stderr, "[b3c] %lld counts beyond 65535 (largest %llu): 16-bit forms + correction list\n", (long long)n_big, vmax_counts);
+        } else {
+            v16 = nullptr;                                       // too many: 32-bit values in the row kernels
         }
     }
+    info->big_counts = n_big;
     // ---- tile-local column dictionaries (16-bit counts only) ----
     const bool tcd = tcd_may && v16 != nullptr;
     const bool want_tlog = tcd && getenv("B3C_KR_TCD_TLOG") != nullptr;
@@ -2243,6 +2333,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                 ev_tick.push_back(ticks);
                 HIP_TRY(ctx, hipEventRecord(e0, s));
             }
+            if (n_big) hipLaunchKernelGGL(kr_big_fix, dim3((unsigned)((n_big + 255) / 256)), dim3(256), 0, s, s0, n_big, bk, bh, u.p, corr.p);
             // KB consumes pk1 (from KA, G partials; first inner iteration only), produces pkb (GS partials)
             const double *kbp = dist ? D.scal : pk1.p;
             const int kbP = dist ? D.world : G, kbS = cS;
@@ -2256,7 +2347,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len,     \
         getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0,                                                                   \
         getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu,                     \
-        want_tlog ? tlog.p : nullptr, tails_xt ? yhi.p : nullptr, tails_xt ? ylo.p : nullptr, tails_xt ? tex.p : nullptr
+        want_tlog ? tlog.p : nullptr, tails_xt ? yhi.p : nullptr, tails_xt ? ylo.p : nullptr, tails_xt ? tex.p : nullptr, corr_p
 #define KR_TCD2(L, U, TL, T)                                                                                                 \
     do {                                                                                                                     \
         if (tails_xt) hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, true>), KR_TCD2_ARGS);                                    \
@@ -2268,17 +2359,17 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 #undef KR_TCD2
             } else {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
-                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
-                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
+                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
+                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
                 else if (avg > 128 && a->kind == B3C_U32 && vec_shape >= 0)    // 4 entries per lane and load: 0.505 vs 0.544 ms at C3
-                    launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
-                else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
-                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
-                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
-                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len);
+                    launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
+                else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
+                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
+                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
+                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
             }
             if (n_hub) {       // the rows the row-group kernel left out; same state slot, partials behind its GS
-                if (a->kind == B3C_U32 && v16)
+                if (a->kind == B3C_U32 && v16 && !n_big)           // (hub rows read the full 32-bit counts when some are large)
                     hipLaunchKernelGGL(kr_kb_hub<uint16_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices, v16,
                                        rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p + GS);
                 else if (a->kind == B3C_U32)

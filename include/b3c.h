@@ -58,6 +58,8 @@ typedef struct {
     int64_t tcd_tiles, tcd_dict_max, tcd_dict_total, tcd_tail_entries;
     /* tails summed by their own pass (kr_kb_tails, maps beyond 2^19 contigs on one GPU); 0: by the row kernel */
     int64_t tcd_xt_tails;
+    /* counts beyond 65535 handled by the correction list beside the 16-bit forms (0: none, or too many: 32-bit values) */
+    int64_t big_counts;
 } b3c_kr_info;
 
 typedef struct {

@@ -157,6 +157,42 @@ def test_tail_pass_with_long_tails(ctx, monkeypatch):
         assert np.array_equal(xt, xt2)
 
 
+@pytest.mark.parametrize('n,e,env', [(6000, 150000, {}), (6000, 150000, {'B3C_KR_TCD_XT': '1'}), (6000, 150000, {'B3C_KR_NO_TCD': '1'}),
+                                     (40000, 1300000, {}), (3000, 20000, {})])
+def test_a_few_counts_beyond_16_bits_keep_the_16_bit_forms(ctx, oracle_lib, monkeypatch, n, e, env):
+    """Hub-to-hub contacts of a power-law map exceed 65535; the map must still run on the 16-bit SpMV forms (dictionary tiles,
+    tail pass, 16-bit CSR values) with the high halves of those few counts in a correction list, and agree with the oracle."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(n, e, 31)
+    counts = sm.counts.copy()
+    rows = np.repeat(np.arange(sm.n), np.diff(sm.indptr))
+    rs = np.random.RandomState(3)
+    up = np.flatnonzero(rows < sm.indices)
+    pick = rs.choice(up, 40, replace=False)
+    big = rs.choice([70000, 65536, 200000, 5000000, 4000000000], pick.shape[0]).astype(np.uint32)
+    a = sp.csr_matrix((counts, sm.indices, sm.indptr), shape=(sm.n, sm.n)).tolil()
+    for k, v in zip(pick.tolist(), big.tolist()):
+        i, j = int(rows[k]), int(sm.indices[k])
+        a[i, j] = v
+        a[j, i] = v
+    a = a.tocsr()
+    a.sort_indices()
+    ip, ix, cnt = a.indptr.astype(np.int64), a.indices.astype(np.int32), a.data.astype(np.uint32)
+    nd = oracle_lib.site_norm(ip, ix, cnt.astype(np.float64), sm.sites)
+    rc, xo, st = oracle_lib.kr_balance(ip, ix, nd)
+    assert rc == oracle_lib.OK
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cm = ctx.upload(ip, ix, cnt)
+    _, x, info = ctx.kr_balance_counts(cm, sm.sites)
+    assert info.n_iter == st.n_iter
+    assert info.value_bits == 16 and info.big_counts == 80, (info.value_bits, info.big_counts)
+    np.testing.assert_allclose(x, xo, rtol=1e-9)
+    _, x2, _ = ctx.kr_balance_counts(cm, sm.sites)
+    assert np.array_equal(x, x2)
+    cm.free()
+
+
 def test_symmetry_guard_fast_and_exact_paths(ctx):
     """Checksum path (bitwise symmetric), exact path (asymmetric beyond tol, and within tol but not bitwise)."""
     g = np.load(os.path.join(GOLDEN, 'kr_random1000.npz'))
