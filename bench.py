@@ -6,7 +6,7 @@ One "step" = one pass of the cluster hot path over one synthetic contact map tha
 resident in HBM: acceptance mask -> site normalisation -> Knight-Ruiz balancing -> X A X ->
 mask compaction -> weight scaling -> Louvain labels on the host (bin3c_amd/pipeline.py).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3|C5]
 
 N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  `--mode`:
   sharded   contig-row blocks of ONE map over all GPUs (BASELINE.json configs[3]; strong scaling; bin3c_amd/dist.py:
@@ -111,7 +111,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--config', default='C3', choices=['C1', 'C2', 'C3'])
+    ap.add_argument('--config', default='C3', choices=['C1', 'C2', 'C3', 'C5'],
+                    help="C5: 5M contigs / 1e9 edge draws, power law (BASELINE.json's largest map; fits ONE GPU; no CPU baseline)")
+    ap.add_argument('--max-iter', type=int, default=None,
+                    help='KR iteration limit (the reference default 1000; C5 defaults to 5000: its heavy-tailed degrees need ~2450)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline', default='same', choices=['same', 'sample'],
                     help="'same': the oracle on the very map the GPU ran (about two minutes at C3); 'sample': on a bounded "
@@ -143,6 +146,9 @@ def main():
     from bin3c_amd.synth import CONFIGS, make_edges
 
     n, n_edges, seed, law = CONFIGS[args.config]
+    max_iter = args.max_iter if args.max_iter else (5000 if args.config == 'C5' else 1000)
+    if args.config == 'C5':
+        args.no_cpu_baseline = True          # the oracle would need hours on this map
     ctx = make_context(local_rank, pin=True)       # one process per GPU: stay on the CPUs of its NUMA node
     # pair stream drawn on the host (numpy RandomState, deterministic), accumulated into the symmetric count matrix on
     # the device (b3c_coo_symmetrise: the ingest tail, bit-identical to synth.symmetrise_to_csr).  Every rank builds
@@ -167,13 +173,13 @@ def main():
         acc = {'stage': {}, 'spmv_ms': 0.0, 'spmv_n': 0, 'move_ms': 0.0, 'move_n': 0, 'move_nnz': 0, 'move_rows': 0}
         last = None
         for _ in range(args.warmup):
-            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig)
+            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, max_iter=max_iter)
         gc.collect()
         gc.disable()            # a generation-2 collection in the middle of a step shows up as a 20 ms hole in the GPU timeline
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig)
+            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, max_iter=max_iter)
             for k, v in last.timings.items():
                 acc['stage'][k] = acc['stage'].get(k, 0.0) + v
             acc['spmv_ms'] += last.kr_info.spmv_ms
