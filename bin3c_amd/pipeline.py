@@ -225,26 +225,62 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
             res.processed                      # the caller owns `counts` and may free it: materialise now
             res._lazy = None
 
+        # mask, signal and x are final here: their way back to the host (gather into the caller's numbering, copy into
+        # pinned memory) runs on a side stream while the cluster stage keeps libb3c's stream busy; only the labels are
+        # left for the end
+        early = _start_download(ctx, o2n, mask_w, signal_w, x_w) if cluster else None
+
         labels_t = None
         if cluster:
             labels_t = _cluster_stage(ctx, res, mask_w, n_sub)
 
         # results to the host, in the caller's numbering
         t0 = time.perf_counter()
-        if o2n is not None:
-            back = o2n.long()
-            mask_w, x_w = mask_w[back], x_w[back]
-            signal_w = signal_w[back] if signal_w is not None else None
-        res.mask = mask_w.cpu().numpy().astype(bool)
-        if signal_w is not None:
-            res.signal = signal_w.cpu().numpy().view(np.uint32)
-        res.x = x_w.cpu().numpy()
+        if early is None:
+            early = _start_download(ctx, o2n, mask_w, signal_w, x_w)
+        h_labels = None
         if labels_t is not None:
-            res.labels = labels_t.cpu().numpy()
+            h_labels = torch.empty(labels_t.shape, dtype=labels_t.dtype, pin_memory=True)
+            h_labels.copy_(labels_t, non_blocking=True)
+        h_mask, h_signal, h_x, dl = early
+        dl.synchronize()
+        torch.cuda.current_stream().synchronize()
+        res.mask = h_mask.numpy().astype(bool)
+        if h_signal is not None:
+            res.signal = h_signal.numpy().view(np.uint32)
+        res.x = h_x.numpy()
+        if h_labels is not None:
+            res.labels = h_labels.numpy()
         t['download'] = time.perf_counter() - t0
     if not keep:
         res.free()
     return res
+
+
+def _start_download(ctx, o2n, mask_w, signal_w, x_w):
+    """Enqueue, on the context's side stream, the per-contig results' way to the host: back to the caller's numbering, then
+    asynchronous copies into pinned host tensors (torch caches pinned blocks, so a warm step allocates nothing).
+    -> (mask, signal | None, x, stream): host tensors valid once the stream is synchronised."""
+    import torch
+    dl = getattr(ctx, '_dl_stream', None)
+    if dl is None:
+        dl = ctx._dl_stream = torch.cuda.Stream(device=ctx.device)
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream())
+    with torch.cuda.stream(dl):
+        dl.wait_event(ready)
+        back = o2n.long() if o2n is not None else None
+        outs = []
+        for src in (mask_w, signal_w, x_w):
+            if src is None:
+                outs.append(None)
+                continue
+            src.record_stream(dl)
+            d = src[back] if back is not None else src
+            h = torch.empty(d.shape, dtype=d.dtype, pin_memory=True)
+            h.copy_(d, non_blocking=True)
+            outs.append(h)
+    return outs[0], outs[1], outs[2], dl
 
 
 def _cluster_stage(ctx, res, mask_w, n_sub=0):
