@@ -17,8 +17,8 @@ def _free_port():
     return p
 
 
-def _launch(mode, timeout):
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+def _launch(mode, timeout, world=2):
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dist_worker.py'), mode]
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1')
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
@@ -36,6 +36,13 @@ def test_sharding_host_logic_two_ranks_cpu():
 def test_sharded_hot_path_two_ranks_one_gpu():
     text = _launch('gpu', 900)
     assert 'rank 0 gpu ok' in text and 'rank 1 gpu ok' in text
+
+
+@pytest.mark.gpu
+def test_sharded_hot_path_three_ranks_one_gpu():
+    """An odd number of ranks: row blocks of unequal size, the last one ragged (gloo, all ranks on cuda:0)."""
+    text = _launch('gpu', 1200, world=3)
+    assert all('rank %d gpu ok' % r in text for r in range(3))
 
 
 def _bench_two_ranks(mode, expect_failure=False, **extra_env):
