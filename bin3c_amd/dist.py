@@ -119,6 +119,7 @@ class DistSession(object):
                     self.comm.value if self.comm else None, C.cast(self._cb2, C.c_void_p))
         self._struct = d
         ctx._check(lib.b3c_ctx_set_dist(ctx.h, C.byref(d)))
+        torch.cuda.synchronize(dev)                       # the buffers were zero-filled on torch's stream, libb3c writes them on its own
         ctx.dist_session = self                           # pipeline.run_hot_path shards the map over the ranks when set
 
     @property
