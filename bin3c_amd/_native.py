@@ -37,6 +37,33 @@ class LouvainInfo(C.Structure):
                 ('move_rows', C.c_int64)]
 
 
+class B3CDist(C.Structure):
+    _fields_ = [('rank', C.c_int32), ('world', C.c_int32), ('chunk', C.c_int64), ('vec', C.c_void_p),
+                ('scal', C.c_void_p), ('labels', C.c_void_p), ('isum', C.c_void_p), ('allgather', C.c_void_p),
+                ('user', C.c_void_p), ('comm', C.c_void_p), ('allreduce', C.c_void_p)]
+
+
+# structs that cross the ABI, by the `which` of b3c_abi_layout
+ABI_STRUCTS = {0: KRInfo, 1: LouvainInfo, 2: B3CDist}
+
+
+def struct_layout(cls):
+    """[sizeof, n_fields, offset of every field in declaration order] -- the form b3c_abi_layout reports"""
+    return [C.sizeof(cls), len(cls._fields_)] + [getattr(cls, f[0]).offset for f in cls._fields_]
+
+
+def check_abi(lib):
+    """The library's compiled struct layouts against this module's ctypes definitions; a mismatch would let the library
+    write past a ctypes object, so it is an ImportError, not a warning."""
+    for which, cls in ABI_STRUCTS.items():
+        buf = (C.c_int32 * 64)()
+        k = lib.b3c_abi_layout(which, buf, 64)
+        got = list(buf[:max(k, 0)])
+        if got != struct_layout(cls):
+            raise ImportError('libb3c.so and bin3c_amd/_native.py disagree on the layout of {}: library {} vs binding {} '
+                              '(rebuild the library, or update the binding from include/b3c.h)'.format(cls.__name__, got, struct_layout(cls)))
+
+
 # every symbol include/b3c.h declares: (name, restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = [
@@ -76,6 +103,7 @@ SYMBOLS = [
     ('b3c_mat_permute', C.c_int, [_VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
     ('b3c_mat_ids', C.c_int, [_VP, _VP, _VP]),
     ('b3c_version', C.c_char_p, []),
+    ('b3c_abi_layout', C.c_int, [C.c_int, C.POINTER(C.c_int32), C.c_int]),
 ]
 
 _lib = None
@@ -100,6 +128,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        check_abi(lib)
         if os.environ.get('B3C_TRACE'):
             lib = _Traced(lib)
         _lib = lib

@@ -3,7 +3,38 @@
 
 #include <cstdlib>
 
+#include <cstddef>
+
 extern "C" const char *b3c_version(void) { return "b3c 0.1 (gfx950)"; }
+
+extern "C" int b3c_abi_layout(int which, int32_t *out, int cap)
+{
+#define F(T, f) (int32_t)offsetof(T, f)
+    static const int32_t kr[] = {(int32_t)sizeof(b3c_kr_info), 0,
+                                 F(b3c_kr_info, n_iter), F(b3c_kr_info, n_outer), F(b3c_kr_info, n_zero_diag),
+                                 F(b3c_kr_info, is_symmetric), F(b3c_kr_info, hit_max_iter), F(b3c_kr_info, hit_delta),
+                                 F(b3c_kr_info, hit_Delta), F(b3c_kr_info, rout), F(b3c_kr_info, spmv_ms), F(b3c_kr_info, n_spmv),
+                                 F(b3c_kr_info, bitwise_symmetric), F(b3c_kr_info, value_bits), F(b3c_kr_info, tcd_tiles),
+                                 F(b3c_kr_info, tcd_dict_max), F(b3c_kr_info, tcd_dict_total), F(b3c_kr_info, tcd_tail_entries),
+                                 F(b3c_kr_info, tcd_xt_tails), F(b3c_kr_info, big_counts)};
+    static const int32_t lv[] = {(int32_t)sizeof(b3c_louvain_info), 0,
+                                 F(b3c_louvain_info, n_comm), F(b3c_louvain_info, n_levels), F(b3c_louvain_info, n_sweeps),
+                                 F(b3c_louvain_info, n_moves), F(b3c_louvain_info, quant_shift), F(b3c_louvain_info, reserved),
+                                 F(b3c_louvain_info, modularity), F(b3c_louvain_info, move_ms), F(b3c_louvain_info, n_move_launch),
+                                 F(b3c_louvain_info, move_nnz), F(b3c_louvain_info, move_rows)};
+    static const int32_t ds[] = {(int32_t)sizeof(b3c_dist), 0,
+                                 F(b3c_dist, rank), F(b3c_dist, world), F(b3c_dist, chunk), F(b3c_dist, vec), F(b3c_dist, scal),
+                                 F(b3c_dist, labels), F(b3c_dist, isum), F(b3c_dist, allgather), F(b3c_dist, user),
+                                 F(b3c_dist, comm), F(b3c_dist, allreduce)};
+#undef F
+    const int32_t *src = which == B3C_ABI_KR_INFO ? kr : which == B3C_ABI_LOUVAIN_INFO ? lv : which == B3C_ABI_DIST ? ds : nullptr;
+    const int len = which == B3C_ABI_KR_INFO ? (int)(sizeof(kr) / 4) : which == B3C_ABI_LOUVAIN_INFO ? (int)(sizeof(lv) / 4)
+                                                                                                   : (int)(sizeof(ds) / 4);
+    if (!src || !out || cap < len) return B3C_E_ARG;
+    for (int i = 0; i < len; i++) out[i] = src[i];
+    out[1] = len - 2;
+    return len;
+}
 
 extern "C" int b3c_ctx_create(int device, void *stream, b3c_ctx **out)
 {

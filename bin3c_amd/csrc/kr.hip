@@ -150,6 +150,41 @@ __device__ void reduce_partials3(const double *__restrict__ pmin, const double *
     __syncthreads();
 }
 
+// What a SpMV kernel needs of the control state: whether this tick forms a product at all and which epilogue follows.
+// The fields are read with uniform loads (no per-lane copy of the 128-byte state: round 2's `KRState st = *sin` sat in
+// 88 bytes of scratch per lane, 214 MB of stores per launch at C3); only block 0 / thread 0 carries the state forward.
+// RED(partials, P, stride, lds) is the kernel's block-wide sum, identical in every block.
+struct KBMode { bool run, inner; };
+template <class RED>
+__device__ __forceinline__ KBMode kb_enter(const KRState *__restrict__ sin, KRState *__restrict__ sout,
+                                           const double *__restrict__ partA, int PA, int PS, double *lds, RED red)
+{
+    const int32_t phase = sin->phase, next = sin->next;
+    const long long k = sin->k, n_outer = sin->n_outer, n_iter = sin->n_iter;
+    const bool first = phase == A_INNER && k == 1;
+    double rho = 0.0;
+    if (first) rho = red(partA, PA, PS, lds);                                        // :160
+    int32_t np = phase;
+    if (phase == A_INNER) np = B_INNER;
+    else if (phase == A_OUTER) np = (n_outer == 0 && n_iter == 0 && next == P_INIT) ? B_INIT : B_OUTER;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        static_assert(sizeof(KRState) == 128, "KRState is copied as eight 16-byte words");
+        const uint4 *__restrict__ a = (const uint4 *)sin;
+        uint4 *__restrict__ b = (uint4 *)sout;
+        uint4 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) t[q] = a[q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) b[q] = t[q];
+        if (first) sout->rho_km1 = rho;
+        sout->phase = np;
+    }
+    KBMode m;
+    m.inner = phase == A_INNER;
+    m.run = np == B_INNER || np == B_OUTER || np == B_INIT;
+    return m;
+}
+
 constexpr int KV_E = 4;      // elements per thread and pass of the vector kernels (requested before the control state is known)
 
 // ---------------------------------------------------------------------------------------------
@@ -392,13 +427,10 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
                                                   const double *__restrict__ corr)
 {
     __shared__ double lds[BLK];
-    KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
-    const bool inner = st.phase == A_INNER;
-    if (st.phase == A_INNER) st.phase = B_INNER;
-    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) return;   // no SpMV in this tick (done, or a bound cut pending)
+    const KBMode md = kb_enter(sin, sout, partA, PA, PS, lds,
+                               [](const double *pp, int P, int S, double *l) { return reduce_partials<0>(pp, P, S, l); });
+    const bool inner = md.inner;
+    if (!md.run) return;                        // no SpMV in this tick (done, or a bound cut pending)
 
     constexpr int RPW = 64 / LPR;
     constexpr int CH = LPR * UN;
@@ -529,13 +561,10 @@ __global__ void __launch_bounds__(BLK) kr_kb_vec(int64_t r0, int64_t n, const KR
                                                   const double *__restrict__ corr)
 {
     __shared__ double lds[BLK];
-    KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_partials<0>(partA, PA, PS, lds);  // :160
-    const bool inner = st.phase == A_INNER;
-    if (st.phase == A_INNER) st.phase = B_INNER;
-    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if (st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) return;   // no SpMV in this tick (done, or a bound cut pending)
+    const KBMode md = kb_enter(sin, sout, partA, PA, PS, lds,
+                               [](const double *pp, int P, int S, double *l) { return reduce_partials<0>(pp, P, S, l); });
+    const bool inner = md.inner;
+    if (!md.run) return;                        // no SpMV in this tick (done, or a bound cut pending)
 
     constexpr int RPW = 64 / LPR;
     constexpr int CH = LPR * UN * 4;
@@ -1131,8 +1160,8 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
     unsigned long long *acc = xt_lds;                 // XT_S 64-bit sums
     int *lo = (int *)(acc + XT_S);                    // XT_S 32-bit sums of the remainders
     double *red = (double *)(lo + XT_S);              // XT_NT doubles
-    const KRState st = *sin;
-    if (st.phase != A_INNER && st.phase != A_OUTER) return;     // no SpMV in this tick (the row kernel decides the same way)
+    const int32_t phase = sin->phase;
+    if (phase != A_INNER && phase != A_OUTER) return;           // no SpMV in this tick (the row kernel decides the same way)
     const double umax = reduce_max_n<XT_NT>(pumax, PU, red);
     int E = 0;
     const bool live = umax > 0.0 && umax < INFINITY;
@@ -1253,13 +1282,10 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     int xt_l = 0, xt_e = 0;
     int xt_lb = 20;
     if (XT && tid < nrows) { xt_h = (long long)yhi[ra - r0 + tid]; xt_l = ylo[ra - r0 + tid]; xt_e = tex[0]; xt_lb = tex[1]; }
-    KRState st = *sin;
-    if (st.phase == A_INNER && st.k == 1) st.rho_km1 = reduce_sum_n<TBK>(partA, PA, PS, lds);   // :160
-    const bool inner = st.phase == A_INNER;
-    if (st.phase == A_INNER) st.phase = B_INNER;
-    else if (st.phase == A_OUTER) st.phase = (st.n_outer == 0 && st.n_iter == 0 && st.next == P_INIT) ? B_INIT : B_OUTER;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    if ((st.phase != B_INNER && st.phase != B_OUTER && st.phase != B_INIT) || !live) return;   // no SpMV in this tick
+    const KBMode md = kb_enter(sin, sout, partA, PA, PS, lds,
+                               [](const double *pp, int P, int S, double *l) { return reduce_sum_n<TBK>(pp, P, S, l); });
+    const bool inner = md.inner;
+    if (!md.run || !live) return;             // no SpMV in this tick
     const long long tl1 = tlog ? wall_clock64() : 0;
     {
         const int32_t *__restrict__ dc1 = dict_cols + (live ? tile : 0) * (int64_t)dstride;

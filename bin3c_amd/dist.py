@@ -1,7 +1,8 @@
 """
-Row-sharded multi-GPU execution of the hot path: one process per GPU (launched by torch.distributed.run), every rank
-holds the whole locality-ordered map and works on the contig-row range [rank*chunk, (rank+1)*chunk)
-(include/b3c.h "multi-GPU").
+Row-sharded multi-GPU execution of the hot path: one process per GPU (launched by torch.distributed.run).  Every rank
+holds the raw count map (the input); from the permutation on it forms and works on its ROW BLOCK
+[rank*chunk, (rank+1)*chunk) of the locality-ordered map only (b3c_mat_permute_rows; include/b3c.h "multi-GPU",
+DESIGN.md section 6).
 
 Transport.  On real multi-GPU runs (torch.distributed backend "nccl") the session creates an RCCL communicator INSIDE
 libb3c (b3c_dist_comm_create; the 128-byte unique id travels over torch.distributed once) and libb3c then issues every
@@ -30,10 +31,7 @@ from . import _native
 BUF_VEC, BUF_SCAL, BUF_LABELS, BUF_ISUM, BUF_SCAL_VEC = 0, 1, 2, 3, 4
 
 
-class B3CDist(C.Structure):
-    _fields_ = [('rank', C.c_int32), ('world', C.c_int32), ('chunk', C.c_int64), ('vec', C.c_void_p),
-                ('scal', C.c_void_p), ('labels', C.c_void_p), ('isum', C.c_void_p), ('allgather', C.c_void_p),
-                ('user', C.c_void_p), ('comm', C.c_void_p), ('allreduce', C.c_void_p)]
+B3CDist = _native.B3CDist      # b3c_dist, include/b3c.h (layout checked against the library at load time)
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
@@ -50,6 +48,7 @@ def shard_range(n, rank, world, align=64):
 
 def allgather_inplace(full, rank, world, group=None):
     """All-gather `full` (world equal slices, this rank's already in place).  One collective."""
+    import torch
     import torch.distributed as dist
     cnt = full.numel() // world
     mine = full[rank * cnt:(rank + 1) * cnt]
@@ -61,11 +60,14 @@ def allgather_inplace(full, rank, world, group=None):
             mine = mine.clone()
         dist.all_gather_into_tensor(full, mine, group=group)
     elif full.is_cuda:
-        # gloo moves CUDA tensors only for all_reduce/broadcast (single-GPU CI): gather = sum with zeros
-        keep = mine.clone()
-        full.zero_()
-        full[rank * cnt:(rank + 1) * cnt] = keep
-        dist.all_reduce(full, group=group)
+        # gloo moves CUDA tensors only for all_reduce/broadcast (single-GPU CI): gather = sum with zeros -- on an INTEGER
+        # view, because libb3c sends raw 64-bit words through the float64 buffers (symmetry checksums, packed row-best
+        # words, degrees) and a floating-point add would quieten a payload that happens to be a signalling NaN
+        v = full.view(torch.int64 if full.element_size() == 8 else torch.int32)
+        keep = v[rank * cnt:(rank + 1) * cnt].clone()
+        v.zero_()
+        v[rank * cnt:(rank + 1) * cnt] = keep
+        dist.all_reduce(v, group=group)
     else:
         dist.all_gather(list(full.view(world, cnt).unbind(0)), mine.clone(), group=group)
 

@@ -278,6 +278,16 @@ int b3c_graph_quantise(b3c_ctx *ctx, const b3c_mat *a, double scl, int64_t *q /*
 /* ---- build info ---------------------------------------------------------------------------- */
 const char *b3c_version(void);
 
+/* Layout of the three structs that cross this ABI, as the library was COMPILED: out[0] = sizeof, out[1] = number of
+ * fields, out[2 ..] = offsetof of every field in declaration order.  which: B3C_ABI_KR_INFO, B3C_ABI_LOUVAIN_INFO,
+ * B3C_ABI_DIST.  Returns the number of ints written, or B3C_E_ARG (unknown struct, cap too small).  A binding checks
+ * this against its own struct definitions before the first call that writes through them (bin3c_amd/_native.py does at
+ * load time; tests/test_abi.py holds header, library, ctypes table and the INTEGRATION.md stub to one layout). */
+#define B3C_ABI_KR_INFO 0
+#define B3C_ABI_LOUVAIN_INFO 1
+#define B3C_ABI_DIST 2
+int b3c_abi_layout(int which, int32_t *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif
