@@ -632,10 +632,23 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
     o->value_symmetric = ns ? ns->graph_form != 0 : a->value_symmetric;
     o->sorted_cols = a->sorted_cols;      // compaction keeps the relative order inside a row
     if (a->row1 >= 0) {
-        // a row block stays a row block: its bounds in the compacted numbering
-        int64_t b[2] = {0, 0};
-        { const int rb_ = b3c_readback(ctx, &b[0], newid.p + a->row0, sizeof(int64_t)); if (rb_) { return rb_; } }
-        { const int rb_ = b3c_readback(ctx, &b[1], newid.p + a->row1, sizeof(int64_t)); if (rb_) { return rb_; } }
+        // a row block stays a row block: its bounds in the compacted numbering.  Bounds at 0 and n are known (0 and m) -- a
+        // whole matrix that went through b3c_mat_permute carries [0, n) and costs no read-back; an inner bound is newid[bound]
+        int64_t b[2] = {0, m};
+        const bool need0 = a->row0 > 0 && a->row0 < n, need1 = a->row1 > 0 && a->row1 < n;
+        if (a->row0 >= n) b[0] = m;
+        if (a->row1 <= 0) b[1] = 0;
+        if ((need0 || need1) && ctx->pin) {
+            int64_t *pin = (int64_t *)ctx->pin;
+            if (need0) HIP_TRY(ctx, hipMemcpyAsync(pin, newid.p + a->row0, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            if (need1) HIP_TRY(ctx, hipMemcpyAsync(pin + 1, newid.p + a->row1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));      // both bounds, one wait
+            if (need0) b[0] = pin[0];
+            if (need1) b[1] = pin[1];
+        } else {
+            if (need0) { const int rb_ = b3c_readback(ctx, &b[0], newid.p + a->row0, sizeof(int64_t)); if (rb_) { return rb_; } }
+            if (need1) { const int rb_ = b3c_readback(ctx, &b[1], newid.p + a->row1, sizeof(int64_t)); if (rb_) { return rb_; } }
+        }
         o->row0 = b[0];
         o->row1 = b[1];
     }

@@ -200,6 +200,46 @@ int b3c_dist_allgather_rows(b3c_ctx *ctx, void *full, int esz, const int64_t *st
     return B3C_OK;
 }
 
+// Ragged gather of (key, value) pairs: rank r contributes cnt_r pairs of 64-bit words; afterwards every rank holds the
+// keys of all ranks in rank order followed by the values (2 * total words in one pooled block, *out).  The counts travel
+// through the integer exchange buffer; the payload is summed into a zeroed buffer of the final layout (every word has
+// exactly one non-zero contributor, so the integer all-reduce IS the gather, bit for bit, on both transports).  A ring
+// all-reduce moves twice what a ragged all-gather would; these runs are the already reduced community pairs of a level,
+// a few percent of the entries a rank streamed to form them.
+int b3c_dist_gather_pairs(b3c_ctx *ctx, const int64_t *keys, const int64_t *vals, int64_t cnt, int64_t **out, int64_t *total)
+{
+    const b3c_dist &D = ctx->dist;
+    *out = nullptr;
+    *total = 0;
+    const int64_t mine[2] = {cnt, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    int rc = b3c_dist_exchange(ctx, B3C_BUF_ISUM);
+    if (rc) return rc;
+    std::vector<int64_t> all(2 * (size_t)D.world);
+    if ((rc = b3c_readback(ctx, all.data(), D.isum, sizeof(int64_t) * all.size()))) return rc;
+    int64_t off = 0, tot = 0;
+    for (int r = 0; r < D.world; r++) {
+        if (all[2 * (size_t)r] < 0) return ctx->fail(B3C_E_ARG, "b3c_dist_gather_pairs: negative count from rank %d", r);
+        if (r < D.rank) off += all[2 * (size_t)r];
+        tot += all[2 * (size_t)r];
+    }
+    int64_t *buf = (int64_t *)ctx->alloc(sizeof(int64_t) * 2 * (size_t)(tot > 0 ? tot : 1));
+    if (!buf) return ctx->fail(B3C_E_NOMEM, "b3c_dist_gather_pairs: %lld pairs", (long long)tot);
+    struct Hold { b3c_ctx *c; int64_t *p; ~Hold() { c->release(p); } } hold{ctx, buf};
+    if (tot) {
+        HIP_TRY(ctx, hipMemsetAsync(buf, 0, sizeof(int64_t) * 2 * (size_t)tot, ctx->stream));
+        if (cnt) {
+            HIP_TRY(ctx, hipMemcpyAsync(buf + off, keys, sizeof(int64_t) * (size_t)cnt, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(buf + tot + off, vals, sizeof(int64_t) * (size_t)cnt, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if ((rc = b3c_dist_allreduce_u64(ctx, buf, 2 * tot))) return rc;
+    }
+    hold.p = nullptr;
+    *out = buf;
+    *total = tot;
+    return B3C_OK;
+}
+
 // Maximum of one double over the ranks (host value in, host value out); identity when no sharding is installed.
 extern "C" int b3c_dist_max_f64(b3c_ctx *ctx, double *value)
 {

@@ -538,7 +538,8 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
                                                       const int32_t *__restrict__ indices,
                                                       const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
                                                       const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
-                                                      const int32_t *__restrict__ csize, int32_t *__restrict__ nxt)
+                                                      const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
+                                                      int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out, int32_t epoch)
 {
     constexpr int CAP = 512;                       // >= 1.25 * LPR * UN + 1
     constexpr int LG = 9;
@@ -669,6 +670,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
             // staying: i removed from its own community first (python-louvain __remove)
             const i128 g = (i128)own * (i128)m2 - (i128)(ta - ki) * (i128)ki;
             best_take(b, g, a);
+            if (own_out) { own_out[i] = own; stamp_out[i] = epoch; }      // row-sharded pruning: own_i as of this sub-round's start
         }
         // arg-max inside the group
 #pragma unroll
@@ -743,11 +745,17 @@ __global__ void __launch_bounds__(BLK) k_lv_unpack_init(int64_t n, const int32_t
 // gain(c) = dnc(c)*2m - tot(c)*k_i <= F_i*2m.  If that bound is below the (positive) gain of staying, or F_i == 0, no
 // neighbour community can win whatever the labels of the neighbours are: the node stays and its row is never read.
 // The others are appended to `out` (any order: decisions do not depend on one another inside a sub-round).
+// Row-sharded runs (stamp != nullptr): a rank keeps own_i exact with respect to the movers whose rows it holds; a mover of
+// ANOTHER rank changes own_i only if it leaves or joins i's community, and every rank knows which communities the foreign
+// movers of a sub-round touched (tstamp[c] = that sub-round, k_lv_apply) without seeing their rows.  own_i is trusted iff
+// it was formed (stamp[i]: by the neighbour scan, the full recount, or as a mover) after the last such touch of its
+// community; the others go through the scan, which refreshes them.  No exchange beyond the label gather is needed.
 __global__ void __launch_bounds__(BLK) k_lv_prune(int64_t cnt, const NodeRec *__restrict__ list, u64 m2,
                                                    const int64_t *__restrict__ kdeg, const int64_t *__restrict__ wnl,
                                                    const int64_t *__restrict__ own, const int64_t *__restrict__ tot,
                                                    const int32_t *__restrict__ com, int32_t *__restrict__ nxt,
-                                                   NodeRec *__restrict__ out, unsigned long long *__restrict__ out_cnt)
+                                                   NodeRec *__restrict__ out, unsigned long long *__restrict__ out_cnt,
+                                                   const int32_t *__restrict__ stamp, const int32_t *__restrict__ tstamp)
 {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * BLK;
@@ -762,7 +770,8 @@ __global__ void __launch_bounds__(BLK) k_lv_prune(int64_t cnt, const NodeRec *__
             const int32_t a = com[i];
             const long long ki = kdeg[i], o = own[i], f = wnl[i] - o;
             const i128 stay = (i128)o * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
-            const bool stays = f <= 0 || (stay > 0 && (i128)f * (i128)m2 < stay);
+            bool stays = f <= 0 || (stay > 0 && (i128)f * (i128)m2 < stay);
+            if (stamp && !(tstamp[a] < stamp[i])) stays = false;      // own_i may miss a foreign mover: rescan
             if (stays) nxt[i] = a;
             keep = !stays;
         }
@@ -778,7 +787,8 @@ __global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int roun
                                                    const int64_t *__restrict__ kdeg,
                                                    int64_t *__restrict__ tot, int32_t *__restrict__ com,
                                                    const int32_t *__restrict__ nxt, int32_t *__restrict__ csize,
-                                                   u64 *__restrict__ moved)
+                                                   u64 *__restrict__ moved, int64_t r0, int64_t r1, int32_t *__restrict__ tstamp,
+                                                   int32_t epoch)
 {
     const int64_t stride = (int64_t)gridDim.x * BLK;
     int cnt = 0;
@@ -786,6 +796,8 @@ __global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int roun
         if (bucket_of(ids ? ids[i] : (int32_t)i, n_sub) != (uint32_t)round) continue;
         const int32_t a = com[i], b = nxt[i];
         if (a == b) continue;
+        // a mover whose row another rank holds: its old and new community are "touched" in this sub-round (k_lv_prune)
+        if (tstamp && (i < r0 || i >= r1)) { tstamp[a] = epoch; tstamp[b] = epoch; }
         const long long ki = kdeg[i];
         atomicAdd((u64 *)&tot[a], (u64)(-ki));
         atomicAdd((u64 *)&tot[b], (u64)ki);
@@ -836,7 +848,8 @@ __global__ void __launch_bounds__(BLK) k_lv_apply_list(int64_t cnt, const NodeRe
 __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, const int64_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices,
                                                       const int64_t *__restrict__ q, const int32_t *__restrict__ com,
-                                                      u64 *__restrict__ i2, int64_t *__restrict__ own)
+                                                      u64 *__restrict__ i2, int64_t *__restrict__ own,
+                                                      int32_t *__restrict__ stamp, int32_t epoch)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -868,7 +881,10 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
         }
         if (own) {                                            // by-product for k_lv_prune (wave-uniform branch)
             mine = wave_sum_ll(mine);
-            if (lane == 0) own[row] = mine;
+            if (lane == 0) {
+                own[row] = mine;
+                if (stamp) stamp[row] = epoch;
+            }
         }
     }
     __shared__ long long red[WPB];
@@ -882,7 +898,8 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
 __global__ void __launch_bounds__(BLK) k_lv_delta_internal(int64_t cnt, const NodeRec *__restrict__ list,
                                                             const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
                                                             const int32_t *__restrict__ com, const int32_t *__restrict__ nxt,
-                                                            u64 *__restrict__ i2, int64_t *__restrict__ own)
+                                                            u64 *__restrict__ i2, int64_t *__restrict__ own, int64_t r0, int64_t r1,
+                                                            int32_t *__restrict__ stamp, int32_t epoch)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -902,12 +919,16 @@ __global__ void __launch_bounds__(BLK) k_lv_delta_internal(int64_t cnt, const No
             if (own) {
                 if (nj == b) mine += q[k];
                 // a neighbour that stays: this mover leaves or joins its community (movers recompute theirs from scratch)
-                if (cj == nj && (cj == a || cj == b)) atomicAdd((u64 *)&own[j], (u64)(cj == a ? -q[k] : q[k]));
+                // (row-sharded: own[] of another rank's nodes is that rank's business -- see k_lv_prune)
+                if (cj == nj && (cj == a || cj == b) && j >= r0 && j < r1) atomicAdd((u64 *)&own[j], (u64)(cj == a ? -q[k] : q[k]));
             }
         }
         if (own) {
             mine = wave_sum_ll(mine);
-            if (lane == 0) own[rec.node] = mine;
+            if (lane == 0) {
+                own[rec.node] = mine;
+                if (stamp) stamp[rec.node] = epoch;                 // formed from the labels AFTER this sub-round's moves
+            }
         }
     }
     acc = wave_sum_ll(acc);
@@ -1503,8 +1524,18 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // trip costs as much as k_lv_tot2); moved == 0 leaves *out alone.
         // exact pruning of the neighbour scan (k_lv_prune): single GPU, grouped lists, during the sweeps that track the
         // internal weight through the movers' rows (the same pass keeps own[] current)
-        const bool can_prune = grouped && !dist && getenv("B3C_LV_NO_PRUNE") == nullptr;
+        // Row-sharded runs prune too (round 3): validity stamps replace the exchange the neighbours' own[] would need
+        const bool can_prune = grouped && getenv("B3C_LV_NO_PRUNE") == nullptr;
         int64_t *own_p = can_prune ? own.p : nullptr;
+        const bool stamps = can_prune && dist;
+        DevBuf<int32_t> stamp(ctx, stamps ? n : 1), tstamp(ctx, stamps ? n : 1);
+        if (!stamp.p || !tstamp.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: stamps");
+        if (stamps) {
+            HIP_TRY(ctx, hipMemsetAsync(stamp.p, 0, sizeof(int32_t) * (size_t)n, s));
+            HIP_TRY(ctx, hipMemsetAsync(tstamp.p, 0, sizeof(int32_t) * (size_t)n, s));
+        }
+        int32_t *stamp_p = stamps ? stamp.p : nullptr, *tstamp_p = stamps ? tstamp.p : nullptr;
+        int32_t epoch = 0;                               // sub-rounds of this level so far
         int64_t max_list = 0;
         for (int r = 0; r < n_sub; r++) max_list = std::max(max_list, loff[r + 1] - loff[r]);
         DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1);
@@ -1514,7 +1545,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
             if (full) {
                 HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64), s));
-                hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2, own_p);
+                hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2, own_p,
+                                   stamp_p, epoch + 1);
             }
             hipLaunchKernelGGL(k_lv_tot2, dim3(gv), dim3(BLK), 0, s, n, tot.p, ctr.p + 3);
             u64 h[8];
@@ -1555,6 +1587,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             // the movers' rows instead of rescanning the whole graph after the sweep
             const bool incr = grouped && prev_moved != ~0ull && prev_moved * (u64)incr_div < (u64)n && getenv("B3C_LV_NO_INCR") == nullptr;
             for (int r = 0; r < n_sub; r++) {
+                epoch++;
                 evs.rec();
                 if (grouped && loff[r + 1] > loff[r]) {
                     const int64_t cntr = loff[r + 1] - loff[r];
@@ -1564,13 +1597,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                         // nodes that provably stay are settled from four numbers each; the rest go through the scan
                         HIP_TRY(ctx, hipMemsetAsync(pcnt.p, 0, sizeof(unsigned long long), s));
                         hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(cntr, BLK, 8 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, m2, kdeg.p,
-                                           wnl.p, own.p, tot.p, com.p, nxt_p, plist.p, pcnt.p);
+                                           wnl.p, own.p, tot.p, com.p, nxt_p, plist.p, pcnt.p, stamp_p, tstamp_p);
                         lst = plist.p;
                         cnt_dev = (const int64_t *)pcnt.p;
                     }
 #define LV_DECIDE_G(L, U)                                                                                                \
     hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, cnt_dev, lst, \
-                       m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p)
+                       m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch)
                     switch (short_max) {
                     case 256:      // C3 sweep of shapes, ms of delta-Q scan per step: 64x4 11.3, 32x8 12.2, 16x16 22.4
                         if (getenv("B3C_LV_SHAPE") && !strcmp(getenv("B3C_LV_SHAPE"), "32x8")) { LV_DECIDE_G(32, 8); }
@@ -1611,9 +1644,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (incr) {
                     const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
                     if (c1) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c1, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c1,
-                                               nlist_p + loff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p);
+                                               nlist_p + loff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p, r0, r1, stamp_p, epoch + 1);
                     if (c2) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c2, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c2,
-                                               hlist_p + hoff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p);
+                                               hlist_p + hoff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p, r0, r1, stamp_p, epoch + 1);
                 }
                 if (grouped && !dist) {
                     // only the nodes that decided in this sub-round can have moved
@@ -1624,7 +1657,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                                                hlist_p + hoff[r], kdeg.p, tot.p, com.p, nxt_p, csize.p, ctr.p + 1);
                 } else {
                     hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt_p,
-                                       csize.p, ctr.p + 1);
+                                       csize.p, ctr.p + 1, r0, r1, tstamp_p, epoch);
                 }
             }
             info->move_nnz += g.nnz;
@@ -1658,6 +1691,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 
         // ---- induced graph ----
         LvGraph h;
+        GraphGuard next_guard{ctx, &h};               // an early return while h is under construction releases its blocks
         if (kc <= AGG_BINS_KC && getenv("B3C_LV_AGG_SORT") == nullptr) {
             // few communities: exact integer sums straight into kc x kc bins (see k_agg_bins)
             const size_t nb = (size_t)kc * (size_t)kc;
@@ -1695,43 +1729,61 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             hipLaunchKernelGGL(k_bins_fill, dim3(gk), dim3(BLK), 0, s, kc, bins.p, h.indptr, h.indices, h.q);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipStreamSynchronize(s));
-        } else if (blk0) {
-            free_graph(ctx, g);
-            return ctx->fail(B3C_E_ARG, "b3c_louvain: a sharded level with more than %lld communities is not supported on row blocks", (long long)AGG_BINS_KC);
         } else {
-        // many communities: sort (community pair) keys, sum weights
+        // many communities: sort (community pair) keys, sum weights.  On a row block every rank reduces the pairs of ITS rows,
+        // the reduced runs of all ranks are gathered (b3c_dist_gather_pairs) and reduced once more: integer sums, so the
+        // induced graph is bit for bit the single-GPU one whatever the split ("tuples keyed by community pair,
+        // then local sort-reduce"; the graph of the next level is small against level 0 and stays replicated).
         DevBuf<int64_t> pcnt(ctx, n + 1), ppos(ctx, n + 1);
-        if (!pcnt.p || !ppos.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation counts"); }
+        if (!pcnt.p || !ppos.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation counts");
         hipLaunchKernelGGL(k_pairs_count, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, cn.p, pcnt.p);
-        if ((rc = b3c_exclusive_scan_i64(ctx, pcnt.p, ppos.p, n + 1))) { free_graph(ctx, g); return rc; }
+        if ((rc = b3c_exclusive_scan_i64(ctx, pcnt.p, ppos.p, n + 1))) return rc;
         int64_t m = 0;
         { const int rb_ = b3c_readback(ctx, &m, ppos.p + n, sizeof(int64_t)); if (rb_) return rb_; }
-        DevBuf<int64_t> k_in(ctx, m), k_out(ctx, m), v_in(ctx, m), v_out(ctx, m), nruns(ctx, 1);
-        if (!k_in.p || !k_out.p || !v_in.p || !v_out.p || !nruns.p) {
-            free_graph(ctx, g);
-            return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation buffers");
-        }
-        hipLaunchKernelGGL(k_pairs_fill, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, ppos.p, k_in.p, v_in.p);
         int end_bit = 1;
         while (end_bit < 63 && ((unsigned __int128)1 << end_bit) < (unsigned __int128)kc * (unsigned __int128)kc) end_bit++;
-        size_t tb = 0;
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)m, 0, end_bit, s));
-        {
-            DevBuf<char> tmp(ctx, tb);
-            if (!tmp.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "sort workspace"); }
-            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (int64_t)m, 0, end_bit, s));
-        }
-        tb = 0;
-        HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tb, k_out.p, k_in.p, v_out.p, v_in.p, nruns.p,
-                                                       hipcub::Sum(), (int64_t)m, s));
-        {
-            DevBuf<char> tmp(ctx, tb);
-            if (!tmp.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "reduce workspace"); }
-            HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(tmp.p, tb, k_out.p, k_in.p, v_out.p, v_in.p, nruns.p,
-                                                           hipcub::Sum(), (int64_t)m, s));
-        }
+        // (keys, vals)[0, cnt) in ka/va -> sorted by key, equal keys summed, back in ka/va; kb/vb are scratch of the same size
+        auto sort_reduce = [&](int64_t *ka, int64_t *va, int64_t *kb, int64_t *vb, int64_t cnt, int64_t *nruns_dev, int64_t *nu_out) -> int {
+            *nu_out = 0;
+            if (cnt == 0) return B3C_OK;
+            size_t tb = 0;
+            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ka, kb, va, vb, cnt, 0, end_bit, s));
+            {
+                DevBuf<char> tmp(ctx, tb);
+                if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "sort workspace");
+                HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, ka, kb, va, vb, cnt, 0, end_bit, s));
+            }
+            tb = 0;
+            HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tb, kb, ka, vb, va, nruns_dev, hipcub::Sum(), cnt, s));
+            {
+                DevBuf<char> tmp(ctx, tb);
+                if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "reduce workspace");
+                HIP_TRY(ctx, hipcub::DeviceReduce::ReduceByKey(tmp.p, tb, kb, ka, vb, va, nruns_dev, hipcub::Sum(), cnt, s));
+            }
+            return b3c_readback(ctx, nu_out, nruns_dev, sizeof(int64_t));
+        };
+        DevBuf<int64_t> nruns(ctx, 1);
+        if (!nruns.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation buffers");
         int64_t nu = 0;
-        { const int rb_ = b3c_readback(ctx, &nu, nruns.p, sizeof(int64_t)); if (rb_) return rb_; }
+        struct Runs { b3c_ctx *c; int64_t *p = nullptr; ~Runs() { c->release(p); } } merged{ctx};   // gathered runs (row blocks)
+        const int64_t *ukeys = nullptr, *uvals = nullptr;
+        DevBuf<int64_t> k_in(ctx, m), k_out(ctx, m), v_in(ctx, m), v_out(ctx, m);
+        if (!k_in.p || !k_out.p || !v_in.p || !v_out.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation buffers");
+        if (m) hipLaunchKernelGGL(k_pairs_fill, dim3(gw), dim3(BLK), 0, s, n, kc, g.indptr, g.indices, g.q, cn.p, ppos.p, k_in.p, v_in.p);
+        if ((rc = sort_reduce(k_in.p, v_in.p, k_out.p, v_out.p, m, nruns.p, &nu))) return rc;
+        ukeys = k_in.p;
+        uvals = v_in.p;
+        if (blk0) {
+            int64_t total = 0;
+            if ((rc = b3c_dist_gather_pairs(ctx, k_in.p, v_in.p, nu, &merged.p, &total))) return rc;
+            DevBuf<int64_t> k2(ctx, total), v2(ctx, total);
+            if (!k2.p || !v2.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation buffers");
+            // a community whose members sit in two ranks' blocks has runs on both: second reduction over the gathered runs
+            if ((rc = sort_reduce(merged.p, merged.p + total, k2.p, v2.p, total, nruns.p, &nu))) return rc;
+            ukeys = merged.p;
+            uvals = merged.p + total;
+            info->agg_gathered_runs += total;
+        }
 
         h.n = kc; h.nnz = nu; h.owned = true;
         h.indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(kc + 1));
@@ -1739,18 +1791,23 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu > 0 ? nu : 1));
         if (!h.indptr || !h.indices || !h.q) {
             free_graph(ctx, h);
-            free_graph(ctx, g);
             return ctx->fail(B3C_E_NOMEM, "b3c_louvain: next level");
         }
-        hipLaunchKernelGGL(k_rows_from_keys, dim3((unsigned)((kc + 256) / 256)), dim3(256), 0, s, kc, nu, k_in.p, h.indptr);
+        hipLaunchKernelGGL(k_rows_from_keys, dim3((unsigned)((kc + 256) / 256)), dim3(256), 0, s, kc, nu, ukeys, h.indptr);
         if (nu)
-            hipLaunchKernelGGL(k_fill_from_keys, dim3(grid_for(nu, 256, 8 * ctx->n_cu)), dim3(256), 0, s, kc, nu, k_in.p,
-                               v_in.p, h.indices, h.q);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+            hipLaunchKernelGGL(k_fill_from_keys, dim3(grid_for(nu, 256, 8 * ctx->n_cu)), dim3(256), 0, s, kc, nu, ukeys,
+                               uvals, h.indices, h.q);
+        {
+            const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(s);      // the runs are read until here
+            if (e1 != hipSuccess || e2 != hipSuccess) {
+                free_graph(ctx, h);
+                return ctx->fail(B3C_E_HIP, "b3c_louvain: aggregation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            }
+        }
         }
         free_graph(ctx, g);
         g = h;
+        h = LvGraph();                                // handed over
         ids = nullptr;
     }
     free_graph(ctx, g);

@@ -169,13 +169,18 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
         sess = getattr(ctx, 'dist_session', None)
         block = None
         if reorder and n >= REORDER_MIN_N and counts.nnz >= REORDER_MIN_NNZ:
-            n2o = torch.empty(n, dtype=torch.int32, device=dev)
-            o2n = torch.empty(n, dtype=torch.int32, device=dev)
-            ctx._check(ctx.lib.b3c_locality_order(ctx.h, counts.h, _native._ptr(n2o), _native._ptr(o2n)))
-            if sess is not None and sess.world > 1 and sess.n == n:
-                block = (sess.r0, sess.r1)
-            # canonical (columns re-sorted inside each row): unsorted rows cost the SpMV 12 % more than the sort saves
-            work = ctx.permute(counts, n2o, rows=block)
+            try:
+                n2o = torch.empty(n, dtype=torch.int32, device=dev)
+                o2n = torch.empty(n, dtype=torch.int32, device=dev)
+                ctx._check(ctx.lib.b3c_locality_order(ctx.h, counts.h, _native._ptr(n2o), _native._ptr(o2n)))
+                if sess is not None and sess.world > 1 and sess.n == n:
+                    block = (sess.r0, sess.r1)
+                # canonical (columns re-sorted inside each row): unsorted rows cost the SpMV 12 % more than the sort saves
+                work = ctx.permute(counts, n2o, rows=block)
+            except Exception:
+                if adopt_counts:
+                    counts.free()              # the result never took it over
+                raise
             idx = n2o.long()
             sites_t, lengths_t = sites_t[idx], lengths_t[idx]
         res._n2o, res._o2n = n2o, o2n
@@ -301,7 +306,10 @@ def _cluster_stage(ctx, res, mask_w, n_sub=0):
         _c, work, sites_t, x_w, graph_form, _owned = res._lazy
         sub = ctx.normalise_scale_compress(work, sites_t, x_w, mask_w, graph_form=graph_form)
         res.sub = sub
-    if sub.n == 0 or sub.nnz == 0:
+    # a rank of a row-sharded run decides from the GLOBAL entry count: its own block may be empty (all its rows masked) while
+    # the others still cluster, and the calls below are collective over the ranks
+    nnz_all = sub.nnz if res.row_block is None else int(ctx.dist_max(float(sub.nnz)))
+    if sub.n == 0 or nnz_all == 0:
         # nothing passed the acceptance mask: the reference raises NoneAcceptedException one level up
         # (contact_map.py:927); at this level the answer is simply "no accepted contigs, no labels"
         res.scl = None

@@ -54,8 +54,8 @@ class SynthMap(object):
         return sp.csr_matrix((self.counts.astype(dtype), self.indices, self.indptr), shape=(self.n, self.n))
 
 
-def _genome_sizes(n, n_genomes):
-    w = np.arange(1, n_genomes + 1, dtype=np.float64) ** -0.5
+def _genome_sizes(n, n_genomes, exponent=0.5):
+    w = np.arange(1, n_genomes + 1, dtype=np.float64) ** -exponent
     sizes = np.maximum(2, np.floor(w / w.sum() * n).astype(np.int64))
     # fix rounding drift on the largest genome
     sizes[0] += n - sizes.sum()
@@ -78,18 +78,31 @@ def _solve_draws(target_unique, pair_cap, share):
     return hi
 
 
-def make_edges(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5):
+def genome_layout(n, genomes=None, genome_law='sqrt'):
+    """Genome sizes of a map.  'sqrt' (hic-synth-v1 as benchmarked): G = max(4, n // 500) genomes, sizes ~ rank**-0.5.
+    'survey' (SURVEY.md 8(d) to the letter): G = max(2, n // 200), sizes ~ Zipf(1.5) -- 38 % of the contigs in the largest
+    genome, most genomes of a handful.  `genomes` overrides G (tests: thousands of small genomes)."""
+    if genome_law == 'survey':
+        g = max(2, n // 200) if genomes is None else int(genomes)
+        return _genome_sizes(n, min(g, n // 2), 1.5)
+    if genome_law != 'sqrt':
+        raise ValueError('unknown genome_law {}'.format(genome_law))
+    g = max(4, n // 500) if genomes is None else int(genomes)
+    return _genome_sizes(n, min(g, n // 2), 0.5)
+
+
+def make_edges(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5, genomes=None, genome_law='sqrt'):
     """
     Draw the contact pair stream.  `noise`: share of the edges that join two random contigs (inter-genome); `intra_boost`:
     multiplier of the intra-genome counts.  The defaults are hic-synth-v1; larger noise / boost 1 give a HARD clustering
-    problem (modularity ~0.4-0.6, several Louvain levels) for the tests.
+    problem (modularity ~0.4-0.6, several Louvain levels) for the tests.  `genomes` / `genome_law`: see genome_layout.
 
     :return: (i, j, count) with i < j, possibly holding duplicates (the consumer sums them),
              diag counts (uint32[n]), lengths (int32[n]), sites (float64[n]), genome id (int32[n])
     """
     rs = np.random.RandomState(seed)
-    n_genomes = max(4, n // 500)
-    sizes = _genome_sizes(n, n_genomes)
+    sizes = genome_layout(n, genomes, genome_law)
+    n_genomes = sizes.shape[0]
     starts = np.concatenate(([0], np.cumsum(sizes)[:-1]))
     perm = rs.permutation(n).astype(np.int64)       # position-in-genome-order -> contig id
     genome = np.empty(n, dtype=np.int32)
@@ -172,8 +185,8 @@ def symmetrise_to_csr(n, lo, hi, c, diag):
     return indptr, indices, counts
 
 
-def make_synth(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5):
+def make_synth(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5, genomes=None, genome_law='sqrt'):
     """Full host-side generation -> :class:`SynthMap`."""
-    lo, hi, c, diag, lengths, sites, genome = make_edges(n, n_edges, seed, degree_law, noise, intra_boost)
+    lo, hi, c, diag, lengths, sites, genome = make_edges(n, n_edges, seed, degree_law, noise, intra_boost, genomes, genome_law)
     indptr, indices, counts = symmetrise_to_csr(n, lo, hi, c, diag)
     return SynthMap(n, indptr, indices, counts, lengths, sites, genome)

@@ -111,9 +111,98 @@ def gpu_mode(rank, world):
     ctx.close()
 
 
+def _agree(res, single, rank):
+    import graphs
+    assert res.kr_info.n_iter == single.kr_info.n_iter
+    assert np.array_equal(res.mask, single.mask)
+    np.testing.assert_allclose(res.x, single.x, rtol=1e-10)
+    assert graphs.same_partition(res.labels, single.labels)
+    assert res.lv_info.n_sweeps == single.lv_info.n_sweeps and res.lv_info.n_levels == single.lv_info.n_levels
+    assert res.lv_info.modularity == single.lv_info.modularity       # exact integer modularity: the same induced graphs
+    lab = torch.as_tensor(res.labels.astype(np.int64))
+    ref = lab.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(lab, ref)
+
+
+def gpu_many_mode(rank, world):
+    """Row blocks whose level 0 leaves MORE communities than the kc x kc bin table holds (4096): the aggregation goes through
+    per-rank pair runs, the ragged gather and the second reduction (b3c_dist_gather_pairs).  A power-law map of thousands of
+    small genomes (C5's shape: BASELINE.json configs[4] ends level 0 with 5,590+ communities), and the pruned neighbour scan of
+    the later sweeps on row blocks (validity stamps)."""
+    from bin3c_amd.dist import DistSession
+    from bin3c_amd.pipeline import make_context, run_hot_path
+    from bin3c_amd.synth import make_synth
+    ctx = make_context(0)
+    sm = make_synth(90000, 2400000, 31, 'powerlaw', genomes=6000)
+    counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    single = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5, max_iter=5000)
+    assert single.lv_info.n_levels >= 1 and single.lv_info.agg_gathered_runs == 0
+    sess = DistSession(ctx, sm.n)
+    res = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5, max_iter=5000)
+    sess.check()
+    assert res.row_block == (sess.r0, sess.r1) and res.work_nnz < 0.8 * counts.nnz
+    _agree(res, single, rank)
+    # the sort path ran on the row blocks: runs were gathered, and level 0 left more communities than the bins hold
+    assert res.lv_info.agg_gathered_runs > 4096, res.lv_info.agg_gathered_runs
+    sess.close()
+    # the same path forced on a map with few communities (every level through sort + gather), pruning on and off
+    sm2 = make_synth(40000, 1300000, 21, noise=0.4, intra_boost=1)
+    c2 = ctx.upload(sm2.indptr, sm2.indices, sm2.counts)
+    single2 = run_hot_path(ctx, c2, sm2.sites, sm2.lengths, 1000, 5)
+    for env in ({'B3C_LV_AGG_SORT': '1'}, {'B3C_LV_NO_PRUNE': '1'}, {}):
+        os.environ.update(env)
+        sess = DistSession(ctx, sm2.n)
+        res2 = run_hot_path(ctx, c2, sm2.sites, sm2.lengths, 1000, 5)
+        sess.check()
+        _agree(res2, single2, rank)
+        if 'B3C_LV_AGG_SORT' in env:
+            assert res2.lv_info.agg_gathered_runs > 0
+        sess.close()
+        for k in env:
+            os.environ.pop(k)
+    c2.free()
+    counts.free()
+    print('rank %d gpu-many ok (%d communities after level 0 runs gathered: %d)' % (rank, single.lv_info.n_comm, res.lv_info.agg_gathered_runs))
+    ctx.close()
+
+
+def gpu_empty_mode(rank, world):
+    """One rank's row block is masked out completely (all its contigs shorter than min_len): that rank still has to take part
+    in every collective of the cluster stage (maximum, degrees, label gathers, bins) with an empty sub-map."""
+    from bin3c_amd.dist import DistSession, shard_range
+    from bin3c_amd.pipeline import make_context, run_hot_path
+    from bin3c_amd.synth import make_synth
+    ctx = make_context(0)
+    sm = make_synth(40000, 1300000, 23)
+    counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    probe = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5, cluster=False)
+    n2o = probe._n2o.cpu().numpy()
+    lengths = np.maximum(sm.lengths, 1000)
+    r0, r1, _ = shard_range(sm.n, world - 1, world)
+    lengths[n2o[r0:r1]] = 500                       # the whole block of the last rank falls under min_len
+    single = run_hot_path(ctx, counts, sm.sites, lengths, 1000, 5)
+    assert not single.mask[n2o[r0:r1]].any() and single.mask.sum() > 0
+    sess = DistSession(ctx, sm.n)
+    res = run_hot_path(ctx, counts, sm.sites, lengths, 1000, 5, keep=True)
+    sess.check()
+    if rank == world - 1:
+        assert res.sub is not None and res.sub.nnz == 0, res.sub.nnz       # this rank's block of the sub-map is empty
+    _agree(res, single, rank)
+    res.free()
+    # ... and nothing accepted anywhere: every rank takes the early return together
+    none = run_hot_path(ctx, counts, sm.sites, np.full(sm.n, 500), 1000, 5)
+    assert none.mask.sum() == 0 and none.labels.shape[0] == 0
+    sess.close()
+    counts.free()
+    print('rank %d gpu-empty ok' % rank)
+    ctx.close()
+
+
 if __name__ == '__main__':
     dist.init_process_group(backend='gloo')
+    print('rank %d rendezvous done' % dist.get_rank(), flush=True)
     r, w = dist.get_rank(), dist.get_world_size()
-    (cpu_mode if sys.argv[1] == 'cpu' else gpu_mode)(r, w)
+    {'cpu': cpu_mode, 'gpu': gpu_mode, 'gpu-many': gpu_many_mode, 'gpu-empty': gpu_empty_mode}[sys.argv[1]](r, w)
     dist.barrier()
     dist.destroy_process_group()
