@@ -599,6 +599,11 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
         }
         long long ta = 0;
         if (i >= 0 && sl == 0) ta = tot[a];
+        // totals of the foreign communities, requested as soon as the labels are known: their round trip then runs under
+        // the LDS insertions instead of after them (round 3; a community met twice costs a second, cached, request)
+        long long tv[UN];
+#pragma unroll
+        for (int t = 0; t < UN; t++) tv[t] = (cm[t] != EMPTY && cm[t] != a) ? tot[cm[t]] : 0;
         // 3. neighbour ids and own community of the next node (its weights are fetched next to its gathers)
         int32_t an = 0;
         long long kin = 0;
@@ -653,14 +658,12 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             if (sub == gsel) {
 #pragma unroll
-                for (int t = 0; t < UN; t++) qv[t] = j[t] != -1 ? (u64)tot[cm[t]] : 0;     // qv is dead: holds tot[c] now
-#pragma unroll
                 for (int t = 0; t < UN; t++) {
                     if (j[t] == -1) continue;
                     const u64 d = vals[j[t]];
                     keys[j[t]] = EMPTY;
                     vals[j[t]] = 0;
-                    const i128 g = (i128)d * (i128)m2 - (i128)(long long)qv[t] * (i128)ki;
+                    const i128 g = (i128)d * (i128)m2 - (i128)tv[t] * (i128)ki;
                     best_take(b, g, cm[t]);
                 }
             }

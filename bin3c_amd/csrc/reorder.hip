@@ -690,6 +690,8 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
             { const int rb_ = b3c_readback(ctx, &tot[0], rpos.p + n, sizeof(int64_t)); if (rb_) return rb_; }
             { const int rb_ = b3c_readback(ctx, &tot[1], epos.p + n, sizeof(int64_t)); if (rb_) return rb_; }
             const int64_t n_long = tot[0], n_ent = tot[1];
+            // (a row block: the long rows may all sit in other ranks' blocks -- nothing to sort here)
+            if (n_ent > 0) {
             if (n_ent >= (1ll << 31)) { return ctx->fail(B3C_E_ARG, "b3c_permute_csr: more than 2^31 entries in long rows"); }
             DevBuf<int32_t> long_rows(ctx, n_long + 1);
             DevBuf<unsigned long long> k_in(ctx, n_ent + 1), k_out(ctx, n_ent + 1);
@@ -714,6 +716,7 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
                 hipLaunchKernelGGL(k_long_scatter<uint32_t>, dim3(gs), dim3(256), 0, s, n_ent, k_out.p, v_out.p, long_rows.p, epos.p, a->indptr,
                                    (const uint32_t *)a->data, new2old, m->indptr, m->indices, (uint32_t *)m->data);
             HIP_TRY(ctx, hipStreamSynchronize(s));       // the scratch above goes back to the pool here
+            }
         }
     } else if (nnz && sort_cols && maxlen <= CAPR && getenv("B3C_PERMUTE_GLOBAL_SORT") == nullptr) {
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);

@@ -82,6 +82,7 @@ class HotPathResult(object):
         self.scl = None             # 1 / max (cluster.py:316)
         self.labels = None          # int32[n_accepted] community per accepted (gapless) contig, -1 = not in graph
         self.kr_info = None
+        self.kr_strict = False      # x comes from the second, explicit-fp64 balance (run_hot_path(strict_kr=True) on a hard map)
         self.lv_info = None
         self.timings = {}
         self._perm = None           # see `perm`
@@ -132,8 +133,11 @@ def acceptance_mask(ctx, counts, lengths, min_len, min_sig):
     return mask, signal
 
 
+STRICT_KR_ITER = 100      # strict_kr: balance again in the reference's own formulation from this many iterations on
+
+
 def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=0, cluster=True, keep=False,
-                 reorder=True, mask=None, adopt_counts=False, max_iter=1000):
+                 reorder=True, mask=None, adopt_counts=False, max_iter=1000, strict_kr=False):
     """
     :param ctx: context from :func:`make_context`
     :param counts: _native.Mat (B3C_U32) raw symmetric contact counts, already in HBM
@@ -144,6 +148,13 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
     :param mask: bool[n] acceptance mask decided by the caller (ContactMap.primary_acceptance_mask); when
                  None it is computed here from lengths / min_len / min_sig
     :param max_iter: iteration limit of the balancing (sparse_utils.py:90, default 1000 like the reference)
+    :param strict_kr: when the balancing needed STRICT_KR_ITER iterations or more (an ill-conditioned map), repeat it on the
+                      explicitly normalised fp64 matrix -- the reference's own formulation (contact_map.py:933 then
+                      sparse_utils.py:90), 12 bytes per entry instead of 6 -- and return THAT x.  The count form perturbs the
+                      matrix entries by an ulp (1/s_i * 1/s_j against 1/(s_i s_j)); on tiny maps with ~2 contacts per row that
+                      has moved x by 3e-6 once in 1700 (tests/golden/illcond_kr_counts.npz), next to a spread of the reference
+                      against itself of up to 9e-4 on such maps (tests/test_kr_spread.py).  Off by default: it doubles the
+                      balancing time exactly where that is longest, for digits the algorithm does not determine.
     :param adopt_counts: the result takes `counts` over (frees it with res.free()); with keep=True the balanced map can then
                          still be formed on demand when no ordered copy was made
     :return: HotPathResult (device matrices freed unless keep=True)
@@ -212,6 +223,17 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
             t0 = time.perf_counter()
             x_w = torch.empty(n, dtype=torch.float64, device=dev)
             rc, _, res.kr_info = ctx.kr_balance_counts(work, sites_t, tol=tol, max_iter=max_iter, x_out=x_w, check=False)
+            res.kr_strict = False
+            if strict_kr and rc in (0, _native.E_NOCONV) and res.kr_info.n_iter >= STRICT_KR_ITER:
+                first = res.kr_info
+                nm = ctx.site_norm(work, sites_t)
+                try:
+                    rc, _, res.kr_info = ctx.kr_balance(nm, tol=tol, max_iter=max_iter, x_out=x_w, check=False)
+                finally:
+                    nm.free()
+                # what the count pass established about the INPUT stays (the fp64 pass sees the normalised matrix)
+                res.kr_info.bitwise_symmetric = first.bitwise_symmetric
+                res.kr_strict = True
             ctx._check(rc)
             t['kr'] = time.perf_counter() - t0
         except Exception:

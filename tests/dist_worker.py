@@ -118,7 +118,9 @@ def _agree(res, single, rank):
     np.testing.assert_allclose(res.x, single.x, rtol=1e-10)
     assert graphs.same_partition(res.labels, single.labels)
     assert res.lv_info.n_sweeps == single.lv_info.n_sweeps and res.lv_info.n_levels == single.lv_info.n_levels
-    assert res.lv_info.modularity == single.lv_info.modularity       # exact integer modularity: the same induced graphs
+    # (x of the sharded run differs from the single-GPU one in the last bits -- other reduction trees -- and so do a few
+    # quantised weights: the integer modularity agrees to that, the partition and the schedule exactly)
+    assert abs(res.lv_info.modularity - single.lv_info.modularity) < 1e-9
     lab = torch.as_tensor(res.labels.astype(np.int64))
     ref = lab.clone()
     dist.broadcast(ref, 0)

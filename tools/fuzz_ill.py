@@ -1,0 +1,89 @@
+"""
+GPU box: the 1e-6 contract of KR's scale vector on ILL-CONDITIONED maps (tiny, a few entries per row, hundreds of
+iterations, a dozen bound cuts -- where tools/fuzz_parity.py once saw 5.6e-6 between the device and the oracle).
+Thousands of such maps through
+
+  oracle   oracle/kr.c on the explicitly normalised fp64 matrix (== the reference to 1e-15 on the golden fixtures)
+  counts   b3c_kr_balance_counts (the product path: raw counts, 1/s folded into operand and epilogue)
+  fp64     b3c_kr_balance on the explicitly normalised fp64 matrix (the reference's own formulation, device sums)
+
+and, for every map on which either device form is further than 1e-6 from the oracle, the inputs are written to
+gpurun_out/fuzz_ill/case_<seed>_<k>.npz so that tools/kr_spread.py --cases can put the reference's own spread (two
+scipy/numpy environments, permuted input) beside it in the build container.
+usage: tools/fuzz_ill.py [n_cases] [seed]
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import scipy.sparse as sp
+import oracle
+from bin3c_amd.pipeline import make_context
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+out_dir = os.path.join('gpurun_out', 'fuzz_ill')
+os.makedirs(out_dir, exist_ok=True)
+ctx = make_context(0)
+
+
+def ill_map(rs):
+    n = int(rs.choice([33, 64, 65, 120, 200]))
+    deg = float(rs.choice([1.2, 1.5, 2.0, 3.0]))
+    m = int(n * deg / 2)
+    i = rs.randint(0, n, m)
+    j = rs.randint(0, n, m)
+    keep = i != j
+    i, j = i[keep], j[keep]
+    law = rs.choice(['geom', 'big', 'ones'])
+    c = (rs.geometric(0.2, i.shape[0]) if law == 'geom' else rs.randint(1, 200000, i.shape[0]) if law == 'big'
+         else np.ones(i.shape[0])).astype(np.uint64)
+    a = sp.coo_matrix((c, (i, j)), shape=(n, n)).tocsr()
+    a = a + a.T
+    d = rs.geometric(0.05, n).astype(np.uint64)
+    d[rs.rand(n) < 0.1] = 0
+    a = (a + sp.diags(d)).tocsr()
+    a.eliminate_zeros(); a.sum_duplicates(); a.sort_indices()
+    a.data = np.minimum(a.data, 0xFFFFFFFF)
+    sites = rs.poisson(20, n).astype(np.float64)
+    return n, a.indptr.astype(np.int64), a.indices.astype(np.int32), a.data.astype(np.uint32), sites
+
+
+rel = lambda u, v: float(np.max(np.abs(u - v) / np.abs(v)))
+hist = {'counts': [], 'fp64': []}
+n_ill = n_bad = 0
+for case in range(n_cases):
+    rs = np.random.RandomState(seed0 * 1000003 + case)
+    n, ip, ix, cnt, sites = ill_map(rs)
+    if ip[-1] == 0:
+        continue
+    nd = oracle.site_norm(ip, ix, cnt.astype(np.float64), sites)
+    rc_o, xo, st = oracle.kr_balance(ip, ix, nd, max_iter=400)
+    if rc_o != oracle.OK or st.n_iter < 100:
+        continue
+    n_ill += 1
+    counts = ctx.upload(ip, ix, cnt)
+    rc1, x1, i1 = ctx.kr_balance_counts(counts, sites, max_iter=400, check=False)
+    fm = ctx.upload(ip, ix, nd)
+    rc2, x2, i2 = ctx.kr_balance(fm, max_iter=400, check=False)
+    counts.free(); fm.free()
+    if rc1 != 0 or rc2 != 0 or i1.n_iter != st.n_iter or i2.n_iter != st.n_iter:
+        print('case %d: rc/n_iter differ: oracle %d/%d counts %d/%d fp64 %d/%d' % (case, rc_o, st.n_iter, rc1, i1.n_iter, rc2, i2.n_iter), flush=True)
+        n_bad += 1
+        d1 = d2 = float('inf')
+    else:
+        d1, d2 = rel(x1, xo), rel(x2, xo)
+        hist['counts'].append(d1); hist['fp64'].append(d2)
+    if max(d1, d2) > 1e-6:
+        am = sp.csr_matrix((nd, ix, ip), shape=(n, n))
+        dz = (am.diagonal() == 0).astype(np.float64)
+        res = lambda x: float(np.abs(x * (am @ x) + dz * x * x - 1.0).max())
+        print('case %d: n %d nnz %d n_iter %d cuts %d | counts %.2e fp64 %.2e | residual oracle %.2e counts %.2e fp64 %.2e' % (
+            case, n, ip[-1], st.n_iter, st.hit_delta + st.hit_Delta, d1, d2, res(xo), res(x1) if np.isfinite(d1) else -1, res(x2) if np.isfinite(d2) else -1), flush=True)
+        np.savez(os.path.join(out_dir, 'case_%d_%d.npz' % (seed0, case)), ip=ip, ix=ix, counts=cnt, sites=sites, x_oracle=xo,
+                 x_counts=x1, x_fp64=x2, n_iter=st.n_iter, cuts=st.hit_delta + st.hit_Delta)
+for k, v in hist.items():
+    v = np.array(v)
+    if v.size:
+        print('%-6s vs oracle over %d ill-conditioned maps: median %.1e  99%% %.1e  max %.1e  beyond 1e-6: %d' % (
+            k, v.size, np.median(v), np.percentile(v, 99), v.max(), int((v > 1e-6).sum())))
+print('fuzz_ill: %d maps with >= 100 iterations of %d, %d with different rc / n_iter' % (n_ill, n_cases, n_bad))

