@@ -10,7 +10,7 @@ mask compaction -> weight scaling -> Louvain labels on the host (bin3c_amd/pipel
 
 N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  `--mode`:
   sharded   contig-row blocks of ONE map over all GPUs (BASELINE.json configs[3]; strong scaling; bin3c_amd/dist.py:
-            every rank forms and works on its row block of the ordered map; RCCL collectives issued inside libb3c, two per
+            every rank forms and works on its row block of the ordered map; RCCL collectives issued inside libb3c, one per
             SpMV and one per Louvain sub-round)
   replicas  one map per GPU (weak scaling, no data-path collective)
   auto      (default) both, replicas first: `value` is the SHARDED figure ("scaling": "strong") and the replica
@@ -258,7 +258,7 @@ def main():
                            args.config, ' power law' if law == 'powerlaw' else '', n, e_true, nnz, seed, variant, synth_note),
                        'kr_max_iter': max_iter, 'kr_max_iter_reference_default': 1000,
                        'parallelism': 'single GPU' if world == 1 else (
-                           'one map over {} GPUs by contig-row blocks (each rank forms and works on its rows of the ordered map); RCCL: 2 exchanges per SpMV, 1 per Louvain sub-round'.format(world)
+                           'one map over {} GPUs by contig-row blocks (each rank forms and works on its rows of the ordered map); RCCL: 1 exchange per SpMV, 1 per Louvain sub-round'.format(world)
                            if sharded else 'replicas x{} (one map per GPU)'.format(world)),
                        'accepted_contigs': n_acc, 'kr_spmv_per_step': int(spmv_n // args.steps),
                        'louvain_sweeps_per_step': int(last.lv_info.n_sweeps), 'louvain_levels': int(last.lv_info.n_levels),

@@ -1521,10 +1521,16 @@ __global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams pr
                                                KRState *__restrict__ sout, const double *__restrict__ pkb, int PA, int PS,
                                                const double *__restrict__ y, const double *__restrict__ p,
                                                double *__restrict__ rk, const double *__restrict__ w,
-                                               const double *__restrict__ v, double *__restrict__ Z,
+                                               double *v, double *__restrict__ Z,
                                                double *__restrict__ pmin, double *__restrict__ pmax,
-                                               double *__restrict__ psum, int z_first)
+                                               double *__restrict__ psum, int z_first, int64_t mr0, int64_t mr1,
+                                               const double *vx)
 {
+    // Sharded runs (round 3): this kernel covers ALL rows on every rank.  `w` is then the vector exchange buffer with the
+    // ranks' slices of w gathered by the tick's one exchange, `pkb` the gathered partials of p.w | rk.rk; after an outer
+    // SpMV the buffer holds the slices of v = x*(A x) instead (vx != nullptr): rows outside [mr0, mr1) take v and
+    // rk = 1 - v from there (this rank's rows have them from KB).  The min / max / rk.Z partials this kernel leaves are
+    // then complete on every rank and the KA that follows needs no exchange: ONE collective per SpMV instead of two.
     __shared__ double lds[BLK];
     const int64_t stride = (int64_t)gridDim.x * BLK;
     const int64_t i0 = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x;
@@ -1574,6 +1580,21 @@ __global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams pr
         st.next = P_DONE;   // any value but P_INIT: marks the initial SpMV as consumed
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if (vx && (sin->phase == B_OUTER || sin->phase == B_INIT)) {
+        // the other ranks' rows of v and rk (sparse_utils.py:196-198) from the gathered slices; the registers loaded above
+        // are stale for them
+        for (int64_t base = i0; base < n; base += KV_E * stride) {
+#pragma unroll
+            for (int e = 0; e < KV_E; e++) {
+                const int64_t i = base + e * stride;
+                if (i >= n || (i >= mr0 && i < mr1)) continue;
+                const double vn = vx[i];
+                v[i] = vn;
+                rk[i] = 1.0 - vn;
+                if (base == i0) { ev[e] = vn; erk[e] = 1.0 - vn; }
+            }
+        }
+    }
     if (z_first && st.phase == P_INNER_FIRST) {
         // sharded: the first inner iteration starts from Z = rk / v (:158) and rk.Z (:160); formed here, on this rank's rows,
         // so that they travel with the exchange that follows this launch and KA needs none
@@ -1881,6 +1902,23 @@ __global__ void __launch_bounds__(BLK) kr_fold(const double *__restrict__ part, 
     if (threadIdx.x == 0) *dst = r;
 }
 
+// Sharded tick, after KB: block 0 folds the rank's block partials of p.w | rk.rk into its slot of the scalar exchange
+// buffer; on an OUTER tick (state as KB left it) all blocks also copy this rank's slice of v = x*(A x) into the vector
+// exchange buffer -- on an inner tick KB wrote its slice of w there itself.  One launch in front of the tick's ONE exchange.
+__global__ void __launch_bounds__(BLK) kr_fold_pack(const KRState *__restrict__ st, const double *__restrict__ part, int P,
+                                                     double *__restrict__ dst, int64_t r0, int64_t r1, const double *__restrict__ v,
+                                                     double *__restrict__ vec)
+{
+    __shared__ double lds[BLK];
+    const int32_t phase = st->phase;
+    if (phase == B_OUTER || phase == B_INIT)
+        for (int64_t i = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x; i < r1; i += (int64_t)gridDim.x * BLK) vec[i] = v[i];
+    if (blockIdx.x == 0) {
+        const double r = reduce_partials<0>(part, P, 1, lds);
+        if (threadIdx.x == 0) *dst = r;
+    }
+}
+
 // count form: when every count fits 16 bits the SpMV streams a uint16 copy of the values (6 B per entry instead of 8)
 __global__ void kr_max_u32(int64_t nnz, const uint32_t *__restrict__ a, unsigned int *__restrict__ out)
 {
@@ -1992,6 +2030,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // geometry: fixed for a given (n, nnz, world) so that reductions are reproducible
     const int G = grid_for(nloc, BLK * KV_E, 4 * ctx->n_cu);          // vector kernels over this rank's rows (KCD)
     const int GA = grid_for(n, BLK * KV_E, 4 * ctx->n_cu);            // ... over all rows (KA: p, y, x and the operand are kept whole on every rank)
+    const int GK = dist ? GA : G;                                     // KCD: this rank's rows on one GPU, ALL rows when sharded (one exchange per SpMV)
     // (a row block holds the entries of this rank's rows only)
     const double avg = (double)a->nnz / (double)((a->row1 >= 0 && (a->row0 > 0 || a->row1 < n)) ? std::max<int64_t>(1, a->row1 - a->row0) : n);
     unsigned long long maxdeg = 0;
@@ -2036,8 +2075,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int hub_len = hub_kb ? hub_thr : 0x7fffffff;
     const int P = (int)std::max<int64_t>(GA, (int64_t)GS_max + hub_cap);
 
-    DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z_own(ctx, dist ? 1 : n), rk(ctx, n), v(ctx, n), w(ctx, n), u(ctx, n), dfix(ctx, n);
-    struct { double *p; } Z{dist ? D.vec : Z_own.p};   // sharded: Z lives in the exchange buffer (slices gathered after every KCD)
+    DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z_own(ctx, n), rk(ctx, n), v(ctx, n), w(ctx, n), u(ctx, n), dfix(ctx, n);
+    struct { double *p; } Z{Z_own.p};
     DevBuf<double> pmin(ctx, P), pmax(ctx, P), psum(ctx, P), pgam(ctx, P), pk1(ctx, P), pkb(ctx, P);   // block partials, see the kernels
     DevBuf<KRState> states(ctx, 2);
     DevBuf<unsigned long long> counters(ctx, 4);
@@ -2333,7 +2372,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // been enqueued, so the device never idles on the read-back (ticks after convergence are no-ops: at most two batches of them).
     KRState *hstate = (KRState *)ctx->pin;               // two slots of the pinned staging buffer
     hipEvent_t ev_state[2] = {ctx->ev0, ctx->ev1};
-    const bool pipelined = ctx->pin != nullptr && ctx->ev0 != nullptr && ctx->ev1 != nullptr && !dist;
+    const bool pipelined = ctx->pin != nullptr && ctx->ev0 != nullptr && ctx->ev1 != nullptr;
     long long batches = 0;
     bool done = false;
     const bool tick_timing = getenv("B3C_KR_TIMING") != nullptr;
@@ -2343,10 +2382,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         for (int b = 0; b < BATCH; b++) {
             KRState *s0 = states.p + (t & 1), *s1 = states.p + ((t + 1) & 1);
             tmark();
-            // KA: all rows on every rank (sharded: no exchange needed before the SpMV)
-            hipLaunchKernelGGL(kr_ka, dim3(GA), dim3(BLK), 0, s, (int64_t)0, n, prm, s0, s1, dist ? D.scal + 1 : pmin.p, dist ? D.scal + 2 : pmax.p,
-                               dist ? D.scal : psum.p, dist ? cP : G, cS, pgam.p, GA, dist ? 1 : 0, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, rs,
-                               pk1.p, pgam.p, flags, tails_xt ? pumax.p : nullptr);
+            // KA: all rows on every rank.  Sharded: the partials it consumes were formed over all rows by KCD on every rank
+            // (see kr_kcd), so they are read exactly as on one GPU and no exchange precedes the SpMV
+            hipLaunchKernelGGL(kr_ka, dim3(GA), dim3(BLK), 0, s, (int64_t)0, n, prm, s0, s1, pmin.p, pmax.p, psum.p, GK, 1, pgam.p, GA,
+                               dist ? 1 : 0, x.p, y.p, p.p, Z.p, rk.p, v.p, u.p, rs, pk1.p, pgam.p, flags, tails_xt ? pumax.p : nullptr);
             t++;
             tmark();
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
@@ -2361,8 +2400,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             }
             if (n_big) hipLaunchKernelGGL(kr_big_fix, dim3((unsigned)((n_big + 255) / 256)), dim3(256), 0, s, s0, n_big, bk, bh, u.p, corr.p);
             // KB consumes pk1 (from KA, G partials; first inner iteration only), produces pkb (GS partials)
-            const double *kbp = dist ? D.scal : pk1.p;
-            const int kbP = dist ? D.world : G, kbS = cS;
+            // (sharded: rk.Z of a first inner iteration comes from KCD's pass over all rows, G blocks, like the other partials)
+            const double *kbp = dist ? psum.p : pk1.p;
+            const int kbP = dist ? GK : G, kbS = 1;
+            double *const w_kb = dist ? D.vec : w.p;             // sharded: KB writes its slice of w straight into the exchange buffer
             if (tcd) {
                 if (tails_xt)
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
@@ -2370,7 +2411,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                 // dictionary waves and tail waves side by side (512-thread workgroups)
 #define KR_TCD2_ARGS                                                                                                         \
     dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \
-        kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len,     \
+        kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len,     \
         getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0,                                                                   \
         getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu,                     \
         want_tlog ? tlog.p : nullptr, tails_xt ? yhi.p : nullptr, tails_xt ? ylo.p : nullptr, tails_xt ? tex.p : nullptr, corr_p
@@ -2385,46 +2426,41 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 #undef KR_TCD2
             } else {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
-                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
-                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
+                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
+                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
                 else if (avg > 128 && a->kind == B3C_U32 && vec_shape >= 0)    // 4 entries per lane and load: 0.505 vs 0.544 ms at C3
-                    launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
-                else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
-                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
-                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
-                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p, hub_len, corr_p);
+                    launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
+                else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
+                else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
+                else if (avg > 24) launch_kb_pipe<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
+                else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
             }
             if (n_hub) {       // the rows the row-group kernel left out; same state slot, partials behind its GS
                 if (a->kind == B3C_U32 && v16 && !n_big)           // (hub rows read the full 32-bit counts when some are large)
                     hipLaunchKernelGGL(kr_kb_hub<uint16_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices, v16,
-                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p + GS);
+                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p + GS);
                 else if (a->kind == B3C_U32)
                     hipLaunchKernelGGL(kr_kb_hub<uint32_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p + GS);
+                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p + GS);
                 else
                     hipLaunchKernelGGL(kr_kb_hub<double>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w.p, pkb.p + GS);
+                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p + GS);
             }
             if (timed) HIP_TRY(ctx, hipEventRecord(evs.back(), s));
             if (dist) {
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pkb.p, GSP, 0, my_scal);
+                // the tick's ONE exchange: the partial of p.w | rk.rk with this rank's slice of w (inner) or of v (outer)
+                hipLaunchKernelGGL(kr_fold_pack, dim3(nloc > 0 ? grid_for(nloc, BLK, 4 * ctx->n_cu) : 1), dim3(BLK), 0, s, s1, pkb.p, GSP, my_scal, r0, r1,
+                                   v.p, D.vec);
                 int rc;
-                if ((rc = xchg(B3C_BUF_SCAL))) return rc;
+                if ((rc = xchg(B3C_BUF_SCAL_VEC))) return rc;
             }
             t++;
             tmark();
             s0 = states.p + (t & 1); s1 = states.p + ((t + 1) & 1);
-            // KCD consumes pkb (GSP), produces pmin / pmax / psum (G)
-            hipLaunchKernelGGL(kr_kcd, dim3(G), dim3(BLK), 0, s, r0, r1, prm, s0, s1, dist ? D.scal : pkb.p, dist ? cP : GSP, cS, y.p, p.p,
-                               rk.p, w.p, v.p, Z.p, pmin.p, pmax.p, psum.p, dist ? 1 : 0);
-            if (dist) {
-                // second (and last) exchange of the tick: this rank's slice of Z with the partials of rk.Z, min and max
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, psum.p, G, 0, my_scal);
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pmin.p, G, 1, my_scal + 1);
-                hipLaunchKernelGGL(kr_fold, dim3(1), dim3(BLK), 0, s, pmax.p, G, 2, my_scal + 2);
-                int rc;
-                if ((rc = xchg(B3C_BUF_SCAL_VEC))) return rc;
-            }
+            // KCD consumes pkb (GSP; sharded: the gathered rank partials), produces pmin / pmax / psum (GK blocks).  Sharded:
+            // over ALL rows on every rank, so that KA finds complete partials and nothing has to travel after it
+            hipLaunchKernelGGL(kr_kcd, dim3(GK), dim3(BLK), 0, s, dist ? (int64_t)0 : r0, dist ? n : r1, prm, s0, s1, dist ? D.scal : pkb.p, dist ? cP : GSP, cS,
+                               y.p, p.p, rk.p, dist ? D.vec : w.p, v.p, Z.p, pmin.p, pmax.p, psum.p, dist ? 1 : 0, r0, r1, dist ? D.vec : nullptr);
             t++;
             ticks++;
         }

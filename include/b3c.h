@@ -102,14 +102,15 @@ int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
  * `allgather(user, buffer_id)` instead, which must enqueue the same collective on the context's stream and return 0
  * (torch.distributed with gloo in the CPU / one-GPU tests, bin3c_amd/dist.py).
  *
- * KR: two exchanges per SpMV -- the partial of p.w | rk.rk after the SpMV (B3C_BUF_SCAL), and after the vector step the
- * slice of Z = rk*v together with the partials of min/max(ynew) and rk.Z (B3C_BUF_SCAL_VEC, one grouped launch); p, y, x
- * and the operand x*p are then advanced for ALL rows by every rank, so the operand itself is never exchanged.
+ * KR: ONE exchange per SpMV (B3C_BUF_SCAL_VEC, one grouped launch) -- the rank's partial of p.w | rk.rk together with its
+ * slice of w (inner iteration) or of v = x*(A x) (outer iteration).  The vector steps on both sides of the SpMV (alpha,
+ * y, rk, Z, the bound checks; then p and the operand x*p) run over ALL rows on every rank from the gathered slices, so
+ * their reductions are complete everywhere and nothing else travels: 8n bytes + 32 bytes per rank and SpMV.
  * Louvain level 0: the decided labels once per sub-round (B3C_BUF_LABELS), one integer per modularity evaluation
  * (B3C_BUF_ISUM); moves are applied by every rank.
  * b3c_locality_order: the two passes over the (whole, un-ordered) matrix run on this rank's rows; their per-row results
  * travel through B3C_BUF_LABELS (once) and B3C_BUF_VEC (twice).  All of these calls are collective over the ranks. */
-#define B3C_BUF_VEC 0     /* double[world*chunk]  KR: Z slices                     */
+#define B3C_BUF_VEC 0     /* double[world*chunk]  KR: slices of w | v               */
 #define B3C_BUF_SCAL 1    /* double[world*4]      KR partial sums / min / max      */
 #define B3C_BUF_LABELS 2  /* int32[world*chunk]   Louvain decided communities      */
 #define B3C_BUF_ISUM 3    /* int64[world*2]       Louvain integer partial sums     */
