@@ -123,6 +123,7 @@ def main():
     ap.add_argument('--synth', default='default', choices=['default', 'survey'],
                     help="genome layout of the synthetic map: 'default' = G = n/500 genomes ~ rank^-0.5 (the headline workload, "
                          "DESIGN.md section 5); 'survey' = SURVEY.md 8(d) to the letter, G = n/200 genomes ~ Zipf(1.5)")
+    ap.add_argument('--n-sub', type=int, default=0, help='sub-rounds per Louvain sweep (0: the library default, 4)')
     ap.add_argument('--hard', action='store_true',
                     help='a HARD clustering problem on the same contigs: 45 %% inter-genome noise, intra-genome counts not '
                          'boosted (several Louvain levels, a dozen sweeps) instead of the easy planted structure')
@@ -193,13 +194,13 @@ def main():
         acc = {'stage': {}, 'spmv_ms': 0.0, 'spmv_n': 0, 'move_ms': 0.0, 'move_n': 0, 'move_nnz': 0, 'move_rows': 0}
         last = None
         for _ in range(args.warmup):
-            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, max_iter=max_iter)
+            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub)
         gc.collect()
         gc.disable()            # a generation-2 collection in the middle of a step shows up as a 20 ms hole in the GPU timeline
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, max_iter=max_iter)
+            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub)
             for k, v in last.timings.items():
                 acc['stage'][k] = acc['stage'].get(k, 0.0) + v
             acc['spmv_ms'] += last.kr_info.spmv_ms

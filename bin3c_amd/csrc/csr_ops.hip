@@ -295,12 +295,13 @@ extern "C" int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *
     if (!counts || counts->kind != B3C_U32 || !sites || !out) return ctx->fail(B3C_E_ARG, "b3c_site_norm: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t n = counts->n;
-    b3c_mat *m = nullptr;
-    int rc = b3c_mat_alloc(ctx, n, counts->nnz, B3C_F64, &m);
+    MatOwner own(ctx);            // released on every early return below (HIP_TRY included)
+    int rc = b3c_mat_alloc(ctx, n, counts->nnz, B3C_F64, &own.m);
     if (rc) return rc;
+    b3c_mat *m = own.m;
     DevBuf<double> ds(ctx, n);
-    if (!ds.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_site_norm"); }
-    if ((rc = b3c_copy_in(ctx, ds.p, sites, sizeof(double) * (size_t)n))) { b3c_mat_free(ctx, m); return rc; }
+    if (!ds.p) return ctx->fail(B3C_E_NOMEM, "b3c_site_norm");
+    if ((rc = b3c_copy_in(ctx, ds.p, sites, sizeof(double) * (size_t)n))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(m->indptr, counts->indptr, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(m->indices, counts->indices, sizeof(int32_t) * (size_t)counts->nnz, hipMemcpyDeviceToDevice, ctx->stream));
     if (n) {
@@ -314,12 +315,12 @@ extern "C" int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *
     m->sorted_cols = counts->sorted_cols;
     if (counts->ids) {
         m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
-        if (!m->ids) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_site_norm"); }
+        if (!m->ids) return ctx->fail(B3C_E_NOMEM, "b3c_site_norm");
         HIP_TRY(ctx, hipMemcpyAsync(m->ids, counts->ids, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *out = m;
+    *out = own.release();
     return B3C_OK;
 }
 
@@ -368,13 +369,13 @@ extern "C" int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const do
     if (!counts || counts->kind != B3C_U32 || !sites || !x || !out) return ctx->fail(B3C_E_ARG, "b3c_normalise_scale: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t n = counts->n;
-    b3c_mat *m = nullptr;
-    int rc = b3c_mat_alloc(ctx, n, counts->nnz, B3C_F64, &m);
+    MatOwner own(ctx);            // released on every early return below (HIP_TRY included)
+    int rc = b3c_mat_alloc(ctx, n, counts->nnz, B3C_F64, &own.m);
     if (rc) return rc;
+    b3c_mat *m = own.m;
     DevBuf<double> ds(ctx, n), dx(ctx, n);
-    if (!ds.p || !dx.p) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale"); }
+    if (!ds.p || !dx.p) return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale");
     if ((rc = b3c_copy_in(ctx, ds.p, sites, sizeof(double) * (size_t)n)) || (rc = b3c_copy_in(ctx, dx.p, x, sizeof(double) * (size_t)n))) {
-        b3c_mat_free(ctx, m);
         return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(m->indptr, counts->indptr, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, ctx->stream));
@@ -391,12 +392,12 @@ extern "C" int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const do
     m->value_symmetric = graph_form != 0;
     if (counts->ids) {
         m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
-        if (!m->ids) { b3c_mat_free(ctx, m); return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale"); }
+        if (!m->ids) return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale");
         HIP_TRY(ctx, hipMemcpyAsync(m->ids, counts->ids, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *out = m;
+    *out = own.release();
     return B3C_OK;
 }
 

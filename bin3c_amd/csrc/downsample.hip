@@ -325,14 +325,15 @@ extern "C" int b3c_downsample(b3c_ctx *ctx, const b3c_mat *a, int64_t block_size
     if ((rc = b3c_exclusive_scan_i64(ctx, cnt.p, optr.p, nb + 1))) return rc;
     int64_t nnz = 0;
     { const int rb_ = b3c_readback(ctx, &nnz, optr.p + nb, sizeof(int64_t)); if (rb_) return rb_; }
-    b3c_mat *o = nullptr;
-    if ((rc = b3c_mat_alloc(ctx, nb, nnz, B3C_F64, &o))) return rc;
+    MatOwner own(ctx);            // released on every early return below
+    if ((rc = b3c_mat_alloc(ctx, nb, nnz, B3C_F64, &own.m))) return rc;
+    b3c_mat *o = own.m;
     HIP_TRY(ctx, hipMemcpyAsync(o->indptr, optr.p, sizeof(int64_t) * (size_t)(nb + 1), hipMemcpyDeviceToDevice, s));
     if (nnz) {
         const double area = (double)b * (double)b;
         if (method == B3C_DS_MAX) {
             DevBuf<unsigned int> oc(ctx, nnz);
-            if (!oc.p) { b3c_mat_free(ctx, o); return ctx->fail(B3C_E_NOMEM, "b3c_downsample"); }
+            if (!oc.p) return ctx->fail(B3C_E_NOMEM, "b3c_downsample");
             if (wave_form)
                 hipLaunchKernelGGL(k_dw_fill<true>, dim3(g), dim3(DS_BLK), 0, s, n, nb, (uint32_t)b, a->indptr, a->indices,
                                    (const double *)a->data, optr.p, o->indices, (double *)o->data, oc.p, 1.0 / area,
@@ -353,6 +354,6 @@ extern "C" int b3c_downsample(b3c_ctx *ctx, const b3c_mat *a, int64_t block_size
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    *out = o;
+    *out = own.release();
     return B3C_OK;
 }

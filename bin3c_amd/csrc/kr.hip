@@ -1523,13 +1523,13 @@ __global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams pr
                                                double *__restrict__ rk, const double *__restrict__ w,
                                                double *v, double *__restrict__ Z,
                                                double *__restrict__ pmin, double *__restrict__ pmax,
-                                               double *__restrict__ psum, int z_first, int64_t mr0, int64_t mr1,
-                                               const double *vx)
+                                               double *__restrict__ psum, int z_first, const double *vx)
 {
     // Sharded runs (round 3): this kernel covers ALL rows on every rank.  `w` is then the vector exchange buffer with the
     // ranks' slices of w gathered by the tick's one exchange, `pkb` the gathered partials of p.w | rk.rk; after an outer
-    // SpMV the buffer holds the slices of v = x*(A x) instead (vx != nullptr): rows outside [mr0, mr1) take v and
-    // rk = 1 - v from there (this rank's rows have them from KB).  The min / max / rk.Z partials this kernel leaves are
+    // SpMV the buffer holds the slices of v = x*(A x) instead (vx != nullptr): ALL rows take v and rk = 1 - v from there --
+    // this rank's own rows too, although KB left them: the compiler may have contracted KB's 1 - x*t into one fma, and every
+    // rank must hold the same bits or the ranks' iterates drift apart.  The min / max / rk.Z partials this kernel leaves are
     // then complete on every rank and the KA that follows needs no exchange: ONE collective per SpMV instead of two.
     __shared__ double lds[BLK];
     const int64_t stride = (int64_t)gridDim.x * BLK;
@@ -1581,13 +1581,12 @@ __global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams pr
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
     if (vx && (sin->phase == B_OUTER || sin->phase == B_INIT)) {
-        // the other ranks' rows of v and rk (sparse_utils.py:196-198) from the gathered slices; the registers loaded above
-        // are stale for them
+        // v and rk (sparse_utils.py:196-198) of all rows from the gathered slices; the registers loaded above are stale
         for (int64_t base = i0; base < n; base += KV_E * stride) {
 #pragma unroll
             for (int e = 0; e < KV_E; e++) {
                 const int64_t i = base + e * stride;
-                if (i >= n || (i >= mr0 && i < mr1)) continue;
+                if (i >= n) continue;
                 const double vn = vx[i];
                 v[i] = vn;
                 rk[i] = 1.0 - vn;
@@ -1974,10 +1973,13 @@ void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRStat
                     const double *x, const double *p, double *v, double *rk, double *w, double *part_out, int hub_len,
                     const double *corr = nullptr)
 {
-    if (m->kind == B3C_U32 && getenv("B3C_KR_NOGATHER"))   // wrong results by design: the kernel without its random gathers
+#ifdef B3C_PROBES      // timing probe with WRONG RESULTS (the kernel without its random gathers): development builds only, never in the shipped library
+    if (m->kind == B3C_U32 && getenv("B3C_KR_NOGATHER"))
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t, true>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
                            m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
-    else if (m->kind == B3C_U32 && v16)
+    else
+#endif
+    if (m->kind == B3C_U32 && v16)
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint16_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
                            m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
     else if (m->kind == B3C_U32)
@@ -2344,6 +2346,14 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     std::vector<long long> ev_tick;        // which SpMV (0-based) each event pair brackets
     constexpr long long PROF_EVERY = 4;
 
+    // timing probes of the dictionary SpMV that produce WRONG RESULTS exist in development builds only (-DB3C_PROBES)
+#ifdef B3C_PROBES
+    const int tcd_probe = getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0;
+    const uint32_t tcd_probe_mask = getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu;
+#else
+    const int tcd_probe = 0;
+    const uint32_t tcd_probe_mask = 0xFFFFFFFFu;
+#endif
     int t = 0;  // state ping-pong index
     const int BATCH = getenv("B3C_KR_BATCH") ? std::max(1, atoi(getenv("B3C_KR_BATCH"))) : 4;   // ticks per state look (C3: 8 -> 4 saves 0.4 ms of no-op ticks after convergence)
     const int vec_shape = getenv("B3C_KR_VEC") ? atoi(getenv("B3C_KR_VEC")) : 0;   // other kr_kb_vec<LPR, UN> shapes, e.g. 164; -1: scalar-load form
@@ -2412,8 +2422,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 #define KR_TCD2_ARGS                                                                                                         \
     dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \
         kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len,     \
-        getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0,                                                                   \
-        getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu,                     \
+        tcd_probe, tcd_probe_mask,                                                                                                            \
         want_tlog ? tlog.p : nullptr, tails_xt ? yhi.p : nullptr, tails_xt ? ylo.p : nullptr, tails_xt ? tex.p : nullptr, corr_p
 #define KR_TCD2(L, U, TL, T)                                                                                                 \
     do {                                                                                                                     \
@@ -2460,7 +2469,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             // KCD consumes pkb (GSP; sharded: the gathered rank partials), produces pmin / pmax / psum (GK blocks).  Sharded:
             // over ALL rows on every rank, so that KA finds complete partials and nothing has to travel after it
             hipLaunchKernelGGL(kr_kcd, dim3(GK), dim3(BLK), 0, s, dist ? (int64_t)0 : r0, dist ? n : r1, prm, s0, s1, dist ? D.scal : pkb.p, dist ? cP : GSP, cS,
-                               y.p, p.p, rk.p, dist ? D.vec : w.p, v.p, Z.p, pmin.p, pmax.p, psum.p, dist ? 1 : 0, r0, r1, dist ? D.vec : nullptr);
+                               y.p, p.p, rk.p, dist ? D.vec : w.p, v.p, Z.p, pmin.p, pmax.p, psum.p, dist ? 1 : 0, dist ? D.vec : nullptr);
             t++;
             ticks++;
         }
