@@ -187,6 +187,7 @@ extern "C" int b3c_mat_free(b3c_ctx *ctx, b3c_mat *m)
     ctx->release(m->indices);
     ctx->release(m->data);
     ctx->release(m->ids);
+    ctx->release(m->rowmax);
     delete m;
     return B3C_OK;
 }

@@ -114,10 +114,18 @@ struct b3c_mat {
     // rows [row0, row1) are the ones this matrix holds; the others are empty (row block of one rank of the sharded path).
     // row1 < 0: all rows
     int64_t row0 = 0, row1 = -1;
+    // this matrix IS such a row block (b3c_mat_permute_rows with a proper sub-range; kept by site_norm / compress): a flag
+    // and not a test of the bounds, because after compress a block may legitimately cover [0, n) -- all kept rows in one
+    // rank's block -- while another rank's block is empty, and the ranks must agree on which code path they are on
+    bool row_block = false;
     // largest stored value with fmax semantics (-inf: no entries), once a kernel or b3c_max_value has seen all of them.
     // Matrices are immutable after creation; b3c_mat_device_ptrs hands out writable pointers and therefore drops it.
     double vmax = 0.0;
     bool vmax_valid = false;
+    // B3C_U32 matrices: the largest off-diagonal count of every ROW (= of every column when the map is symmetric,
+    // sparse_utils.py:269-281), a by-product of the pass b3c_kr_balance_counts makes over the counts anyway (kr_prep_counts);
+    // b3c_max_offdiag_u32(assume_symmetric) then answers from it without another pass.  Pooled block of n uint32, or null.
+    uint32_t *rowmax = nullptr;
 };
 
 #define HIP_TRY(ctx, expr)                                                                          \

@@ -273,6 +273,8 @@ extern "C" int b3c_max_offdiag_u32(b3c_ctx *ctx, const b3c_mat *counts, int assu
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t n = counts->n;
     if (n == 0) return B3C_OK;
+    // left behind by the balancing's pass over the counts (kr_prep_counts): no second pass
+    if (assume_symmetric && counts->rowmax) return b3c_copy_out(ctx, out, counts->rowmax, sizeof(uint32_t) * (size_t)n);
     DevBuf<uint32_t> d(ctx, n);
     if (!d.p) return ctx->fail(B3C_E_NOMEM, "b3c_max_offdiag_u32");
     const int lpr = pick_lpr(counts);
@@ -312,6 +314,7 @@ extern "C" int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *
     m->ordered = counts->ordered;
     m->row0 = counts->row0;
     m->row1 = counts->row1;
+    m->row_block = counts->row_block;
     m->sorted_cols = counts->sorted_cols;
     if (counts->ids) {
         m->ids = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
@@ -388,6 +391,7 @@ extern "C" int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const do
     m->ordered = counts->ordered;
     m->row0 = counts->row0;
     m->row1 = counts->row1;
+    m->row_block = counts->row_block;
     m->sorted_cols = counts->sorted_cols;
     m->value_symmetric = graph_form != 0;
     if (counts->ids) {
@@ -652,6 +656,7 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
         }
         o->row0 = b[0];
         o->row1 = b[1];
+        o->row_block = a->row_block;
     }
     if (a->ids && n) {
         DevBuf<int64_t> keep_o(ctx, n + 1), rank_o(ctx, n + 1);

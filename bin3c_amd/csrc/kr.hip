@@ -1771,7 +1771,8 @@ __global__ void __launch_bounds__(BLK) kr_prep_counts(int64_t n, int64_t c0, int
                                                        const int32_t *__restrict__ indices, const uint32_t *__restrict__ a,
                                                        double *__restrict__ dfix, uint16_t *__restrict__ out16,
                                                        unsigned long long *__restrict__ sums,      // [0..3] checksums, [4] largest count
-                                                       unsigned long long *__restrict__ n_zero)
+                                                       unsigned long long *__restrict__ n_zero,
+                                                       uint32_t *__restrict__ rowmax)               // largest off-diagonal count per row, or null
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
@@ -1782,6 +1783,7 @@ __global__ void __launch_bounds__(BLK) kr_prep_counts(int64_t n, int64_t c0, int
     for (int64_t row = wave; row < n; row += nwave) {
         const int64_t s = indptr[row], e = indptr[row + 1];
         bool found = false;                                   // this lane holds a non-zero diagonal entry
+        uint32_t rmax = 0;                                    // largest off-diagonal count of the row (max_offdiag, sparse_utils.py:269-281)
         for (int64_t base = s; base < e; base += 256) {
             int32_t j[4];
             uint32_t c[4];
@@ -1798,6 +1800,7 @@ __global__ void __launch_bounds__(BLK) kr_prep_counts(int64_t n, int64_t c0, int
                 out16[base + t * 64 + lane] = (uint16_t)c[t];
                 vmax = c[t] > vmax ? c[t] : vmax;
                 if (j[t] == (int32_t)row) { found = found || c[t] != 0u; continue; }
+                rmax = c[t] > rmax ? c[t] : rmax;
                 const bool up = j[t] > (int32_t)row;
                 const unsigned long long lo = up ? (unsigned long long)row : (unsigned long long)j[t];
                 const unsigned long long hi = up ? (unsigned long long)j[t] : (unsigned long long)row;
@@ -1809,6 +1812,14 @@ __global__ void __launch_bounds__(BLK) kr_prep_counts(int64_t n, int64_t c0, int
             }
         }
         const bool z = __ballot(found) == 0ull;
+        if (rowmax) {                                         // wave-uniform
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t = (uint32_t)__shfl_down((int)rmax, o, 64);
+                rmax = t > rmax ? t : rmax;
+            }
+            if (lane == 0) rowmax[row] = rmax;
+        }
         if (lane == 0) {
             dfix[row] = z ? 1.0 : 0.0;
             zeros += (z && row >= c0 && row < c1) ? 1 : 0;
@@ -2034,7 +2045,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int GA = grid_for(n, BLK * KV_E, 4 * ctx->n_cu);            // ... over all rows (KA: p, y, x and the operand are kept whole on every rank)
     const int GK = dist ? GA : G;                                     // KCD: this rank's rows on one GPU, ALL rows when sharded (one exchange per SpMV)
     // (a row block holds the entries of this rank's rows only)
-    const double avg = (double)a->nnz / (double)((a->row1 >= 0 && (a->row0 > 0 || a->row1 < n)) ? std::max<int64_t>(1, a->row1 - a->row0) : n);
+    const double avg = (double)a->nnz / (double)(a->row_block ? std::max<int64_t>(1, a->row1 - a->row0) : n);
     unsigned long long maxdeg = 0;
     {
         DevBuf<unsigned long long> md(ctx, 1);
@@ -2102,7 +2113,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int gscan = grid_for(n, BLK / 64, 16 * ctx->n_cu);
     // row block (a rank of the sharded path holds only its rows): zero diagonals are counted over its rows, the checksums
     // cover its rows, and both are combined over the ranks below
-    const bool block = dist && a->row1 >= 0 && (a->row0 > 0 || a->row1 < n);
+    const bool block = dist && a->row_block;
     if (block && (a->row0 != r0 || a->row1 != r1))
         return ctx->fail(B3C_E_ARG, "b3c_kr_balance: the row block of the matrix is not this rank's row range");
     if (block && !a->ordered) return ctx->fail(B3C_E_ARG, "b3c_kr_balance: a row block must come from b3c_mat_permute_rows");
@@ -2129,7 +2140,13 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (!hs.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
         HIP_TRY(ctx, hipMemsetAsync(hs.p, 0, sizeof(unsigned long long) * 5, s));
         const int gh = grid_for(n, 4, 4 * ctx->n_cu);
-        if (fused_prep) hipLaunchKernelGGL(kr_prep_counts, dim3(gh), dim3(BLK), 0, s, n, zc0, zc1, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, v16buf.p, hs.p, counters.p);
+        if (fused_prep) {
+            // by-product kept with the matrix (immutable once created): the off-diagonal maximum of every row
+            b3c_mat *am = const_cast<b3c_mat *>(a);
+            uint32_t *rm = am->rowmax ? nullptr : (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
+            hipLaunchKernelGGL(kr_prep_counts, dim3(gh), dim3(BLK), 0, s, n, zc0, zc1, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, v16buf.p, hs.p, counters.p, rm);
+            if (rm) am->rowmax = rm;          // (read on this stream only; the read-back below orders it before any use)
+        }
         else if (counts) hipLaunchKernelGGL(kr_sym_hash<uint32_t>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, hs.p);
         else hipLaunchKernelGGL(kr_sym_hash<double>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, hs.p);
         if (fused_prep) { const int rb_ = b3c_readback(ctx, &prep_max, hs.p + 4, sizeof(prep_max)); if (rb_) return rb_; }

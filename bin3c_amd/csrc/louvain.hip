@@ -1399,7 +1399,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     if (!labels.p || !q0.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
     int32_t shift = 0;
     // sharded level 0 on a row block (b3c_mat_permute_rows + compress): this rank holds the entries of its rows only
-    const bool blockm = ctx->has_dist && a->row1 >= 0 && (a->row0 > 0 || a->row1 < n0);
+    const bool blockm = ctx->has_dist && a->row_block;
     if (blockm && reorder) return ctx->fail(B3C_E_ARG, "b3c_louvain: a row block must be ordered by the caller");
     rc = quantise_graph(ctx, a, ids0, scl, q0.p, &shift, blockm);
     if (rc) return rc;

@@ -823,6 +823,7 @@ extern "C" int b3c_mat_permute_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_
     m->value_symmetric = a->value_symmetric;
     m->row0 = row0;
     m->row1 = row1;
+    m->row_block = row0 > 0 || row1 < n;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *out = own.release();
     return B3C_OK;
