@@ -21,7 +21,8 @@ extern "C" int b3c_abi_layout(int which, int32_t *out, int cap)
                                  F(b3c_louvain_info, n_comm), F(b3c_louvain_info, n_levels), F(b3c_louvain_info, n_sweeps),
                                  F(b3c_louvain_info, n_moves), F(b3c_louvain_info, quant_shift), F(b3c_louvain_info, reserved),
                                  F(b3c_louvain_info, modularity), F(b3c_louvain_info, move_ms), F(b3c_louvain_info, n_move_launch),
-                                 F(b3c_louvain_info, move_nnz), F(b3c_louvain_info, move_rows), F(b3c_louvain_info, agg_gathered_runs)};
+                                 F(b3c_louvain_info, move_nnz), F(b3c_louvain_info, move_rows), F(b3c_louvain_info, n_comm_level0),
+                                 F(b3c_louvain_info, agg_gathered_runs)};
     static const int32_t ds[] = {(int32_t)sizeof(b3c_dist), 0,
                                  F(b3c_dist, rank), F(b3c_dist, world), F(b3c_dist, chunk), F(b3c_dist, vec), F(b3c_dist, scal),
                                  F(b3c_dist, labels), F(b3c_dist, isum), F(b3c_dist, allgather), F(b3c_dist, user),
@@ -75,6 +76,12 @@ extern "C" int b3c_ctx_destroy(b3c_ctx *ctx)
     for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipEventDestroy(ctx->ev_fork);
+        (void)hipEventDestroy(ctx->ev_join);
+        (void)hipStreamDestroy(ctx->side);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return B3C_OK;
@@ -229,6 +236,7 @@ extern "C" int b3c_mat_device_ptrs(const b3c_mat *m, void **indptr, void **indic
     if (data) {
         *data = m->data;
         const_cast<b3c_mat *>(m)->vmax_valid = false;      // the caller may write through this pointer
+        const_cast<b3c_mat *>(m)->rowmax_valid = false;
     }
     return B3C_OK;
 }

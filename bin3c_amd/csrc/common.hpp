@@ -34,6 +34,22 @@ struct b3c_ctx {
         return hipEventCreate(&e) == hipSuccess ? e : nullptr;
     }
     void ev_put(hipEvent_t e) { if (e) evpool.push_back(e); }
+    // a second stream for short kernels that are independent of the one just launched (Louvain: the few hub nodes of a
+    // sub-round beside the grouped scan); forked and joined with the two events below
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_ok()
+    {
+        if (side) return true;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(side);
+            side = nullptr;
+            return false;
+        }
+        return true;
+    }
     void *pin = nullptr;      // pinned host staging for small read-backs (a pageable destination costs a staged copy)
     b3c_dist dist;            // row-sharded multi-GPU execution (b3c_ctx_set_dist); world <= 1: off
     bool has_dist = false;
@@ -126,6 +142,7 @@ struct b3c_mat {
     // sparse_utils.py:269-281), a by-product of the pass b3c_kr_balance_counts makes over the counts anyway (kr_prep_counts);
     // b3c_max_offdiag_u32(assume_symmetric) then answers from it without another pass.  Pooled block of n uint32, or null.
     uint32_t *rowmax = nullptr;
+    bool rowmax_valid = false;      // cleared when b3c_mat_device_ptrs hands out a writable data pointer
 };
 
 #define HIP_TRY(ctx, expr)                                                                          \

@@ -274,7 +274,7 @@ extern "C" int b3c_max_offdiag_u32(b3c_ctx *ctx, const b3c_mat *counts, int assu
     const int64_t n = counts->n;
     if (n == 0) return B3C_OK;
     // left behind by the balancing's pass over the counts (kr_prep_counts): no second pass
-    if (assume_symmetric && counts->rowmax) return b3c_copy_out(ctx, out, counts->rowmax, sizeof(uint32_t) * (size_t)n);
+    if (assume_symmetric && counts->rowmax && counts->rowmax_valid) return b3c_copy_out(ctx, out, counts->rowmax, sizeof(uint32_t) * (size_t)n);
     DevBuf<uint32_t> d(ctx, n);
     if (!d.p) return ctx->fail(B3C_E_NOMEM, "b3c_max_offdiag_u32");
     const int lpr = pick_lpr(counts);

@@ -2143,9 +2143,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (fused_prep) {
             // by-product kept with the matrix (immutable once created): the off-diagonal maximum of every row
             b3c_mat *am = const_cast<b3c_mat *>(a);
-            uint32_t *rm = am->rowmax ? nullptr : (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
+            if (!am->rowmax) am->rowmax = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
+            uint32_t *rm = am->rowmax_valid ? nullptr : am->rowmax;
             hipLaunchKernelGGL(kr_prep_counts, dim3(gh), dim3(BLK), 0, s, n, zc0, zc1, a->indptr, a->indices, (const uint32_t *)a->data, dfix.p, v16buf.p, hs.p, counters.p, rm);
-            if (rm) am->rowmax = rm;          // (read on this stream only; the read-back below orders it before any use)
+            if (rm) am->rowmax_valid = true;  // (read on this stream only; the read-back below orders it before any use)
         }
         else if (counts) hipLaunchKernelGGL(kr_sym_hash<uint32_t>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data, hs.p);
         else hipLaunchKernelGGL(kr_sym_hash<double>, dim3(gh), dim3(BLK), 0, s, n, a->indptr, a->indices, (const double *)a->data, hs.p);

@@ -487,8 +487,9 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_direct(int64_t n, int n_sub, 
 // summed in registers; only groups that saw a foreign community take turns on the wave's LDS table.
 // The node list of a sub-round is fixed for a level (the bucket depends on the id only), so it is built once.
 // ---------------------------------------------------------------------------------------------
-// Node lists of one level, all at once.  Segment r < n_sub: the nodes of sub-round r with at most max_deg entries (grouped
-// kernel); segment n_sub + r: those with more (wave-per-node kernel).  A node sets the flag of its segment; ONE exclusive
+// Node lists of one level, all at once.  Without hubs: segment r = the nodes of sub-round r.  With hubs: segment 2r = the nodes of
+// sub-round r with at most max_deg entries (grouped kernel), segment 2r + 1 = those with more (wave-per-node kernel) -- adjacent,
+// so that the passes that treat both alike (apply, internal-weight delta) cover a sub-round in ONE launch.  A node sets the flag of its segment; ONE exclusive
 // scan over the n_seg * nloc flags gives every listed node its position in the common list and, at the segment starts,
 // the list boundaries.  Inside a segment the nodes ascend, as they did when every segment had its own scan.
 __device__ __forceinline__ int lv_list_segment(int64_t i, int n_sub, int max_deg, int with_hubs, const int64_t *__restrict__ indptr,
@@ -498,8 +499,8 @@ __device__ __forceinline__ int lv_list_segment(int64_t i, int n_sub, int max_deg
     const int64_t deg = indptr[i + 1] - indptr[i];
     const int32_t id = ids ? ids[i] : (int32_t)i;
     const int b = (int)bucket_of(id, n_sub);
-    if (deg <= max_deg) return b;
-    return with_hubs ? n_sub + b : -1;
+    if (deg <= max_deg) return with_hubs ? 2 * b : b;
+    return with_hubs ? 2 * b + 1 : -1;
 }
 
 __global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, int max_deg, int with_hubs,
@@ -1275,7 +1276,7 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
     hipStream_t s = ctx->stream;
     const int64_t n = a->n, nnz = a->nnz;
     *shift_out = 0;
-    if (nnz == 0) return B3C_OK;
+    if (nnz == 0 && !blockm) return B3C_OK;          // (an EMPTY row block still takes part in the two exchanges below)
     // value-symmetric matrices (the normal case: graph form) need no materialised weights: a * scl is formed on the fly
     const bool direct = a->value_symmetric;
     DevBuf<double> w(ctx, direct ? 1 : nnz);
@@ -1500,8 +1501,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // grouped lists and, behind them, the hubs the grouped kernel leaves out (usually a handful): one flag pass, one
         // scan, one fill, one read-back of the boundaries for all sub-rounds
         DevBuf<NodeRec> lists(ctx, grouped ? nloc + 1 : 1);
-        const NodeRec *nlist_p = lists.p, *hlist_p = lists.p;
-        std::vector<int64_t> loff(n_sub + 1, 0), hoff(n_sub + 1, 0);
+        const NodeRec *nlist_p = lists.p;
+        std::vector<int64_t> loff(n_sub + 1, 0), hoff(n_sub + 1, 0), lend(n_sub + 1, 0);
         if (grouped) {
             const int n_seg = need_wave_kernel ? 2 * n_sub : n_sub;
             const int64_t tot = (int64_t)n_seg * nloc + 1;
@@ -1515,10 +1516,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             hipLaunchKernelGGL(k_lv_list_bounds, dim3(1), dim3(64), 0, s, n_seg, nloc, lpos.p, bnd.p);
             std::vector<int64_t> hb(n_seg + 1, 0);
             { const int rb_ = b3c_readback(ctx, hb.data(), bnd.p, sizeof(int64_t) * hb.size()); if (rb_) return rb_; }
-            for (int r = 0; r <= n_sub; r++) loff[r] = hb[r];
-            if (need_wave_kernel) {
-                hlist_p = lists.p + hb[n_sub];
-                for (int r = 0; r <= n_sub; r++) hoff[r] = hb[n_sub + r] - hb[n_sub];
+            // [loff[r], hoff[r]) grouped nodes of sub-round r, [hoff[r], loff[r] + span[r]) its hubs
+            for (int r = 0; r < n_sub; r++) {
+                loff[r] = need_wave_kernel ? hb[2 * r] : hb[r];
+                hoff[r] = need_wave_kernel ? hb[2 * r + 1] : hb[r + 1];
+                lend[r] = need_wave_kernel ? hb[2 * r + 2] : hb[r + 1];
             }
         }
 
@@ -1540,7 +1542,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         int32_t *stamp_p = stamps ? stamp.p : nullptr, *tstamp_p = stamps ? tstamp.p : nullptr;
         int32_t epoch = 0;                               // sub-rounds of this level so far
         int64_t max_list = 0;
-        for (int r = 0; r < n_sub; r++) max_list = std::max(max_list, loff[r + 1] - loff[r]);
+        for (int r = 0; r < n_sub; r++) max_list = std::max(max_list, hoff[r] - loff[r]);
         DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1);
         DevBuf<unsigned long long> pcnt(ctx, 1);
         if (!plist.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
@@ -1592,8 +1594,17 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             for (int r = 0; r < n_sub; r++) {
                 epoch++;
                 evs.rec();
-                if (grouped && loff[r + 1] > loff[r]) {
-                    const int64_t cntr = loff[r + 1] - loff[r];
+                // the handful of hub nodes of the sub-round run on the side stream BESIDE the grouped scan (both read the
+                // state of the sub-round's start and write nxt[] of their own nodes): 17 us that used to follow it
+                const bool hub_side = grouped && need_wave_kernel && lend[r] > hoff[r] && hoff[r] > loff[r] && ctx->side_ok();
+                hipStream_t hs = s;
+                if (hub_side) {
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+                    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+                    hs = ctx->side;
+                }
+                if (grouped && hoff[r] > loff[r]) {
+                    const int64_t cntr = hoff[r] - loff[r];
                     const NodeRec *lst = nlist_p + loff[r];
                     const int64_t *cnt_dev = nullptr;
                     if (incr && can_prune) {
@@ -1623,13 +1634,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     hipLaunchKernelGGL(k_lv_decide_direct<LV_DIRECT_CAP>, dim3(grid_for(n, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, n_sub, r, m2,
                                        g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p, csize.p, nxt_p);
                 } else
-                if (need_wave_kernel && (!grouped || hoff[r + 1] > hoff[r])) {
+                if (need_wave_kernel && (!grouped || lend[r] > hoff[r])) {
                     // all rows of this rank (small levels), or just the hubs the grouped kernel left out
-                    const NodeRec *hubs = grouped ? hlist_p + hoff[r] : nullptr;
-                    const int64_t w0 = grouped ? 0 : r0, w1 = grouped ? hoff[r + 1] - hoff[r] : r1;
+                    const NodeRec *hubs = grouped ? nlist_p + hoff[r] : nullptr;
+                    const int64_t w0 = grouped ? 0 : r0, w1 = grouped ? lend[r] - hoff[r] : r1;
                     const int gwh = grid_for(w1 - w0, WPB, 16 * ctx->n_cu);
 #define LV_DECIDE(C)                                                                                                     \
-    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gwh), dim3(BLK), 0, s, w0, w1, hubs, -1, n_sub, r, m2, g.indptr, g.indices, g.q, ids, \
+    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gwh), dim3(BLK), 0, hs, w0, w1, hubs, -1, n_sub, r, m2, g.indptr, g.indices, g.q, ids, \
                        kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p)
                     switch (cap) {
                     case 128: LV_DECIDE(128); break;
@@ -1640,24 +1651,25 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     }
 #undef LV_DECIDE
                 }
+                if (hub_side) {
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+                    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+                }
                 evs.rec();
                 // every rank decided for its rows: gather the decisions
                 if (dist && (rc = b3c_dist_allgather_rows(ctx, nxt.p, 4, starts.data(), starts_dev.p))) { free_graph(ctx, g); return rc; }
                 info->n_move_launch++;
                 if (incr) {
-                    const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
+                    // grouped nodes and hubs of the sub-round are adjacent in the list: one launch
+                    const int64_t c1 = lend[r] - loff[r];
                     if (c1) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c1, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c1,
                                                nlist_p + loff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p, r0, r1, stamp_p, epoch + 1);
-                    if (c2) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c2, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c2,
-                                               hlist_p + hoff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p, r0, r1, stamp_p, epoch + 1);
                 }
                 if (grouped && !dist) {
                     // only the nodes that decided in this sub-round can have moved
-                    const int64_t c1 = loff[r + 1] - loff[r], c2 = need_wave_kernel ? hoff[r + 1] - hoff[r] : 0;
+                    const int64_t c1 = lend[r] - loff[r];
                     if (c1) hipLaunchKernelGGL(k_lv_apply_list, dim3(grid_for(c1, BLK, 4 * ctx->n_cu)), dim3(BLK), 0, s, c1,
                                                nlist_p + loff[r], kdeg.p, tot.p, com.p, nxt_p, csize.p, ctr.p + 1);
-                    if (c2) hipLaunchKernelGGL(k_lv_apply_list, dim3(grid_for(c2, BLK, 4 * ctx->n_cu)), dim3(BLK), 0, s, c2,
-                                               hlist_p + hoff[r], kdeg.p, tot.p, com.p, nxt_p, csize.p, ctr.p + 1);
                 } else {
                     hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt_p,
                                        csize.p, ctr.p + 1, r0, r1, tstamp_p, epoch);
@@ -1691,6 +1703,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         hipLaunchKernelGGL(k_update_labels, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, n0, labels.p, cn.p);
         HIP_TRY(ctx, hipStreamSynchronize(s));
         info->n_comm = (int32_t)kc;
+        if (info->n_levels == 1) info->n_comm_level0 = kc;
 
         // ---- induced graph ----
         LvGraph h;

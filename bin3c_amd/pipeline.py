@@ -199,22 +199,6 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
         t['order'] = time.perf_counter() - t0
 
         try:
-            # set_primary_acceptance_mask (contact_map.py:888-905)
-            t0 = time.perf_counter()
-            signal_w = None
-            if mask is None:
-                signal_w = torch.empty(n, dtype=torch.int32, device=dev)          # uint32 bit pattern
-                ctx.max_offdiag_u32(work, assume_symmetric=True, out=signal_w)
-                if block is not None:
-                    ctx.dist_allgather_i32(signal_w)           # every rank scanned its rows
-                sig64 = signal_w.long() & 0xFFFFFFFF
-                mask_w = ((lengths_t >= int(min_len)) & (sig64 >= int(min_sig))).to(torch.uint8)
-            else:
-                mask_w = torch.as_tensor(np.asarray(mask, dtype=np.uint8), device=dev)
-                if n2o is not None:
-                    mask_w = mask_w[n2o.long()]
-            t['mask'] = time.perf_counter() - t0
-
             # contact_map.py:933 + :939 (-> sparse_utils.py:90): site normalisation folded into the balancing of the
             # raw counts (8 bytes per entry instead of 12), then one pass writes the balanced map: normalisation
             # exactly as the reference forms it and X A X (sparse_utils.py:223-224).  A bitwise-symmetric A (the
@@ -236,6 +220,24 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
                 res.kr_strict = True
             ctx._check(rc)
             t['kr'] = time.perf_counter() - t0
+            # set_primary_acceptance_mask (contact_map.py:888-905).  After the balancing: its pass over the counts leaves the
+            # off-diagonal maximum of every row with the matrix, so the signal costs no pass of its own (the mask is first
+            # needed by the sub-map below; the balancing works on the whole map, contact_map.py:929-945)
+            t0 = time.perf_counter()
+            signal_w = None
+            if mask is None:
+                signal_w = torch.empty(n, dtype=torch.int32, device=dev)          # uint32 bit pattern
+                ctx.max_offdiag_u32(work, assume_symmetric=True, out=signal_w)
+                if block is not None:
+                    ctx.dist_allgather_i32(signal_w)           # every rank scanned its rows
+                sig64 = signal_w.long() & 0xFFFFFFFF
+                mask_w = ((lengths_t >= int(min_len)) & (sig64 >= int(min_sig))).to(torch.uint8)
+            else:
+                mask_w = torch.as_tensor(np.asarray(mask, dtype=np.uint8), device=dev)
+                if n2o is not None:
+                    mask_w = mask_w[n2o.long()]
+            t['mask'] = time.perf_counter() - t0
+
         except Exception:
             if work is not counts:
                 work.free()

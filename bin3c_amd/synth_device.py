@@ -8,8 +8,8 @@ already: 1e9 draws at 5M contigs leave 4.6e8 unique edges, and the stated 1e9 un
 draws -- minutes of numpy and >100 GB of host memory.  Here batches of draws are merged into a sorted (pair, count) set
 until the number of UNIQUE intra-genome edges hits its target (within `tol`), each batch sized from the yield of the one
 before.  The model is the host generator's: same genome layout, contig tables (numpy RandomState(seed): permutation,
-lengths, sites), 90 % intra-genome / 10 % uniform noise, counts Geometric(0.2) x 5 | x 1 with duplicates summed
-(saturating at 2^32 - 1), diagonal Geometric(0.02) with 5 % zeros.  The draws themselves come from torch's Philox
+lengths, sites), 90 % intra-genome / 10 % uniform noise, counts Geometric(0.2) x 5 | x 1 -- one per unique pair by default, or
+with duplicates summed like the host generator (`dup`, see make_counts_device; saturating at 2^32 - 1), diagonal Geometric(0.02) with 5 % zeros.  The draws themselves come from torch's Philox
 generator on the device (seeded), so a map is reproducible on this software stack but is not the host generator's map.
 """
 import numpy as np
@@ -54,8 +54,14 @@ def _reduce_batch(key, c):
 
 
 def make_counts_device(ctx, n, n_edges, seed, degree_law='powerlaw', noise=0.1, intra_boost=5, genomes=None,
-                       genome_law='sqrt', batch=1 << 28, tol=0.005, max_batches=200, verbose=False, extra=None):
+                       genome_law='sqrt', batch=1 << 28, tol=0.005, max_batches=200, verbose=False, extra=None, dup='first'):
     """
+    :param dup: what a pair drawn more than once keeps.  'sum': the sum of its draws' counts, as the host generator does -- under
+                the power law a hub pair is then drawn thousands of times and carries a count of 10^5..10^6 beside tail pairs of 5,
+                and Knight-Ruiz needs TENS OF THOUSANDS of iterations at the stated edge counts (measured: 400k contigs / 1.6e7
+                edges > 5,000; 4M / 3e8 > 20,000 -- the reference's limit is 1,000).  'first' (default): ONE count per unique
+                pair, Geometric(0.2) x boost, drawn after de-duplication: the DEGREES follow the power law (hub contigs with
+                10^5..10^6 partners), the counts do not explode, and the balancing stays in the hundreds of iterations.
     :param extra: optional (lo, hi, count) numpy arrays of further pairs (lo < hi) merged into the stream (tests: planted hubs)
     :return: (counts Mat in HBM, E = unique undirected off-diagonal edges, lengths int32[n], sites float64[n],
               genome int32[n], info dict with the draws it took)
@@ -117,8 +123,11 @@ def make_counts_device(ctx, n, n_edges, seed, degree_law='powerlaw', noise=0.1, 
         b = perm_t[(base + b)[keep]]
         del g, sz, base, keep
         key = torch.minimum(a, b) * n + torch.maximum(a, b)
-        c = geometric(key.shape[0], 0.2) * intra_boost
         del a, b
+        if dup == 'sum':
+            c = geometric(key.shape[0], 0.2) * intra_boost
+        else:
+            c = torch.zeros(key.shape[0], dtype=torch.int64, device=dev)       # counts are drawn per unique pair below
         k2, c2 = _reduce_batch(key, c)
         del key, c
         keys, cnts = _merge(keys, cnts, k2, c2)
@@ -135,16 +144,21 @@ def make_counts_device(ctx, n, n_edges, seed, degree_law='powerlaw', noise=0.1, 
         m = int(min(batch, max(1 << 16, (n_intra - nu) / per_draw)))
     info['intra_draws'] = draws
     info['intra_unique'] = nu
+    if dup != 'sum' and keys is not None:
+        cnts = geometric(keys.shape[0], 0.2) * intra_boost                       # one count per unique intra-genome pair
     if n_noise > 0:
         na = torch.randint(0, n, (int(n_noise * 1.01) + 8,), device=dev, generator=gen)
         nb = torch.randint(0, n, (na.shape[0],), device=dev, generator=gen)
         keep = na != nb
         na, nb = na[keep], nb[keep]
         key = torch.minimum(na, nb) * n + torch.maximum(na, nb)
-        c = geometric(key.shape[0], 0.2)
         del na, nb, keep
-        k2, c2 = _reduce_batch(key, c)
-        del key, c
+        if dup == 'sum':
+            k2, c2 = _reduce_batch(key, geometric(key.shape[0], 0.2))
+        else:
+            k2 = torch.unique(key)
+            c2 = geometric(k2.shape[0], 0.2)
+        del key
         keys, cnts = _merge(keys, cnts, k2, c2)
     if extra is not None:
         xl = torch.as_tensor(np.asarray(extra[0], dtype=np.int64), device=dev)

@@ -74,6 +74,7 @@ typedef struct {
     int64_t n_move_launch;
     int64_t move_nnz;     /* stored entries scanned by those launches (for the roofline) */
     int64_t move_rows;    /* rows visited by those launches */
+    int64_t n_comm_level0; /* communities level 0 ended with (later levels merge them: n_comm is the final count) */
     int64_t agg_gathered_runs; /* row blocks, levels with more communities than the bin table holds: (community pair,
                                 * weight) runs gathered over the ranks for the second reduction; 0 otherwise */
 } b3c_louvain_info;

@@ -142,6 +142,7 @@ def gpu_many_mode(rank, world):
     counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
     single = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5, max_iter=5000)
     assert single.lv_info.n_levels >= 1 and single.lv_info.agg_gathered_runs == 0
+    assert single.lv_info.n_comm_level0 > 4096, single.lv_info.n_comm_level0          # beyond the kc x kc bin table
     sess = DistSession(ctx, sm.n)
     res = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5, max_iter=5000)
     sess.check()
@@ -167,7 +168,8 @@ def gpu_many_mode(rank, world):
             os.environ.pop(k)
     c2.free()
     counts.free()
-    print('rank %d gpu-many ok (%d communities after level 0 runs gathered: %d)' % (rank, single.lv_info.n_comm, res.lv_info.agg_gathered_runs))
+    assert res.lv_info.n_comm_level0 == single.lv_info.n_comm_level0
+    print('rank %d gpu-many ok (%d communities after level 0, runs gathered: %d)' % (rank, single.lv_info.n_comm_level0, res.lv_info.agg_gathered_runs))
     ctx.close()
 
 
