@@ -123,6 +123,10 @@ def main():
     ap.add_argument('--synth', default='default', choices=['default', 'survey'],
                     help="genome layout of the synthetic map: 'default' = G = n/500 genomes ~ rank^-0.5 (the headline workload, "
                          "DESIGN.md section 5); 'survey' = SURVEY.md 8(d) to the letter, G = n/200 genomes ~ Zipf(1.5)")
+    ap.add_argument('--c5-counts', default='unique', choices=['unique', 'summed-draws'],
+                    help="power-law maps: 'unique' = the stated number of UNIQUE edges, one count per pair (default); 'summed-draws' "
+                         "= that many DRAWS with duplicates summed, the host generator's rule (round 2's C5: 4.6e8 edges whose hub "
+                         "pairs carry counts of 10^5..10^6 -- about 2,450 KR iterations)")
     ap.add_argument('--n-sub', type=int, default=0, help='sub-rounds per Louvain sweep (0: the library default, 4)')
     ap.add_argument('--hard', action='store_true',
                     help='a HARD clustering problem on the same contigs: 45 %% inter-genome noise, intra-genome counts not '
@@ -167,10 +171,12 @@ def main():
         # the host generator sizes its draws for uniform endpoints; under the power law they collapse onto hub pairs (1e9 draws
         # -> 4.6e8 unique edges at C5).  The device generator draws until the number of UNIQUE edges is the stated one.
         from bin3c_amd.synth_device import make_counts_device
+        summed = args.c5_counts == 'summed-draws'
         counts, e_true, lengths_h, sites_h, _genome, sinfo = make_counts_device(ctx, n, n_edges, seed, law, noise, boost,
-                                                                                genome_law=genome_law)
-        synth_note = ', drawn on the device ({:.3g} intra-genome draws for {:.3g} unique intra-genome edges)'.format(
-            sinfo['intra_draws'], sinfo['intra_unique'])
+                                                                                genome_law=genome_law, dup='sum' if summed else 'first',
+                                                                                draws_only=summed)
+        synth_note = ', drawn on the device ({:.3g} intra-genome draws for {:.3g} unique intra-genome edges; {})'.format(
+            sinfo['intra_draws'], sinfo['intra_unique'], 'duplicate draws summed' if summed else 'one count per unique pair')
     else:
         lo, hi, cnt, diag, lengths_h, sites_h, _genome = make_edges(n, n_edges, seed, law, noise, boost, genome_law=genome_law)
         counts, e_true = ctx.coo_symmetrise(n, lo, hi, cnt, diag)

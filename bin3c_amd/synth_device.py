@@ -54,7 +54,7 @@ def _reduce_batch(key, c):
 
 
 def make_counts_device(ctx, n, n_edges, seed, degree_law='powerlaw', noise=0.1, intra_boost=5, genomes=None,
-                       genome_law='sqrt', batch=1 << 28, tol=0.005, max_batches=200, verbose=False, extra=None, dup='first'):
+                       genome_law='sqrt', batch=1 << 28, tol=0.005, max_batches=200, verbose=False, extra=None, dup='first', draws_only=False):
     """
     :param dup: what a pair drawn more than once keeps.  'sum': the sum of its draws' counts, as the host generator does -- under
                 the power law a hub pair is then drawn thousands of times and carries a count of 10^5..10^6 beside tail pairs of 5,
@@ -62,6 +62,8 @@ def make_counts_device(ctx, n, n_edges, seed, degree_law='powerlaw', noise=0.1, 
                 edges > 5,000; 4M / 3e8 > 20,000 -- the reference's limit is 1,000).  'first' (default): ONE count per unique
                 pair, Geometric(0.2) x boost, drawn after de-duplication: the DEGREES follow the power law (hub contigs with
                 10^5..10^6 partners), the counts do not explode, and the balancing stays in the hundreds of iterations.
+    :param draws_only: stop after as many intra-genome DRAWS as intra-genome edges were asked for, however few unique pairs they
+                       leave (the host generator's behaviour; with dup='sum' this is round 2's C5: 1e9 draws -> 4.6e8 edges)
     :param extra: optional (lo, hi, count) numpy arrays of further pairs (lo < hi) merged into the stream (tests: planted hubs)
     :return: (counts Mat in HBM, E = unique undirected off-diagonal edges, lengths int32[n], sites float64[n],
               genome int32[n], info dict with the draws it took)
@@ -137,11 +139,13 @@ def make_counts_device(ctx, n, n_edges, seed, degree_law='powerlaw', noise=0.1, 
         info['batches'] += 1
         if verbose:
             print('[synth] batch {}: {} draws -> {} unique intra edges (target {})'.format(info['batches'], m, nu, n_intra), flush=True)
-        if nu >= n_intra * (1.0 - tol) or info['batches'] >= max_batches:
+        if nu >= n_intra * (1.0 - tol) or info['batches'] >= max_batches or (draws_only and draws >= n_intra):
             break
         # the next batch from this one's marginal yield (it only falls: aim slightly short, the loop tops up)
         per_draw = max(gained / float(m), 1e-6)
         m = int(min(batch, max(1 << 16, (n_intra - nu) / per_draw)))
+        if draws_only:
+            m = int(min(batch, n_intra - draws))
     info['intra_draws'] = draws
     info['intra_unique'] = nu
     if dup != 'sum' and keys is not None:

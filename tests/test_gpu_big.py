@@ -56,7 +56,7 @@ def test_power_law_map_beyond_2_31_bytes(ctx):
     # (heavy-tailed degrees: more balancing iterations than the flat maps need; with duplicate draws SUMMED instead -- dup='sum',
     # the host generator's rule -- this map does not balance within 20,000 iterations, synth_device.make_counts_device)
     res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=20000)
-    assert 100 < res.kr_info.n_iter < 20000
+    assert 50 < res.kr_info.n_iter < 20000
     assert res.kr_info.bitwise_symmetric == 1 and np.isfinite(res.x).all() and (res.x > 0).all()
     assert res.labels.shape[0] == int(res.mask.sum()) and res.labels.min() >= 0
     longest = _row_sums_are_one(counts, sites, res.x, hubs + rs.randint(0, n, 2000).tolist())
