@@ -1912,6 +1912,16 @@ __global__ void __launch_bounds__(BLK) kr_fold(const double *__restrict__ part, 
     if (threadIdx.x == 0) *dst = r;
 }
 
+// many hub-row partials -> one per chunk (block b sums part[b * chunk ...) in the fixed order of reduce_partials)
+__global__ void __launch_bounds__(BLK) kr_fold_chunks(const double *__restrict__ part, int64_t P, int chunk, double *__restrict__ dst)
+{
+    __shared__ double lds[BLK];
+    const int64_t at = (int64_t)blockIdx.x * chunk;
+    const int cnt = (int)(P - at < chunk ? P - at : chunk);
+    const double r = reduce_partials<0>(part + at, cnt, 1, lds);
+    if (threadIdx.x == 0) dst[blockIdx.x] = r;
+}
+
 // Sharded tick, after KB: block 0 folds the rank's block partials of p.w | rk.rk into its slot of the scalar exchange
 // buffer; on an OUTER tick (state as KB left it) all blocks also copy this rank's slice of v = x*(A x) into the vector
 // exchange buffer -- on an inner tick KB wrote its slice of w there itself.  One launch in front of the tick's ONE exchange.
@@ -2082,7 +2092,13 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // hub rows add one partial each behind the GS of the row kernel (at most nnz / HUB_LEN of them)
     // threshold: twice the pipelined chunk of the row-group kernel that will run, at least HUB_LEN (sweep on a power-law
     // map of 300k contigs / 28M entries, average row 93: 137 us per SpMV at 256, 151 at 512, 194 at 2048, 232 without)
-    const int hub_thr = getenv("B3C_KR_HUB_LEN") ? std::max(64, atoi(getenv("B3C_KR_HUB_LEN"))) : (avg > 128 ? 2 * HUB_LEN : HUB_LEN);
+    // ... and at least 16 average rows (round 3): on a heavy-tailed map of many entries per row -- C5 at its stated size,
+    // 400 per row -- a fixed 512 made 16 % of the ROWS "hubs" (802,389 of them, over half of the entries), which then ran on
+    // the CSR hub kernel instead of the dictionary form: 1.97 of 4.4 ms per SpMV.  Row-group lanes loop over long rows; what
+    // the hub kernel is for are rows so long that one lane group would hold its tile up
+    const int hub_floor = avg > 128 ? 2 * HUB_LEN : HUB_LEN;
+    const int hub_thr = getenv("B3C_KR_HUB_LEN") ? std::max(64, atoi(getenv("B3C_KR_HUB_LEN")))
+                                                  : std::max(hub_floor, (int)std::min<double>(16384.0, 16.0 * avg));
     const bool hub_kb = maxdeg > (unsigned long long)hub_thr && getenv("B3C_KR_NO_HUB") == nullptr;
     const int64_t hub_cap = hub_kb ? a->nnz / hub_thr + 1 : 0;
     const int hub_len = hub_kb ? hub_thr : 0x7fffffff;
@@ -2346,7 +2362,15 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                     (long long)n_tails, (long long)xt_super, XT_S, hx[0], hx[1]);
     }
     const int GS = tcd ? (int)tcd_tiles : GS_rows;
-    const int GSP = GS + (int)n_hub;          // partials the SpMV step leaves behind: row groups / tiles + hub rows
+    // partials the SpMV step leaves behind: row groups / tiles + hub rows.  EVERY block of KCD reduces all of them, so many
+    // hub rows (a power-law map: 10^5) are first summed in chunks by their own launch (fixed order: deterministic)
+    constexpr int HUB_CHUNK = 2048;
+    const bool hub_fold = n_hub > 4096;
+    const int hub_parts = hub_fold ? (int)((n_hub + HUB_CHUNK - 1) / HUB_CHUNK) : (int)n_hub;
+    DevBuf<double> hubraw(ctx, hub_fold ? n_hub : 1);
+    if (!hubraw.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: hub partials");
+    double *const hub_out = hub_fold ? hubraw.p : pkb.p + GS;
+    const int GSP = GS + hub_parts;
 
     KRParams prm;
     prm.tol = tol; prm.delta = delta; prm.Delta = Delta; prm.rt = tol * tol; prm.stop_tol = tol * 0.5;
@@ -2465,13 +2489,14 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             if (n_hub) {       // the rows the row-group kernel left out; same state slot, partials behind its GS
                 if (a->kind == B3C_U32 && v16 && !n_big)           // (hub rows read the full 32-bit counts when some are large)
                     hipLaunchKernelGGL(kr_kb_hub<uint16_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices, v16,
-                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p + GS);
+                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out);
                 else if (a->kind == B3C_U32)
                     hipLaunchKernelGGL(kr_kb_hub<uint32_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p + GS);
+                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out);
                 else
                     hipLaunchKernelGGL(kr_kb_hub<double>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p + GS);
+                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out);
+                if (hub_fold) hipLaunchKernelGGL(kr_fold_chunks, dim3((unsigned)hub_parts), dim3(BLK), 0, s, hubraw.p, n_hub, HUB_CHUNK, pkb.p + GS);
             }
             if (timed) HIP_TRY(ctx, hipEventRecord(evs.back(), s));
             if (dist) {

@@ -292,8 +292,10 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
                                                     const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
                                                     const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
                                                     const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
-                                                    u64 *__restrict__ gvals)
+                                                    u64 *__restrict__ gvals, const int64_t *__restrict__ cnt_dev)
 {
+    // cnt_dev: the list was thinned on the device (k_lv_prune) and its length sits in device memory
+    if (cnt_dev) { const int64_t c = *cnt_dev; n = r0 + (c < n - r0 ? c : n - r0); }
     __shared__ int32_t skeys[WPB][CAP];
     __shared__ u64 svals[WPB][CAP];
     const int lane = threadIdx.x & 63;
@@ -1543,9 +1545,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         int32_t epoch = 0;                               // sub-rounds of this level so far
         int64_t max_list = 0;
         for (int r = 0; r < n_sub; r++) max_list = std::max(max_list, hoff[r] - loff[r]);
-        DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1);
-        DevBuf<unsigned long long> pcnt(ctx, 1);
-        if (!plist.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
+        int64_t max_hlist = 0;
+        for (int r = 0; r < n_sub; r++) max_hlist = std::max(max_hlist, lend[r] - hoff[r]);
+        DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1), plist_h(ctx, can_prune ? max_hlist + 1 : 1);
+        DevBuf<unsigned long long> pcnt(ctx, 2);          // [0] grouped nodes left after pruning, [1] hubs left
+        if (!plist.p || !plist_h.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
         auto modularity = [&](double *out, bool full, u64 *moved) -> int {
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
             if (full) {
@@ -1594,6 +1598,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             for (int r = 0; r < n_sub; r++) {
                 epoch++;
                 evs.rec();
+                // (both pruned-list counters are cleared BEFORE the fork below: the side stream only waits for what precedes it)
+                if (incr && can_prune) HIP_TRY(ctx, hipMemsetAsync(pcnt.p, 0, sizeof(unsigned long long) * 2, s));
                 // the handful of hub nodes of the sub-round run on the side stream BESIDE the grouped scan (both read the
                 // state of the sub-round's start and write nxt[] of their own nodes): 17 us that used to follow it
                 const bool hub_side = grouped && need_wave_kernel && lend[r] > hoff[r] && hoff[r] > loff[r] && ctx->side_ok();
@@ -1609,7 +1615,6 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     const int64_t *cnt_dev = nullptr;
                     if (incr && can_prune) {
                         // nodes that provably stay are settled from four numbers each; the rest go through the scan
-                        HIP_TRY(ctx, hipMemsetAsync(pcnt.p, 0, sizeof(unsigned long long), s));
                         hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(cntr, BLK, 8 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, m2, kdeg.p,
                                            wnl.p, own.p, tot.p, com.p, nxt_p, plist.p, pcnt.p, stamp_p, tstamp_p);
                         lst = plist.p;
@@ -1638,10 +1643,21 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     // all rows of this rank (small levels), or just the hubs the grouped kernel left out
                     const NodeRec *hubs = grouped ? nlist_p + hoff[r] : nullptr;
                     const int64_t w0 = grouped ? 0 : r0, w1 = grouped ? lend[r] - hoff[r] : r1;
+                    const int64_t *hcnt_dev = nullptr;
+                    if (grouped && incr && can_prune && !stamps) {
+                        // the hubs are pruned like the grouped nodes (round 3: on a heavy-tailed map with hundreds of entries per
+                        // row -- C5 -- most of the WEIGHT sits in rows beyond the grouped kernel's 256 entries, and scanning all of
+                        // them in every late sweep was 85 % of the stage).  Row-sharded runs keep scanning them: this kernel
+                        // does not refresh own[] / stamp[] (see k_lv_prune)
+                        hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(w1, BLK, 8 * ctx->n_cu)), dim3(BLK), 0, hs, w1, hubs, m2, kdeg.p,
+                                           wnl.p, own.p, tot.p, com.p, nxt_p, plist_h.p, pcnt.p + 1, stamp_p, tstamp_p);
+                        hubs = plist_h.p;
+                        hcnt_dev = (const int64_t *)(pcnt.p + 1);
+                    }
                     const int gwh = grid_for(w1 - w0, WPB, 16 * ctx->n_cu);
 #define LV_DECIDE(C)                                                                                                     \
     hipLaunchKernelGGL(k_lv_decide<C>, dim3(gwh), dim3(BLK), 0, hs, w0, w1, hubs, -1, n_sub, r, m2, g.indptr, g.indices, g.q, ids, \
-                       kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p)
+                       kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p, hcnt_dev)
                     switch (cap) {
                     case 128: LV_DECIDE(128); break;
                     case 256: LV_DECIDE(256); break;

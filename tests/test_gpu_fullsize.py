@@ -104,7 +104,7 @@ def test_power_law_map_matches_the_oracle(ctx, oracle_lib, dup):
     bin3c_amd/synth_device.py).  'first': 400k contigs, 1.6e7 UNIQUE edges -- the draws go on until the stated count is reached,
     every pair keeps one count: hub contigs with 10^4 partners, well conditioned.  'sum': 300k contigs, 1.08e7 draws whose
     duplicates are SUMMED (the host generator's rule: the draws collapse onto hub pairs, counts of 10^4..10^5 beside 5s):
-    hundreds of KR iterations with bound cuts, hub rows through kr_kb_hub, counts beyond 65535 through the correction list."""
+    a hundred KR iterations with bound cuts, hub rows through kr_kb_hub, counts beyond 65535 through the correction list."""
     from bin3c_amd.pipeline import run_hot_path
     from bin3c_amd.synth_device import make_counts_device
     if dup == 'first':
@@ -119,7 +119,7 @@ def test_power_law_map_matches_the_oracle(ctx, oracle_lib, dup):
     res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, keep=True, max_iter=5000)
     try:
         st, ref = compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res, max_iter=5000, seq=False)
-        assert st.n_iter > (50 if dup == 'first' else 150), st.n_iter
+        assert st.n_iter > (50 if dup == 'first' else 80), st.n_iter
         # the planted genomes are found on this law too (the sequential oracle is left out: minutes on hub-heavy graphs)
         assert res.lv_info.modularity > 0.8
     finally:

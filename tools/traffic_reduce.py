@@ -1,15 +1,21 @@
 """Reduce the --pmc passes of tools/profile_round.sh to profiles/: the counter rows without the mangled signatures
 (profiles/<round>_c3_FETCH_SIZE.csv, ..._WRITE_SIZE.csv) and profiles/traffic.json (bytes per launch of the dominant
 kernel, corrected as MI355X_MICROARCH.md's HBM section prescribes, with the check on two streaming kernels of known size).
-usage: python tools/traffic_reduce.py gpurun_out/<tag> <round, e.g. r02>"""
-import csv, glob, json, sys
+usage: python tools/traffic_reduce.py gpurun_out/<tag> <round, e.g. r03> [C3|C5]
+(C5: tools/run_c5.sh's passes; only the SpMV kernels are collected there, so the calibration kernels are skipped)"""
+import csv, glob, json, re, sys
 
 src, rnd = sys.argv[1], sys.argv[2]
+CFG = sys.argv[3] if len(sys.argv) > 3 else 'C3'
 NNZ, N = 200903927, 1000000            # C3 (bench.py prints them in config.workload)
+if CFG != 'C3':
+    line = [l for l in open(glob.glob('%s/bench_%s.json' % (src, CFG.lower()))[0]) if l.startswith('{')][-1]
+    wl = json.loads(line)['config']['workload']
+    NNZ, N = int(re.search(r'nnz=(\d+)', wl).group(1)), int(re.search(r'n=(\d+)', wl).group(1))
 
 for tag, c in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
     f = glob.glob('%s/pmc_%s/*/*counter_collection.csv' % (src, tag))[0]
-    with open('profiles/%s_c3_%s.csv' % (rnd, c), 'w', newline='') as fh:
+    with open('profiles/%s_%s_%s.csv' % (rnd, CFG.lower(), c), 'w', newline='') as fh:
         w = csv.writer(fh)
         w.writerow(['Dispatch_Id', 'Kernel', 'Grid_Size', 'Workgroup_Size', 'LDS_Block_Size', 'Scratch_Size', 'VGPR_Count',
                     'SGPR_Count', 'Counter_Name', 'Counter_Value', 'Duration_ns'])
@@ -22,7 +28,7 @@ for tag, c in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
 
 def active(counter, kern):
     """mean counter value (bytes; the counters are in KB) over the launches that did work (>= half the longest)"""
-    rows = [r for r in csv.DictReader(open('profiles/%s_c3_%s.csv' % (rnd, counter))) if r['Kernel'].startswith(kern)]
+    rows = [r for r in csv.DictReader(open('profiles/%s_%s_%s.csv' % (rnd, CFG.lower(), counter))) if r['Kernel'].startswith(kern)]
     mx = max(int(r['Duration_ns']) for r in rows)
     a = [float(r['Counter_Value']) for r in rows if int(r['Duration_ns']) >= 0.5 * mx]
     return sum(a) / len(a) * 1024.0, len(a), len(rows)
@@ -32,7 +38,28 @@ import os
 prev = {}
 if os.path.exists('profiles/traffic.json'):
     prev = json.load(open('profiles/traffic.json'))
-kernels = sorted({r['Kernel'].split('<')[0] for r in csv.DictReader(open('profiles/%s_c3_FETCH_SIZE.csv' % rnd))})
+kernels = sorted({r['Kernel'].split('<')[0] for r in csv.DictReader(open('profiles/%s_%s_FETCH_SIZE.csv' % (rnd, CFG.lower())))})
+if CFG != 'C3':
+    # power-law map: one SpMV = kr_kb_tails + kr_kb_tcd2 + kr_kb_hub
+    tot, det = 0.0, {}
+    for k in ('kr_kb_tails', 'kr_kb_tcd2', 'kr_kb_hub'):
+        if k not in kernels:
+            continue
+        f_, na, nt = active('FETCH_SIZE', k)
+        w_, _, _ = active('WRITE_SIZE', k)
+        det[k] = {'FETCH_SIZE_raw_bytes_per_launch': f_, 'WRITE_SIZE_raw_bytes_per_launch': w_}
+        tot += 2.0 * f_ + w_
+    out = dict(prev)
+    out[CFG] = dict(det, kernel='kr_kb_tails + kr_kb_tcd2' + (' + kr_kb_hub' if 'kr_kb_hub' in det else '') + ' (one SpMV)',
+                    hbm_bytes_per_launch=tot, launches_counted=na, launches_total=nt,
+                    algorithmic_bytes_per_launch=12.0 * NNZ + 20.0 * N,
+                    correction='FETCH_SIZE doubled (128-byte fabric requests tallied at 64 bytes), WRITE_SIZE as reported: the '
+                               'correction calibrated on C3 in the same round (see C3)',
+                    source='profiles/%s_%s_FETCH_SIZE.csv, profiles/%s_%s_WRITE_SIZE.csv (rocprofv3 --pmc, one counter per pass, '
+                           'bench.py --config %s --steps 1 --warmup 0)' % (rnd, CFG.lower(), rnd, CFG.lower(), CFG))
+    json.dump(out, open('profiles/traffic.json', 'w'), indent=1)
+    print(json.dumps(out[CFG], indent=1))
+    sys.exit(0)
 fp, _, _ = active('FETCH_SIZE', 'kr_prep_counts')
 wp, _, _ = active('WRITE_SIZE', 'kr_prep_counts')
 fq, _, _ = active('FETCH_SIZE', 'k_quantise')
