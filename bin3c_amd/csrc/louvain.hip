@@ -407,6 +407,103 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
     }
 }
 
+// MEGA rows: one WORKGROUP per node.  A row of 10^5 .. 10^6 entries -- a planted hub contig at level 0, or at level 1 the
+// community of a genome that holds a third of all contigs, which the noise links to every other community -- kept ONE wave of
+// k_lv_decide busy for milliseconds per sub-round while the rest of the chip idled (round 3, the surveyed genome-size law:
+// 5.3 ms per sub-round of level 1, 40 % of the whole step).  Same protocol: the node's table in global memory (goff), inserts
+// by compare-and-swap, then every slot of the table is evaluated and cleared; own-community weight and arg-max are reduced
+// over the workgroup (integer sums and an order-free arg-max with ties to the lowest id: the same result as one wave's).
+constexpr int MEGA_NT = 1024;
+constexpr int64_t MEGA_DEG = 8192;         // rows beyond this many entries
+__global__ void __launch_bounds__(MEGA_NT) k_lv_decide_mega(const NodeRec *__restrict__ list, u64 m2, const int32_t *__restrict__ indices,
+                                                             const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
+                                                             const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
+                                                             const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
+                                                             const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
+                                                             u64 *__restrict__ gvals)
+{
+    __shared__ long long red_own[MEGA_NT / 64];
+    __shared__ long long red_hi[MEGA_NT / 64];
+    __shared__ u64 red_lo[MEGA_NT / 64];
+    __shared__ int32_t red_com[MEGA_NT / 64], red_have[MEGA_NT / 64];
+    const NodeRec rec = list[blockIdx.x];
+    const int32_t i = rec.node;
+    const long long ki = kdeg[i];
+    const int32_t a = com[i];
+    const int lg = table_lg(rec.deg);
+    const uint32_t mask = (1u << lg) - 1u;
+    int32_t *keys = gkeys + goff[i];
+    u64 *vals = gvals + goff[i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long own = 0;
+    for (int64_t base = rec.start + threadIdx.x; base < rec.start + rec.deg; base += 4 * MEGA_NT) {
+        int32_t j[4];
+        u64 qv[4];
+        int32_t c[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int64_t k = base + (int64_t)t * MEGA_NT;
+            const bool ok = k < rec.start + rec.deg;
+            j[t] = ok ? indices[k] : i;
+            qv[t] = ok ? (u64)q[k] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) c[t] = j[t] != i ? com[j[t]] : EMPTY;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (c[t] == EMPTY) continue;
+            if (c[t] == a) { own += (long long)qv[t]; continue; }
+            uint32_t slot = hash_slot(c[t], lg);
+            for (;;) {
+                const int32_t prev = atomicCAS(&keys[slot], EMPTY, c[t]);
+                if (prev == EMPTY || prev == c[t]) { atomicAdd(&vals[slot], qv[t]); break; }
+                slot = (slot + 1) & mask;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __syncthreads();
+    Best b;
+    b.gain = 0; b.com = a; b.have = 0;
+    for (uint32_t t = threadIdx.x; t <= mask; t += MEGA_NT) {
+        const int32_t c = keys[t];
+        if (c != EMPTY) {
+            const u64 d = vals[t];
+            keys[t] = EMPTY;
+            vals[t] = 0;
+            const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
+            best_take(b, g, c);
+        }
+    }
+    own = wave_sum_ll(own);
+    b = best_wave_reduce(b);
+    if (lane == 0) {
+        red_own[wv] = own;
+        red_hi[wv] = (long long)(b.gain >> 64);
+        red_lo[wv] = (u64)b.gain;
+        red_com[wv] = b.com;
+        red_have[wv] = b.have;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long o = 0;
+        Best r;
+        r.gain = 0; r.com = a; r.have = 0;
+        for (int w = 0; w < MEGA_NT / 64; w++) {
+            o += red_own[w];
+            const i128 g = ((i128)red_hi[w] << 64) | (i128)red_lo[w];
+            if (red_have[w] && (!r.have || g > r.gain || (g == r.gain && red_com[w] < r.com))) { r.gain = g; r.com = red_com[w]; r.have = 1; }
+        }
+        // staying: i removed from its own community first (python-louvain __remove)
+        const i128 g = (i128)o * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+        best_take(r, g, a);
+        int32_t best = r.have ? r.com : a;
+        if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
+        nxt[i] = best;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+}
+
 // Small levels (the induced graphs: n <= CAPD nodes, often dense rows): the weight towards every community goes into a
 // DIRECT table indexed by the community id in the wave's LDS -- no hashing, no compare-and-swap, and no global-memory
 // tables for rows of more than CAP/2 entries.  Same gains, same arg-max (ties to the lowest id) as k_lv_decide.
@@ -489,9 +586,10 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_direct(int64_t n, int n_sub, 
 // summed in registers; only groups that saw a foreign community take turns on the wave's LDS table.
 // The node list of a sub-round is fixed for a level (the bucket depends on the id only), so it is built once.
 // ---------------------------------------------------------------------------------------------
-// Node lists of one level, all at once.  Without hubs: segment r = the nodes of sub-round r.  With hubs: segment 2r = the nodes of
-// sub-round r with at most max_deg entries (grouped kernel), segment 2r + 1 = those with more (wave-per-node kernel) -- adjacent,
-// so that the passes that treat both alike (apply, internal-weight delta) cover a sub-round in ONE launch.  A node sets the flag of its segment; ONE exclusive
+// Node lists of one level, all at once.  Without hubs: segment r = the nodes of sub-round r.  With hubs: segment 3r = the nodes of
+// sub-round r with at most max_deg entries (grouped kernel), 3r + 1 = those with more (wave-per-node kernel), 3r + 2 = the MEGA rows
+// (workgroup-per-node kernel) -- adjacent, so that the passes that treat them alike (apply, internal-weight delta) cover a
+// sub-round in ONE launch.  A node sets the flag of its segment; ONE exclusive
 // scan over the n_seg * nloc flags gives every listed node its position in the common list and, at the segment starts,
 // the list boundaries.  Inside a segment the nodes ascend, as they did when every segment had its own scan.
 __device__ __forceinline__ int lv_list_segment(int64_t i, int n_sub, int max_deg, int with_hubs, const int64_t *__restrict__ indptr,
@@ -501,8 +599,8 @@ __device__ __forceinline__ int lv_list_segment(int64_t i, int n_sub, int max_deg
     const int64_t deg = indptr[i + 1] - indptr[i];
     const int32_t id = ids ? ids[i] : (int32_t)i;
     const int b = (int)bucket_of(id, n_sub);
-    if (deg <= max_deg) return with_hubs ? 2 * b : b;
-    return with_hubs ? 2 * b + 1 : -1;
+    if (deg <= max_deg) return with_hubs ? 3 * b : b;
+    return with_hubs ? (deg > MEGA_DEG ? 3 * b + 2 : 3 * b + 1) : -1;
 }
 
 __global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, int max_deg, int with_hubs,
@@ -1504,9 +1602,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // scan, one fill, one read-back of the boundaries for all sub-rounds
         DevBuf<NodeRec> lists(ctx, grouped ? nloc + 1 : 1);
         const NodeRec *nlist_p = lists.p;
-        std::vector<int64_t> loff(n_sub + 1, 0), hoff(n_sub + 1, 0), lend(n_sub + 1, 0);
+        std::vector<int64_t> loff(n_sub + 1, 0), hoff(n_sub + 1, 0), moff(n_sub + 1, 0), lend(n_sub + 1, 0);
         if (grouped) {
-            const int n_seg = need_wave_kernel ? 2 * n_sub : n_sub;
+            const int n_seg = need_wave_kernel ? 3 * n_sub : n_sub;
             const int64_t tot = (int64_t)n_seg * nloc + 1;
             DevBuf<int64_t> lflag(ctx, tot), lpos(ctx, tot), bnd(ctx, n_seg + 1);
             if (!lists.p || !lflag.p || !lpos.p || !bnd.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: node lists"); }
@@ -1518,11 +1616,12 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             hipLaunchKernelGGL(k_lv_list_bounds, dim3(1), dim3(64), 0, s, n_seg, nloc, lpos.p, bnd.p);
             std::vector<int64_t> hb(n_seg + 1, 0);
             { const int rb_ = b3c_readback(ctx, hb.data(), bnd.p, sizeof(int64_t) * hb.size()); if (rb_) return rb_; }
-            // [loff[r], hoff[r]) grouped nodes of sub-round r, [hoff[r], loff[r] + span[r]) its hubs
+            // [loff[r], hoff[r]) grouped nodes of sub-round r, [hoff[r], moff[r]) its hubs, [moff[r], lend[r]) its mega rows
             for (int r = 0; r < n_sub; r++) {
-                loff[r] = need_wave_kernel ? hb[2 * r] : hb[r];
-                hoff[r] = need_wave_kernel ? hb[2 * r + 1] : hb[r + 1];
-                lend[r] = need_wave_kernel ? hb[2 * r + 2] : hb[r + 1];
+                loff[r] = need_wave_kernel ? hb[3 * r] : hb[r];
+                hoff[r] = need_wave_kernel ? hb[3 * r + 1] : hb[r + 1];
+                moff[r] = need_wave_kernel ? hb[3 * r + 2] : hb[r + 1];
+                lend[r] = need_wave_kernel ? hb[3 * r + 3] : hb[r + 1];
             }
         }
 
@@ -1546,7 +1645,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         int64_t max_list = 0;
         for (int r = 0; r < n_sub; r++) max_list = std::max(max_list, hoff[r] - loff[r]);
         int64_t max_hlist = 0;
-        for (int r = 0; r < n_sub; r++) max_hlist = std::max(max_hlist, lend[r] - hoff[r]);
+        for (int r = 0; r < n_sub; r++) max_hlist = std::max(max_hlist, moff[r] - hoff[r]);
         DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1), plist_h(ctx, can_prune ? max_hlist + 1 : 1);
         DevBuf<unsigned long long> pcnt(ctx, 2);          // [0] grouped nodes left after pruning, [1] hubs left
         if (!plist.p || !plist_h.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
@@ -1639,10 +1738,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     hipLaunchKernelGGL(k_lv_decide_direct<LV_DIRECT_CAP>, dim3(grid_for(n, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, n_sub, r, m2,
                                        g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p, csize.p, nxt_p);
                 } else
-                if (need_wave_kernel && (!grouped || lend[r] > hoff[r])) {
+                if (grouped && lend[r] > moff[r])         // mega rows: one workgroup per node (side stream, beside the others)
+                    hipLaunchKernelGGL(k_lv_decide_mega, dim3((unsigned)(lend[r] - moff[r])), dim3(MEGA_NT), 0, hs, nlist_p + moff[r], m2, g.indices,
+                                       g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p);
+                if (need_wave_kernel && (!grouped || moff[r] > hoff[r])) {
                     // all rows of this rank (small levels), or just the hubs the grouped kernel left out
                     const NodeRec *hubs = grouped ? nlist_p + hoff[r] : nullptr;
-                    const int64_t w0 = grouped ? 0 : r0, w1 = grouped ? lend[r] - hoff[r] : r1;
+                    const int64_t w0 = grouped ? 0 : r0, w1 = grouped ? moff[r] - hoff[r] : r1;
                     const int64_t *hcnt_dev = nullptr;
                     if (grouped && incr && can_prune && !stamps) {
                         // the hubs are pruned like the grouped nodes (round 3: on a heavy-tailed map with hundreds of entries per

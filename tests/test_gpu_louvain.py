@@ -147,3 +147,18 @@ def test_hard_maps_multilevel(ctx, oracle_lib, n, e, seed, noise):
     _assert_same(ref, labels, info)
     seq = oracle_lib.louvain_seq(gr['indptr'], gr['indices'], gr['w'])
     assert info.modularity > seq['Q'] - 0.03 and abs(seq['Q'] - info.modularity) < 0.06
+
+
+def test_mega_rows_take_the_workgroup_kernel(ctx, oracle_lib):
+    """Rows beyond 8192 entries (k_lv_decide_mega, one workgroup per node): two stars of degree 20,000 and 9,000 on a ring of
+    5000 cliques -- at level 0 as nodes, and again at later levels as the rows of the communities they end up in.  Labels,
+    sweep and level counts and the exact modularity must equal the scalar schedule's, as for every other kernel of the scan."""
+    rs = np.random.RandomState(12)
+    n, edges = graphs.ring_of_cliques(5000, 6, 1.0, 0.2)
+    for hub, deg in ((n, 20000), (n + 1, 9000)):
+        edges += [(hub, int(v), float(rs.uniform(0.01, 0.5))) for v in rs.choice(n, deg, replace=False)]
+    edges.append((n, n + 1, 5.0))
+    ip, ix, w = graphs.csr_from_edges(n + 2, edges)
+    assert int(np.diff(ip).max()) > 8192
+    ref, labels, info = _run_both(ctx, oracle_lib, ip, ix, w, 1.0 / w.max())
+    _assert_same(ref, labels, info)
