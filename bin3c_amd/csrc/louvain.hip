@@ -410,19 +410,67 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
 // MEGA rows: one WORKGROUP per node.  A row of 10^5 .. 10^6 entries -- a planted hub contig at level 0, or at level 1 the
 // community of a genome that holds a third of all contigs, which the noise links to every other community -- kept ONE wave of
 // k_lv_decide busy for milliseconds per sub-round while the rest of the chip idled (round 3, the surveyed genome-size law:
-// 5.3 ms per sub-round of level 1, 40 % of the whole step).  Same protocol: the node's table in global memory (goff), inserts
-// by compare-and-swap, then every slot of the table is evaluated and cleared; own-community weight and arg-max are reduced
-// over the workgroup (integer sums and an order-free arg-max with ties to the lowest id: the same result as one wave's).
+// 5.3 ms per sub-round of level 1, 40 % of the whole step).  Same protocol in two passes: workgroups of 4096 entries insert into
+// the node's table in global memory (goff) by compare-and-swap, then one workgroup per node evaluates and clears every slot;
+// own-community weight and arg-max are reduced with integer sums and an order-free arg-max (ties to the lowest id): the same
+// result as one wave's.
 constexpr int MEGA_NT = 1024;
 constexpr int64_t MEGA_DEG = 8192;         // rows beyond this many entries
-__global__ void __launch_bounds__(MEGA_NT) k_lv_decide_mega(const NodeRec *__restrict__ list, u64 m2, const int32_t *__restrict__ indices,
-                                                             const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
-                                                             const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
-                                                             const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
+constexpr int MEGA_CHUNK = 4 * MEGA_NT;    // entries one workgroup of the insert pass takes
+
+// pass 1: workgroup (node m, chunk c) inserts entries [c * MEGA_CHUNK, ...) of the node's row into the node's table and adds
+// its share of the own-community weight to own_acc[m] (integer atomics: order-free)
+__global__ void __launch_bounds__(MEGA_NT) k_lv_mega_insert(const NodeRec *__restrict__ list, int chunks, const int32_t *__restrict__ indices,
+                                                             const int64_t *__restrict__ q, const int32_t *__restrict__ com,
                                                              const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
-                                                             u64 *__restrict__ gvals)
+                                                             u64 *__restrict__ gvals, u64 *__restrict__ own_acc)
 {
-    __shared__ long long red_own[MEGA_NT / 64];
+    __shared__ long long red[MEGA_NT / 64];
+    const int m = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const NodeRec rec = list[m];
+    if ((int64_t)ch * MEGA_CHUNK >= rec.deg) return;                 // (uniform per workgroup)
+    const int32_t i = rec.node;
+    const int32_t a = com[i];
+    const int lg = table_lg(rec.deg);
+    const uint32_t mask = (1u << lg) - 1u;
+    int32_t *keys = gkeys + goff[i];
+    u64 *vals = gvals + goff[i];
+    const int64_t end = rec.start + rec.deg;
+    const int64_t base = rec.start + (int64_t)ch * MEGA_CHUNK + threadIdx.x;
+    int32_t j[4];
+    u64 qv[4];
+    int32_t c[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int64_t k = base + (int64_t)t * MEGA_NT;
+        const bool ok = k < end;
+        j[t] = ok ? indices[k] : i;
+        qv[t] = ok ? (u64)q[k] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = j[t] != i ? com[j[t]] : EMPTY;
+    long long own = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (c[t] == EMPTY) continue;
+        if (c[t] == a) { own += (long long)qv[t]; continue; }
+        uint32_t slot = hash_slot(c[t], lg);
+        for (;;) {
+            const int32_t prev = atomicCAS(&keys[slot], EMPTY, c[t]);
+            if (prev == EMPTY || prev == c[t]) { atomicAdd(&vals[slot], qv[t]); break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+    block_atomic_add_u64(own, own_acc + m, red);
+}
+
+// pass 2: one workgroup per node evaluates (and clears) every slot of the node's table, four slots per thread in flight
+__global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval(const NodeRec *__restrict__ list, u64 m2, const int64_t *__restrict__ kdeg,
+                                                           const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
+                                                           const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
+                                                           const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
+                                                           u64 *__restrict__ gvals, u64 *__restrict__ own_acc)
+{
     __shared__ long long red_hi[MEGA_NT / 64];
     __shared__ u64 red_lo[MEGA_NT / 64];
     __shared__ int32_t red_com[MEGA_NT / 64], red_have[MEGA_NT / 64];
@@ -431,54 +479,39 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_decide_mega(const NodeRec *__res
     const long long ki = kdeg[i];
     const int32_t a = com[i];
     const int lg = table_lg(rec.deg);
-    const uint32_t mask = (1u << lg) - 1u;
+    const uint32_t size = 1u << lg;
     int32_t *keys = gkeys + goff[i];
     u64 *vals = gvals + goff[i];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    long long own = 0;
-    for (int64_t base = rec.start + threadIdx.x; base < rec.start + rec.deg; base += 4 * MEGA_NT) {
-        int32_t j[4];
-        u64 qv[4];
-        int32_t c[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int64_t k = base + (int64_t)t * MEGA_NT;
-            const bool ok = k < rec.start + rec.deg;
-            j[t] = ok ? indices[k] : i;
-            qv[t] = ok ? (u64)q[k] : 0;
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) c[t] = j[t] != i ? com[j[t]] : EMPTY;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (c[t] == EMPTY) continue;
-            if (c[t] == a) { own += (long long)qv[t]; continue; }
-            uint32_t slot = hash_slot(c[t], lg);
-            for (;;) {
-                const int32_t prev = atomicCAS(&keys[slot], EMPTY, c[t]);
-                if (prev == EMPTY || prev == c[t]) { atomicAdd(&vals[slot], qv[t]); break; }
-                slot = (slot + 1) & mask;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    __syncthreads();
     Best b;
     b.gain = 0; b.com = a; b.have = 0;
-    for (uint32_t t = threadIdx.x; t <= mask; t += MEGA_NT) {
-        const int32_t c = keys[t];
-        if (c != EMPTY) {
-            const u64 d = vals[t];
+    for (uint32_t t0 = threadIdx.x; t0 < size; t0 += 4 * MEGA_NT) {
+        int32_t c[4];
+        u64 d[4];
+        long long tc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t t = t0 + u * MEGA_NT;
+            c[u] = t < size ? keys[t] : EMPTY;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t t = t0 + u * MEGA_NT;
+            d[u] = c[u] != EMPTY ? vals[t] : 0;
+            tc[u] = c[u] != EMPTY ? tot[c[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (c[u] == EMPTY) continue;
+            const uint32_t t = t0 + u * MEGA_NT;
             keys[t] = EMPTY;
             vals[t] = 0;
-            const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
-            best_take(b, g, c);
+            const i128 g = (i128)d[u] * (i128)m2 - (i128)tc[u] * (i128)ki;
+            best_take(b, g, c[u]);
         }
     }
-    own = wave_sum_ll(own);
     b = best_wave_reduce(b);
     if (lane == 0) {
-        red_own[wv] = own;
         red_hi[wv] = (long long)(b.gain >> 64);
         red_lo[wv] = (u64)b.gain;
         red_com[wv] = b.com;
@@ -486,11 +519,11 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_decide_mega(const NodeRec *__res
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        long long o = 0;
+        const long long o = (long long)own_acc[blockIdx.x];
+        own_acc[blockIdx.x] = 0;                                       // ready for the next sub-round
         Best r;
         r.gain = 0; r.com = a; r.have = 0;
         for (int w = 0; w < MEGA_NT / 64; w++) {
-            o += red_own[w];
             const i128 g = ((i128)red_hi[w] << 64) | (i128)red_lo[w];
             if (red_have[w] && (!r.have || g > r.gain || (g == r.gain && red_com[w] < r.com))) { r.gain = g; r.com = red_com[w]; r.have = 1; }
         }
@@ -501,7 +534,6 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_decide_mega(const NodeRec *__res
         if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
         nxt[i] = best;
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
 }
 
 // Small levels (the induced graphs: n <= CAPD nodes, often dense rows): the weight towards every community goes into a
@@ -1644,8 +1676,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         int32_t epoch = 0;                               // sub-rounds of this level so far
         int64_t max_list = 0;
         for (int r = 0; r < n_sub; r++) max_list = std::max(max_list, hoff[r] - loff[r]);
-        int64_t max_hlist = 0;
-        for (int r = 0; r < n_sub; r++) max_hlist = std::max(max_hlist, moff[r] - hoff[r]);
+        int64_t max_hlist = 0, max_mega = 0;
+        for (int r = 0; r < n_sub; r++) { max_hlist = std::max(max_hlist, moff[r] - hoff[r]); max_mega = std::max(max_mega, lend[r] - moff[r]); }
+        DevBuf<u64> mega_own(ctx, max_mega + 1);            // own-community weight of the mega rows of a sub-round (cleared by the eval pass)
+        if (!mega_own.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: mega rows");
+        HIP_TRY(ctx, hipMemsetAsync(mega_own.p, 0, sizeof(u64) * (size_t)(max_mega + 1), s));
         DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1), plist_h(ctx, can_prune ? max_hlist + 1 : 1);
         DevBuf<unsigned long long> pcnt(ctx, 2);          // [0] grouped nodes left after pruning, [1] hubs left
         if (!plist.p || !plist_h.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
@@ -1738,9 +1773,14 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     hipLaunchKernelGGL(k_lv_decide_direct<LV_DIRECT_CAP>, dim3(grid_for(n, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, n_sub, r, m2,
                                        g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p, csize.p, nxt_p);
                 } else
-                if (grouped && lend[r] > moff[r])         // mega rows: one workgroup per node (side stream, beside the others)
-                    hipLaunchKernelGGL(k_lv_decide_mega, dim3((unsigned)(lend[r] - moff[r])), dim3(MEGA_NT), 0, hs, nlist_p + moff[r], m2, g.indices,
-                                       g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p);
+                if (grouped && lend[r] > moff[r]) {       // mega rows: workgroups per node (side stream, beside the others)
+                    const int64_t nm = lend[r] - moff[r];
+                    const int chunks = (int)((maxdeg + MEGA_CHUNK - 1) / MEGA_CHUNK);
+                    hipLaunchKernelGGL(k_lv_mega_insert, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), 0, hs, nlist_p + moff[r], chunks, g.indices, g.q,
+                                       com.p, goff.p, gkeys.p, gvals.p, mega_own.p);
+                    hipLaunchKernelGGL(k_lv_mega_eval, dim3((unsigned)nm), dim3(MEGA_NT), 0, hs, nlist_p + moff[r], m2, kdeg.p, tot.p, com.p, csize.p,
+                                       nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p);
+                }
                 if (need_wave_kernel && (!grouped || moff[r] > hoff[r])) {
                     // all rows of this rank (small levels), or just the hubs the grouped kernel left out
                     const NodeRec *hubs = grouped ? nlist_p + hoff[r] : nullptr;
