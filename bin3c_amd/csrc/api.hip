@@ -78,9 +78,12 @@ extern "C" int b3c_ctx_destroy(b3c_ctx *ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamSynchronize(ctx->side2);
         (void)hipEventDestroy(ctx->ev_fork);
         (void)hipEventDestroy(ctx->ev_join);
+        (void)hipEventDestroy(ctx->ev_join2);
         (void)hipStreamDestroy(ctx->side);
+        (void)hipStreamDestroy(ctx->side2);
     }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

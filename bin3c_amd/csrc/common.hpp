@@ -36,16 +36,19 @@ struct b3c_ctx {
     void ev_put(hipEvent_t e) { if (e) evpool.push_back(e); }
     // a second stream for short kernels that are independent of the one just launched (Louvain: the few hub nodes of a
     // sub-round beside the grouped scan); forked and joined with the two events below
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     bool side_ok()
     {
         if (side) return true;
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming) != hipSuccess) {
             (void)hipStreamDestroy(side);
-            side = nullptr;
+            if (side2) (void)hipStreamDestroy(side2);
+            side = side2 = nullptr;
             return false;
         }
         return true;

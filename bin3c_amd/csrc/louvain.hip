@@ -1737,11 +1737,17 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 // the handful of hub nodes of the sub-round run on the side stream BESIDE the grouped scan (both read the
                 // state of the sub-round's start and write nxt[] of their own nodes): 17 us that used to follow it
                 const bool hub_side = grouped && need_wave_kernel && lend[r] > hoff[r] && hoff[r] > loff[r] && ctx->side_ok();
-                hipStream_t hs = s;
+                hipStream_t hs = s, ms = s;               // streams of the hub and of the mega-row kernels
                 if (hub_side) {
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
                     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
                     hs = ctx->side;
+                    if (lend[r] > moff[r]) {
+                        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+                        ms = ctx->side2;
+                    } else {
+                        ms = hs;
+                    }
                 }
                 if (grouped && hoff[r] > loff[r]) {
                     const int64_t cntr = hoff[r] - loff[r];
@@ -1776,10 +1782,14 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (grouped && lend[r] > moff[r]) {       // mega rows: workgroups per node (side stream, beside the others)
                     const int64_t nm = lend[r] - moff[r];
                     const int chunks = (int)((maxdeg + MEGA_CHUNK - 1) / MEGA_CHUNK);
-                    hipLaunchKernelGGL(k_lv_mega_insert, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), 0, hs, nlist_p + moff[r], chunks, g.indices, g.q,
+                    hipLaunchKernelGGL(k_lv_mega_insert, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], chunks, g.indices, g.q,
                                        com.p, goff.p, gkeys.p, gvals.p, mega_own.p);
-                    hipLaunchKernelGGL(k_lv_mega_eval, dim3((unsigned)nm), dim3(MEGA_NT), 0, hs, nlist_p + moff[r], m2, kdeg.p, tot.p, com.p, csize.p,
+                    hipLaunchKernelGGL(k_lv_mega_eval, dim3((unsigned)nm), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], m2, kdeg.p, tot.p, com.p, csize.p,
                                        nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p);
+                    if (ms != s && ms != hs) {
+                        HIP_TRY(ctx, hipEventRecord(ctx->ev_join2, ms));
+                        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join2, 0));
+                    }
                 }
                 if (need_wave_kernel && (!grouped || moff[r] > hoff[r])) {
                     // all rows of this rank (small levels), or just the hubs the grouped kernel left out
