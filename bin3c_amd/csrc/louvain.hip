@@ -414,6 +414,8 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
 // the node's table in global memory (goff) by compare-and-swap, then one workgroup per node evaluates and clears every slot;
 // own-community weight and arg-max are reduced with integer sums and an order-free arg-max (ties to the lowest id): the same
 // result as one wave's.
+constexpr int64_t SIDE_MIN_HUBS = 512;     // hub nodes of a sub-round from which the side stream pays (see b3c_louvain)
+constexpr int64_t PRUNE_MIN_HUBS = 1024;   // ... and from which pruning them is worth its launch
 constexpr int MEGA_NT = 1024;
 constexpr int64_t MEGA_DEG = 8192;         // rows beyond this many entries
 constexpr int MEGA_CHUNK = 4 * MEGA_NT;    // entries one workgroup of the insert pass takes
@@ -1664,6 +1666,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // internal weight through the movers' rows (the same pass keeps own[] current)
         // Row-sharded runs prune too (round 3): validity stamps replace the exchange the neighbours' own[] would need
         const bool can_prune = grouped && getenv("B3C_LV_NO_PRUNE") == nullptr;
+        const bool use_side = getenv("B3C_LV_NO_SIDE") == nullptr;      // hubs / mega rows beside the grouped scan on side streams
         int64_t *own_p = can_prune ? own.p : nullptr;
         const bool stamps = can_prune && dist;
         DevBuf<int32_t> stamp(ctx, stamps ? n : 1), tstamp(ctx, stamps ? n : 1);
@@ -1734,9 +1737,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 evs.rec();
                 // (both pruned-list counters are cleared BEFORE the fork below: the side stream only waits for what precedes it)
                 if (incr && can_prune) HIP_TRY(ctx, hipMemsetAsync(pcnt.p, 0, sizeof(unsigned long long) * 2, s));
-                // the handful of hub nodes of the sub-round run on the side stream BESIDE the grouped scan (both read the
-                // state of the sub-round's start and write nxt[] of their own nodes): 17 us that used to follow it
-                const bool hub_side = grouped && need_wave_kernel && lend[r] > hoff[r] && hoff[r] > loff[r] && ctx->side_ok();
+                // many hub nodes or any mega row: they run on side streams BESIDE the grouped scan (both read the state of the
+                // sub-round's start and write nxt[] of their own nodes).  A handful of hubs (C3: 17 us of work) stays on the main
+                // stream: forking and joining costs as much as it hides (A/B at C3: 14.80 ms with, 14.70 without)
+                const bool hub_side = grouped && need_wave_kernel && hoff[r] > loff[r] && use_side && (lend[r] > moff[r] || moff[r] - hoff[r] >= SIDE_MIN_HUBS) &&
+                                      ctx->side_ok();
                 hipStream_t hs = s, ms = s;               // streams of the hub and of the mega-row kernels
                 if (hub_side) {
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
@@ -1774,11 +1779,12 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     }
 #undef LV_DECIDE_G
                 }
-                if (!grouped && !dist && n <= LV_DIRECT_CAP && getenv("B3C_LV_NO_DIRECT") == nullptr) {
+                const bool direct_level = !grouped && !dist && n <= LV_DIRECT_CAP && getenv("B3C_LV_NO_DIRECT") == nullptr;
+                if (direct_level) {
                     // small level: direct community table in LDS
                     hipLaunchKernelGGL(k_lv_decide_direct<LV_DIRECT_CAP>, dim3(grid_for(n, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, n_sub, r, m2,
                                        g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p, csize.p, nxt_p);
-                } else
+                }
                 if (grouped && lend[r] > moff[r]) {       // mega rows: workgroups per node (side stream, beside the others)
                     const int64_t nm = lend[r] - moff[r];
                     const int chunks = (int)((maxdeg + MEGA_CHUNK - 1) / MEGA_CHUNK);
@@ -1791,12 +1797,12 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join2, 0));
                     }
                 }
-                if (need_wave_kernel && (!grouped || moff[r] > hoff[r])) {
+                if (!direct_level && need_wave_kernel && (!grouped || moff[r] > hoff[r])) {
                     // all rows of this rank (small levels), or just the hubs the grouped kernel left out
                     const NodeRec *hubs = grouped ? nlist_p + hoff[r] : nullptr;
                     const int64_t w0 = grouped ? 0 : r0, w1 = grouped ? moff[r] - hoff[r] : r1;
                     const int64_t *hcnt_dev = nullptr;
-                    if (grouped && incr && can_prune && !stamps) {
+                    if (grouped && incr && can_prune && !stamps && w1 >= PRUNE_MIN_HUBS) {
                         // the hubs are pruned like the grouped nodes (round 3: on a heavy-tailed map with hundreds of entries per
                         // row -- C5 -- most of the WEIGHT sits in rows beyond the grouped kernel's 256 entries, and scanning all of
                         // them in every late sweep was 85 % of the stage).  Row-sharded runs keep scanning them: this kernel
