@@ -380,14 +380,31 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
                 }
             }
         } else {
-            for (uint32_t t = lane; t <= mask; t += 64) {
-                const int32_t c = keys[t];
-                if (c != EMPTY) {
-                    const u64 d = vals[t];
+            // four slots per lane in flight: the totals of the communities found are gathered together, not one dependent
+            // round trip per slot (a 2048-slot table is 32 slots per lane; round 3)
+            for (uint32_t t0 = lane; t0 <= mask; t0 += 4 * 64) {
+                int32_t c[4];
+                u64 d[4];
+                long long tc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t = t0 + u * 64;
+                    c[u] = t <= mask ? keys[t] : EMPTY;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t = t0 + u * 64;
+                    d[u] = c[u] != EMPTY ? vals[t] : 0;
+                    tc[u] = c[u] != EMPTY ? tot[c[u]] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (c[u] == EMPTY) continue;
+                    const uint32_t t = t0 + u * 64;
                     keys[t] = EMPTY;
                     vals[t] = 0;
-                    const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
-                    best_take(b, g, c);
+                    const i128 g = (i128)d[u] * (i128)m2 - (i128)tc[u] * (i128)ki;
+                    best_take(b, g, c[u]);
                 }
             }
         }
@@ -1613,7 +1630,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 
         // LDS table capacity per wave for this level; nodes beyond it use the global table
         const int64_t need = 1ll << table_lg(maxdeg);
-        const int cap = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
+        // LDS table of the wave-per-node kernel: 12 bytes per slot and wave, four waves per workgroup -- 2048 slots are 96 KB, ONE
+        // workgroup per CU.  B3C_LV_CAP_MAX clamps it (nodes beyond the cap use their global table): see DESIGN.md section 4
+        const int cap_max = getenv("B3C_LV_CAP_MAX") ? atoi(getenv("B3C_LV_CAP_MAX")) : 2048;
+        const int cap0 = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
+        const int cap = cap0 > cap_max ? cap_max : cap0;
         hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap, g.indptr, gsz.p);
         if ((rc = b3c_exclusive_scan_i64(ctx, gsz.p, goff.p, n + 1))) { free_graph(ctx, g); return rc; }
         int64_t gtab = 0;
