@@ -993,205 +993,6 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
     if (tid < nrows && nback[tid]) atomicAdd(&stats[3], (unsigned long long)nback[tid]);
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same layout from ONE pass per tile over a WINDOW of columns (round 3).  In the locality order the columns a tile
-// shares between its rows -- the ones worth a dictionary slot -- sit around the tile's own rows (its genome and the
-// neighbouring ones); what lies far away is inter-genome noise, which hardly ever repeats inside 192 rows.  So the two
-// bitmaps cover only the 2^18 columns centred on the tile and everything outside goes to the row's tail unseen: no chunk
-// loop over the whole column range (two passes at C3, ten at C5), 64 KB of bitmaps instead of 128 (two workgroups per
-// CU), every entry read exactly once per sweep.  A far column that does repeat in the tile is a tail instead of a
-// dictionary entry: the product is the same, it only travels by the other path.  C3: 2.88 -> see DESIGN.md section 4.
-// ---------------------------------------------------------------------------------------------
-constexpr int TCW_LG = 18;                            // window: 2^18 columns
-constexpr int TCW_WORDS = 1 << (TCW_LG - 5);          // 8192 words = 32 KB per bitmap
-constexpr int TCW_GROUPS = TCW_WORDS / 4;             // one 16-bit prefix per 128 columns
-constexpr size_t TCW_BUILD_LDS = sizeof(uint32_t) * 2 * TCW_WORDS + sizeof(uint16_t) * TCW_GROUPS + sizeof(uint32_t) * (32 + 2 * TCD_RMAX) +
-                                 sizeof(int64_t) * (TCD_RMAX + 2);
-
-__global__ void __launch_bounds__(TCD_TB) kr_tcd_build_win(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap,
-                                                            const int64_t *__restrict__ indptr,
-                                                            const int32_t *__restrict__ indices,
-                                                            const uint32_t *__restrict__ counts, uint32_t *__restrict__ packed,
-                                                            int32_t *__restrict__ pcol, int32_t *__restrict__ n1_out,
-                                                            int32_t *__restrict__ dict_cols, int32_t *__restrict__ dict_cnt,
-                                                            unsigned long long *__restrict__ stats)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t tsm[];
-    uint32_t *bm1 = tsm;                              // column seen
-    uint32_t *bm2 = tsm + TCW_WORDS;                  // column seen more than once
-    uint16_t *pre1 = (uint16_t *)(tsm + 2 * TCW_WORDS);   // dictionary columns before the group
-    uint32_t *wsum = tsm + 2 * TCW_WORDS + TCW_GROUPS / 2;    // 16 wave sums
-    uint32_t *nfront = wsum + 32;                     // per row: entries placed from the front / from the back
-    uint32_t *nback = nfront + TCD_RMAX;
-    int64_t *ipl = (int64_t *)(nback + TCD_RMAX);     // row pointers of the tile
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t tile = blockIdx.x;
-    const int64_t ra = r0 + tile * R;
-    const int nrows = (int)((ra + R < r1 ? ra + R : r1) - ra);
-    constexpr int64_t WIN = (int64_t)1 << TCW_LG;
-    // window start: centred on the tile, clamped to the column range
-    int64_t c0 = ra + nrows / 2 - WIN / 2;
-    if (c0 > ncols - WIN) c0 = ncols - WIN;
-    if (c0 < 0) c0 = 0;
-    uint4 *b14 = (uint4 *)bm1, *b24 = (uint4 *)bm2;
-    constexpr int GPT = TCW_GROUPS / TCD_TB;          // groups of 128 columns per thread
-    constexpr int NW = TCD_TB / 64;
-    for (int i = tid; i < TCW_WORDS / 4; i += TCD_TB) { b14[i] = make_uint4(0, 0, 0, 0); b24[i] = make_uint4(0, 0, 0, 0); }
-    for (int i = tid; i <= nrows; i += TCD_TB) ipl[i] = indptr[ra + i];
-    int32_t *__restrict__ dc = dict_cols + tile * (int64_t)d1cap;
-    __syncthreads();
-    // ---- sweep 1: which columns of the window does the tile use, which more than once ----
-    {
-        int32_t nx[4];                                 // first slice of the next row, in flight
-        auto first_slice = [&](int r, int32_t (&j)[4]) {
-            if (r < nrows) {
-                const int64_t s = ipl[r], e = ipl[r + 1];
-#pragma unroll
-                for (int t = 0; t < 4; t++) { const int64_t k = s + t * 64 + lane; j[t] = k < e ? indices[k] : 0x7FFFFFFF; }
-            }
-        };
-        first_slice(wv, nx);
-        for (int rl = wv; rl < nrows; rl += NW) {
-            int32_t j[4] = {nx[0], nx[1], nx[2], nx[3]};
-            first_slice(rl + NW, nx);
-            const int64_t s0 = ipl[rl], e = ipl[rl + 1];
-            if (e - s0 > hub_len) continue;            // hub rows run on the CSR arrays (kr_kb_hub)
-            for (int64_t s = s0;;) {
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int64_t c = (int64_t)j[t] - c0;
-                    if (j[t] != 0x7FFFFFFF && c >= 0 && c < WIN) {
-                        const uint32_t bit = 1u << (c & 31);
-                        const uint32_t old = atomicOr(&bm1[c >> 5], bit);
-                        if (old & bit) atomicOr(&bm2[c >> 5], bit);
-                    }
-                }
-                s += 256;
-                if (s >= e) break;
-#pragma unroll
-                for (int t = 0; t < 4; t++) { const int64_t k = s + t * 64 + lane; j[t] = k < e ? indices[k] : 0x7FFFFFFF; }
-            }
-        }
-    }
-    __syncthreads();
-    // prefix popcounts of bm2 over groups of 128 columns
-    uint32_t e1[GPT], run1 = 0;
-#pragma unroll
-    for (int g = 0; g < GPT; g++) {
-        const uint4 m2 = b24[tid * GPT + g];
-        e1[g] = run1;
-        run1 += __popc(m2.x) + __popc(m2.y) + __popc(m2.z) + __popc(m2.w);
-    }
-    uint32_t inc1 = run1;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t1 = __shfl_up(inc1, o, 64);
-        if (lane >= o) inc1 += t1;
-    }
-    if (lane == 63) wsum[wv] = inc1;
-    if (tid < 2 * TCD_RMAX) nfront[tid] = 0;          // nfront and nback are adjacent
-    __syncthreads();
-    uint32_t base1 = inc1 - run1, tot1 = 0;
-#pragma unroll
-    for (int q = 0; q < NW; q++) {
-        const uint32_t t1 = wsum[q];
-        if (q < wv) base1 += t1;
-        tot1 += t1;
-    }
-#pragma unroll
-    for (int g = 0; g < GPT; g++) {
-        const uint32_t pv = base1 + e1[g];
-        pre1[tid * GPT + g] = (uint16_t)(pv < 65535u ? pv : 65535u);    // only ranks below d1cap <= 16384 are used
-    }
-    // the dictionary: ascending columns, as many as the LDS budget of the SpMV kernel takes
-    {
-        uint32_t p1 = base1;
-        for (int i = 0; i < GPT * 4 && p1 < (uint32_t)d1cap; i++) {
-            const int wd = tid * GPT * 4 + i;
-            uint32_t bits = bm2[wd];
-            while (bits && p1 < (uint32_t)d1cap) {
-                const int b = __ffs(bits) - 1;
-                bits &= bits - 1;
-                dc[p1++] = (int32_t)(c0 + (int64_t)wd * 32 + b);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- sweep 2: the rows, dictionary entries to the front (index << 16 | count), the others to the back ----
-    {
-        int32_t nx[4];
-        uint32_t nv[4];
-        auto first_slice = [&](int r, int32_t (&j)[4], uint32_t (&cv)[4]) {
-            if (r < nrows) {
-                const int64_t s = ipl[r], e = ipl[r + 1];
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int64_t k = s + t * 64 + lane;
-                    j[t] = k < e ? indices[k] : 0x7FFFFFFF;
-                    cv[t] = k < e ? counts[k] & 0xFFFFu : 0u;
-                }
-            }
-        };
-        first_slice(wv, nx, nv);
-        for (int rl = wv; rl < nrows; rl += NW) {
-            int32_t j[4] = {nx[0], nx[1], nx[2], nx[3]};
-            uint32_t cv[4] = {nv[0], nv[1], nv[2], nv[3]};
-            first_slice(rl + NW, nx, nv);
-            const int64_t s0 = ipl[rl], e = ipl[rl + 1];
-            const int len = (int)(e - s0);
-            if (len > hub_len) continue;
-            uint32_t nf = 0, nb = 0;
-            for (int64_t s = s0; s < e; s += 256) {
-                if (s > s0) {
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int64_t k = s + t * 64 + lane;
-                        j[t] = k < e ? indices[k] : 0x7FFFFFFF;
-                        cv[t] = k < e ? counts[k] & 0xFFFFu : 0u;
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const bool ok = j[t] != 0x7FFFFFFF;
-                    const int64_t c = (int64_t)j[t] - c0;
-                    bool front = false;
-                    uint32_t r = 0;
-                    if (ok && c >= 0 && c < WIN) {
-                        const int wd = (int)(c >> 5), g = wd >> 2;
-                        const uint32_t w = bm2[wd];
-                        if ((w >> (c & 31)) & 1u) {
-                            r = pre1[g];
-                            for (int q = g * 4; q < wd; q++) r += __popc(bm2[q]);
-                            r += __popc(w & ((1u << (c & 31)) - 1u));
-                            front = r < (uint32_t)d1cap;
-                        }
-                    }
-                    const unsigned long long mf = __ballot(ok && front), mb = __ballot(ok && !front);
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    if (ok && front) packed[s0 + nf + __popcll(mf & below)] = (r << 16) | cv[t];
-                    if (ok && !front) {
-                        const int64_t at = s0 + len - 1 - (int64_t)(nb + __popcll(mb & below));
-                        packed[at] = cv[t];
-                        pcol[at] = j[t];
-                    }
-                    nf += __popcll(mf);
-                    nb += __popcll(mb);
-                }
-            }
-            if (lane == 0) { nfront[rl] = nf; nback[rl] = nb; }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < nrows; i += TCD_TB) n1_out[ra + i - r0] = (int32_t)nfront[i];
-    if (tid == 0) {
-        const int d1 = (int)(tot1 < (uint32_t)d1cap ? tot1 : (uint32_t)d1cap);
-        dict_cnt[tile] = d1;
-        atomicMax(&stats[0], (unsigned long long)d1);
-        atomicAdd(&stats[2], (unsigned long long)d1);
-    }
-    if (tid < nrows && nback[tid]) atomicAdd(&stats[3], (unsigned long long)nback[tid]);   // entries left in the tails (statistics only)
-}
-
 template <int OP>
 __device__ void block_partial_at(double v, double *__restrict__ part, int64_t at, double *lds)
 {
@@ -2486,12 +2287,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         DevBuf<unsigned long long> stt(ctx, 4);
         if (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
         HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 4, s));
-        { static bool build_attr = false; if (!build_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS)); HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build_win, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCW_BUILD_LDS)); build_attr = true; } }
-        // one pass over a window of columns around the tile (default), or bitmap passes over the whole column range
-        if (getenv("B3C_KR_TCD_BUILD_CHUNKS") == nullptr)
-            hipLaunchKernelGGL(kr_tcd_build_win, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCW_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
-                               a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
-        else
+        { static bool build_attr = false; if (!build_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS)); build_attr = true; } }
+        // (round 3 tried ONE pass per tile over a window of 2^18 columns centred on the tile, everything outside going to the tails
+        // unseen: the build fell from 2.9 to 1.1 ms, but the SpMV rose from 0.289 to 0.375 ms at C3 -- the locality order keeps a
+        // cluster together, not a genome: the pieces of a genome sit far apart and their columns DO repeat inside a tile)
         hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
                            a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
         unsigned long long hst[4];
