@@ -86,6 +86,8 @@ SYMBOLS = [
     ('b3c_mat_download', C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     ('b3c_mat_device_ptrs', C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     ('b3c_max_offdiag_u32', C.c_int, [_VP, _VP, C.c_int, _VP]),
+    ('b3c_acceptance_mask', C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int64, C.c_int64, _VP]),
+    ('b3c_vec_permute', C.c_int, [_VP, C.c_int64, C.c_int, _VP, _VP, _VP, C.c_int]),
     ('b3c_site_norm', C.c_int, [_VP, _VP, _VP, C.POINTER(_VP)]),
     ('b3c_scale_sym', C.c_int, [_VP, _VP, _VP]),
     ('b3c_scale_sym_graph', C.c_int, [_VP, _VP, _VP]),
@@ -326,6 +328,24 @@ class Context(object):
         res = np.empty(mat.n, dtype=np.uint32) if out is None else out
         self._check(self.lib.b3c_max_offdiag_u32(self.h, mat.h, int(bool(assume_symmetric)), _ptr(res)))
         return res
+
+    def acceptance_mask(self, lengths, signal, min_len, min_sig, out=None):
+        """set_primary_acceptance_mask (contact_map.py:888-905): (lengths >= min_len) & (signal >= min_sig) -> uint8[n]"""
+        n = lengths.numel() if hasattr(lengths, 'numel') else len(lengths)
+        if isinstance(lengths, np.ndarray):
+            lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+        if isinstance(signal, np.ndarray):
+            signal = np.ascontiguousarray(signal, dtype=np.uint32)
+        mask = np.empty(n, dtype=np.uint8) if out is None else out
+        self._check(self.lib.b3c_acceptance_mask(self.h, int(n), _ptr(lengths), _ptr(signal), int(min_len), int(min_sig), _ptr(mask)))
+        return mask
+
+    def vec_permute(self, src, idx, out, scatter=False):
+        """out[i] = src[idx[i]] (or out[idx[i]] = src[i]); numpy arrays or device tensors of 1-, 4- or 8-byte elements"""
+        n = idx.numel() if hasattr(idx, 'numel') else len(idx)
+        esz = src.element_size() if hasattr(src, 'element_size') else src.dtype.itemsize
+        self._check(self.lib.b3c_vec_permute(self.h, int(n), int(esz), _ptr(src), _ptr(idx), _ptr(out), 1 if scatter else 0))
+        return out
 
     def site_norm(self, counts, sites):
         if isinstance(sites, np.ndarray):

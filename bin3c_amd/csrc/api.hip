@@ -130,6 +130,19 @@ int b3c_copy_out(b3c_ctx *ctx, void *dst, const void *src, size_t bytes)
     return B3C_OK;
 }
 
+// the same without the wait when `dst` is device memory: the copy is ordered on the context's stream, which is all a caller
+// that keeps working on that stream needs (small helpers called several times per step)
+int b3c_copy_out_lazy(b3c_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return B3C_OK;
+    hipPointerAttribute_t at;
+    const bool dev = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeDevice;
+    if (!dev) (void)hipGetLastError();           // an unregistered host pointer reports an error: not ours
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
+    if (!dev) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return B3C_OK;
+}
+
 int b3c_readback(b3c_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return B3C_OK;

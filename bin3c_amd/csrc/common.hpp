@@ -260,6 +260,7 @@ int b3c_dist_gather_pairs(b3c_ctx *ctx, const int64_t *keys, const int64_t *vals
 int b3c_mat_alloc(b3c_ctx *ctx, int64_t n, int64_t nnz, int kind, b3c_mat **out);
 int b3c_copy_in(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
 int b3c_copy_out(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
+int b3c_copy_out_lazy(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);   // no wait when dst is device memory
 // device -> host read-back of a few values the host logic waits for: through the context's pinned buffer, then sync
 int b3c_readback(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
 constexpr size_t B3C_PIN_BYTES = 64 * 1024;

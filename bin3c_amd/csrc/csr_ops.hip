@@ -291,6 +291,63 @@ extern "C" int b3c_max_offdiag_u32(b3c_ctx *ctx, const b3c_mat *counts, int assu
     return b3c_copy_out(ctx, out, d.p, sizeof(uint32_t) * (size_t)n);
 }
 
+namespace {
+__global__ void k_accept_mask(int64_t n, const int64_t *__restrict__ len, const uint32_t *__restrict__ sig, int64_t min_len, int64_t min_sig,
+                              uint8_t *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mask[i] = (len[i] >= min_len && (int64_t)sig[i] >= min_sig) ? 1 : 0;
+}
+
+template <typename T>
+__global__ void k_vec_permute(int64_t n, const T *__restrict__ src, const int32_t *__restrict__ idx, T *__restrict__ dst, int scatter)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (scatter) dst[idx[i]] = src[i];
+    else dst[i] = src[idx[i]];
+}
+}  // namespace
+
+extern "C" int b3c_acceptance_mask(b3c_ctx *ctx, int64_t n, const int64_t *lengths, const uint32_t *signal, int64_t min_len,
+                                   int64_t min_sig, uint8_t *mask)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (n < 0 || (n > 0 && (!lengths || !signal || !mask))) return ctx->fail(B3C_E_ARG, "b3c_acceptance_mask: bad argument");
+    if (n == 0) return B3C_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<int64_t> dl(ctx, n);
+    DevBuf<uint32_t> ds(ctx, n);
+    DevBuf<uint8_t> dm(ctx, n);
+    if (!dl.p || !ds.p || !dm.p) return ctx->fail(B3C_E_NOMEM, "b3c_acceptance_mask");
+    int rc;
+    if ((rc = b3c_copy_in(ctx, dl.p, lengths, sizeof(int64_t) * (size_t)n)) || (rc = b3c_copy_in(ctx, ds.p, signal, sizeof(uint32_t) * (size_t)n)))
+        return rc;
+    hipLaunchKernelGGL(k_accept_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, dl.p, ds.p, min_len, min_sig, dm.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return b3c_copy_out_lazy(ctx, mask, dm.p, (size_t)n);
+}
+
+extern "C" int b3c_vec_permute(b3c_ctx *ctx, int64_t n, int elem_bytes, const void *src, const int32_t *idx, void *dst, int scatter)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (n < 0 || (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8) || (n > 0 && (!src || !idx || !dst)))
+        return ctx->fail(B3C_E_ARG, "b3c_vec_permute: bad argument");
+    if (n == 0) return B3C_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<char> ds(ctx, (size_t)n * elem_bytes), dd(ctx, (size_t)n * elem_bytes);
+    DevBuf<int32_t> di(ctx, n);
+    if (!ds.p || !dd.p || !di.p) return ctx->fail(B3C_E_NOMEM, "b3c_vec_permute");
+    int rc;
+    if ((rc = b3c_copy_in(ctx, ds.p, src, (size_t)n * elem_bytes)) || (rc = b3c_copy_in(ctx, di.p, idx, sizeof(int32_t) * (size_t)n))) return rc;
+    const unsigned g = (unsigned)((n + 255) / 256);
+    if (elem_bytes == 8) hipLaunchKernelGGL(k_vec_permute<uint64_t>, dim3(g), dim3(256), 0, ctx->stream, n, (const uint64_t *)ds.p, di.p, (uint64_t *)dd.p, scatter);
+    else if (elem_bytes == 4) hipLaunchKernelGGL(k_vec_permute<uint32_t>, dim3(g), dim3(256), 0, ctx->stream, n, (const uint32_t *)ds.p, di.p, (uint32_t *)dd.p, scatter);
+    else hipLaunchKernelGGL(k_vec_permute<uint8_t>, dim3(g), dim3(256), 0, ctx->stream, n, (const uint8_t *)ds.p, di.p, (uint8_t *)dd.p, scatter);
+    HIP_TRY(ctx, hipGetLastError());
+    return b3c_copy_out_lazy(ctx, dst, dd.p, (size_t)n * elem_bytes);
+}
+
 extern "C" int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *sites, b3c_mat **out)
 {
     if (!ctx) return B3C_E_ARG;

@@ -192,8 +192,9 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
                 if adopt_counts:
                     counts.free()              # the result never took it over
                 raise
-            idx = n2o.long()
-            sites_t, lengths_t = sites_t[idx], lengths_t[idx]
+            # the per-contig tables in the working order (libb3c gathers: torch is plumbing here, not arithmetic)
+            sites_t = ctx.vec_permute(sites_t, n2o, torch.empty_like(sites_t))
+            lengths_t = ctx.vec_permute(lengths_t, n2o, torch.empty_like(lengths_t))
         res._n2o, res._o2n = n2o, o2n
         res.row_block, res.work_nnz = block, work.nnz
         t['order'] = time.perf_counter() - t0
@@ -230,12 +231,11 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
                 ctx.max_offdiag_u32(work, assume_symmetric=True, out=signal_w)
                 if block is not None:
                     ctx.dist_allgather_i32(signal_w)           # every rank scanned its rows
-                sig64 = signal_w.long() & 0xFFFFFFFF
-                mask_w = ((lengths_t >= int(min_len)) & (sig64 >= int(min_sig))).to(torch.uint8)
+                mask_w = ctx.acceptance_mask(lengths_t, signal_w, min_len, min_sig, out=torch.empty(n, dtype=torch.uint8, device=dev))
             else:
                 mask_w = torch.as_tensor(np.asarray(mask, dtype=np.uint8), device=dev)
                 if n2o is not None:
-                    mask_w = mask_w[n2o.long()]
+                    mask_w = ctx.vec_permute(mask_w, n2o, torch.empty_like(mask_w))
             t['mask'] = time.perf_counter() - t0
 
         except Exception:
@@ -354,8 +354,7 @@ def _cluster_stage(ctx, res, mask_w, n_sub=0):
         labels_t = labels_w
     else:
         ctx._check(has_ids)
-        labels_t = torch.empty_like(labels_w)
-        labels_t[ids.long()] = labels_w                                     # back to gapless caller-side ids
+        labels_t = ctx.vec_permute(labels_w, ids, torch.empty_like(labels_w), scatter=True)   # back to gapless caller-side ids
     t['louvain'] = time.perf_counter() - t0
     return labels_t
 
@@ -367,7 +366,7 @@ def cluster_prepared(ctx, res, mask, n_sub=0):
     with torch.cuda.stream(ctx.torch_stream):
         mask_w = torch.as_tensor(np.asarray(mask, dtype=np.uint8), device=dev)
         if res._n2o is not None:
-            mask_w = mask_w[res._n2o.long()]
+            mask_w = ctx.vec_permute(mask_w, res._n2o, torch.empty_like(mask_w))
         labels_t = _cluster_stage(ctx, res, mask_w, n_sub)
         res.mask = np.asarray(mask, dtype=bool)
         res.labels = labels_t.cpu().numpy()
@@ -382,7 +381,7 @@ def device_subspace(ctx, res, mask, order=None):
     with torch.cuda.stream(ctx.torch_stream):
         mask_w = torch.as_tensor(np.asarray(mask, dtype=np.uint8), device=dev)
         if res._n2o is not None:
-            mask_w = mask_w[res._n2o.long()]
+            mask_w = ctx.vec_permute(mask_w, res._n2o, torch.empty_like(mask_w))
         if res._processed is not None or res._lazy is None:
             sub = ctx.compress(res.processed, mask_w)
         else:

@@ -206,6 +206,17 @@ int b3c_mat_ids(b3c_ctx *ctx, const b3c_mat *m, int32_t *out /*host|dev*/);
  * construction, sparse_utils.py:261-266). */
 int b3c_max_offdiag_u32(b3c_ctx *ctx, const b3c_mat *counts, int assume_symmetric, uint32_t *out /*host|dev*/);
 
+/* set_primary_acceptance_mask (contact_map.py:888-905) from its two per-contig inputs: mask[i] = lengths[i] >= min_len and
+ * signal[i] >= min_sig, with signal = b3c_max_offdiag_u32.  lengths: int64[n], signal: uint32[n], mask: uint8[n]; host|dev. */
+int b3c_acceptance_mask(b3c_ctx *ctx, int64_t n, const int64_t *lengths /*host|dev*/, const uint32_t *signal /*host|dev*/,
+                        int64_t min_len, int64_t min_sig, uint8_t *mask /*host|dev*/);
+
+/* Per-contig vectors between the caller's numbering and a permuted one (b3c_locality_order): gather dst[i] = src[idx[i]], or with
+ * scatter != 0 dst[idx[i]] = src[i]; elem_bytes 1, 4 or 8; idx int32[n]; host|dev.  (SeqOrder does the same on the host,
+ * contact_map.py:203-251.) */
+int b3c_vec_permute(b3c_ctx *ctx, int64_t n, int elem_bytes, const void *src /*host|dev*/, const int32_t *idx /*host|dev*/,
+                    void *dst /*host|dev*/, int scatter);
+
 /* _norm_seq(use_sites=True) (contact_map.py:1110-1129) + fast_norm_fullseq_bysite (:100-113) after
  * the astype(float) of :929: out_ij = counts_ij * (1.0 / (s_i * s_j)), zero sites -> 1 (:1103-1108).
  * Creates a new B3C_F64 matrix that shares no storage with `counts`. */

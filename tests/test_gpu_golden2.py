@@ -82,3 +82,32 @@ def test_compress_fixture(ctx, which):
     assert np.array_equal(data, g['out_data_' + which])
     sub.free()
     a.free()
+
+
+def test_acceptance_mask_and_vec_permute(ctx):
+    """b3c_acceptance_mask (contact_map.py:888-905) against its definition on the pipeline fixture's signal, and b3c_vec_permute
+    (gather / scatter of 1-, 4- and 8-byte per-contig vectors) against numpy, host and device pointers."""
+    import torch
+    rs = np.random.RandomState(3)
+    n = 5000
+    lengths = rs.randint(200, 20000, n).astype(np.int64)
+    signal = rs.randint(0, 40, n).astype(np.uint32)
+    signal[::97] = 0xFFFFFFF0                                  # beyond int32: the comparison is unsigned
+    for min_len, min_sig in ((1000, 5), (0, 0), (10 ** 9, 1)):
+        want = ((lengths >= min_len) & (signal.astype(np.int64) >= min_sig)).astype(np.uint8)
+        assert np.array_equal(ctx.acceptance_mask(lengths, signal, min_len, min_sig), want)
+        dev = torch.empty(n, dtype=torch.uint8, device='cuda')
+        ctx.acceptance_mask(torch.as_tensor(lengths, device='cuda'), torch.as_tensor(signal.view(np.int32), device='cuda'), min_len, min_sig, out=dev)
+        ctx.sync()
+        assert np.array_equal(dev.cpu().numpy(), want)
+    perm = rs.permutation(n).astype(np.int32)
+    for dt in (np.uint8, np.int32, np.float64):
+        src = (rs.rand(n) * 200).astype(dt)
+        assert np.array_equal(ctx.vec_permute(src, perm, np.empty_like(src)), src[perm])
+        out = np.empty_like(src)
+        out[perm] = src
+        assert np.array_equal(ctx.vec_permute(src, perm, np.empty_like(src), scatter=True), out)
+    t = torch.as_tensor(rs.rand(n), device='cuda')
+    got = ctx.vec_permute(t, torch.as_tensor(perm, device='cuda'), torch.empty_like(t))
+    ctx.sync()
+    assert torch.equal(got, t[torch.as_tensor(perm, device='cuda').long()])
