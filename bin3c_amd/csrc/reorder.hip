@@ -113,6 +113,57 @@ __global__ void __launch_bounds__(BLK) k_best_external(int64_t r0, int64_t n, co
         if (sample > 0 && e - s > sample) e = s + sample;     // the first entries of a row stand for all of them (B3C_ORDER_SAMPLE)
         const int32_t li = label[row];
         unsigned long long best = 0;
+        if (e - s <= 4 * LPR && sample == 0) {                  // (B3C_ORDER_SAMPLE=-1 forces the full-gather loop below: the A/B of the test)
+            // The whole row sits in the group's registers (round 3).  What bounds this kernel is one random 4-byte label gather
+            // per stored entry (2.0e8 of them at C3, twice per step); but the heaviest entry LEAVING the cluster is almost
+            // always among the few heaviest entries of the row -- the clusters are small at this point.  So: T = the 4th
+            // largest DISTINCT weight of the row (weights only, no gathers), labels are gathered for the entries of weight
+            // >= T alone, and if one of them leaves the cluster the best such entry is the row's answer: every entry outside
+            // the set is lighter, and all entries of equal weight are inside it, so the (weight, lowest label) tie-break sees
+            // the same candidates.  Only if none of them leaves the cluster are the remaining labels fetched.  Same result
+            // bit for bit, a fraction of the gathers.
+            int32_t j[4];
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t k = s + q * LPR + sl;
+                const bool ok = k < e;
+                const int64_t kc = ok ? k : s;
+                j[q] = ok ? indices[kc] : (int32_t)row;
+                v[q] = ok ? (float)a[kc] : 0.f;
+            }
+            float thr = INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float m = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; q++) m = (v[q] < thr && v[q] > m) ? v[q] : m;
+#pragma unroll
+                for (int o = LPR / 2; o > 0; o >>= 1) { const float t = __shfl_xor(m, o, LPR); m = t > m ? t : m; }
+                thr = m;                                    // 0 once the row has fewer distinct positive weights: the set is the whole row
+            }
+            int32_t l[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) l[q] = (v[q] >= thr && v[q] > 0.f) ? label[j[q]] : li;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned long long c = ((unsigned long long)__float_as_uint(v[q]) << 32) | (0xFFFFFFFFu - (uint32_t)l[q]);
+                if (l[q] != li && v[q] > 0.f && c > best) best = c;
+            }
+            // did any lane of the group find an entry that leaves the cluster?
+            unsigned long long any = best;
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) any |= (unsigned long long)__shfl_xor((long long)any, o, LPR);
+            if (any == 0 && thr > 0.f) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) l[q] = (v[q] < thr && v[q] > 0.f) ? label[j[q]] : li;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned long long c = ((unsigned long long)__float_as_uint(v[q]) << 32) | (0xFFFFFFFFu - (uint32_t)l[q]);
+                    if (l[q] != li && v[q] > 0.f && c > best) best = c;
+                }
+            }
+        } else
         // four masked slots per lane and pass: all index loads, then all label gathers are in flight together (a slot past
         // the end of the row points at the row itself, whose label is li, so it never wins)
         for (int64_t base = s; base < e; base += 4 * LPR) {

@@ -3,6 +3,8 @@ GPU suite: shapes that steer libb3c onto its less travelled kernels, each agains
 rows long enough for the 4-entries-per-lane SpMV (average > 128) with 16-bit and with 32-bit counts, rows past one
 pipelined chunk (> 256) and past the register sort of the permutation (> 512), and degenerate maps.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -154,3 +156,32 @@ def test_very_long_hub_row(ctx, oracle_lib):
         assert res.kr_info.n_iter == st.n_iter
         np.testing.assert_allclose(res.x, xo, rtol=1e-8)
     counts.free()
+
+
+def test_locality_order_shortcut_equals_the_full_gather(ctx):
+    """k_best_external fetches cluster labels for the few heaviest entries of a row first and for the rest only when none of
+    those leaves the cluster; B3C_ORDER_SAMPLE=-1 forces the label gather for every entry (the loop of rounds 1-2).  Same
+    heaviest leaving edge for every row, hence the same order, on flat, power-law and all-ones (every weight tied) maps."""
+    import scipy.sparse as sp
+    from bin3c_amd.synth import make_synth
+    maps = []
+    for args in ((60000, 3000000, 4), (40000, 1500000, 5, 'powerlaw')):
+        sm = make_synth(*args)
+        maps.append((sm.indptr, sm.indices, sm.counts))
+    rs = np.random.RandomState(2)
+    a = sp.random(40000, 40000, density=60.0 / 40000, random_state=rs, format='csr')
+    a.data[:] = 1.0
+    a = ((a + a.T) > 0).astype(np.uint32).tocsr()
+    a.sort_indices()
+    maps.append((a.indptr.astype(np.int64), a.indices.astype(np.int32), a.data.astype(np.uint32)))
+    for ip, ix, cnt in maps:
+        m = ctx.upload(ip, ix, cnt)
+        os.environ.pop('B3C_ORDER_SAMPLE', None)
+        fast = ctx.locality_order(m)
+        os.environ['B3C_ORDER_SAMPLE'] = '-1'
+        try:
+            full = ctx.locality_order(m)
+        finally:
+            os.environ.pop('B3C_ORDER_SAMPLE', None)
+        assert np.array_equal(fast[0], full[0]) and np.array_equal(fast[1], full[1])
+        m.free()
