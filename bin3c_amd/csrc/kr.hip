@@ -94,47 +94,6 @@ __device__ double reduce_partials(const double *__restrict__ part, int P, int st
     return r;
 }
 
-// The same sum with the first round of partials ALREADY in registers (loaded by the caller before anything else it waits
-// for, so that their round trip is not the last link of the kernel's dependent chain: state -> partials -> tree).  Folds in
-// the order of reduce_partials<0>: bit-identical result.
-constexpr int RP_U = 16;
-__device__ __forceinline__ void preload_partials(const double *__restrict__ part, int P, int stride, double (&q)[RP_U])
-{
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < RP_U; u++) {
-        const int i = t + u * BLK;
-        q[u] = i < P ? part[(size_t)i * stride] : 0.0;
-    }
-}
-__device__ double reduce_partials_pre(const double (&q0)[RP_U], const double *__restrict__ part, int P, int stride, double *lds)
-{
-    const int t = threadIdx.x;
-    double v = 0.0;
-#pragma unroll
-    for (int u = 0; u < RP_U; u++) v = v + q0[u];
-    for (int base = BLK * RP_U; base < P; base += BLK * RP_U) {
-        double q[RP_U];
-#pragma unroll
-        for (int u = 0; u < RP_U; u++) {
-            const int i = base + t + u * BLK;
-            q[u] = i < P ? part[(size_t)i * stride] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < RP_U; u++) v = v + q[u];
-    }
-    lds[t] = v;
-    __syncthreads();
-#pragma unroll
-    for (int s = BLK / 2; s > 0; s >>= 1) {
-        if (t < s) lds[t] = lds[t] + lds[t + s];
-        __syncthreads();
-    }
-    const double r = lds[0];
-    __syncthreads();
-    return r;
-}
-
 // Block-wide reduction of one value per thread into part[blockIdx.x].
 template <int OP>
 __device__ void block_partial(double v, double *__restrict__ part, double *lds)
@@ -1575,10 +1534,7 @@ __global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams pr
     __shared__ double lds[BLK];
     const int64_t stride = (int64_t)gridDim.x * BLK;
     const int64_t i0 = r0 + (int64_t)blockIdx.x * BLK + threadIdx.x;
-    // the SpMV's partials first (both branches below reduce them), then the operands of the inner step: all requested
-    // before the state is known
-    double pq[RP_U];
-    preload_partials(pkb, PA, PS, pq);
+    // the operands of the inner step, requested before the state is known
     double ey[KV_E], ep[KV_E], erk[KV_E], ew[KV_E], ev[KV_E];
 #pragma unroll
     for (int e = 0; e < KV_E; e++) {
@@ -1592,11 +1548,11 @@ __global__ void __launch_bounds__(BLK) kr_kcd(int64_t r0, int64_t n, KRParams pr
     }
     KRState st = *sin;
     if (st.phase == B_INNER) {
-        double pw = reduce_partials_pre(pq, pkb, PA, PS, lds);
+        double pw = reduce_partials<0>(pkb, PA, PS, lds);
         st.alpha = st.rho_km1 / pw;  // :166
         st.phase = C_PENDING;
     } else if (st.phase == B_OUTER || st.phase == B_INIT) {
-        double s = reduce_partials_pre(pq, pkb, PA, PS, lds);
+        double s = reduce_partials<0>(pkb, PA, PS, lds);
         st.rho_km1 = s;  // :139 / :199
         st.rout = s;
         if (st.phase == B_INIT) {
@@ -2095,11 +2051,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int64_t r1 = dist ? std::min<int64_t>(n, r0 + D.chunk) : n;
     const int64_t nloc = r1 - r0;
     // geometry: fixed for a given (n, nnz, world) so that reductions are reproducible
-    // vector kernels: 148 / 146 VGPRs -> three workgroups per CU; at most that many are launched, so that the whole grid is
-    // resident at once (a fourth per CU would queue behind the first three and double the kernel's latency chain)
-    const int gvec = (getenv("B3C_KR_GVEC") ? std::max(1, atoi(getenv("B3C_KR_GVEC"))) : 3) * ctx->n_cu;
-    const int G = grid_for(nloc, BLK * KV_E, gvec);                   // ... over this rank's rows (KCD)
-    const int GA = grid_for(n, BLK * KV_E, gvec);                     // ... over all rows (KA: p, y, x and the operand are kept whole on every rank)
+    const int G = grid_for(nloc, BLK * KV_E, 4 * ctx->n_cu);          // vector kernels over this rank's rows (KCD)
+    const int GA = grid_for(n, BLK * KV_E, 4 * ctx->n_cu);            // ... over all rows (KA: p, y, x and the operand are kept whole on every rank)
     const int GK = dist ? GA : G;                                     // KCD: this rank's rows on one GPU, ALL rows when sharded (one exchange per SpMV)
     // (a row block holds the entries of this rank's rows only)
     const double avg = (double)a->nnz / (double)(a->row_block ? std::max<int64_t>(1, a->row1 - a->row0) : n);
