@@ -38,55 +38,65 @@ def add_cluster_names(clustering, prefix='CL'):
 
 # ---- solver wire formats --------------------------------------------------------------------------
 
+def _records(pathname, skip_comments=False):
+    """The stripped lines of a solver output file up to the first empty one (where the reference's readers stop)."""
+    with open(pathname, 'r') as handle:
+        for raw in handle:
+            text = raw.strip()
+            if not text:
+                return
+            if skip_comments and text[0] == '#':
+                continue
+            yield text
+
+
+def _grouped(keys, members):
+    """[(key, int64 array of its members in file order)] in order of the keys' first appearance -- the iteration order of the
+    dict the reference fills line by line.  One stable argsort instead of a Python append per line."""
+    members = np.asarray(members, dtype=np.int64)
+    if members.shape[0] == 0:
+        return []
+    uniq, first, inverse = np.unique(np.asarray(keys), return_index=True, return_inverse=True)
+    by_key = np.argsort(inverse, kind='stable')
+    ends = np.cumsum(np.bincount(inverse, minlength=uniq.shape[0]))
+    chunks = np.split(members[by_key], ends[:-1])
+    return [(uniq[k], chunks[k]) for k in np.argsort(first, kind='stable')]
+
+
 def read_mcl(pathname):
-    """One cluster per line, members space separated (cluster.py:57-74)."""
-    cl_map = {}
-    with open(pathname, 'r') as h_in:
-        for cl_id, line in enumerate(h_in):
-            line = line.rstrip()
-            if not line:
-                break
-            cl_map[cl_id] = np.array(sorted(int(tok) for tok in line.split()))
-    return cl_map
+    """MCL output: one cluster per line, space separated gapless ids, returned ascending; cluster id = line number
+    (cluster.py:57-74)."""
+    return {cl_id: np.sort(np.array(text.split(), dtype=np.int64)) for cl_id, text in enumerate(_records(pathname))}
 
 
 def read_table(pathname, seq_col=0, cl_col=1):
-    """``seq cluster`` per line, or implicit sequence numbering with seq_col=None (cluster.py:76-109)."""
+    """``seq cl`` pairs, or with seq_col=None one cluster id per line for sequence 0, 1, 2 ... (cluster.py:76-109)."""
     assert seq_col != cl_col, 'sequence and cluster columns must be different'
-    cl_map = {}
-    n = 0
-    with open(pathname, 'r') as h_in:
-        for line in h_in:
-            line = line.strip()
-            if not line:
-                break
-            if seq_col is None:
-                cl_id, seq_id = int(line), n
-                n += 1
-            else:
-                t = line.split()
-                if len(t) != 2:
-                    logger.warning('invalid line encountered when reading cluster table: {}'.format(line))
-                seq_id, cl_id = int(t[seq_col]), int(t[cl_col])
-            cl_map.setdefault(cl_id, []).append(seq_id)
-    return {k: np.array(v, dtype=np.int64) for k, v in cl_map.items()}
+    lines = list(_records(pathname))
+    if seq_col is None:
+        clusters = [int(text) for text in lines]
+        sequences = np.arange(len(lines), dtype=np.int64)
+    else:
+        tokens = [text.split() for text in lines]
+        for text, tok in zip(lines, tokens):
+            if len(tok) != 2:
+                logger.warning('invalid line encountered when reading cluster table: {}'.format(text))
+        clusters = [int(tok[cl_col]) for tok in tokens]
+        sequences = [int(tok[seq_col]) for tok in tokens]
+    return {int(cl_id): ids for cl_id, ids in _grouped(clusters, sequences)}
 
 
 def read_tree(pathname):
-    """Infomap ``.tree``: cluster = path minus the leaf, renumbered by descending size (cluster.py:111-137)."""
-    cl_map = {}
-    with open(pathname, 'r') as in_h:
-        for line in in_h:
-            line = line.strip()
-            if not line:
-                break
-            if line.startswith('#'):
-                continue
-            fields = line.split()
-            hierarchy = fields[0].split(':')
-            cl_map.setdefault(tuple(['orig'] + hierarchy[:-1]), []).append(fields[-1])
-    desc_key = sorted(cl_map, key=lambda x: len(cl_map[x]), reverse=True)
-    return {n: np.array(cl_map[k], dtype=np.int64) for n, k in enumerate(desc_key)}
+    """Infomap ``.tree``: a leaf line is ``path flow "name" id``; its cluster is the path minus the leaf position, and clusters
+    are renumbered by descending size, equal sizes in order of first appearance (cluster.py:111-137)."""
+    paths, leaves = [], []
+    for text in _records(pathname, skip_comments=True):
+        fields = text.split()
+        paths.append(fields[0].rpartition(':')[0])
+        leaves.append(int(fields[-1]))
+    groups = _grouped(paths, leaves)
+    ranked = sorted(range(len(groups)), key=lambda k: -groups[k][1].shape[0])      # stable: ties keep first-appearance order
+    return {rank: groups[k][1] for rank, k in enumerate(ranked)}
 
 
 def write_edges(graph, parent_dir, base_name, sep=' '):
@@ -131,15 +141,14 @@ def to_graph(contact_map, norm=True, bisto=False, scale=False, extern_ids=False,
     whose both directions hold the value nx.Graph would hold (the later, lower-triangle entry wins,
     cluster.py:319-321) -- or a networkx.Graph with as_networkx=True for code that wants the reference's type.
     """
-    if not min_len and not min_sig:
-        contact_map.set_primary_acceptance_mask()
-    else:
+    if min_len or min_sig:                      # explicit criteria replace a cached mask (cluster.py:301-304)
         contact_map.set_primary_acceptance_mask(min_len, min_sig, update=True)
+    else:
+        contact_map.set_primary_acceptance_mask()
     if contact_map.processed_map is None:
         contact_map.prepare_seq_map(norm=norm, bisto=bisto)
-    _map = contact_map.get_subspace(marginalise=True, flatten=False)
+    c = sp.csr_matrix(contact_map.get_subspace(marginalise=True, flatten=False))
     logger.info('Graph will have {} nodes'.format(contact_map.order.count_accepted()))
-    c = sp.csr_matrix(_map)
     c.sort_indices()
     scl = 1.0 / c.max() if scale else 1
     # lower triangle wins: mirror it over the upper triangle
@@ -290,65 +299,64 @@ def _run_external(method, g, seed, work_dir, base_name):
 _read_mcl, _read_table, _read_tree, _write_edges = read_mcl, read_table, read_tree, write_edges
 
 
+def _select_clusters(clustering, wanted, min_extent, ordered_only):
+    """The cluster ids of `wanted` that pass the enabled criteria, ascending; every criterion logs how many are left and
+    raises when none is (the messages are the reference's, cluster.py:348-362)."""
+    criteria = []
+    if min_extent:
+        criteria.append(('minimum extent', lambda k: clustering[k]['extent'] >= min_extent,
+                         'No clusters passed min_extent criterion of >= {}'.format(min_extent)))
+    if ordered_only:
+        criteria.append(('ordered-only', lambda k: 'order' in clustering[k], 'No clusters passed ordered-only criterion'))
+    left = list(wanted)
+    for label, passes, complaint in criteria:
+        left = [k for k in left if passes(k)]
+        logger.info('Clusters passing {} criterion: {}'.format(label, len(left)))
+        if not left:
+            raise NoRemainingClustersException(complaint)
+    return sorted(left)
+
+
 def enable_clusters(contact_map, clustering, cl_list=None, ordered_only=True, min_extent=None):
     """
-    Given a clustering and list of cluster ids (or none), enable (unmask) the related sequences in the contact map
-    (cluster.py:327-387). If a requested cluster has not been ordered, it will be dropped.
+    Unmask the sequences of the given clusters (all of them for cl_list=None) in the contact map and put them in cluster
+    order: each cluster's determined order and orientation with ordered_only, else its sequence ids as they come
+    (cluster.py:327-387).  Clusters under `min_extent` (default: the map's own) or, with ordered_only, without an order are
+    dropped.
 
-    :return: the filtered list of cluster ids in ascending numerical order
+    :return: the ids of the clusters that remain, ascending
     """
-    if cl_list is None:
-        cl_list = clustering.keys()
-    if min_extent is None:
-        min_extent = contact_map.min_extent
-    if min_extent:
-        cl_list = [k for k in cl_list if clustering[k]['extent'] >= min_extent]
-        logger.info('Clusters passing minimum extent criterion: {}'.format(len(cl_list)))
-        if len(cl_list) == 0:
-            raise NoRemainingClustersException('No clusters passed min_extent criterion of >= {}'.format(min_extent))
-    if ordered_only:
-        cl_list = [k for k in cl_list if 'order' in clustering[k]]
-        logger.info('Clusters passing ordered-only criterion: {}'.format(len(cl_list)))
-        if len(cl_list) == 0:
-            raise NoRemainingClustersException('No clusters passed ordered-only criterion')
-    cl_list = sorted(cl_list)
-    if ordered_only:
-        cmb_ord = np.hstack([clustering[k]['order'] for k in cl_list])
-    else:
-        cmb_ord = np.hstack([SeqOrder.asindex(clustering[k]['seq_ids']) for k in cl_list])
-    if len(cmb_ord) == 0:
+    chosen = _select_clusters(clustering, clustering.keys() if cl_list is None else cl_list,
+                              contact_map.min_extent if min_extent is None else min_extent, ordered_only)
+    placement = np.hstack([clustering[k]['order'] if ordered_only else SeqOrder.asindex(clustering[k]['seq_ids']) for k in chosen])
+    if placement.shape[0] == 0:
         raise NoRemainingClustersException('No requested cluster contained ordering information')
-    logger.info('Total number of sequences in the clustering: {}'.format(len(cmb_ord)))
-    _mask = np.zeros_like(contact_map.order.mask_vector(), dtype=np.bool_)
-    _mask[cmb_ord['index']] = True
-    _mask &= contact_map.get_primary_acceptance_mask()
-    logger.info('After joining with active sequence mask map: {}'.format(_mask.sum()))
-    contact_map.order.set_mask_only(_mask)
-    contact_map.order.set_order_and_orientation(cmb_ord, implicit_excl=True)
-    return cl_list
+    logger.info('Total number of sequences in the clustering: {}'.format(placement.shape[0]))
+    shown = np.zeros(contact_map.order.mask_vector().shape, dtype=np.bool_)
+    shown[placement['index']] = True
+    shown &= contact_map.get_primary_acceptance_mask()
+    logger.info('After joining with active sequence mask map: {}'.format(int(shown.sum())))
+    contact_map.order.set_mask_only(shown)
+    contact_map.order.set_order_and_orientation(placement, implicit_excl=True)
+    return chosen
 
 
 def plot_clusters(contact_map, fname, clustering, cl_list=None, simple=True, permute=False, max_image_size=None,
                   ordered_only=False, min_extent=None, use_taxo=False, flatten=False, **kwargs):
     """
-    Plot the contact map, annotating the map with cluster names and boundaries (cluster.py:390-449). For large
-    contact maps the raster is block-reduced on the device (``max_image_size``).
+    The heat-map of the clustered map with one tick per cluster, labelled by cluster name (or taxon with use_taxo)
+    (cluster.py:390-449).  The raster is permuted and block-reduced on the device (``max_image_size``).
     """
-    if cl_list is None:
-        logger.info('Plotting heatmap of complete solution')
-    else:
-        logger.info('Plotting heatmap for {} specified clusters'.format(len(cl_list)))
+    logger.info('Plotting heatmap of complete solution' if cl_list is None
+                else 'Plotting heatmap for {} specified clusters'.format(len(cl_list)))
     assert simple or contact_map.bin_size is None, 'extent (binned) maps are outside the accelerated path'
     if not contact_map.has_processed_map():
         contact_map.prepare_seq_map(norm=True, bisto=True)
-    cl_list = enable_clusters(contact_map, clustering, cl_list=cl_list, ordered_only=ordered_only, min_extent=min_extent)
-    tick_locs = np.cumsum([0] + [len(clustering[k]['seq_ids']) for k in cl_list])
-    if use_taxo:
-        _labels = [clustering[cl_id]['taxon'] for cl_id in cl_list]
-    else:
-        _labels = [clustering[cl_id]['name'] for cl_id in cl_list]
-    contact_map.plot(fname, permute=permute, simple=simple, tick_locs=tick_locs, tick_labs=_labels,
-                     max_image_size=max_image_size, flatten=flatten, **kwargs)
+    shown = enable_clusters(contact_map, clustering, cl_list=cl_list, ordered_only=ordered_only, min_extent=min_extent)
+    sizes = np.array([len(clustering[k]['seq_ids']) for k in shown], dtype=np.int64)
+    label_key = 'taxon' if use_taxo else 'name'
+    contact_map.plot(fname, permute=permute, simple=simple, tick_locs=np.concatenate(([0], np.cumsum(sizes))),
+                     tick_labs=[clustering[k][label_key] for k in shown], max_image_size=max_image_size, flatten=flatten, **kwargs)
 
 
 def write_mcl(contact_map, fname, clustering):
