@@ -180,8 +180,12 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
                                                   int64_t *__restrict__ tot, int32_t *__restrict__ com,
                                                   int32_t *__restrict__ nxt, int32_t *__restrict__ csize,
                                                   u64 *__restrict__ m2, int64_t *__restrict__ wnl, int64_t r0, int64_t r1,
-                                                  u64 *__restrict__ i2)
+                                                  u64 *__restrict__ i2, const double *__restrict__ wq, double wscl, int shift,
+                                                  int64_t *__restrict__ q_out)
 {
+    // wq != nullptr (level 0 of a value-symmetric map): the fixed-point weights are FORMED here, q = rint(a * scl * 2^shift)
+    // exactly as k_quantise forms them, and written to q_out for the kernels that follow -- the quantisation costs no pass of
+    // its own (round 3)
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * WPB;
@@ -197,7 +201,12 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
                 const int64_t k = base + t * 64 + lane;
                 const bool ok = k < e;
                 j[t] = ok ? indices[k] : -1;
-                w[t] = ok ? q[k] : 0;
+                if (wq) {
+                    w[t] = ok ? __double2ll_rn(ldexp(wq[k] * wscl, shift)) : 0;
+                    if (ok) q_out[k] = w[t];
+                } else {
+                    w[t] = ok ? q[k] : 0;
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -1422,7 +1431,10 @@ struct Events {
     }
 };
 
-int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double scl, int64_t *q, int32_t *shift_out, bool blockm = false)
+struct DeferredQuant { const double *src = nullptr; double scl = 1.0; };      // set: k_lv_init forms q itself from src * scl
+
+int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double scl, int64_t *q, int32_t *shift_out, bool blockm = false,
+                   DeferredQuant *defer = nullptr)
 {
     hipStream_t s = ctx->stream;
     const int64_t n = a->n, nnz = a->nnz;
@@ -1482,7 +1494,12 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
         while (bits < 64 && (tot >> bits)) bits++;
         shift = 61 - (bits - 20 + e);
     }
-    hipLaunchKernelGGL(k_quantise, dim3(grid_for(nnz, BLK * 4, 8 * ctx->n_cu)), dim3(BLK), 0, s, nnz, wsrc, wscl, shift, q);
+    if (defer && direct && nnz > 0) {
+        defer->src = wsrc;              // (the matrix's own values: they outlive this call)
+        defer->scl = wscl;
+    } else {
+        hipLaunchKernelGGL(k_quantise, dim3(grid_for(nnz, BLK * 4, 8 * ctx->n_cu)), dim3(BLK), 0, s, nnz, wsrc, wscl, shift, q);
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
     *shift_out = shift;
@@ -1553,7 +1570,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     // sharded level 0 on a row block (b3c_mat_permute_rows + compress): this rank holds the entries of its rows only
     const bool blockm = ctx->has_dist && a->row_block;
     if (blockm && reorder) return ctx->fail(B3C_E_ARG, "b3c_louvain: a row block must be ordered by the caller");
-    rc = quantise_graph(ctx, a, ids0, scl, q0.p, &shift, blockm);
+    DeferredQuant dq;
+    rc = quantise_graph(ctx, a, ids0, scl, q0.p, &shift, blockm, &dq);
     if (rc) return rc;
     info->quant_shift = shift;
     hipLaunchKernelGGL(k_init_labels, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, n0, a->indptr, labels.p);
@@ -1612,8 +1630,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int gw = grid_for(n, WPB, 16 * ctx->n_cu);     // wave-per-row kernels
         const int gv = grid_for(n, BLK, 8 * ctx->n_cu);      // thread-per-node kernels
         HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 8, s));
-        hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, g.q, ids, kdeg.p, tot.p, com.p,
-                           nxt_p, csize.p, ctr.p, wnl.p, r0, r1, ctr.p + 2);
+        const bool form_q = first && dq.src != nullptr;       // level 0: the weights are quantised by this pass (see k_lv_init)
+        hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, form_q ? nullptr : g.q, ids, kdeg.p, tot.p, com.p,
+                           nxt_p, csize.p, ctr.p, wnl.p, r0, r1, ctr.p + 2, form_q ? dq.src : nullptr, dq.scl, (int)shift, form_q ? q0.p : nullptr);
         hipLaunchKernelGGL(k_max_degree, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
         if (blk0) {
             // degrees (and which rows exist) of the other ranks' rows, then totals / sizes / labels / 2m from the whole vector
