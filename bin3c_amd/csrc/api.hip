@@ -253,6 +253,7 @@ extern "C" int b3c_mat_device_ptrs(const b3c_mat *m, void **indptr, void **indic
         *data = m->data;
         const_cast<b3c_mat *>(m)->vmax_valid = false;      // the caller may write through this pointer
         const_cast<b3c_mat *>(m)->rowmax_valid = false;
+        const_cast<b3c_mat *>(m)->vsum_valid = false;
     }
     return B3C_OK;
 }

@@ -141,6 +141,12 @@ struct b3c_mat {
     // Matrices are immutable after creation; b3c_mat_device_ptrs hands out writable pointers and therefore drops it.
     double vmax = 0.0;
     bool vmax_valid = false;
+    // sum of the stored values with the diagonal counted twice and the number of diagonal entries, left behind by the kernel
+    // that wrote the values (k_compress_fill_ns): an ESTIMATE (floating-point atomics, any order) from which the Louvain
+    // quantisation derives its shift without a pass of its own whenever the estimate is conclusive (quantise_graph)
+    double vsum2 = 0.0;
+    int64_t ndiag = 0;
+    bool vsum_valid = false;
     // B3C_U32 matrices: the largest off-diagonal count of every ROW (= of every column when the map is symmetric,
     // sparse_utils.py:269-281), a by-product of the pass b3c_kr_balance_counts makes over the counts anyway (kr_prep_counts);
     // b3c_max_offdiag_u32(assume_symmetric) then answers from it without another pass.  Pooled block of n uint32, or null.

@@ -474,8 +474,10 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
                                                            int graph_form,
                                                            const int64_t *__restrict__ out_indptr,
                                                            int32_t *__restrict__ out_indices, double *__restrict__ out_a,
-                                                           unsigned long long *__restrict__ vstat)   // [0] bits of the largest value, [1] a negative one was seen
+                                                           unsigned long long *__restrict__ vstat)   // [0] bits of the largest value, [1] a negative one was seen, [2] sum (double), [3] diagonal entries
 {
+    double vsum = 0.0;            // sum of the values written, diagonal entries twice (an estimate: see b3c_mat.vsum2)
+    long long ndg = 0;
     constexpr int U = 4;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
@@ -552,6 +554,9 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
                     out_indices[o + pos] = nj[t].x;
                     out_a[o + pos] = val;
                     vmax = fmax(vmax, val);
+                    const bool dg = nj[t].x == nr.x;
+                    vsum += dg ? 2.0 * val : val;
+                    ndg += dg ? 1 : 0;
                 }
                 o += __popcll(b);
             }
@@ -583,6 +588,12 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
         } else if (vmax < 0.0 && vmax > -INFINITY) {
             vstat[1] = 1ull;
         }
+    }
+    vsum = wave_sum(vsum);
+    ndg = wave_sum_ll(ndg);
+    if (lane == 0) {
+        if (vsum != 0.0) atomicAdd((double *)&vstat[2], vsum);
+        if (ndg) atomicAdd(&vstat[3], (unsigned long long)ndg);
     }
 }
 
@@ -667,13 +678,13 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
             DevBuf<int2> ni(ctx, n + 1);
             if (!ni.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
             hipLaunchKernelGGL(k_pack_ni, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, newid.p, a->ids, ni.p);
-            DevBuf<unsigned long long> vstat(ctx, 2);
+            DevBuf<unsigned long long> vstat(ctx, 4);
             if (!vstat.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
-            HIP_TRY(ctx, hipMemsetAsync(vstat.p, 0, sizeof(unsigned long long) * 2, s));
+            HIP_TRY(ctx, hipMemsetAsync(vstat.p, 0, sizeof(unsigned long long) * 4, s));
             hipLaunchKernelGGL(k_compress_fill_ns, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data,
                                ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data, vstat.p);
             // (the read-back also ends the use of `ni`, which goes back to the pool at the end of this scope)
-            unsigned long long hv[2] = {0, 0};
+            unsigned long long hv[4] = {0, 0, 0, 0};
             { const int rb_ = b3c_readback(ctx, hv, vstat.p, sizeof(hv)); if (rb_) return rb_; }
             if (hv[1] == 0 && nnz > 0) {
                 // all values non-negative: the largest one is known without another pass (b3c_max_value)
@@ -681,6 +692,9 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
                 memcpy(&vm, &hv[0], sizeof(double));
                 o->vmax = vm;
                 o->vmax_valid = true;
+                memcpy(&o->vsum2, &hv[2], sizeof(double));
+                o->ndiag = (int64_t)hv[3];
+                o->vsum_valid = true;
             }
         }
         else if (a->kind == B3C_F64)

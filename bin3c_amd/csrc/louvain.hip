@@ -1477,10 +1477,29 @@ int quantise_graph(b3c_ctx *ctx, const b3c_mat *a, const int32_t *ids, double sc
     if (wmax > 0.0) {
         int e;
         frexp(wmax, &e);   // wmax < 2^e
-        HIP_TRY(ctx, hipMemsetAsync(total.p, 0, sizeof(u64), s));
-        hipLaunchKernelGGL(k_quant_total, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, wsrc, wscl, 20 - e, total.p);
         u64 tot = 0;
-        { const int rb_ = b3c_readback(ctx, &tot, total.p, sizeof(u64)); if (rb_) return rb_; }
+        bool known = false;
+        if (direct && !blockm && a->vsum_valid && a->vmax_valid && scl > 0.0 && scl < INFINITY && a->vsum2 > 0.0 && a->vsum2 < INFINITY) {
+            // Only the BIT LENGTH of the total matters (the shift below), and the total is pinned between two bounds by what the
+            // kernel that wrote the values left behind: T = sum ceil(a*scl*2^(20-e)) (diagonal twice) lies in
+            // [X(1 - d), X(1 + d) + N] with X = vsum2*scl*2^(20-e), N = nnz + ndiag (one unit of ceil per term) and d = 1e-6, far
+            // above the rounding of the products and of the (order-free, atomically accumulated) sum.  If both bounds have the
+            // same bit length it is the total's; otherwise (about one map in 10^4) the exact pass runs.
+            const long double X = (long double)a->vsum2 * (long double)scl * ldexpl(1.0L, 20 - e);
+            const long double lo = X * (1.0L - 1e-6L), hi = X * (1.0L + 1e-6L) + (long double)(a->nnz + a->ndiag);
+            if (lo >= 1.0L && hi < 18446744073709551615.0L) {
+                const u64 l = (u64)lo, h = (u64)hi + 1;
+                int bl = 0, bh = 0;
+                while (bl < 64 && (l >> bl)) bl++;
+                while (bh < 64 && (h >> bh)) bh++;
+                if (bl == bh) { tot = l; known = true; }
+            }
+        }
+        if (!known) {
+            HIP_TRY(ctx, hipMemsetAsync(total.p, 0, sizeof(u64), s));
+            hipLaunchKernelGGL(k_quant_total, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, wsrc, wscl, 20 - e, total.p);
+            { const int rb_ = b3c_readback(ctx, &tot, total.p, sizeof(u64)); if (rb_) return rb_; }
+        }
         if (blockm) {
             const b3c_dist &D = ctx->dist;
             HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, total.p, sizeof(u64), hipMemcpyDeviceToDevice, s));
