@@ -474,7 +474,8 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
                                                            int graph_form,
                                                            const int64_t *__restrict__ out_indptr,
                                                            int32_t *__restrict__ out_indices, double *__restrict__ out_a,
-                                                           unsigned long long *__restrict__ vstat)   // [0] bits of the largest value, [1] a negative one was seen, [2] sum (double), [3] diagonal entries
+                                                           unsigned long long *__restrict__ vstat,   // [0] bits of the largest value, [1] a negative one was seen, [3] diagonal entries
+                                                           double *__restrict__ vpart)               // per-workgroup sums of the values (diagonal twice)
 {
     double vsum = 0.0;            // sum of the values written, diagonal entries twice (an estimate: see b3c_mat.vsum2)
     long long ndg = 0;
@@ -589,11 +590,17 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
             vstat[1] = 1ull;
         }
     }
+    // one partial per workgroup, summed by the host (a double atomicAdd is a compare-and-swap loop here, and 16k waves on one
+    // address cost the kernel more than the pass this estimate saves)
+    __shared__ double vred[BLK / 64];
+    __shared__ long long dred[BLK / 64];
     vsum = wave_sum(vsum);
-    ndg = wave_sum_ll(ndg);
-    if (lane == 0) {
-        if (vsum != 0.0) atomicAdd((double *)&vstat[2], vsum);
-        if (ndg) atomicAdd(&vstat[3], (unsigned long long)ndg);
+    if (lane == 0) vred[threadIdx.x >> 6] = vsum;
+    block_atomic_add_u64(ndg, &vstat[3], dred);          // (syncs the workgroup: vred is visible afterwards)
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLK / 64; w++) t += vred[w];
+        vpart[blockIdx.x] = t;
     }
 }
 
@@ -681,8 +688,12 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
             DevBuf<unsigned long long> vstat(ctx, 4);
             if (!vstat.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
             HIP_TRY(ctx, hipMemsetAsync(vstat.p, 0, sizeof(unsigned long long) * 4, s));
+            DevBuf<double> vpart(ctx, g);
+            if (!vpart.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
             hipLaunchKernelGGL(k_compress_fill_ns, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data,
-                               ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data, vstat.p);
+                               ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data, vstat.p, vpart.p);
+            std::vector<double> hpart((size_t)g);
+            HIP_TRY(ctx, hipMemcpyAsync(hpart.data(), vpart.p, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, s));
             // (the read-back also ends the use of `ni`, which goes back to the pool at the end of this scope)
             unsigned long long hv[4] = {0, 0, 0, 0};
             { const int rb_ = b3c_readback(ctx, hv, vstat.p, sizeof(hv)); if (rb_) return rb_; }
@@ -692,7 +703,9 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
                 memcpy(&vm, &hv[0], sizeof(double));
                 o->vmax = vm;
                 o->vmax_valid = true;
-                memcpy(&o->vsum2, &hv[2], sizeof(double));
+                double vs = 0.0;
+                for (double t : hpart) vs += t;
+                o->vsum2 = vs;
                 o->ndiag = (int64_t)hv[3];
                 o->vsum_valid = true;
             }
