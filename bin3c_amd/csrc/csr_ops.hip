@@ -685,18 +685,16 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
             DevBuf<int2> ni(ctx, n + 1);
             if (!ni.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
             hipLaunchKernelGGL(k_pack_ni, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, newid.p, a->ids, ni.p);
-            DevBuf<unsigned long long> vstat(ctx, 4);
+            // [4 counters | one value-sum partial per workgroup]: read back together through the pinned staging buffer
+            DevBuf<unsigned long long> vstat(ctx, 4 + (size_t)g);
             if (!vstat.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
             HIP_TRY(ctx, hipMemsetAsync(vstat.p, 0, sizeof(unsigned long long) * 4, s));
-            DevBuf<double> vpart(ctx, g);
-            if (!vpart.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
             hipLaunchKernelGGL(k_compress_fill_ns, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data,
-                               ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data, vstat.p, vpart.p);
-            std::vector<double> hpart((size_t)g);
-            HIP_TRY(ctx, hipMemcpyAsync(hpart.data(), vpart.p, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, s));
+                               ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data, vstat.p, (double *)(vstat.p + 4));
             // (the read-back also ends the use of `ni`, which goes back to the pool at the end of this scope)
-            unsigned long long hv[4] = {0, 0, 0, 0};
-            { const int rb_ = b3c_readback(ctx, hv, vstat.p, sizeof(hv)); if (rb_) return rb_; }
+            std::vector<unsigned long long> hvv(4 + (size_t)g, 0ull);
+            { const int rb_ = b3c_readback(ctx, hvv.data(), vstat.p, sizeof(unsigned long long) * hvv.size()); if (rb_) return rb_; }
+            const unsigned long long *hv = hvv.data();
             if (hv[1] == 0 && nnz > 0) {
                 // all values non-negative: the largest one is known without another pass (b3c_max_value)
                 double vm;
@@ -704,7 +702,7 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
                 o->vmax = vm;
                 o->vmax_valid = true;
                 double vs = 0.0;
-                for (double t : hpart) vs += t;
+                for (int b = 0; b < g; b++) { double t; memcpy(&t, &hv[4 + b], sizeof(double)); vs += t; }
                 o->vsum2 = vs;
                 o->ndiag = (int64_t)hv[3];
                 o->vsum_valid = true;
