@@ -141,7 +141,7 @@ struct b3c_mat {
     // Matrices are immutable after creation; b3c_mat_device_ptrs hands out writable pointers and therefore drops it.
     double vmax = 0.0;
     bool vmax_valid = false;
-    // sum of the stored values with the diagonal counted twice and the number of diagonal entries, left behind by the kernel
+    // sum of the stored values with the diagonal counted twice and (an upper bound of) the number of diagonal entries, left behind by the kernel
     // that wrote the values (k_compress_fill_ns): an ESTIMATE (floating-point atomics, any order) from which the Louvain
     // quantisation derives its shift without a pass of its own whenever the estimate is conclusive (quantise_graph)
     double vsum2 = 0.0;

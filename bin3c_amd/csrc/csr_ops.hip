@@ -474,11 +474,10 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
                                                            int graph_form,
                                                            const int64_t *__restrict__ out_indptr,
                                                            int32_t *__restrict__ out_indices, double *__restrict__ out_a,
-                                                           unsigned long long *__restrict__ vstat,   // [0] bits of the largest value, [1] a negative one was seen, [3] diagonal entries
+                                                           unsigned long long *__restrict__ vstat,   // [0] bits of the largest value, [1] a negative one was seen
                                                            double *__restrict__ vpart)               // per-workgroup sums of the values (diagonal twice)
 {
     double vsum = 0.0;            // sum of the values written, diagonal entries twice (an estimate: see b3c_mat.vsum2)
-    long long ndg = 0;
     constexpr int U = 4;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
@@ -557,7 +556,6 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
                     vmax = fmax(vmax, val);
                     const bool dg = nj[t].x == nr.x;
                     vsum += dg ? 2.0 * val : val;
-                    ndg += dg ? 1 : 0;
                 }
                 o += __popcll(b);
             }
@@ -590,13 +588,12 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
             vstat[1] = 1ull;
         }
     }
-    // one partial per workgroup, summed by the host (a double atomicAdd is a compare-and-swap loop here, and 16k waves on one
-    // address cost the kernel more than the pass this estimate saves)
+    // one partial per workgroup, summed by the host: no atomics (a double atomicAdd is a compare-and-swap loop here; and even
+    // an integer atomic per workgroup on the line every wave polls for the maximum cost the C2-sized kernel 390 of its 476 us)
     __shared__ double vred[BLK / 64];
-    __shared__ long long dred[BLK / 64];
     vsum = wave_sum(vsum);
     if (lane == 0) vred[threadIdx.x >> 6] = vsum;
-    block_atomic_add_u64(ndg, &vstat[3], dred);          // (syncs the workgroup: vred is visible afterwards)
+    __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < BLK / 64; w++) t += vred[w];
@@ -704,7 +701,7 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
                 double vs = 0.0;
                 for (int b = 0; b < g; b++) { double t; memcpy(&t, &hv[4 + b], sizeof(double)); vs += t; }
                 o->vsum2 = vs;
-                o->ndiag = (int64_t)hv[3];
+                o->ndiag = o->n;                     // (an upper bound is all the estimate needs)
                 o->vsum_valid = true;
             }
         }
