@@ -2151,34 +2151,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (a->sorted_cols) hipLaunchKernelGGL(kr_diag_fix<double>, dim3(gn1), dim3(256), 0, s, n, zc0, zc1, a->indptr, a->indices, (const double *)a->data, dfix.p, counters.p);
         else hipLaunchKernelGGL(kr_diag_fix_scan<double>, dim3(gscan), dim3(BLK), 0, s, n, zc0, zc1, a->indptr, a->indices, (const double *)a->data, dfix.p, counters.p);
     }
-    // The dictionary layout is built SPECULATIVELY beside the set-up pass (round 3): kr_tcd_build is latency bound (one
-    // workgroup per CU: 128 KB of bitmaps), kr_prep_counts streams -- they overlap well, and the layout only depends on the
-    // matrix.  Whether it is used is known once the prep pass has reported the largest count (16-bit forms or not).
-    DevBuf<uint32_t> packed(ctx, tcd_may ? a->nnz + 8 : 1);
-    DevBuf<int32_t> pcol(ctx, tcd_may ? a->nnz + 8 : 1), n1v(ctx, tcd_may ? nloc : 1);
-    DevBuf<int32_t> dict_cols(ctx, tcd_may ? (size_t)tcd_tiles * (size_t)tcd_dcap : 1), dict_cnt(ctx, tcd_may ? tcd_tiles : 1);
-    DevBuf<unsigned long long> stt(ctx, 4);
-    if (tcd_may && (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p)) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
-    struct SideJoin { b3c_ctx *c; bool pending = false; ~SideJoin() { if (pending) (void)hipStreamSynchronize(c->side); } } side_join{ctx};
-    const bool spec_tcd = tcd_may && fused_prep && getenv("B3C_KR_NO_SPEC") == nullptr && ctx->side_ok();
-    auto launch_tcd_build = [&](hipStream_t st) -> int {
-        static bool build_attr = false;
-        if (!build_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS)); build_attr = true; }
-        // (round 3 tried ONE pass per tile over a window of 2^18 columns centred on the tile, everything outside going to the tails
-        // unseen: the build fell from 2.9 to 1.1 ms, but the SpMV rose from 0.289 to 0.375 ms at C3 -- the locality order keeps a
-        // cluster together, not a genome: the pieces of a genome sit far apart and their columns DO repeat inside a tile)
-        hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, st, r0, r1, tcd_R, n, hub_len, tcd_dcap,
-                           a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
-        return B3C_OK;
-    };
-    if (spec_tcd) {
-        HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 4, s));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-        { const int rl_ = launch_tcd_build(ctx->side); if (rl_) return rl_; }
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
-        side_join.pending = true;
-    }
     {
         DevBuf<unsigned long long> hs(ctx, 5);
         if (!hs.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
@@ -2307,16 +2279,20 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     DevBuf<unsigned long long> tlog(ctx, want_tlog ? (size_t)tcd_tiles * 8 : 1);     // (a pooled block even when unused: the kernel gets nullptr then)
     if (want_tlog && !tlog.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: timeline log");
     if (want_tlog) HIP_TRY(ctx, hipMemsetAsync(tlog.p, 0, sizeof(unsigned long long) * (size_t)tcd_tiles * 8, s));
+    DevBuf<uint32_t> packed(ctx, tcd ? a->nnz + 8 : 1);
+    DevBuf<int32_t> pcol(ctx, tcd ? a->nnz + 8 : 1), n1v(ctx, tcd ? nloc : 1);
+    DevBuf<int32_t> dict_cols(ctx, tcd ? (size_t)tcd_tiles * (size_t)tcd_dcap : 1), dict_cnt(ctx, tcd ? tcd_tiles : 1);
     int tcd_lds_d = 0;                     // operands the SpMV kernel keeps in LDS: the largest dictionary, even
-    if (spec_tcd) {                        // the speculative build: joined here whether or not its layout is used
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-        side_join.pending = false;
-    }
     if (tcd) {
-        if (!spec_tcd) {
-            HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 4, s));
-            { const int rl_ = launch_tcd_build(s); if (rl_) return rl_; }
-        }
+        DevBuf<unsigned long long> stt(ctx, 4);
+        if (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
+        HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 4, s));
+        { static bool build_attr = false; if (!build_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS)); build_attr = true; } }
+        // (round 3 tried ONE pass per tile over a window of 2^18 columns centred on the tile, everything outside going to the tails
+        // unseen: the build fell from 2.9 to 1.1 ms, but the SpMV rose from 0.289 to 0.375 ms at C3 -- the locality order keeps a
+        // cluster together, not a genome: the pieces of a genome sit far apart and their columns DO repeat inside a tile)
+        hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
+                           a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
         unsigned long long hst[4];
         { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
         tcd_lds_d = (int)((hst[0] + 1) & ~1ull);
