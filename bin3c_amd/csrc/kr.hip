@@ -824,9 +824,17 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
     int32_t *__restrict__ dc = dict_cols + tile * (int64_t)d1cap;
     int64_t a1 = 0;                                   // dictionary columns of the passes before (uncapped)
     const int64_t CHUNK = (int64_t)1 << TCD_CHUNK_LG;
+#ifdef B3C_PROBES
+    long long tph[6] = {0, 0, 0, 0, 0, 0};               // phase clocks of this tile (development builds: B3C_KR_TCD_BLOG)
+    long long tq = wall_clock64();
+#define TCD_PH(k) do { __syncthreads(); const long long tn_ = wall_clock64(); tph[k] += tn_ - tq; tq = tn_; } while (0)
+#else
+#define TCD_PH(k) do { } while (0)
+#endif
     for (int64_t c0 = 0; c0 < ncols; c0 += CHUNK) {
         for (int i = tid; i < TCD_WORDS / 4; i += TCD_TB) { b14[i] = make_uint4(0, 0, 0, 0); b24[i] = make_uint4(0, 0, 0, 0); }
         __syncthreads();
+        TCD_PH(0);
         // ---- sweep 1: which columns does the tile use, which more than once ----
         {
             int rl = wv;
@@ -870,13 +878,24 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
             }
         }
         __syncthreads();
-        // per thread: its GPT groups of 128 columns
+        TCD_PH(1);
+        // Prefix popcounts of bm2 per group of 128 columns, free of LDS bank conflicts (round 3): a thread that walks ITS
+        // contiguous groups reads 16-byte words 64 bytes apart from its neighbours' -- every lane on the same two banks; the
+        // phase clocks of a development build showed this stretch at 33 of a tile's 137 us.  So the bitmap is always read with
+        // consecutive lanes on consecutive words (groups tid, tid + TB, ...), the per-group counts go through pre1, and only
+        // the scan itself walks a thread's contiguous groups (8 bytes per thread).
+#pragma unroll
+        for (int k = 0; k < GPT; k++) {
+            const int g = tid + k * TCD_TB;
+            const uint4 m2 = b24[g];
+            pre1[g] = (uint16_t)(__popc(m2.x) + __popc(m2.y) + __popc(m2.z) + __popc(m2.w));
+        }
+        __syncthreads();
         uint32_t e1[GPT], run1 = 0;
 #pragma unroll
         for (int g = 0; g < GPT; g++) {
-            const uint4 m2 = b24[tid * GPT + g];
             e1[g] = run1;
-            run1 += __popc(m2.x) + __popc(m2.y) + __popc(m2.z) + __popc(m2.w);
+            run1 += pre1[tid * GPT + g];
         }
         uint32_t inc1 = run1;                            // inclusive scan over the wave
 #pragma unroll
@@ -899,19 +918,25 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
             pre1[tid * GPT + g] = (uint16_t)(pv < 65535u ? pv : 65535u);    // only ranks below d1cap <= 16384 are used
         }
         __syncthreads();
-        // the dictionary: ascending columns, as many as the LDS budget takes
-        {
-            int64_t p1 = a1 + base1;
-            for (int i = 0; i < GPT * 4 && p1 < d1cap; i++) {
-                const int wd = tid * GPT * 4 + i;
-                uint32_t bits = bm2[wd];
+        // the dictionary: ascending columns, as many as the LDS budget takes (again consecutive lanes on consecutive groups)
+#pragma unroll
+        for (int k = 0; k < GPT; k++) {
+            const int g = tid + k * TCD_TB;
+            int64_t p1 = a1 + pre1[g];
+            if (p1 >= d1cap) continue;
+            const uint4 m2 = b24[g];
+            const uint32_t wds[4] = {m2.x, m2.y, m2.z, m2.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t bits = wds[i];
                 while (bits && p1 < d1cap) {
                     const int b = __ffs(bits) - 1;
                     bits &= bits - 1;
-                    dc[p1++] = (int32_t)(c0 + (int64_t)wd * 32 + b);
+                    dc[p1++] = (int32_t)(c0 + ((int64_t)g * 4 + i) * 32 + b);
                 }
             }
         }
+        TCD_PH(2);
         // ---- sweep 2: the rows, dictionary entries to the front (index << 16 | count), the others to the back ----
         {
             int rl = wv;
@@ -956,11 +981,14 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
                         bool front = false;
                         int64_t r = 0;
                         if (in) {
-                            const int wd = (int)(c >> 5), g = wd >> 2;
-                            if ((bm2[wd] >> (c & 31)) & 1u) {
-                                r = a1 + pre1[g];
-                                for (int q = g * 4; q < wd; q++) r += __popc(bm2[q]);
-                                r += __popc(bm2[wd] & ((1u << (c & 31)) - 1u));
+                            // the group's four bitmap words in ONE 16-byte LDS read; rank = prefix of the group + the set bits
+                            // of the words below + those below the column's bit (no loop over words, no divergence)
+                            const int wd = (int)(c >> 5), g = wd >> 2, k = wd & 3;
+                            const uint4 m = b24[g];
+                            const uint32_t wk = k == 0 ? m.x : k == 1 ? m.y : k == 2 ? m.z : m.w;
+                            if ((wk >> (c & 31)) & 1u) {
+                                r = a1 + pre1[g] + (k > 0 ? __popc(m.x) : 0) + (k > 1 ? __popc(m.y) : 0) + (k > 2 ? __popc(m.z) : 0) +
+                                    __popc(wk & ((1u << (c & 31)) - 1u));
                                 front = r < d1cap;
                             }
                         }
@@ -981,7 +1009,11 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
         }
         a1 += tot1;
         __syncthreads();
+        TCD_PH(3);
     }
+#ifdef B3C_PROBES
+    if (tid == 0) for (int k = 0; k < 4; k++) atomicAdd(&stats[8 + k], (unsigned long long)tph[k]);
+#endif
     for (int i = tid; i < nrows; i += TCD_TB) n1_out[ra + i - r0] = (int32_t)nfront[i];
     if (tid == 0) {
         const int d1 = (int)(a1 < d1cap ? a1 : d1cap);
@@ -2284,17 +2316,22 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     DevBuf<int32_t> dict_cols(ctx, tcd ? (size_t)tcd_tiles * (size_t)tcd_dcap : 1), dict_cnt(ctx, tcd ? tcd_tiles : 1);
     int tcd_lds_d = 0;                     // operands the SpMV kernel keeps in LDS: the largest dictionary, even
     if (tcd) {
-        DevBuf<unsigned long long> stt(ctx, 4);
+        DevBuf<unsigned long long> stt(ctx, 16);           // [0..3] layout statistics, [8..11] phase clocks (development builds)
         if (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
-        HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 4, s));
+        HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 16, s));
         { static bool build_attr = false; if (!build_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS)); build_attr = true; } }
         // (round 3 tried ONE pass per tile over a window of 2^18 columns centred on the tile, everything outside going to the tails
         // unseen: the build fell from 2.9 to 1.1 ms, but the SpMV rose from 0.289 to 0.375 ms at C3 -- the locality order keeps a
         // cluster together, not a genome: the pieces of a genome sit far apart and their columns DO repeat inside a tile)
         hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
                            a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
-        unsigned long long hst[4];
+        unsigned long long hst[16];
         { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
+#ifdef B3C_PROBES
+        if (getenv("B3C_KR_TCD_BLOG"))
+            fprintf(stderr, "[b3c] kr_tcd_build phases, mean us per tile (100 MHz clock): zero %.1f  sweep1 %.1f  prefix+dictionary %.1f  sweep2 %.1f\n",
+                    hst[8] * 0.01 / tcd_tiles, hst[9] * 0.01 / tcd_tiles, hst[10] * 0.01 / tcd_tiles, hst[11] * 0.01 / tcd_tiles);
+#endif
         tcd_lds_d = (int)((hst[0] + 1) & ~1ull);
         if (tcd_lds_d < 2) tcd_lds_d = 2;
         info->tcd_tiles = tcd_tiles;
