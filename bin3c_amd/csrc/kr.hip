@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_hub(const int64_t *__restrict__ hub
 //                  masked lanes), results leave through LDS as coalesced stores.
 // ---------------------------------------------------------------------------------------------
 constexpr int TCD_TB = 1024;                          // threads of the build kernel (one workgroup per CU: 140 KB of LDS)
-constexpr int TCD_CHUNK_LG = 19;                      // columns per bitmap pass (2^18 with two workgroups per CU: 4.0 instead of 2.9 ms at C3)
+constexpr int TCD_CHUNK_LG = 19;                      // columns per bitmap pass (2^18 with two workgroups per CU: 3.9 instead of 2.6 ms at C3, measured again in round 3)
 constexpr int TCD_L2_LG = 19;                         // operand vectors up to 2^19 doubles sit in one XCD's L2
 constexpr int TCD_WORDS = 1 << (TCD_CHUNK_LG - 5);    // 16384 words = 64 KB per bitmap
 constexpr int TCD_GROUPS = TCD_WORDS / 4;             // one 16-bit prefix per 128 columns
