@@ -29,6 +29,8 @@ for tag, c in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
 def active(counter, kern):
     """mean counter value (bytes; the counters are in KB) over the launches that did work (>= half the longest)"""
     rows = [r for r in csv.DictReader(open('profiles/%s_%s_%s.csv' % (rnd, CFG.lower(), counter))) if r['Kernel'].startswith(kern)]
+    if not rows:
+        return 0.0, 0, 0
     mx = max(int(r['Duration_ns']) for r in rows)
     a = [float(r['Counter_Value']) for r in rows if int(r['Duration_ns']) >= 0.5 * mx]
     return sum(a) / len(a) * 1024.0, len(a), len(rows)
@@ -67,9 +69,10 @@ wq, _, _ = active('WRITE_SIZE', 'k_quantise')
 correction = ('MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies the 128-byte fabric requests of coalesced reads at 64 '
               'bytes, so it is doubled; WRITE_SIZE is exact. Checked in the same two passes on two pure streaming kernels of '
               'known size: kr_prep_counts reads 8*nnz+8*n = %.0f MB and reports %.0f MB (x%.3f), writes 2*nnz+8*n = %.0f MB '
-              'and reports %.0f MB; k_quantise reads and writes 8 bytes per sub-map entry and reports %.0f MB fetched / '
-              '%.0f MB written (x%.3f).' % ((8 * NNZ + 8 * N) / 1e6, fp / 1e6, fp / (8 * NNZ + 8 * N), (2 * NNZ + 8 * N) / 1e6,
-                                            wp / 1e6, fq / 1e6, wq / 1e6, fq / wq))
+              'and reports %.0f MB%s.' % ((8 * NNZ + 8 * N) / 1e6, fp / 1e6, fp / (8 * NNZ + 8 * N), (2 * NNZ + 8 * N) / 1e6, wp / 1e6,
+                                         '; k_quantise reads and writes 8 bytes per sub-map entry and reports %.0f MB fetched / %.0f MB '
+                                         'written (x%.3f)' % (fq / 1e6, wq / 1e6, fq / wq) if wq else
+                                         ' (the second calibration kernel of rounds 1-2, k_quantise, no longer exists: its work moved into k_lv_init)'))
 source = ('profiles/%s_c3_FETCH_SIZE.csv, profiles/%s_c3_WRITE_SIZE.csv (rocprofv3 --pmc, one counter per pass, '
           'bench.py --config C3 --steps 1 --warmup 0)' % (rnd, rnd))
 out = dict(prev)
