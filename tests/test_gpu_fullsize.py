@@ -98,6 +98,26 @@ def test_full_size_matches_the_oracle(ctx, oracle_lib, cfg):
         counts.free()
 
 
+@pytest.mark.parametrize('variant', ['survey', 'hard'])
+def test_c2_on_other_workload_definitions_matches_the_oracle(ctx, oracle_lib, variant):
+    """C2's size on the workload as SURVEY 8(d) writes it (G = n/200 genomes ~ Zipf(1.5): one genome holds 38 % of the contigs, its
+    community is a MEGA row of the level-1 graph -- k_lv_mega_insert / k_lv_mega_eval -- and the Louvain needs three levels and
+    twenty sweeps) and on a hard clustering problem (45 % inter-genome noise, no intra-genome boost: modularity 0.62): every stage
+    against the oracle, as at C2 / C3."""
+    from bin3c_amd.pipeline import run_hot_path
+    from bin3c_amd.synth import make_edges
+    kw = dict(genome_law='survey') if variant == 'survey' else dict(noise=0.45, intra_boost=1)
+    lo, hi, c, diag, lengths, sites, genome = make_edges(100000, 5000000, 2, 'flat', **kw)
+    counts, n_edges = ctx.coo_symmetrise(100000, lo, hi, c, diag)
+    res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, keep=True)
+    try:
+        st, ref = compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res, seq=False)
+        assert ref['n_sweeps'] >= 15 and (ref['n_levels'] >= 2 or variant == 'hard')
+    finally:
+        res.free()
+        counts.free()
+
+
 @pytest.mark.parametrize('dup', ['first', 'sum'])
 def test_power_law_map_matches_the_oracle(ctx, oracle_lib, dup):
     """C5's SHAPE at sizes the oracle finishes in a minute (rank^-0.8 endpoint preference, drawn on the device,
