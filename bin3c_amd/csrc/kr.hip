@@ -1109,11 +1109,14 @@ __global__ void __launch_bounds__(256) kr_big_fix(const KRState *__restrict__ si
 // 2^-70 of the largest term, i.e. more accurate than the fp64 sum it replaces.
 // Stand-alone measurement (tools/probes/tails_probe.hip): 26 M gathers in row order 273 us, this way 100 us.
 // ---------------------------------------------------------------------------------------------
-constexpr int XT_S = 8192;           // rows per super-tile (13 bits of a tail word)
+constexpr int XT_S = 8192;           // rows per super-tile (13 bits of a tail word) ...
+constexpr int XT_S_BIG = 12288;      // ... or, on maps whose operand vector is beyond the L2s, all the row sums the LDS holds (14 bits)
 constexpr int XT_NT = 1024;          // threads of kr_kb_tails
 constexpr int XT_CHUNKS = 2;         // workgroups per super-tile at least (more when a rank has few super-tiles)
 
-// tail word: super-tile << 53 | column << 29 | row inside the super-tile << 16 | count
+// tail word: super-tile << (16 + rbits + cbits) | column << (16 + rbits) | row inside the super-tile << 16 | count, with rbits = 13 | 14
+// (rows per super-tile) and cbits = bits of the largest column: the sorted field (super-tile, column / 8) is as narrow as the map
+// allows -- 24 bits at C3, one radix pass fewer than with fixed fields
 __global__ void __launch_bounds__(256) kr_tails_count(int64_t r0, int64_t r1, int hub_len, const int64_t *__restrict__ indptr,
                                                        const int32_t *__restrict__ n1v, int64_t *__restrict__ tcnt)
 {
@@ -1129,7 +1132,7 @@ __global__ void __launch_bounds__(256) kr_tails_count(int64_t r0, int64_t r1, in
 
 __global__ void __launch_bounds__(256) kr_tails_emit(int64_t r0, int64_t r1, int hub_len, const int64_t *__restrict__ indptr,
                                                       const uint32_t *__restrict__ packed, const int32_t *__restrict__ pcol,
-                                                      const int32_t *__restrict__ n1v, const int64_t *__restrict__ toff,
+                                                      const int32_t *__restrict__ n1v, const int64_t *__restrict__ toff, int S, int cshift, int st_shift,
                                                       unsigned long long *__restrict__ words, unsigned long long *__restrict__ stats)
 {
     // eight lanes per row
@@ -1144,10 +1147,10 @@ __global__ void __launch_bounds__(256) kr_tails_emit(int64_t r0, int64_t r1, int
             const int n1 = n1v[row - r0];
             const int64_t o = toff[row - r0];
             const int64_t rr = row - r0;               // super-tiles count from the first row of this rank
-            const unsigned long long hi = ((unsigned long long)(rr / XT_S) << 53) | ((unsigned long long)(rr % XT_S) << 16);
+            const unsigned long long hi = ((unsigned long long)(rr / S) << st_shift) | ((unsigned long long)(rr % S) << 16);
             for (int64_t t = n1 + sl; t < len; t += 8) {
                 const unsigned long long c = packed[base + t] & 0xFFFFu;
-                words[o + (t - n1)] = hi | ((unsigned long long)(uint32_t)pcol[base + t] << 29) | c;
+                words[o + (t - n1)] = hi | ((unsigned long long)(uint32_t)pcol[base + t] << cshift) | c;
                 cmax = c > cmax ? c : cmax;
             }
             tmax = (unsigned long long)(len - n1);
@@ -1185,13 +1188,13 @@ __device__ double reduce_max_n(const double *__restrict__ part, int P, double *l
 
 __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__ sin, const double *__restrict__ pumax, int PU,
                                                       int lg_bound, int lo_bits, int chunks, int64_t n_tails, const int64_t *__restrict__ toff, int64_t r0, int64_t n,
-                                                      const unsigned long long *__restrict__ words, const double *__restrict__ u,
+                                                      int S, int rbits, uint32_t cmask, const unsigned long long *__restrict__ words, const double *__restrict__ u,
                                                       unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long xt_lds[];
-    unsigned long long *acc = xt_lds;                 // XT_S 64-bit sums
-    int *lo = (int *)(acc + XT_S);                    // XT_S 32-bit sums of the remainders
-    double *red = (double *)(lo + XT_S);              // XT_NT doubles
+    unsigned long long *acc = xt_lds;                 // S 64-bit sums
+    int *lo = (int *)(acc + S);                       // S 32-bit sums of the remainders
+    double *red = (double *)(lo + S);                 // XT_NT doubles (S is a multiple of 2)
     const int32_t phase = sin->phase;
     if (phase != A_INNER && phase != A_OUTER) return;           // no SpMV in this tick (the row kernel decides the same way)
     const double umax = reduce_max_n<XT_NT>(pumax, PU, red);
@@ -1202,10 +1205,19 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) { tex[0] = E; tex[1] = lo_bits; }
     if (!live) return;
     const double scale = ldexp(1.0, E), lo_scale = ldexp(1.0, lo_bits);
-    const int stile = blockIdx.x / chunks, ch = blockIdx.x % chunks;
-    for (int i = threadIdx.x; i < XT_S; i += XT_NT) { acc[i] = 0; lo[i] = 0; }
+    int stile = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    if (chunks > 8 && (chunks & 7) == 0) {
+        // phases of eight chunks: workgroup b runs on XCD b % 8, so XCD k sees the column slices k, 8 + k, 16 + k, ... one after the other
+        const int per = 8 * (int)(gridDim.x / chunks);
+        const int phase = blockIdx.x / per, rem = blockIdx.x % per;
+        stile = rem >> 3;
+        ch = phase * 8 + (rem & 7);
+    }
+    for (int i = threadIdx.x; i < S; i += XT_NT) { acc[i] = 0; lo[i] = 0; }
     __syncthreads();
-    const int64_t ra = r0 + (int64_t)stile * XT_S, rb = ra + XT_S < n ? ra + XT_S : n;
+    const int64_t ra = r0 + (int64_t)stile * S, rb = ra + S < n ? ra + S : n;
+    const int cshift = 16 + rbits;
+    const uint32_t rmask = (1u << rbits) - 1u;
     const int64_t a = toff[ra - r0], b = rb >= n ? n_tails : toff[rb - r0];
     const int64_t len = (b - a + chunks - 1) / chunks;
     const int64_t s0 = a + ch * len, e0 = s0 + len < b ? s0 + len : b;
@@ -1215,20 +1227,20 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
 #pragma unroll
         for (int q = 0; q < 4; q++) w[q] = k0 + q * XT_NT < e0 ? words[k0 + q * XT_NT] : 0ull;
 #pragma unroll
-        for (int q = 0; q < 4; q++) g[q] = u[(uint32_t)(w[q] >> 29) & 0xFFFFFFu];
+        for (int q = 0; q < 4; q++) g[q] = u[(uint32_t)(w[q] >> cshift) & cmask];
 #pragma unroll
         for (int q = 0; q < 4; q++)
             if (k0 + q * XT_NT < e0) {
                 const double ps = (g[q] * (double)(uint32_t)(w[q] & 0xFFFFu)) * scale;
                 const long long f = __double2ll_rn(ps);
                 const int l = __double2int_rn((ps - (double)f) * lo_scale);       // |.| <= 2^(lo_bits - 1)
-                const uint32_t r = (uint32_t)(w[q] >> 16) & (XT_S - 1);
+                const uint32_t r = (uint32_t)(w[q] >> 16) & rmask;
                 atomicAdd(&acc[r], (unsigned long long)f);
                 if (l) atomicAdd(&lo[r], l);
             }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < XT_S && ra + i < n; i += XT_NT) {
+    for (int i = threadIdx.x; i < S && ra + i < n; i += XT_NT) {
         if (acc[i]) atomicAdd(&yhi[ra - r0 + i], acc[i]);
         if (lo[i]) atomicAdd(&ylo[ra - r0 + i], lo[i]);
     }
@@ -2347,17 +2359,36 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // rank has the tails of ITS rows (the operand vector and its maximum are complete on every rank after KA)
     const bool tails_xt = tcd && xt_want && info->tcd_tail_entries > 0;
     int64_t n_tails = 0;                 // tails outside hub rows (counted below)
-    const int64_t xt_super = (nloc + XT_S - 1) / XT_S;
-    // two workgroups per super-tile fill the chip from ~110 super-tiles on (C3); a rank of the sharded path with fewer of them
-    // splits each over more workgroups (each clears and flushes all 8192 row sums, so not more than 16)
-    const int xt_chunks = 4 * XT_CHUNKS * xt_super >= 3 * (int64_t)ctx->n_cu || xt_super == 0
-                              ? XT_CHUNKS : (int)std::min<int64_t>(16, (ctx->n_cu + xt_super - 1) / xt_super);   // (3 at C3 costs 20 us per SpMV)
+    // Rows per super-tile, workgroups per super-tile.  A workgroup sweeps its share of a super-tile's column-ordered words, i.e. a
+    // slice of the operand vector, and workgroup b runs on XCD b % 8.  Up to 1M columns (8 MB of operands, C3) two chunks per
+    // super-tile leave every XCD with half the vector, which its 4 MB L2 holds: the gathers are L2 hits.  Beyond that (C5: 40 MB)
+    // every super-tile pulled most of the vector through the fabric again (38 bytes of operand lines per 8-byte word, measured);
+    // there the column range is cut into 8 * P slices of at most ~3 MB and the grid runs them in P phases of eight (see the
+    // kernel), so that an XCD gathers from ONE slice at a time, and a super-tile takes all the row sums the LDS holds (12288:
+    // fewer sweeps of the vector, fewer flushes).  C5: 4.43 -> 3.9 ms per SpMV.
+    int xt_cbits = 1;                                  // bits of a column id (columns are global: a->n)
+    while ((1ll << xt_cbits) < (int64_t)n) xt_cbits++;
+    const bool xt_far = (int64_t)n * 8 > (8ll << 20);
+    int xt_S = xt_far ? XT_S_BIG : XT_S;
+    if (getenv("B3C_KR_XT_S")) xt_S = atoi(getenv("B3C_KR_XT_S")) == XT_S_BIG ? XT_S_BIG : XT_S;
+    {
+        int sb = 1;
+        while ((1ll << sb) < (nloc + XT_S_BIG - 1) / XT_S_BIG) sb++;
+        if (16 + 14 + xt_cbits + sb > 64) xt_S = XT_S;      // the word has no room for 14 row bits (n beyond 2^23)
+    }
+    const int xt_rbits = xt_S == XT_S ? 13 : 14;
+    const int64_t xt_super = (nloc + xt_S - 1) / xt_S;
+    const int xt_st_shift = 16 + xt_rbits + xt_cbits;
+    int xt_chunks = 4 * XT_CHUNKS * xt_super >= 3 * (int64_t)ctx->n_cu || xt_super == 0
+                        ? XT_CHUNKS : (int)std::min<int64_t>(16, (ctx->n_cu + xt_super - 1) / xt_super);   // (3 at C3 costs 20 us per SpMV)
+    if (xt_far) xt_chunks = 8 * (int)std::min<int64_t>(4, ((int64_t)n * 8 + (24ll << 20) - 1) / (24ll << 20));
+    if (getenv("B3C_KR_XT_CHUNKS")) xt_chunks = std::min(64, std::max(1, atoi(getenv("B3C_KR_XT_CHUNKS"))));
     DevBuf<double> pumax(ctx, tails_xt ? GA : 1);
     DevBuf<unsigned long long> yhi(ctx, tails_xt ? nloc : 1), xt_words(ctx, tails_xt ? info->tcd_tail_entries + 4 : 1);
     DevBuf<int> ylo(ctx, tails_xt ? nloc : 1), tex(ctx, 2);
     DevBuf<int64_t> xt_off(ctx, tails_xt ? nloc + 2 : 1);
     int xt_lg_bound = 0, xt_lo_bits = 20;
-    const size_t xt_shmem = sizeof(unsigned long long) * XT_S + sizeof(int) * XT_S + sizeof(double) * XT_NT;
+    const size_t xt_shmem = sizeof(unsigned long long) * (size_t)xt_S + sizeof(int) * (size_t)xt_S + sizeof(double) * XT_NT;
     if (tails_xt) {
         DevBuf<int64_t> tcnt(ctx, nloc + 2);
         DevBuf<unsigned long long> words_in(ctx, info->tcd_tail_entries + 4), xst(ctx, 2);
@@ -2371,7 +2402,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         int rct;
         if ((rct = b3c_exclusive_scan_i64(ctx, tcnt.p, xt_off.p, nloc + 1))) return rct;
         hipLaunchKernelGGL(kr_tails_emit, dim3((unsigned)((nloc * 8 + 255) / 256)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, packed.p, pcol.p,
-                           n1v.p, xt_off.p, words_in.p, xst.p);
+                           n1v.p, xt_off.p, xt_S, 16 + xt_rbits, xt_st_shift, words_in.p, xst.p);
         { const int rb_ = b3c_readback(ctx, &n_tails, xt_off.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
         if (n_tails < 0 || n_tails > info->tcd_tail_entries)
             return ctx->fail(B3C_E_HIP, "b3c_kr_balance: tail count out of bounds (%lld of %lld)", (long long)n_tails, (long long)info->tcd_tail_entries);
@@ -2384,22 +2415,24 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         xt_lg_bound = lgc + lgt;
         // the 32-bit remainder sums: a tail of T terms of at most 2^(lo_bits - 1) each must stay below 2^31
         xt_lo_bits = std::max(4, std::min(20, 31 - lgt));
-        // column order inside every super-tile: sort on (super-tile, column) = bits [29, 53 + bits of the super-tile index)
+        // column order inside every super-tile: sort on (super-tile, column / 8) -- the words of a 64-byte line of u stay in
+        // emission order (the sort is stable), which costs the gather nothing and saves three key bits
         int st_bits = 1;
         while ((1ll << st_bits) < xt_super) st_bits++;
+        const int sort_lo = 16 + xt_rbits + (xt_cbits > 3 ? 3 : 0), sort_hi = xt_st_shift + st_bits;
         size_t tb = 0;
-        hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tb, words_in.p, xt_words.p, (int64_t)n_tails, 29, 53 + st_bits, s);
+        hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tb, words_in.p, xt_words.p, (int64_t)n_tails, sort_lo, sort_hi, s);
         if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort sizing failed");
         DevBuf<char> tmp(ctx, tb);
         if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: tail sort workspace");
-        e = hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, words_in.p, xt_words.p, (int64_t)n_tails, 29, 53 + st_bits, s);
+        e = hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, words_in.p, xt_words.p, (int64_t)n_tails, sort_lo, sort_hi, s);
         if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort of the tails failed");
-        { static bool xt_attr = false; if (!xt_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xt_shmem)); xt_attr = true; } }
+        { static bool xt_attr = false; if (!xt_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT))); xt_attr = true; } }
         HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch above goes back to the pool here
         info->tcd_xt_tails = n_tails;
         if (getenv("B3C_KR_DEBUG"))
             fprintf(stderr, "[b3c] tail pass: %lld tails in %lld super-tiles of %d rows, largest count %llu, longest tail %llu\n",
-                    (long long)n_tails, (long long)xt_super, XT_S, hx[0], hx[1]);
+                    (long long)n_tails, (long long)xt_super, xt_S, hx[0], hx[1]);
     }
     const int GS = tcd ? (int)tcd_tiles : GS_rows;
     // partials the SpMV step leaves behind: row groups / tiles + hub rows.  EVERY block of KCD reduces all of them, so many
@@ -2499,7 +2532,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             if (tcd) {
                 if (tails_xt)
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
-                                       xt_off.p, r0, r1, xt_words.p, u.p, yhi.p, ylo.p, tex.p);
+                                       xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p);
                 // dictionary waves and tail waves side by side (512-thread workgroups)
 #define KR_TCD2_ARGS                                                                                                         \
     dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \

@@ -257,7 +257,11 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
         # mask, signal and x are final here: their way back to the host (gather into the caller's numbering, copy into
         # pinned memory) runs on a side stream while the cluster stage keeps libb3c's stream busy; only the labels are
         # left for the end
-        early = _start_download(ctx, o2n, mask_w, signal_w, x_w) if cluster else None
+        early = None
+        if cluster:
+            ready = torch.cuda.Event()
+            ready.record(ctx.torch_stream)          # libb3c's stream: mask and signal are enqueued on it, not waited for
+            early = _download_worker(ctx).submit(_start_download, ctx, o2n, mask_w, signal_w, x_w, ready)
 
         labels_t = None
         if cluster:
@@ -265,8 +269,7 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
 
         # results to the host, in the caller's numbering
         t0 = time.perf_counter()
-        if early is None:
-            early = _start_download(ctx, o2n, mask_w, signal_w, x_w)
+        early = _start_download(ctx, o2n, mask_w, signal_w, x_w) if early is None else early.result()
         h_labels = None
         if labels_t is not None:
             h_labels = torch.empty(labels_t.shape, dtype=labels_t.dtype, pin_memory=True)
@@ -286,7 +289,17 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
     return res
 
 
-def _start_download(ctx, o2n, mask_w, signal_w, x_w):
+def _download_worker(ctx):
+    """one helper thread per context: the dozen torch calls of _start_download cost ~0.5 ms of HOST time, during which libb3c's
+    stream would sit idle between the balancing and the sub-map (C2: 7 % of a step); libb3c and torch both release the GIL"""
+    ex = getattr(ctx, '_dl_worker', None)
+    if ex is None:
+        from concurrent.futures import ThreadPoolExecutor
+        ex = ctx._dl_worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix='b3c-download')
+    return ex
+
+
+def _start_download(ctx, o2n, mask_w, signal_w, x_w, ready=None):
     """Enqueue, on the context's side stream, the per-contig results' way to the host: back to the caller's numbering, then
     asynchronous copies into pinned host tensors (torch caches pinned blocks, so a warm step allocates nothing).
     -> (mask, signal | None, x, stream): host tensors valid once the stream is synchronised."""
@@ -294,9 +307,11 @@ def _start_download(ctx, o2n, mask_w, signal_w, x_w):
     dl = getattr(ctx, '_dl_stream', None)
     if dl is None:
         dl = ctx._dl_stream = torch.cuda.Stream(device=ctx.device)
-    ready = torch.cuda.Event()
-    ready.record(torch.cuda.current_stream())
-    with torch.cuda.stream(dl):
+    if ready is None:
+        ready = torch.cuda.Event()
+        ready.record(ctx.torch_stream)
+    # (this may run on the helper thread, whose current device and stream are not the caller's)
+    with torch.cuda.device(ctx.device), torch.cuda.stream(dl):
         dl.wait_event(ready)
         back = o2n.long() if o2n is not None else None
         outs = []
@@ -320,13 +335,15 @@ def _cluster_stage(ctx, res, mask_w, n_sub=0):
     if res.sub is not None:
         res.sub.free()
         res.sub = None
-    if bool(mask_w.all().item()):                                          # contact_map.py:977: compress only if needed
-        sub = res.processed
-    elif res._processed is not None:
-        sub = ctx.compress(res._processed, mask_w)
-        res.sub = sub
+    if res._processed is not None:
+        if bool(mask_w.all().item()):                                      # contact_map.py:977: compress only if needed
+            sub = res._processed
+        else:
+            sub = ctx.compress(res._processed, mask_w)
+            res.sub = sub
     else:
-        # get_subspace of the balanced map without writing the balanced map: values straight from the counts
+        # get_subspace of the balanced map without writing the balanced map: values straight from the counts (an all-true
+        # mask gives the whole balanced map, bit for bit what `res.processed` would form: no test of the mask beforehand)
         _c, work, sites_t, x_w, graph_form, _owned = res._lazy
         sub = ctx.normalise_scale_compress(work, sites_t, x_w, mask_w, graph_form=graph_form)
         res.sub = sub

@@ -193,6 +193,30 @@ def test_a_few_counts_beyond_16_bits_keep_the_16_bit_forms(ctx, oracle_lib, monk
     cm.free()
 
 
+@pytest.mark.parametrize('env', [{'B3C_KR_XT_S': '12288', 'B3C_KR_XT_CHUNKS': '16'}, {'B3C_KR_XT_S': '12288', 'B3C_KR_XT_CHUNKS': '8'},
+                                 {'B3C_KR_XT_CHUNKS': '24'}, {'B3C_KR_XT_CHUNKS': '11'}])
+def test_tail_pass_layouts_of_far_maps(ctx, oracle_lib, monkeypatch, env):
+    """Maps whose operand vector is beyond the L2s (more than 1M contigs; C5) run the tail pass on 12288-row super-tiles with the
+    column range cut into phases of eight slices (kr.hip, kr_kb_tails).  Forced here on a 40k-contig map: same iteration count
+    as the oracle, x within 1e-9, and -- the row sums being exact fixed-point integers -- bit for bit the default layout's x."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(40000, 1300000, 37)
+    nd = oracle_lib.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
+    rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
+    assert rc == oracle_lib.OK
+    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    monkeypatch.setenv('B3C_KR_TCD_XT', '1')
+    _, x0, i0 = ctx.kr_balance_counts(cm, sm.sites)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _, x, info = ctx.kr_balance_counts(cm, sm.sites)
+    assert info.tcd_xt_tails > 0 and info.tcd_xt_tails == i0.tcd_xt_tails
+    assert info.n_iter == st.n_iter
+    np.testing.assert_allclose(x, xo, rtol=1e-9)
+    assert np.array_equal(x, x0)
+    cm.free()
+
+
 def test_symmetry_guard_fast_and_exact_paths(ctx):
     """Checksum path (bitwise symmetric), exact path (asymmetric beyond tol, and within tol but not bitwise)."""
     g = np.load(os.path.join(GOLDEN, 'kr_random1000.npz'))

@@ -1,23 +1,39 @@
-"""One-GPU attempt at BASELINE.json's C5 (5M contigs / 1B edges, power law): build, one step, timings (development probe)."""
+"""KR SpMV forms on the C5 map (development probe; GPU box only): dictionary capacity / tile rows / tail pass variants.
+usage: tools/c5_probe.py [n] [edges] [variant ...]   (variant = comma-separated ENV=value list, '' = default)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ['B3C_PROFILE'] = '1'
+os.environ['B3C_KR_DEBUG'] = '1'
 import numpy as np
-from bin3c_amd.pipeline import make_context, run_hot_path
-from bin3c_amd.synth import make_edges
-n, e = int(sys.argv[1]) if len(sys.argv) > 1 else 5000000, int(sys.argv[2]) if len(sys.argv) > 2 else 1000000000
+from bin3c_amd.pipeline import make_context
+from bin3c_amd.synth_device import make_counts_device
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 5000000
+E = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1000000000
+variants = sys.argv[3:] or ['', 'B3C_KR_TCD_DCAP=8192', 'B3C_KR_TCD_DCAP=12288', 'B3C_KR_TCD_R=256', 'B3C_KR_TCD_R=128,B3C_KR_TCD_DCAP=8192']
 ctx = make_context(0)
 t = time.time()
-lo, hi, c, diag, lengths, sites, genome = make_edges(n, e, 5, 'powerlaw')
-print('edges drawn in %.0f s' % (time.time() - t), flush=True)
-t = time.time()
-counts, ne = ctx.coo_symmetrise(n, lo, hi, c, diag)
-del lo, hi, c
-print('map: n %d E %d nnz %d (%.1f GB of entries) in %.1f s' % (n, ne, counts.nnz, counts.nnz * 8 / 1e9, time.time() - t), flush=True)
-for rep in range(2):
-    t = time.time()
-    res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=20000)
-    dt = time.time() - t
-    print('step %d: %.1f ms  (%.3g edges/s)  stages %s  KR n_iter %d  Louvain sweeps %d levels %d communities %d Q %.4f' % (
-        rep, dt * 1e3, ne / dt, {k: round(v * 1e3, 1) for k, v in res.timings.items()}, res.kr_info.n_iter, res.lv_info.n_sweeps,
-        res.lv_info.n_levels, res.lv_info.n_comm, res.lv_info.modularity), flush=True)
-print('HBM held by the context: %.1f GB' % (ctx.bytes() / 1e9 if hasattr(ctx, 'bytes') else -1))
+counts, e_true, lengths_h, sites_h, genome, ginfo = make_counts_device(ctx, n, E, 5, 'powerlaw')
+print('map: n %d edges %d nnz %d in %.0f s' % (n, e_true, counts.nnz, time.time() - t), flush=True)
+n2o, o2n = ctx.locality_order(counts)
+work = ctx.permute(counts, n2o)
+counts.free()
+sites = sites_h[n2o]
+ref = None
+for var in variants:
+    keys = []
+    for kv in var.split(','):
+        if kv:
+            k, v = kv.split('=')
+            os.environ[k] = v
+            keys.append(k)
+    for rep in range(2):
+        t = time.time(); rc, x, info = ctx.kr_balance_counts(work, sites, max_iter=40, check=False); dt = time.time() - t
+    print('%-44s KR %.1f ms, spmv avg %.1f us over %d; tiles %d dmax %d dmean %.0f tails %.1f%% (xt %d)' % (
+        var or '(default)', dt * 1e3, info.spmv_ms / max(info.n_spmv, 1) * 1e3, info.n_spmv, info.tcd_tiles,
+        info.tcd_dict_max, info.tcd_dict_total / max(1, info.tcd_tiles), 100.0 * info.tcd_tail_entries / work.nnz, info.tcd_xt_tails), flush=True)
+    if ref is None:
+        ref = x
+    else:
+        print('    vs first: max rel diff %.2e' % np.nanmax(np.abs(x - ref) / ref), flush=True)
+    for k in keys:
+        os.environ.pop(k, None)
