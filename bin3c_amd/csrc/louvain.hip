@@ -190,42 +190,74 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * WPB;
     long long total = 0, loops = 0;
-    for (int64_t row = wave; row < n; row += nwave) {
-        const int64_t s = indptr[row], e = indptr[row + 1];
-        long long d = 0, lw = 0;
-        for (int64_t base = s; base < e; base += 256) {
-            int32_t j[4];
-            long long w[4];
+    // two rows per wave and pass: the loads of both are in flight together
+    for (int64_t row0 = wave; row0 < n; row0 += 2 * nwave) {
+        int64_t rw[2], rs_[2], re_[2];
+        rw[0] = row0;
+        rw[1] = row0 + nwave < n ? row0 + nwave : -1;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int64_t k = base + t * 64 + lane;
-                const bool ok = k < e;
-                j[t] = ok ? indices[k] : -1;
-                if (wq) {
-                    w[t] = ok ? __double2ll_rn(ldexp(wq[k] * wscl, shift)) : 0;
-                    if (ok) q_out[k] = w[t];
-                } else {
-                    w[t] = ok ? q[k] : 0;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                d += j[t] == (int32_t)row ? 2 * w[t] : w[t];
-                lw += j[t] == (int32_t)row ? w[t] : 0;
-            }
+        for (int h = 0; h < 2; h++) {
+            rs_[h] = rw[h] >= 0 ? indptr[rw[h]] : 0;
+            re_[h] = rw[h] >= 0 ? indptr[rw[h] + 1] : 0;
         }
-        d = wave_sum_ll(d);
-        lw = wave_sum_ll(lw);
-        if (lane == 0) {
-            const int32_t id = ids ? ids[row] : (int32_t)row;   // community ids live in the caller's numbering
-            kdeg[row] = d;
-            wnl[row] = d - 2 * lw;                              // weight towards the OTHER nodes
-            tot[id] = d;
-            com[row] = id;
-            nxt[row] = id;
-            csize[id] = e > s ? 1 : 0;   // empty rows are not graph nodes (cluster.py:321 never adds them)
-            total += d;
-            if (row >= r0 && row < r1) loops += 2 * lw;         // every node alone: I2 is the self-loops (this rank's rows)
+        long long d[2] = {0, 0}, lw[2] = {0, 0};
+        const int64_t span = (re_[0] - rs_[0]) > (re_[1] - rs_[1]) ? (re_[0] - rs_[0]) : (re_[1] - rs_[1]);
+        for (int64_t off = 0; off < span; off += 256) {
+            int32_t j[2][4];
+            long long w[2][4];
+            if (wq) {
+                double a[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int64_t k = rs_[h] + off + t * 64 + lane;
+                        const bool ok = k < re_[h];
+                        j[h][t] = ok ? indices[k] : -1;
+                        a[h][t] = ok ? wq[k] : 0.0;
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int64_t k = rs_[h] + off + t * 64 + lane;
+                        w[h][t] = j[h][t] >= 0 ? __double2ll_rn(ldexp(a[h][t] * wscl, shift)) : 0;
+                        if (j[h][t] >= 0) q_out[k] = w[h][t];
+                    }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int64_t k = rs_[h] + off + t * 64 + lane;
+                        const bool ok = k < re_[h];
+                        j[h][t] = ok ? indices[k] : -1;
+                        w[h][t] = ok ? q[k] : 0;
+                    }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    d[h] += j[h][t] == (int32_t)rw[h] ? 2 * w[h][t] : w[h][t];
+                    lw[h] += j[h][t] == (int32_t)rw[h] ? w[h][t] : 0;
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const long long dd = wave_sum_ll(d[h]), ll = wave_sum_ll(lw[h]);
+            const int64_t row = rw[h];
+            if (lane == 0 && row >= 0) {
+                const int32_t id = ids ? ids[row] : (int32_t)row;   // community ids live in the caller's numbering
+                kdeg[row] = dd;
+                wnl[row] = dd - 2 * ll;                             // weight towards the OTHER nodes
+                tot[id] = dd;
+                com[row] = id;
+                nxt[row] = id;
+                csize[id] = re_[h] > rs_[h] ? 1 : 0;   // empty rows are not graph nodes (cluster.py:321 never adds them)
+                total += dd;
+                if (row >= r0 && row < r1) loops += 2 * ll;         // every node alone: I2 is the self-loops (this rank's rows)
+            }
         }
     }
     __shared__ long long red[WPB];
@@ -1019,35 +1051,56 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * WPB;
     long long acc = 0;
-    for (int64_t row = r0 + wave; row < n; row += nwave) {
-        const int64_t s = indptr[row], e = indptr[row + 1];
-        const int32_t a = com[row];
-        long long mine = 0;                                   // weight towards the other members of the own community
-        // four 64-entry slices in flight: index and weight loads first, then the label gathers (integer sums: any order)
-        for (int64_t base = s; base < e; base += 256) {
-            int32_t j[4];
-            long long w[4];
+    // two rows per wave and pass, so that the loads of both are in flight together (bounds -> entries -> label gathers are
+    // dependent round trips; walked row by row the pass ran at 2.8 TB/s)
+    for (int64_t row0 = r0 + wave; row0 < n; row0 += 2 * nwave) {
+        int64_t rw[2], rs_[2], re_[2];
+        int32_t a[2];
+        rw[0] = row0;
+        rw[1] = row0 + nwave < n ? row0 + nwave : -1;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int64_t k = base + t * 64 + lane;
-                const bool ok = k < e;
-                j[t] = ok ? indices[k] : -1;
-                w[t] = ok ? q[k] : 0;
-            }
-            int32_t c[4];
+        for (int h = 0; h < 2; h++) {
+            rs_[h] = rw[h] >= 0 ? indptr[rw[h]] : 0;
+            re_[h] = rw[h] >= 0 ? indptr[rw[h] + 1] : 0;
+            a[h] = rw[h] >= 0 ? com[rw[h]] : -1;
+        }
+        long long mine[2] = {0, 0};                           // weight towards the other members of the own community
+        const int64_t span = (re_[0] - rs_[0]) > (re_[1] - rs_[1]) ? (re_[0] - rs_[0]) : (re_[1] - rs_[1]);
+        // four 64-entry slices per row in flight: index and weight loads first, then the label gathers (integer sums: any order)
+        for (int64_t off = 0; off < span; off += 256) {
+            int32_t j[2][4];
+            long long w[2][4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) c[t] = j[t] >= 0 ? com[j[t]] : -1;
+            for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                if (j[t] == (int32_t)row) acc += 2 * w[t];
-                else if (j[t] >= 0 && c[t] == a) { acc += w[t]; mine += w[t]; }
-            }
+                for (int t = 0; t < 4; t++) {
+                    const int64_t k = rs_[h] + off + t * 64 + lane;
+                    const bool ok = k < re_[h];
+                    j[h][t] = ok ? indices[k] : -1;
+                    w[h][t] = ok ? q[k] : 0;
+                }
+            int32_t c[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) c[h][t] = j[h][t] >= 0 ? com[j[h][t]] : -2;
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (j[h][t] < 0) continue;
+                    if (j[h][t] == (int32_t)rw[h]) acc += 2 * w[h][t];
+                    else if (c[h][t] == a[h]) { acc += w[h][t]; mine[h] += w[h][t]; }
+                }
         }
         if (own) {                                            // by-product for k_lv_prune (wave-uniform branch)
-            mine = wave_sum_ll(mine);
-            if (lane == 0) {
-                own[row] = mine;
-                if (stamp) stamp[row] = epoch;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const long long m = wave_sum_ll(mine[h]);
+                if (lane == 0 && rw[h] >= 0) {
+                    own[rw[h]] = m;
+                    if (stamp) stamp[rw[h]] = epoch;
+                }
             }
         }
     }
@@ -1257,49 +1310,71 @@ __global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, int64_t
     for (int64_t t = threadIdx.x; t < (int64_t)nslot * kc; t += BLK) agg_lds[t] = 0;
     if (threadIdx.x < AGG_SLOTS) slot_com[threadIdx.x] = -1;
     __syncthreads();
-    for (int64_t row = ra + wib; row < rb; row += WPB) {
-        const int64_t s = indptr[row], e = indptr[row + 1];
-        if (e == s) continue;
-        const int64_t c1 = cn[row];
-        int sl = -1;
-        if (lane == 0) {
-            for (int k = 0; k < nslot; k++) {
-                const int32_t prev = atomicCAS(&slot_com[k], -1, (int32_t)c1);
-                if (prev == -1 || prev == (int32_t)c1) { sl = k; break; }
-            }
+    // two rows per wave and pass: the loads of both are in flight together (a row is one or two dependent round trips --
+    // bounds, entries, community gathers -- and a wave that walks its rows one by one waits for each of them in turn)
+    for (int64_t row0 = ra + wib; row0 < rb; row0 += 2 * WPB) {
+        int64_t rw[2], rs_[2], re_[2], c1[2];
+        rw[0] = row0;
+        rw[1] = row0 + WPB < rb ? row0 + WPB : -1;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            rs_[h] = rw[h] >= 0 ? indptr[rw[h]] : 0;
+            re_[h] = rw[h] >= 0 ? indptr[rw[h] + 1] : 0;
+            c1[h] = rw[h] >= 0 ? cn[rw[h]] : 0;
         }
-        sl = __shfl(sl, 0, 64);
-        u64 *lrow = sl >= 0 ? agg_lds + (int64_t)sl * kc : nullptr;
-        u64 *grow = bins + c1 * kc;
-        long long own = 0;
-        for (int64_t base = s; base < e; base += 256) {
-            int32_t j[4];
-            long long qv[4];
+        u64 *lrow[2], *grow[2];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int64_t k = base + t * 64 + lane;
-                const bool ok = k < e;
-                j[t] = ok ? indices[k] : -1;
-                qv[t] = ok ? q[k] : 0;
-            }
-            int32_t c2[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) c2[t] = j[t] >= 0 ? cn[j[t]] : (int32_t)c1;
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                if (j[t] < 0) continue;
-                if (j[t] == (int32_t)row) own += 2 * qv[t];
-                else if (c2[t] == (int32_t)c1) own += qv[t];
-                else if (qv[t]) {
-                    if (lrow) atomicAdd(&lrow[c2[t]], (u64)qv[t]);
-                    else atomicAdd(&grow[c2[t]], (u64)qv[t]);
+        for (int h = 0; h < 2; h++) {
+            int sl = -1;
+            if (lane == 0 && re_[h] > rs_[h]) {
+                for (int k = 0; k < nslot; k++) {
+                    const int32_t prev = atomicCAS(&slot_com[k], -1, (int32_t)c1[h]);
+                    if (prev == -1 || prev == (int32_t)c1[h]) { sl = k; break; }
                 }
             }
+            sl = __shfl(sl, 0, 64);
+            lrow[h] = sl >= 0 ? agg_lds + (int64_t)sl * kc : nullptr;
+            grow[h] = bins + c1[h] * kc;
         }
-        own = wave_sum_ll(own);
-        if (lane == 0 && own) {
-            if (lrow) atomicAdd(&lrow[c1], (u64)own);
-            else atomicAdd(&grow[c1], (u64)own);
+        long long own[2] = {0, 0};
+        const int64_t span = (re_[0] - rs_[0]) > (re_[1] - rs_[1]) ? (re_[0] - rs_[0]) : (re_[1] - rs_[1]);
+        for (int64_t off = 0; off < span; off += 256) {
+            int32_t j[2][4];
+            long long qv[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int64_t k = rs_[h] + off + t * 64 + lane;
+                    const bool ok = k < re_[h];
+                    j[h][t] = ok ? indices[k] : -1;
+                    qv[h][t] = ok ? q[k] : 0;
+                }
+            int32_t c2[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) c2[h][t] = j[h][t] >= 0 ? cn[j[h][t]] : (int32_t)c1[h];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (j[h][t] < 0) continue;
+                    if (j[h][t] == (int32_t)rw[h]) own[h] += 2 * qv[h][t];
+                    else if (c2[h][t] == (int32_t)c1[h]) own[h] += qv[h][t];
+                    else if (qv[h][t]) {
+                        if (lrow[h]) atomicAdd(&lrow[h][c2[h][t]], (u64)qv[h][t]);
+                        else atomicAdd(&grow[h][c2[h][t]], (u64)qv[h][t]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const long long o = wave_sum_ll(own[h]);
+            if (lane == 0 && o) {
+                if (lrow[h]) atomicAdd(&lrow[h][c1[h]], (u64)o);
+                else atomicAdd(&grow[h][c1[h]], (u64)o);
+            }
         }
     }
     __syncthreads();

@@ -3,5 +3,8 @@
 out=gpurun_out/exp_tails
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1400 python tools/c5_probe.py 5e6 1e9 '' B3C_KR_XT_S=8192 B3C_KR_XT_CHUNKS=8 B3C_KR_XT_CHUNKS=24 2>&1 | grep -v 'tick' > $out/c5.txt; grep -v '^\[b3c\]' $out/c5.txt
-timeout 600 python tools/c5_probe.py 2e6 3e8 '' B3C_KR_XT_S=8192 B3C_KR_XT_CHUNKS=2 B3C_KR_XT_S=8192,B3C_KR_XT_CHUNKS=2 2>&1 | grep -v 'tick' > $out/c5b.txt; grep -v '^\[b3c\]' $out/c5b.txt
+timeout 1200 python -m pytest tests/test_gpu_louvain.py tests/test_gpu_pipeline.py tests/test_gpu_edges.py -x -q -m gpu > $out/tests.log 2>&1
+tail -3 $out/tests.log
+timeout 300 python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_c3.json 2> $out/bench_c3.err
+tail -1 $out/bench_c3.json | python tools/bsum.py
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c3 -- python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_c3.log 2>&1
