@@ -462,15 +462,20 @@ extern "C" int b3c_normalise_scale(b3c_ctx *ctx, const b3c_mat *counts, const do
     return B3C_OK;
 }
 
+// what k_compress_fill_ns needs of a contig, as a row and as a stored column: one 32-byte record
+struct __attribute__((aligned(32))) ColRec {
+    double2 sx;      // (site count, x)
+    int2 ni;         // (new id | -1 when masked out, caller-side id)
+    int2 pad;
+};
+
 // compress of the balanced map WITHOUT materialising it: the kept entries are computed on the fly from the raw counts
-// exactly as k_norm_scale computes them (same expression, same operand order: bit-identical values).  Per column two
-// packed gathers -- (new id or -1 if masked, caller-side id), then for kept entries (site count, x) -- and up to 256
-// entries of a row in flight at once.
+// exactly as k_norm_scale computes them (same expression, same operand order: bit-identical values).  Per column one
+// gathered record -- (site count, x, new id or -1 if masked, caller-side id) -- and up to 256 entries of a row in flight at once.
 __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices,
                                                            const uint32_t *__restrict__ counts,
-                                                           const double2 *__restrict__ sx,      // (site count, x) per row
-                                                           const int2 *__restrict__ ni,         // (new id | -1, caller-side id)
+                                                           const ColRec *__restrict__ rec,      // per contig: site count, x, new id | -1, caller-side id
                                                            int graph_form,
                                                            const int64_t *__restrict__ out_indptr,
                                                            int32_t *__restrict__ out_indices, double *__restrict__ out_a,
@@ -489,7 +494,7 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
     int2 nr = make_int2(-1, 0);
     int64_t s = 0, e = 0;
     if (row < n) {
-        nr = ni[row];
+        nr = rec[row].ni;
         if (nr.x >= 0) { s = indptr[row]; e = indptr[row + 1]; }
     }
     int32_t j[U];
@@ -506,23 +511,25 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
         int2 nrn = make_int2(-1, 0);
         int64_t sn = 0, en = 0;
         if (rown < n) {
-            nrn = ni[rown];
+            nrn = rec[rown].ni;
             if (nrn.x >= 0) { sn = indptr[rown]; en = indptr[rown + 1]; }
         }
         int64_t o = 0;
         double2 pr = make_double2(1.0, 0.0);
-        if (nr.x >= 0) { o = out_indptr[nr.x]; pr = sx[row]; }
+        if (nr.x >= 0) { o = out_indptr[nr.x]; pr = rec[row].sx; }
         const double si = pr.x == 0.0 ? 1.0 : pr.x;
         const double xr = pr.y;
         const int32_t idr = nr.y;
         for (int64_t base = s; base < e; base += 64 * U) {
-            // both gathers are issued for every stored column: the second no longer waits for the first
+            // everything the kernel needs of a column sits in ONE 32-byte record (two loads from one line; as two tables -- 8 + 16
+            // bytes -- every stored column cost two line look-ups)
             int2 nj[U];
             double2 pj[U];
 #pragma unroll
-            for (int t = 0; t < U; t++) nj[t] = j[t] >= 0 ? ni[j[t]] : make_int2(-1, 0);
-#pragma unroll
-            for (int t = 0; t < U; t++) pj[t] = j[t] >= 0 ? sx[j[t]] : make_double2(1.0, 0.0);
+            for (int t = 0; t < U; t++) {
+                nj[t] = j[t] >= 0 ? rec[j[t]].ni : make_int2(-1, 0);
+                pj[t] = j[t] >= 0 ? rec[j[t]].sx : make_double2(1.0, 0.0);
+            }
             // the next 256 entries: of this row, or (after its last chunk) the first ones of the wave's next row
             const bool last = base + 64 * U >= e;
             const int64_t nb = last ? sn : base + 64 * U, ne = last ? en : e;
@@ -602,21 +609,21 @@ __global__ void __launch_bounds__(BLK) k_compress_fill_ns(int64_t n, const int64
 }
 
 struct NormScale {          // when set, compress_impl computes the values from raw counts (k_compress_fill_ns)
-    const double2 *sx;      // (site count, x) per row
+    const double *sites, *x;   // per row, in HBM
     int graph_form;
 };
 
-__global__ void k_pack_ni(int64_t n, const uint8_t *__restrict__ mask, const int64_t *__restrict__ newid,
-                          const int32_t *__restrict__ ids, int2 *__restrict__ ni)
+__global__ void k_pack_rec(int64_t n, const double *__restrict__ sites, const double *__restrict__ x, const uint8_t *__restrict__ mask,
+                           const int64_t *__restrict__ newid, const int32_t *__restrict__ ids, ColRec *__restrict__ rec)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ni[i] = make_int2(mask[i] ? (int)newid[i] : -1, ids ? ids[i] : (int)i);
-}
-
-__global__ void k_pack_sx(int64_t n, const double *__restrict__ sites, const double *__restrict__ x, double2 *__restrict__ sx)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sx[i] = make_double2(sites[i], x[i]);
+    if (i < n) {
+        ColRec r;
+        r.sx = make_double2(sites[i], x[i]);
+        r.ni = make_int2(mask[i] ? (int)newid[i] : -1, ids ? ids[i] : (int)i);
+        r.pad = make_int2(0, 0);
+        rec[i] = r;
+    }
 }
 
 static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, const NormScale *ns, b3c_mat **out);
@@ -641,10 +648,7 @@ extern "C" int b3c_normalise_scale_compress(b3c_ctx *ctx, const b3c_mat *counts,
     int rc;
     if ((rc = b3c_copy_in(ctx, ds.p, sites, sizeof(double) * (size_t)n)) || (rc = b3c_copy_in(ctx, dx.p, x, sizeof(double) * (size_t)n)))
         return rc;
-    DevBuf<double2> sx(ctx, n + 1);
-    if (!sx.p) return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress");
-    if (n) hipLaunchKernelGGL(k_pack_sx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ds.p, dx.p, sx.p);
-    const NormScale ns{sx.p, graph_form ? 1 : 0};
+    const NormScale ns{ds.p, dx.p, graph_form ? 1 : 0};
     return compress_impl(ctx, counts, mask, &ns, out);
 }
 
@@ -679,16 +683,16 @@ static int compress_impl(b3c_ctx *ctx, const b3c_mat *a, const uint8_t *mask, co
     if (n) {
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
         if (ns) {
-            DevBuf<int2> ni(ctx, n + 1);
-            if (!ni.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
-            hipLaunchKernelGGL(k_pack_ni, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dm.p, newid.p, a->ids, ni.p);
+            DevBuf<ColRec> rec(ctx, n + 1);
+            if (!rec.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
+            hipLaunchKernelGGL(k_pack_rec, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ns->sites, ns->x, dm.p, newid.p, a->ids, rec.p);
             // [4 counters | one value-sum partial per workgroup]: read back together through the pinned staging buffer
             DevBuf<unsigned long long> vstat(ctx, 4 + (size_t)g);
             if (!vstat.p) { return ctx->fail(B3C_E_NOMEM, "b3c_normalise_scale_compress"); }
             HIP_TRY(ctx, hipMemsetAsync(vstat.p, 0, sizeof(unsigned long long) * 4, s));
             hipLaunchKernelGGL(k_compress_fill_ns, dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices, (const uint32_t *)a->data,
-                               ns->sx, ni.p, ns->graph_form, optr.p, o->indices, (double *)o->data, vstat.p, (double *)(vstat.p + 4));
-            // (the read-back also ends the use of `ni`, which goes back to the pool at the end of this scope)
+                               rec.p, ns->graph_form, optr.p, o->indices, (double *)o->data, vstat.p, (double *)(vstat.p + 4));
+            // (the read-back also ends the use of `rec`, which goes back to the pool at the end of this scope)
             std::vector<unsigned long long> hvv(4 + (size_t)g, 0ull);
             { const int rb_ = b3c_readback(ctx, hvv.data(), vstat.p, sizeof(unsigned long long) * hvv.size()); if (rb_) return rb_; }
             const unsigned long long *hv = hvv.data();
