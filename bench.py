@@ -282,6 +282,18 @@ def main():
                          'achieved_streamed': streamed / (avg_ms * 1e-3) / 1e9,
                          'frac_streamed': streamed / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        # the same figure for the kernel family that is NOT the dominant one (a roofline-style line for the
+        # Louvain scan beside the SpMV's, and vice versa on maps where the scan dominates)
+        if spmv_ms >= move_ms:
+            o_bytes = (16.0 * acc['move_nnz'] + 28.0 * acc['move_rows']) / max(move_n, 1)
+            o_ms, o_name = move_ms / max(move_n, 1), 'k_lv_decide (Louvain delta-Q neighbour scan; one launch = one sub-round: 1/n_sub of a sweep)'
+        else:
+            o_bytes = (12.0 * nnz + 20.0 * n) * share
+            o_ms, o_name = spmv_ms / max(spmv_n, 1), 'KR SpMV (all launches of one product)'
+        if o_ms > 0:
+            o_ach = o_bytes / (o_ms * 1e-3) / 1e9
+            out['roofline_other'] = {'bound': 'hbm', 'kernel': o_name, 'achieved': o_ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                     'frac': o_ach / HBM_PEAK_GBS, 'bytes_per_launch': o_bytes, 'avg_launch_ms': o_ms}
         out.update(extra)
         return out
 

@@ -10,5 +10,8 @@ for line in sys.stdin:
     print('   kernel_ms', {k: round(v, 2) for k, v in c['kernel_ms'].items()}, 'spmv/step', c['kr_spmv_per_step'], 'sweeps', c['louvain_sweeps_per_step'])
     r = d['roofline']
     print('   roofline %s: %.0f GB/s (%.1f%%) avg %.3f ms, copy %s GB/s' % (r['kernel'][:12], r['achieved'], 100 * r['frac'], r['avg_launch_ms'], r.get('copy_gbs') and round(r['copy_gbs'])))
+    o = d.get('roofline_other')
+    if o:
+        print('   other    %s: %.0f GB/s (%.1f%%) avg %.3f ms' % (o['kernel'][:12], o['achieved'], 100 * o['frac'], o['avg_launch_ms']))
     if 'cpu_baseline' in d:
         print('   cpu', d['cpu_baseline']['value'], d['cpu_baseline']['sample'][:100])
