@@ -228,6 +228,18 @@ __global__ void k_iota(int64_t n, int32_t *__restrict__ v)
     if (i < n) v[i] = (int32_t)i;
 }
 
+// key of row i = its cluster labels of all rounds, the last round in the highest bits; value = i
+__global__ void k_pack_labels(int64_t n, int rounds, int bits, const int32_t *__restrict__ lab, unsigned long long *__restrict__ key,
+                              int32_t *__restrict__ val)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long k = 0;
+    for (int r = rounds - 1; r >= 0; r--) k = (k << bits) | (unsigned long long)(uint32_t)lab[(size_t)r * n + i];
+    key[i] = k;
+    val[i] = (int32_t)i;
+}
+
 __global__ void k_gather_i32(int64_t n, const int32_t *__restrict__ src, const int32_t *__restrict__ idx,
                              int32_t *__restrict__ dst)
 {
@@ -665,9 +677,22 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
             hipLaunchKernelGGL(k_relabel, dim3(gn), dim3(256), 0, s, n, cur, roots);
         }
     }
-    // LSD: stable sorts by cluster_1, cluster_2, cluster_3 starting from the identity
     int bits = 1;
     while ((1ll << bits) < n) bits++;
+    if (ROUNDS * bits <= 64 && getenv("B3C_ORDER_LSD") == nullptr) {
+        // ONE stable sort on the composite key (cluster_R, ..., cluster_2, cluster_1): the order the LSD passes below give, from a
+        // third of the launches (1M keys go through rocPRIM's merge sort, ~20 small kernels per call; n up to 2^21 with three rounds)
+        DevBuf<unsigned long long> k64(ctx, n), k64o(ctx, n);
+        if (!k64.p || !k64o.p) return ctx->fail(B3C_E_NOMEM, "b3c_locality_order: sort keys");
+        hipLaunchKernelGGL(k_pack_labels, dim3(gn), dim3(256), 0, s, n, ROUNDS, bits, lab.p, k64.p, vout.p);
+        size_t tb = 0;
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k64.p, k64o.p, vout.p, new2old, (int64_t)n, 0, ROUNDS * bits, s));
+        DevBuf<char> tmp(ctx, tb);
+        if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_locality_order: sort workspace");
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k64.p, k64o.p, vout.p, new2old, (int64_t)n, 0, ROUNDS * bits, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch above goes back to the pool here
+    } else {
+    // LSD: stable sorts by cluster_1, cluster_2, cluster_3 starting from the identity
     hipLaunchKernelGGL(k_iota, dim3(gn), dim3(256), 0, s, n, new2old);
     size_t tb = 0;
     HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin.p, kout.p, new2old, vout.p, (int64_t)n, 0, bits, s));
@@ -677,6 +702,7 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
         hipLaunchKernelGGL(k_gather_i32, dim3(gn), dim3(256), 0, s, n, lab.p + (size_t)r * n, new2old, kin.p);
         HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kin.p, kout.p, new2old, vout.p, (int64_t)n, 0, bits, s));
         HIP_TRY(ctx, hipMemcpyAsync(new2old, vout.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    }
     }
     hipLaunchKernelGGL(k_invert_perm, dim3(gn), dim3(256), 0, s, n, new2old, old2new);
     HIP_TRY(ctx, hipGetLastError());
