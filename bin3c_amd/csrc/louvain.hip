@@ -899,6 +899,106 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
     }
 }
 
+// The FIRST sub-round of a level, for the nodes of the grouped list: every node is alone, so every stored neighbour j != i IS a
+// candidate community of its own -- weight towards it q_ij, total kdeg[j], size 1 -- the own community holds nothing else (stay
+// gain 0, not taken) and the singleton rule lets i move only to a LOWER community id.  The decision is the arg-max over the
+// entries of q_ij * 2m - kdeg[j] * k_i (ties to the lowest community id): no table, no gather of tot[] by community id (one random
+// line per entry in the general kernel; kdeg[] is in row order like the labels), the same 128-bit arithmetic and the same result.
+template <int LPR, int UN>
+__global__ void __launch_bounds__(BLK) k_lv_first_g(int64_t cnt, const NodeRec *__restrict__ list, u64 m2,
+                                                     const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
+                                                     const int64_t *__restrict__ kdeg, const int32_t *__restrict__ com,
+                                                     const int32_t *__restrict__ csize, int32_t *__restrict__ nxt)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t step = (int64_t)gridDim.x * WPB * RPW;
+    int64_t pos = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * RPW + sub;
+    // software pipeline as in k_lv_decide_g: record, entries and own label of the group's NEXT node are requested while the
+    // gathers of the current one are in flight
+    int32_t i = -1, a = 0;
+    int deg = 0;
+    long long ki = 0;
+    int32_t j[UN];
+    u64 qv[UN];
+    if (pos < cnt) {
+        const NodeRec rec = list[pos];
+        i = rec.node;
+        deg = rec.deg;
+        a = com[i];
+        ki = kdeg[i];
+#pragma unroll
+        for (int t = 0; t < UN; t++) {
+            const int e = t * LPR + sl;
+            j[t] = e < deg ? indices[rec.start + e] : i;
+            qv[t] = e < deg ? (u64)q[rec.start + e] : 0;
+        }
+    }
+    while (__ballot(i >= 0)) {
+        const int64_t posn = pos + step;
+        NodeRec recn;
+        recn.node = -1; recn.deg = 0; recn.start = 0;
+        if (i >= 0 && posn < cnt) recn = list[posn];
+        int32_t cm[UN];
+        long long tv[UN];
+#pragma unroll
+        for (int t = 0; t < UN; t++) {
+            const bool nb = i >= 0 && j[t] != i;
+            cm[t] = nb ? com[j[t]] : EMPTY;
+            tv[t] = nb ? kdeg[j[t]] : 0;
+        }
+        int32_t an = 0;
+        long long kin = 0;
+        int32_t j2[UN];
+        u64 q2[UN];
+        {
+            const int32_t inn = recn.node;
+            if (inn >= 0) { an = com[inn]; kin = kdeg[inn]; }
+#pragma unroll
+            for (int t = 0; t < UN; t++) {
+                const int e = t * LPR + sl;
+                j2[t] = e < recn.deg ? indices[recn.start + e] : inn;
+                q2[t] = e < recn.deg ? (u64)q[recn.start + e] : 0;
+            }
+        }
+        Best b;
+        b.gain = 0; b.com = a; b.have = 0;
+#pragma unroll
+        for (int t = 0; t < UN; t++) {
+            if (cm[t] == EMPTY) continue;
+            const i128 g = (i128)qv[t] * (i128)m2 - (i128)tv[t] * (i128)ki;
+            best_take(b, g, cm[t]);
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            long long hi = __shfl_down((long long)(b.gain >> 64), o, LPR);
+            u64 lo = (u64)__shfl_down((long long)(u64)b.gain, o, LPR);
+            int32_t c = __shfl_down(b.com, o, LPR);
+            int32_t hv = __shfl_down(b.have, o, LPR);
+            i128 g = ((i128)hi << 64) | (i128)lo;
+            if (hv && (!b.have || g > b.gain || (g == b.gain && c < b.com))) {
+                b.gain = g;
+                b.com = c;
+                b.have = 1;
+            }
+        }
+        if (i >= 0 && sl == 0) {
+            int32_t best = b.have ? b.com : a;
+            // two singletons: only towards the lower id (a column whose own row is empty is no graph node: size 0, as in k_lv_decide_g)
+            if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
+            nxt[i] = best;
+        }
+        pos = posn;
+        i = recn.node;
+        deg = recn.deg;
+        a = an;
+        ki = kin;
+#pragma unroll
+        for (int t = 0; t < UN; t++) { j[t] = j2[t]; qv[t] = q2[t]; }
+    }
+}
+
 // Sharded level 0 on a ROW BLOCK (this rank's rows hold entries, the others are empty here): the weighted degrees are
 // gathered over the ranks with a "row is not empty" flag riding in bit 62 (degrees stay below 2^61), then totals, community
 // sizes, the initial labels and 2m are formed from the gathered vector by every rank.
@@ -1902,6 +2002,19 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 #define LV_DECIDE_G(L, U)                                                                                                \
     hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, cnt_dev, lst, \
                        m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch)
+                    if (sweep == 1 && r == 0 && !incr && getenv("B3C_LV_NO_FIRST") == nullptr) {
+                        // every node is still alone: the table-free form (k_lv_first_g)
+#define LV_FIRST_G(L, U)                                                                                                 \
+    hipLaunchKernelGGL((k_lv_first_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, m2,     \
+                       g.indices, g.q, kdeg.p, com.p, csize.p, nxt_p)
+                        switch (short_max) {
+                        case 256: LV_FIRST_G(64, 4); break;
+                        case 128: LV_FIRST_G(16, 8); break;
+                        case 64: LV_FIRST_G(8, 8); break;
+                        default: LV_FIRST_G(4, 8); break;
+                        }
+#undef LV_FIRST_G
+                    } else
                     switch (short_max) {
                     case 256:      // C3 sweep of shapes, ms of delta-Q scan per step: 64x4 11.3, 32x8 12.2, 16x16 22.4
                         if (getenv("B3C_LV_SHAPE") && !strcmp(getenv("B3C_LV_SHAPE"), "32x8")) { LV_DECIDE_G(32, 8); }
