@@ -1398,10 +1398,13 @@ constexpr int AGG_SLOTS = 4;
 // A block takes `rpb` CONSECUTIVE rows: in a locality-ordered map they belong to one or two communities, whose bin rows
 // are kept in LDS (the first `nslot` communities the block meets claim a slot; rows of any further community go straight
 // to the global bins) and flushed once at the end -- a tenth of the global atomics on the bench maps.
-__global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, int64_t rpb, int nslot, const int64_t *__restrict__ indptr,
+__global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, int64_t rpb, int nslot, int64_t long_deg, const int64_t *__restrict__ indptr,
                                                    const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
-                                                   const int32_t *__restrict__ cn, u64 *__restrict__ bins)
+                                                   const int32_t *__restrict__ cn, u64 *__restrict__ bins, const int32_t *__restrict__ order)
 {
+    // order != nullptr: the rows are taken in the order of their NEW community (levels beyond the first, whose nodes are numbered
+    // by the communities of the level before: the members of a new community are scattered, a workgroup's rows would belong to
+    // as many communities as it has rows and nearly every entry would be an atomic on the global bins)
     extern __shared__ u64 agg_lds[];                    // nslot * kc
     __shared__ int32_t slot_com[AGG_SLOTS];
     const int lane = threadIdx.x & 63;
@@ -1414,13 +1417,14 @@ __global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, int64_t
     // bounds, entries, community gathers -- and a wave that walks its rows one by one waits for each of them in turn)
     for (int64_t row0 = ra + wib; row0 < rb; row0 += 2 * WPB) {
         int64_t rw[2], rs_[2], re_[2], c1[2];
-        rw[0] = row0;
-        rw[1] = row0 + WPB < rb ? row0 + WPB : -1;
+        rw[0] = order ? order[row0] : row0;
+        rw[1] = row0 + WPB < rb ? (order ? order[row0 + WPB] : row0 + WPB) : -1;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             rs_[h] = rw[h] >= 0 ? indptr[rw[h]] : 0;
             re_[h] = rw[h] >= 0 ? indptr[rw[h] + 1] : 0;
             c1[h] = rw[h] >= 0 ? cn[rw[h]] : 0;
+            if (re_[h] - rs_[h] > long_deg) re_[h] = rs_[h];          // rows of k_agg_bins_long
         }
         u64 *lrow[2], *grow[2];
 #pragma unroll
@@ -1485,6 +1489,66 @@ __global__ void __launch_bounds__(BLK) k_agg_bins(int64_t n, int64_t kc, int64_t
             const u64 v = agg_lds[(int64_t)k * kc + t];
             if (v) atomicAdd(&bins[(int64_t)c * kc + t], v);
         }
+    }
+}
+
+// Rows of more than AGG_LONG entries -- at level 1 of a heavy-tailed map the community of a genome that the noise links to every
+// other community: 10^5 entries and more -- kept ONE wave of k_agg_bins busy for milliseconds while the chip idled (the surveyed
+// genome-size law at C3: 8 ms for this pass).  They are listed (any order: the sums are integers) and taken by workgroups of
+// AGG_LONG entries each; all entries of a workgroup belong to one row, so its foreign weights go into ONE LDS row of kc sums.
+constexpr int64_t AGG_LONG = 8192;
+__global__ void k_iota32(int64_t n, int32_t *__restrict__ v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
+__global__ void k_agg_long_rows(int64_t n, const int64_t *__restrict__ indptr, int32_t *__restrict__ rows, unsigned long long *__restrict__ cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && indptr[i + 1] - indptr[i] > AGG_LONG) rows[atomicAdd(cnt, 1ull)] = (int32_t)i;
+}
+
+__global__ void __launch_bounds__(BLK) k_agg_bins_long(int64_t kc, int chunks, const int32_t *__restrict__ rows, const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
+                                                        const int32_t *__restrict__ cn, u64 *__restrict__ bins)
+{
+    extern __shared__ u64 agg_lds[];                    // kc sums
+    const int64_t row = rows[blockIdx.x / chunks];
+    const int64_t s = indptr[row] + (int64_t)(blockIdx.x % chunks) * AGG_LONG;
+    const int64_t e = indptr[row + 1] < s + AGG_LONG ? indptr[row + 1] : s + AGG_LONG;
+    if (s >= e) return;                                 // (uniform per workgroup)
+    for (int64_t t = threadIdx.x; t < kc; t += BLK) agg_lds[t] = 0;
+    __syncthreads();
+    const int32_t c1 = cn[row];
+    long long own = 0;
+    for (int64_t base = s + threadIdx.x; base < e; base += 4 * BLK) {
+        int32_t j[4];
+        long long qv[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int64_t k = base + (int64_t)t * BLK;
+            const bool ok = k < e;
+            j[t] = ok ? indices[k] : -1;
+            qv[t] = ok ? q[k] : 0;
+        }
+        int32_t c2[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) c2[t] = j[t] >= 0 ? cn[j[t]] : c1;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (j[t] < 0) continue;
+            if (j[t] == (int32_t)row) own += 2 * qv[t];
+            else if (c2[t] == c1) own += qv[t];
+            else if (qv[t]) atomicAdd(&agg_lds[c2[t]], (u64)qv[t]);
+        }
+    }
+    own = wave_sum_ll(own);
+    if ((threadIdx.x & 63) == 0 && own) atomicAdd(&agg_lds[c1], (u64)own);
+    __syncthreads();
+    for (int64_t t = threadIdx.x; t < kc; t += BLK) {
+        const u64 v = agg_lds[t];
+        if (v) atomicAdd(&bins[(int64_t)c1 * kc + t], v);
     }
 }
 
@@ -2146,8 +2210,40 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 const int nslot = kc <= 512 ? AGG_SLOTS : kc <= 2048 ? 2 : 1;
                 const int64_t rpb = std::max<int64_t>(64, std::min<int64_t>(512, n / (4 * (int64_t)ctx->n_cu)));   // at least four blocks per CU
                 const size_t lds = sizeof(u64) * (size_t)nslot * (size_t)kc;       // at most 32 KB
-                hipLaunchKernelGGL(k_agg_bins, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(BLK), lds, s, n, kc, rpb, nslot, g.indptr, g.indices,
-                                   g.q, cn.p, bins.p);
+                const bool long_rows = maxdeg > AGG_LONG && getenv("B3C_LV_NO_AGG_LONG") == nullptr;
+                // beyond the first level: rows in the order of their new community (one stable sort of n labels)
+                const bool by_com = !first && n >= 4096 && getenv("B3C_LV_NO_AGG_ORDER") == nullptr;
+                DevBuf<int32_t> okey(ctx, by_com ? n : 1), oval(ctx, by_com ? n : 1), oiota(ctx, by_com ? n : 1);
+                if (by_com) {
+                    if (!okey.p || !oval.p || !oiota.p) { free_graph(ctx, h); free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation order"); }
+                    hipLaunchKernelGGL(k_iota32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, oiota.p);
+                    int kb = 1;
+                    while ((1ll << kb) < kc) kb++;
+                    size_t tb = 0;
+                    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, cn.p, okey.p, oiota.p, oval.p, n, 0, kb, s));
+                    DevBuf<char> tmp(ctx, tb);
+                    if (!tmp.p) { free_graph(ctx, h); free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation order"); }
+                    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, cn.p, okey.p, oiota.p, oval.p, n, 0, kb, s));
+                    HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch goes back to the pool here
+                }
+                hipLaunchKernelGGL(k_agg_bins, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(BLK), lds, s, n, kc, rpb, nslot,
+                                   long_rows ? AGG_LONG : INT64_MAX, g.indptr, g.indices, g.q, cn.p, bins.p, by_com ? oval.p : nullptr);
+                if (long_rows) {
+                    DevBuf<int32_t> lrows(ctx, n);
+                    DevBuf<unsigned long long> lcnt(ctx, 1);
+                    if (!lrows.p || !lcnt.p) { free_graph(ctx, h); free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: long rows of the aggregation"); }
+                    HIP_TRY(ctx, hipMemsetAsync(lcnt.p, 0, sizeof(unsigned long long), s));
+                    hipLaunchKernelGGL(k_agg_long_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, lrows.p, lcnt.p);
+                    unsigned long long nl = 0;
+                    { const int rb_ = b3c_readback(ctx, &nl, lcnt.p, sizeof(nl)); if (rb_) { free_graph(ctx, h); free_graph(ctx, g); return rb_; } }
+                    if (nl) {
+                        const int chunks = (int)((maxdeg + AGG_LONG - 1) / AGG_LONG);
+                        hipLaunchKernelGGL(k_agg_bins_long, dim3((unsigned)(nl * (unsigned long long)chunks)), dim3(BLK), sizeof(u64) * (size_t)kc, s, kc, chunks,
+                                           lrows.p, g.indptr, g.indices, g.q, cn.p, bins.p);
+                        HIP_TRY(ctx, hipStreamSynchronize(s));        // lrows goes back to the pool at the end of this scope
+                    }
+                }
+                if (by_com) HIP_TRY(ctx, hipStreamSynchronize(s));        // so does the row order
             }
             if (blk0 && (rc = b3c_dist_allreduce_u64(ctx, bins.p, (int64_t)nb))) { free_graph(ctx, h); free_graph(ctx, g); return rc; }
             const unsigned gk = (unsigned)((kc + 1 + WPB - 1) / WPB);
