@@ -475,6 +475,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
 constexpr int64_t SIDE_MIN_HUBS = 512;     // hub nodes of a sub-round from which the side stream pays (see b3c_louvain)
 constexpr int64_t PRUNE_MIN_HUBS = 1024;   // ... and from which pruning them is worth its launch
 constexpr int MEGA_NT = 1024;
+constexpr int64_t MEGA_FEW = 2048;         // "a few" long rows: fewer than eight per CU
 constexpr int64_t MEGA_DEG = 8192;         // rows beyond this many entries
 constexpr int MEGA_CHUNK = 4 * MEGA_NT;    // entries one workgroup of the insert pass takes
 
@@ -692,7 +693,7 @@ __device__ __forceinline__ int lv_list_segment(int64_t i, int n_sub, int max_deg
     const int32_t id = ids ? ids[i] : (int32_t)i;
     const int b = (int)bucket_of(id, n_sub);
     if (deg <= max_deg) return with_hubs ? 3 * b : b;
-    return with_hubs ? (deg > MEGA_DEG ? 3 * b + 2 : 3 * b + 1) : -1;
+    return with_hubs ? (deg > with_hubs ? 3 * b + 2 : 3 * b + 1) : -1;     // with_hubs = the entry count beyond which a row is a MEGA row
 }
 
 __global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, int max_deg, int with_hubs,
@@ -1641,6 +1642,23 @@ __global__ void k_big_table_sizes(int64_t n, int cap, const int64_t *__restrict_
     if (i == n) sz[i] = 0;
 }
 
+// out[0] += rows of more than 2048 entries, out[1] += rows of more than 4096
+__global__ void k_count_long_rows(int64_t n, const int64_t *__restrict__ indptr, u64 *__restrict__ out)
+{
+    unsigned long long a = 0, b = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = indptr[i + 1] - indptr[i];
+        a += d > 2048;
+        b += d > 4096;
+    }
+    a = (unsigned long long)wave_sum_ll((long long)a);
+    b = (unsigned long long)wave_sum_ll((long long)b);
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(&out[0], a);
+        if (b) atomicAdd(&out[1], b);
+    }
+}
+
 __global__ void k_max_degree(int64_t n, const int64_t *__restrict__ indptr, u64 *__restrict__ out)
 {
     max_row_len_body(n, indptr, (unsigned long long *)out);
@@ -1841,7 +1859,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 
     double mod = 0.0;
     bool first = true;
-    DevBuf<u64> ctr(ctx, 8);   // [0] m2, [1] moved, [2] i2, [3..6] tot2 limbs, [7] max degree
+    DevBuf<u64> ctr(ctx, 10);  // [0] m2, [1] moved, [2] i2, [3..6] tot2 limbs, [7] max degree, [8] rows beyond 2048 entries, [9] beyond 4096
     if (!ctr.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
 
     for (;;) {
@@ -1887,11 +1905,12 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int gwl = grid_for(r1 - r0, WPB, 16 * ctx->n_cu);   // wave-per-row kernels over this rank's rows
         const int gw = grid_for(n, WPB, 16 * ctx->n_cu);     // wave-per-row kernels
         const int gv = grid_for(n, BLK, 8 * ctx->n_cu);      // thread-per-node kernels
-        HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 8, s));
+        HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 10, s));
         const bool form_q = first && dq.src != nullptr;       // level 0: the weights are quantised by this pass (see k_lv_init)
         hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, form_q ? nullptr : g.q, ids, kdeg.p, tot.p, com.p,
                            nxt_p, csize.p, ctr.p, wnl.p, r0, r1, ctr.p + 2, form_q ? dq.src : nullptr, dq.scl, (int)shift, form_q ? q0.p : nullptr);
         hipLaunchKernelGGL(k_max_degree, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
+        hipLaunchKernelGGL(k_count_long_rows, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, n, g.indptr, ctr.p + 8);
         if (blk0) {
             // degrees (and which rows exist) of the other ranks' rows, then totals / sizes / labels / 2m from the whole vector
             if (r1 > r0) hipLaunchKernelGGL(k_lv_pack_flag, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, r0, r1, g.indptr, kdeg.p);
@@ -1899,7 +1918,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64), s));
             hipLaunchKernelGGL(k_lv_unpack_init, dim3(gv), dim3(BLK), 0, s, n, ids, kdeg.p, tot.p, csize.p, labels.p, ctr.p);
         }
-        u64 hc[8];
+        u64 hc[10];
         { const int rb_ = b3c_readback(ctx, hc, ctr.p, sizeof(hc)); if (rb_) return rb_; }
         const u64 m2 = hc[0];
         const int64_t maxdeg = (int64_t)hc[7];
@@ -1935,6 +1954,16 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         DevBuf<NodeRec> lists(ctx, grouped ? nloc + 1 : 1);
         const NodeRec *nlist_p = lists.p;
         std::vector<int64_t> loff(n_sub + 1, 0), hoff(n_sub + 1, 0), moff(n_sub + 1, 0), lend(n_sub + 1, 0);
+        // rows beyond mega_deg entries get workgroups (k_lv_mega_*); they need the node's global table, i.e. more entries than the LDS table
+        // From how many entries on?  The wave kernel copes with long rows as long as there are enough of them to fill the chip (C5:
+        // thousands of hub contigs; handing those to the workgroup kernels and their global tables cost the stage 309 -> 346 ms);
+        // a FEW long rows are the tail everybody waits for (the surveyed genome-size law at level 1: 146 -> 141 ms with 2048).
+        int64_t mega_auto = MEGA_DEG;
+        if ((int64_t)hc[8] <= MEGA_FEW) mega_auto = 2048;
+        else if ((int64_t)hc[9] <= MEGA_FEW) mega_auto = 4096;
+        const int mega_deg = (int)std::max<int64_t>(cap, getenv("B3C_LV_MEGA_DEG") ? atoll(getenv("B3C_LV_MEGA_DEG")) : mega_auto);
+        if (getenv("B3C_LV_DEBUG")) fprintf(stderr, "[b3c] level %d: %llu rows beyond 2048 entries, %llu beyond 4096, longest %lld: workgroup kernels from %d entries on\n",
+                                            (int)info->n_levels, (unsigned long long)hc[8], (unsigned long long)hc[9], (long long)maxdeg, mega_deg);
         if (grouped) {
             const int n_seg = need_wave_kernel ? 3 * n_sub : n_sub;
             const int64_t tot = (int64_t)n_seg * nloc + 1;
@@ -1942,9 +1971,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             if (!lists.p || !lflag.p || !lpos.p || !bnd.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: node lists"); }
             const unsigned gl = (unsigned)((nloc + 255) / 256);
             HIP_TRY(ctx, hipMemsetAsync(lflag.p, 0, sizeof(int64_t) * (size_t)tot, s));
-            if (nloc) hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, short_max, need_wave_kernel ? 1 : 0, g.indptr, ids, kdeg.p, lflag.p);
+            if (nloc) hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, short_max, need_wave_kernel ? mega_deg : 0, g.indptr, ids, kdeg.p, lflag.p);
             if ((rc = b3c_exclusive_scan_i64(ctx, lflag.p, lpos.p, tot))) { free_graph(ctx, g); return rc; }
-            if (nloc) hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, short_max, need_wave_kernel ? 1 : 0, g.indptr, ids, kdeg.p, lpos.p, lists.p);
+            if (nloc) hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, short_max, need_wave_kernel ? mega_deg : 0, g.indptr, ids, kdeg.p, lpos.p, lists.p);
             hipLaunchKernelGGL(k_lv_list_bounds, dim3(1), dim3(64), 0, s, n_seg, nloc, lpos.p, bnd.p);
             std::vector<int64_t> hb(n_seg + 1, 0);
             { const int rb_ = b3c_readback(ctx, hb.data(), bnd.p, sizeof(int64_t) * hb.size()); if (rb_) return rb_; }
