@@ -1146,8 +1146,9 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
                                                       const int32_t *__restrict__ indices,
                                                       const int64_t *__restrict__ q, const int32_t *__restrict__ com,
                                                       u64 *__restrict__ i2, int64_t *__restrict__ own,
-                                                      int32_t *__restrict__ stamp, int32_t epoch)
+                                                      int32_t *__restrict__ stamp, int32_t epoch, int64_t long_deg)
 {
+    // rows of more than long_deg entries are left to k_lv_internal_long (workgroups per row): this pass only clears their own[]
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * WPB;
@@ -1164,6 +1165,7 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
             rs_[h] = rw[h] >= 0 ? indptr[rw[h]] : 0;
             re_[h] = rw[h] >= 0 ? indptr[rw[h] + 1] : 0;
             a[h] = rw[h] >= 0 ? com[rw[h]] : -1;
+            if (re_[h] - rs_[h] > long_deg) re_[h] = rs_[h];
         }
         long long mine[2] = {0, 0};                           // weight towards the other members of the own community
         const int64_t span = (re_[0] - rs_[0]) > (re_[1] - rs_[1]) ? (re_[0] - rs_[0]) : (re_[1] - rs_[1]);
@@ -1207,6 +1209,45 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
     }
     __shared__ long long red[WPB];
     block_atomic_add_u64(acc, i2, red);
+}
+
+// The rows k_lv_internal leaves out (the MEGA rows of the level's node lists: one wave took milliseconds for a row of 10^5
+// entries -- 1.35 ms per recount at level 1 of the surveyed genome-size law): workgroup (m, c) takes entries [c * MEGA_CHUNK, ...)
+// of node list[m]; integer sums, own[] was cleared by k_lv_internal.
+__global__ void __launch_bounds__(1024) k_lv_internal_long(const NodeRec *__restrict__ list, int chunks, const int32_t *__restrict__ indices,
+                                                            const int64_t *__restrict__ q, const int32_t *__restrict__ com,
+                                                            u64 *__restrict__ i2, int64_t *__restrict__ own)
+{
+    const NodeRec rec = list[blockIdx.x / chunks];
+    const int64_t c0 = (int64_t)(blockIdx.x % chunks) * 4096;
+    if (c0 >= rec.deg) return;
+    const int64_t s = rec.start + c0, e = rec.start + (c0 + 4096 < rec.deg ? c0 + 4096 : rec.deg);
+    const int32_t row = rec.node, a = com[row];
+    long long acc = 0, mine = 0;
+    int32_t j[4];
+    long long w[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int64_t k = s + threadIdx.x + (int64_t)t * 1024;
+        const bool ok = k < e;
+        j[t] = ok ? indices[k] : -1;
+        w[t] = ok ? q[k] : 0;
+    }
+    int32_t c[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = j[t] >= 0 ? com[j[t]] : -2;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (j[t] < 0) continue;
+        if (j[t] == row) acc += 2 * w[t];
+        else if (c[t] == a) { acc += w[t]; mine += w[t]; }
+    }
+    acc = wave_sum_ll(acc);
+    mine = wave_sum_ll(mine);
+    if ((threadIdx.x & 63) == 0) {
+        if (acc) atomicAdd(i2, (u64)acc);
+        if (own && mine) atomicAdd((u64 *)&own[row], (u64)mine);
+    }
 }
 
 // Change of I2 caused by the moves a sub-round is about to apply (com = labels before, nxt = labels after; nxt == com
@@ -2018,8 +2059,16 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
             if (full) {
                 HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64), s));
+                const bool long_int = grouped && max_mega > 0 && getenv("B3C_LV_NO_INTERNAL_LONG") == nullptr;
                 hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2, own_p,
-                                   stamp_p, epoch + 1);
+                                   stamp_p, epoch + 1, long_int ? (int64_t)mega_deg : INT64_MAX);
+                if (long_int) {
+                    const int chunks = (int)((maxdeg + 4095) / 4096);
+                    for (int r = 0; r < n_sub; r++)
+                        if (lend[r] > moff[r])
+                            hipLaunchKernelGGL(k_lv_internal_long, dim3((unsigned)((lend[r] - moff[r]) * chunks)), dim3(1024), 0, s, nlist_p + moff[r], chunks,
+                                               g.indices, g.q, com.p, ctr.p + 2, own_p);
+                }
             }
             hipLaunchKernelGGL(k_lv_tot2, dim3(gv), dim3(BLK), 0, s, n, tot.p, ctr.p + 3);
             u64 h[8];
