@@ -162,3 +162,33 @@ def test_mega_rows_take_the_workgroup_kernel(ctx, oracle_lib):
     assert int(np.diff(ip).max()) > 8192
     ref, labels, info = _run_both(ctx, oracle_lib, ip, ix, w, 1.0 / w.max())
     _assert_same(ref, labels, info)
+
+
+@pytest.mark.parametrize('env', [{'B3C_LV_NO_FIRST': '1'}, {'B3C_LV_NO_AGG_ORDER': '1', 'B3C_LV_NO_AGG_LONG': '1'},
+                                 {'B3C_LV_MEGA_DEG': '2048'}, {'B3C_LV_MEGA_DEG': '100000'}, {'B3C_LV_NO_INTERNAL_LONG': '1'}])
+def test_kernel_choices_do_not_show_in_the_result(ctx, oracle_lib, monkeypatch, env):
+    """Round 3's per-level kernel choices -- the table-free first sub-round, the bin aggregation in community order and its
+    long rows by workgroups, the entry count from which a row gets workgroups (automatic: by the number of such rows), the
+    recount of the internal weight for those rows -- are all exact integer arithmetic on the same schedule: switching any
+    of them off or moving the threshold leaves labels, sweep and level counts and the modularity bit for bit, and equal to
+    the scalar schedule's.  The graph has 4500 planted groups under 35 % noise (several levels, the later ones with thousands
+    of nodes) and two stars of 12,000 and 3,000 entries (rows on either side of every threshold)."""
+    rs = np.random.RandomState(5)
+    n, edges = graphs.ring_of_cliques(4500, 5, 1.0, 0.2)
+    m = len(edges)
+    a = rs.randint(0, n, m // 2)
+    b = rs.randint(0, n, m // 2)
+    edges += [(int(i), int(j), float(rs.uniform(0.2, 1.0))) for i, j in zip(a, b) if i != j]
+    for hub, deg in ((n, 12000), (n + 1, 3000)):
+        edges += [(hub, int(v), float(rs.uniform(0.01, 0.5))) for v in rs.choice(n, deg, replace=False)]
+    ip, ix, w = graphs.csr_from_edges(n + 2, edges)
+    ref, labels, info = _run_both(ctx, oracle_lib, ip, ix, w, 1.0 / w.max())
+    _assert_same(ref, labels, info)
+    assert info.n_levels >= 2
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    mat = ctx.upload(ip, ix, w)
+    labels2, info2 = ctx.louvain(mat, 1.0 / w.max())
+    mat.free()
+    assert np.array_equal(labels2, labels)
+    assert (info2.n_levels, info2.n_sweeps, info2.modularity, info2.n_comm) == (info.n_levels, info.n_sweeps, info.modularity, info.n_comm)
