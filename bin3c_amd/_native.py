@@ -4,6 +4,7 @@ device: there is no CPU fallback.  Import fails loudly when the library has not 
 compute call fails loudly when no MI355X is visible.
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -69,6 +70,7 @@ _VP = C.c_void_p
 SYMBOLS = [
     ('b3c_ctx_create', C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     ('b3c_ctx_destroy', C.c_int, [_VP]),
+    ('b3c_ctx_reload_env', C.c_int, [_VP]),
     ('b3c_last_error', C.c_char_p, [_VP]),
     ('b3c_ctx_sync', C.c_int, [_VP]),
     ('b3c_ctx_bytes', C.c_int64, [_VP]),
@@ -207,6 +209,16 @@ class Mat(object):
             pass
 
 
+_LIVE = weakref.WeakSet()      # open contexts (reload_env_all: the test suite flips switches between calls)
+
+
+def reload_env_all():
+    """Have every open context read the B3C_* switches again (b3c_ctx_reload_env)."""
+    for c in list(_LIVE):
+        if c.h is not None:
+            c.reload_env()
+
+
 class Context(object):
     """b3c_ctx*: one device, one stream, one caching HBM pool."""
 
@@ -219,11 +231,17 @@ class Context(object):
                                'libb3c has no CPU fallback'.format(device, rc))
         self.h = h
         self.device = device
+        _LIVE.add(self)
 
     def close(self):
         if self.h is not None:
             self.lib.b3c_ctx_destroy(self.h)
             self.h = None
+        _LIVE.discard(self)
+
+    def reload_env(self):
+        """libb3c reads its B3C_* switches once, in b3c_ctx_create; call this after changing them in os.environ."""
+        self._check(self.lib.b3c_ctx_reload_env(self.h))
 
     def __del__(self):
         try:

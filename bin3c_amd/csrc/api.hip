@@ -37,6 +37,28 @@ extern "C" int b3c_abi_layout(int which, int32_t *out, int cap)
     return len;
 }
 
+extern char **environ;
+
+// THE parser of the B3C_* switches: every entry of the process environment whose name starts with "B3C_" is copied into the
+// context's table.  Nothing else in libb3c reads the environment.
+void b3c_cfg::parse()
+{
+    kv.clear();
+    for (char **e = environ; e && *e; e++) {
+        if (strncmp(*e, "B3C_", 4) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        if (!eq) continue;
+        kv[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+    }
+}
+
+extern "C" int b3c_ctx_reload_env(b3c_ctx *ctx)
+{
+    if (!ctx) return B3C_E_ARG;
+    ctx->cfg.parse();
+    return B3C_OK;
+}
+
 extern "C" int b3c_ctx_create(int device, void *stream, b3c_ctx **out)
 {
     if (!out) return B3C_E_ARG;
@@ -46,6 +68,7 @@ extern "C" int b3c_ctx_create(int device, void *stream, b3c_ctx **out)
     if (device < 0 || device >= count) return B3C_E_ARG;
     if (hipSetDevice(device) != hipSuccess) return B3C_E_HIP;
     b3c_ctx *ctx = new b3c_ctx();
+    ctx->cfg.parse();
     ctx->device = device;
     if (stream) {
         ctx->stream = (hipStream_t)stream;
@@ -109,7 +132,7 @@ extern "C" int b3c_ctx_set_dist(b3c_ctx *ctx, const b3c_dist *dist)
     ctx->dist = *dist;
     // B3C_DIST_FORCE: run the sharded code path (callbacks, exchange buffers) with a single rank too -- a test hook that
     // lets one GPU exercise the RCCL plumbing of the caller
-    ctx->has_dist = dist->world > 1 || (dist->world == 1 && getenv("B3C_DIST_FORCE") != nullptr);
+    ctx->has_dist = dist->world > 1 || (dist->world == 1 && CFG.on("B3C_DIST_FORCE"));
     return B3C_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -14,9 +15,31 @@
 #include "b3c.h"
 
 // ---------------------------------------------------------------------------------------------
+// The B3C_* switches of the process environment, read ONCE -- by b3c_ctx_create, and again only when the
+// caller asks (b3c_ctx_reload_env).  No entry point of the library looks at the environment itself.
+// ---------------------------------------------------------------------------------------------
+struct b3c_cfg {
+    std::map<std::string, std::string> kv;
+    void parse();                                   // api.hip: the one place that reads the environment
+    const char *str(const char *k) const
+    {
+        auto it = kv.find(k);
+        return it == kv.end() ? nullptr : it->second.c_str();
+    }
+    bool on(const char *k) const { return kv.find(k) != kv.end(); }
+    long long num(const char *k, long long dflt) const
+    {
+        const char *v = str(k);
+        if (!v) return dflt;
+        return (v[0] == '0' && (v[1] == 'x' || v[1] == 'X')) ? strtoll(v, nullptr, 16) : strtoll(v, nullptr, 10);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // context: device, stream, caching HBM pool, error text
 // ---------------------------------------------------------------------------------------------
 struct b3c_ctx {
+    b3c_cfg cfg;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -153,6 +176,8 @@ struct b3c_mat {
     uint32_t *rowmax = nullptr;
     bool rowmax_valid = false;      // cleared when b3c_mat_device_ptrs hands out a writable data pointer
 };
+
+#define CFG (ctx->cfg)      // the switches as the context read them (every user has `ctx` in scope)
 
 #define HIP_TRY(ctx, expr)                                                                          \
     do {                                                                                            \

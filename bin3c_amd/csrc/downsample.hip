@@ -315,7 +315,7 @@ extern "C" int b3c_downsample(b3c_ctx *ctx, const b3c_mat *a, int64_t block_size
     if (!cnt.p || !optr.p) return ctx->fail(B3C_E_NOMEM, "b3c_downsample");
     HIP_TRY(ctx, hipMemsetAsync(cnt.p, 0, sizeof(int64_t) * (size_t)(nb + 1), s));
     // plot-sized outputs: one wave per block-row; larger ones: one workgroup per block-row, column chunks
-    const bool wave_form = nb <= DW_CHUNK && getenv("B3C_DS_NO_WAVE") == nullptr;
+    const bool wave_form = nb <= DW_CHUNK && !CFG.on("B3C_DS_NO_WAVE");
     const int g = wave_form ? grid_for(nb, DS_BLK / 64, 16 * ctx->n_cu) : grid_for(nb, 1, 8 * ctx->n_cu);
     if (nb && wave_form)
         hipLaunchKernelGGL(k_dw_count, dim3(g), dim3(DS_BLK), 0, s, n, nb, (uint32_t)b, a->indptr, a->indices, cnt.p);

@@ -2032,6 +2032,10 @@ __global__ void kr_site_scale(int64_t n, double *__restrict__ sites, double *__r
     }
 }
 
+#ifdef B3C_PROBES
+static bool g_probe_nogather = false;      // B3C_KR_NOGATHER of the calling context (development builds only)
+#endif
+
 template <int LPR, int UN>
 void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
                     int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
@@ -2039,7 +2043,7 @@ void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRStat
                     const double *corr = nullptr)
 {
 #ifdef B3C_PROBES      // timing probe with WRONG RESULTS (the kernel without its random gathers): development builds only, never in the shipped library
-    if (m->kind == B3C_U32 && getenv("B3C_KR_NOGATHER"))
+    if (m->kind == B3C_U32 && g_probe_nogather)
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t, true>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
                            m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
     else
@@ -2078,6 +2082,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                            int64_t max_iter, double *x_out, b3c_kr_info *info)
 {
     const bool counts = a->kind == B3C_U32;     // A = diag(1/s) C diag(1/s), never materialised
+#ifdef B3C_PROBES
+    g_probe_nogather = CFG.on("B3C_KR_NOGATHER");
+#endif
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     memset(info, 0, sizeof(*info));
     const int64_t n = a->n;
@@ -2114,24 +2121,24 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     if (!hub_flag.p || !hub_pos.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
     // SpMV form: row groups of lpr_p lanes (kr_kb_pipe / kr_kb_vec), or -- 16-bit counts -- tiles with column dictionaries
     const int lpr_p = avg > 64 ? 16 : avg > 24 ? 8 : 4;   // lanes per row of the pipelined form
-    const int GS_rows = grid_for(nloc, (BLK / 64) * (64 / lpr_p), (getenv("B3C_KR_GSMUL") ? atoi(getenv("B3C_KR_GSMUL")) : 16) * ctx->n_cu);
+    const int GS_rows = grid_for(nloc, (BLK / 64) * (64 / lpr_p), (int)CFG.num("B3C_KR_GSMUL", 16) * ctx->n_cu);
     // The dictionary form is the default while the operand vector fits one XCD's L2 (n <= 2^19); beyond it
     // it runs together with the tail pass (kr_kb_tails: the tails, whose gathers miss L2 there, are summed in
     // column order by their own kernel): C3 0.32 ms per SpMV against 0.50 for kr_kb_vec, which pays for the 5 ms of set-up
     // (62 SpMVs per call).  B3C_KR_TCD_XT=1 / =0 force the tail pass on (where eligible) / off.
-    const char *xt_env = getenv("B3C_KR_TCD_XT");
+    const char *xt_env = CFG.str("B3C_KR_TCD_XT");
     const bool xt_ok = counts && n < ((int64_t)1 << 24) && !(xt_env && atoi(xt_env) <= 0);
     const bool xt_want = xt_ok && (n > ((int64_t)1 << TCD_L2_LG) || (xt_env && atoi(xt_env) > 0));
     // tile geometry of the dictionary form (used once the value width is known, below)
-    const int tcd_R = getenv("B3C_KR_TCD_R") ? std::min(256, std::max(8, atoi(getenv("B3C_KR_TCD_R")) & ~7)) : (xt_want ? 192 : 128);
-    const int tcd_dcap = getenv("B3C_KR_TCD_DCAP") ? std::min(16384, std::max(16, atoi(getenv("B3C_KR_TCD_DCAP")))) : (xt_want ? 5120 : 2560);   // LDS budget of a dictionary (sweeps at C2 / C3)
+    const int tcd_R = CFG.on("B3C_KR_TCD_R") ? std::min(256, std::max(8, (int)CFG.num("B3C_KR_TCD_R", 0) & ~7)) : (xt_want ? 192 : 128);
+    const int tcd_dcap = CFG.on("B3C_KR_TCD_DCAP") ? std::min(16384, std::max(16, (int)CFG.num("B3C_KR_TCD_DCAP", 0))) : (xt_want ? 5120 : 2560);   // LDS budget of a dictionary (sweeps at C2 / C3)
     const int64_t tcd_tiles = (nloc + tcd_R - 1) / tcd_R;
-    const bool tcd_swz = getenv("B3C_KR_TCD_NOSWZ") == nullptr && tcd_tiles >= 64;
+    const bool tcd_swz = !CFG.on("B3C_KR_TCD_NOSWZ") && tcd_tiles >= 64;
     const int64_t tcd_grid = tcd_swz ? 8 * ((tcd_tiles + 7) / 8) : tcd_tiles;
     // (n <= 2^19: C2 runs its SpMV in 32 instead of 39 us and the build is one bitmap pass; without the tail pass the form
     // does not pay at C3: 0.455 ms per SpMV against 0.50, less than its build costs)
     const bool tcd_auto = n >= 4096 && avg >= 16 && (n <= ((int64_t)1 << TCD_L2_LG) || xt_want);
-    const bool tcd_may = counts && nloc > 0 && a->nnz > 0 && (tcd_auto || getenv("B3C_KR_TCD") != nullptr) && getenv("B3C_KR_NO_TCD") == nullptr;
+    const bool tcd_may = counts && nloc > 0 && a->nnz > 0 && (tcd_auto || CFG.on("B3C_KR_TCD")) && !CFG.on("B3C_KR_NO_TCD");
     const int GS_max = (int)std::max<int64_t>(GS_rows, tcd_may ? tcd_tiles : 0);
     // hub rows add one partial each behind the GS of the row kernel (at most nnz / HUB_LEN of them)
     // threshold: twice the pipelined chunk of the row-group kernel that will run, at least HUB_LEN (sweep on a power-law
@@ -2141,9 +2148,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // the CSR hub kernel instead of the dictionary form: 1.97 of 4.4 ms per SpMV.  Row-group lanes loop over long rows; what
     // the hub kernel is for are rows so long that one lane group would hold its tile up
     const int hub_floor = avg > 128 ? 2 * HUB_LEN : HUB_LEN;
-    const int hub_thr = getenv("B3C_KR_HUB_LEN") ? std::max(64, atoi(getenv("B3C_KR_HUB_LEN")))
+    const int hub_thr = CFG.on("B3C_KR_HUB_LEN") ? std::max(64, (int)CFG.num("B3C_KR_HUB_LEN", 0))
                                                   : std::max(hub_floor, (int)std::min<double>(16384.0, 16.0 * avg));
-    const bool hub_kb = maxdeg > (unsigned long long)hub_thr && getenv("B3C_KR_NO_HUB") == nullptr;
+    const bool hub_kb = maxdeg > (unsigned long long)hub_thr && !CFG.on("B3C_KR_NO_HUB");
     const int64_t hub_cap = hub_kb ? a->nnz / hub_thr + 1 : 0;
     const int hub_len = hub_kb ? hub_thr : 0x7fffffff;
     const int P = (int)std::max<int64_t>(GA, (int64_t)GS_max + hub_cap);
@@ -2180,9 +2187,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int64_t zc0 = block ? r0 : 0, zc1 = block ? r1 : n;
     // the iteration reorders a map that is not in a locality order yet (below); a count map that needs no reordering gets
     // its checks, its zero-diagonal vector and its 16-bit value copy from one fused pass (kr_prep_counts)
-    const bool reorder = !a->ordered && n >= 32768 && a->nnz >= (1 << 21) && getenv("B3C_NO_REORDER") == nullptr;
-    const bool want16 = counts && a->nnz && getenv("B3C_KR_NO_U16") == nullptr;
-    const bool fused_prep = want16 && !reorder && getenv("B3C_KR_NO_FUSED_PREP") == nullptr;
+    const bool reorder = !a->ordered && n >= 32768 && a->nnz >= (1 << 21) && !CFG.on("B3C_NO_REORDER");
+    const bool want16 = counts && a->nnz && !CFG.on("B3C_KR_NO_U16");
+    const bool fused_prep = want16 && !reorder && !CFG.on("B3C_KR_NO_FUSED_PREP");
     DevBuf<uint16_t> v16buf(ctx, counts ? a->nnz + 16 : 1);     // slack: kr_kb_vec reads whole 4-entry vectors
     if (want16 && !v16buf.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts");
     unsigned long long prep_max = 0;
@@ -2226,7 +2233,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         // (a row block cannot look its mirror entries up: the exact tolerance search is left to unsharded calls, and an
         // asymmetric map is reported from the checksums alone)
         if (block && !info->bitwise_symmetric) HIP_TRY(ctx, hipMemsetAsync(counters.p + 1, 0xFF, sizeof(unsigned long long), s));
-        if (!block && (!info->bitwise_symmetric || getenv("B3C_KR_EXACT_SYMCHECK"))) {
+        if (!block && (!info->bitwise_symmetric || CFG.on("B3C_KR_EXACT_SYMCHECK"))) {
             const int ga = grid_for(n, 4, 8 * ctx->n_cu);
             if (counts) hipLaunchKernelGGL(kr_asym_count<uint32_t>, dim3(ga), dim3(256), 0, s, n, a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const uint32_t *)a->data, (const double *)sd.p, tol, counters.p + 1);
             else hipLaunchKernelGGL(kr_asym_count<double>, dim3(ga), dim3(256), 0, s, n, a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const double *)a->data, (const double *)nullptr, tol, counters.p + 1);
@@ -2297,7 +2304,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                            (const uint32_t *)a->data, BIG_CAP, big_keys.p, big_hi.p, bc.p);
         unsigned long long hb = 0;
         { const int rb_ = b3c_readback(ctx, &hb, bc.p, sizeof(hb)); if (rb_) return rb_; }
-        if ((int64_t)hb <= BIG_CAP && (int64_t)hb * 64 <= a->nnz && getenv("B3C_KR_NO_BIGFIX") == nullptr) {
+        if ((int64_t)hb <= BIG_CAP && (int64_t)hb * 64 <= a->nnz && !CFG.on("B3C_KR_NO_BIGFIX")) {
             n_big = (int64_t)hb;
             size_t tb = 0;
             hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, big_keys.p, big_keys2.p, big_hi.p, big_hi2.p, n_big, 0, 64, s);
@@ -2311,7 +2318,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             corr_p = corr.p;
             bk = big_keys2.p;
             bh = big_hi2.p;
-            if (getenv("B3C_KR_DEBUG")) fprintf(stderr, "[b3c] %lld counts beyond 65535 (largest %llu): 16-bit forms + correction list\n", (long long)n_big, vmax_counts);
+            if (CFG.on("B3C_KR_DEBUG")) fprintf(stderr, "[b3c] %lld counts beyond 65535 (largest %llu): 16-bit forms + correction list\n", (long long)n_big, vmax_counts);
         } else {
             v16 = nullptr;                                       // too many: 32-bit values in the row kernels
         }
@@ -2319,7 +2326,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     info->big_counts = n_big;
     // ---- tile-local column dictionaries (16-bit counts only) ----
     const bool tcd = tcd_may && v16 != nullptr;
-    const bool want_tlog = tcd && getenv("B3C_KR_TCD_TLOG") != nullptr;
+    const bool want_tlog = tcd && CFG.on("B3C_KR_TCD_TLOG");
     DevBuf<unsigned long long> tlog(ctx, want_tlog ? (size_t)tcd_tiles * 8 : 1);     // (a pooled block even when unused: the kernel gets nullptr then)
     if (want_tlog && !tlog.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: timeline log");
     if (want_tlog) HIP_TRY(ctx, hipMemsetAsync(tlog.p, 0, sizeof(unsigned long long) * (size_t)tcd_tiles * 8, s));
@@ -2340,7 +2347,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         unsigned long long hst[16];
         { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
 #ifdef B3C_PROBES
-        if (getenv("B3C_KR_TCD_BLOG"))
+        if (CFG.on("B3C_KR_TCD_BLOG"))
             fprintf(stderr, "[b3c] kr_tcd_build phases, mean us per tile (100 MHz clock): zero %.1f  sweep1 %.1f  prefix+dictionary %.1f  sweep2 %.1f\n",
                     hst[8] * 0.01 / tcd_tiles, hst[9] * 0.01 / tcd_tiles, hst[10] * 0.01 / tcd_tiles, hst[11] * 0.01 / tcd_tiles);
 #endif
@@ -2350,7 +2357,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         info->tcd_dict_max = (int64_t)hst[0];
         info->tcd_dict_total = (int64_t)hst[2];
         info->tcd_tail_entries = (int64_t)hst[3];
-        if (getenv("B3C_KR_DEBUG"))
+        if (CFG.on("B3C_KR_DEBUG"))
             fprintf(stderr, "[b3c] dictionary layout: %lld tiles of %d rows, largest dictionary %llu (cap %d), mean %.0f, %.1f %% of the entries in tails\n",
                     (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles, 100.0 * (double)hst[3] / (double)a->nnz);
     }
@@ -2370,7 +2377,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     while ((1ll << xt_cbits) < (int64_t)n) xt_cbits++;
     const bool xt_far = (int64_t)n * 8 > (8ll << 20);
     int xt_S = xt_far ? XT_S_BIG : XT_S;
-    if (getenv("B3C_KR_XT_S")) xt_S = atoi(getenv("B3C_KR_XT_S")) == XT_S_BIG ? XT_S_BIG : XT_S;
+    if (CFG.on("B3C_KR_XT_S")) xt_S = CFG.num("B3C_KR_XT_S", 0) == XT_S_BIG ? XT_S_BIG : XT_S;
     {
         int sb = 1;
         while ((1ll << sb) < (nloc + XT_S_BIG - 1) / XT_S_BIG) sb++;
@@ -2382,7 +2389,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     int xt_chunks = 4 * XT_CHUNKS * xt_super >= 3 * (int64_t)ctx->n_cu || xt_super == 0
                         ? XT_CHUNKS : (int)std::min<int64_t>(16, (ctx->n_cu + xt_super - 1) / xt_super);   // (3 at C3 costs 20 us per SpMV)
     if (xt_far) xt_chunks = 8 * (int)std::min<int64_t>(4, ((int64_t)n * 8 + (24ll << 20) - 1) / (24ll << 20));
-    if (getenv("B3C_KR_XT_CHUNKS")) xt_chunks = std::min(64, std::max(1, atoi(getenv("B3C_KR_XT_CHUNKS"))));
+    if (CFG.on("B3C_KR_XT_CHUNKS")) xt_chunks = std::min(64, std::max(1, (int)CFG.num("B3C_KR_XT_CHUNKS", 0)));
     DevBuf<double> pumax(ctx, tails_xt ? GA : 1);
     DevBuf<unsigned long long> yhi(ctx, tails_xt ? nloc : 1), xt_words(ctx, tails_xt ? info->tcd_tail_entries + 4 : 1);
     DevBuf<int> ylo(ctx, tails_xt ? nloc : 1), tex(ctx, 2);
@@ -2430,7 +2437,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         { static bool xt_attr = false; if (!xt_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT))); xt_attr = true; } }
         HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch above goes back to the pool here
         info->tcd_xt_tails = n_tails;
-        if (getenv("B3C_KR_DEBUG"))
+        if (CFG.on("B3C_KR_DEBUG"))
             fprintf(stderr, "[b3c] tail pass: %lld tails in %lld super-tiles of %d rows, largest count %llu, longest tail %llu\n",
                     (long long)n_tails, (long long)xt_super, xt_S, hx[0], hx[1]);
     }
@@ -2456,22 +2463,22 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     HIP_TRY(ctx, hipMemcpyAsync(states.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
 
     // profiling of the SpMV kernel: event pairs around every KB launch
-    const bool prof = ctx->ev0 != nullptr && getenv("B3C_PROFILE") != nullptr;
+    const bool prof = ctx->ev0 != nullptr && CFG.on("B3C_PROFILE");
     std::vector<hipEvent_t> evs;
     std::vector<long long> ev_tick;        // which SpMV (0-based) each event pair brackets
     constexpr long long PROF_EVERY = 4;
 
     // timing probes of the dictionary SpMV that produce WRONG RESULTS exist in development builds only (-DB3C_PROBES)
 #ifdef B3C_PROBES
-    const int tcd_probe = getenv("B3C_KR_TCD_PROBE") ? atoi(getenv("B3C_KR_TCD_PROBE")) : 0;
-    const uint32_t tcd_probe_mask = getenv("B3C_KR_TCD_PROBE_MASK") ? (uint32_t)strtoul(getenv("B3C_KR_TCD_PROBE_MASK"), nullptr, 0) : 0xFFFFFFFFu;
+    const int tcd_probe = (int)CFG.num("B3C_KR_TCD_PROBE", 0);
+    const uint32_t tcd_probe_mask = (uint32_t)CFG.num("B3C_KR_TCD_PROBE_MASK", 0xFFFFFFFFll);
 #else
     const int tcd_probe = 0;
     const uint32_t tcd_probe_mask = 0xFFFFFFFFu;
 #endif
     int t = 0;  // state ping-pong index
-    const int BATCH = getenv("B3C_KR_BATCH") ? std::max(1, atoi(getenv("B3C_KR_BATCH"))) : 4;   // ticks per state look (C3: 8 -> 4 saves 0.4 ms of no-op ticks after convergence)
-    const int vec_shape = getenv("B3C_KR_VEC") ? atoi(getenv("B3C_KR_VEC")) : 0;   // other kr_kb_vec<LPR, UN> shapes, e.g. 164; -1: scalar-load form
+    const int BATCH = std::max(1, (int)CFG.num("B3C_KR_BATCH", 4));   // ticks per state look (C3: 8 -> 4 saves 0.4 ms of no-op ticks after convergence)
+    const int vec_shape = (int)CFG.num("B3C_KR_VEC", 0);   // other kr_kb_vec<LPR, UN> shapes, e.g. 164; -1: scalar-load form
     long long ticks = 0;
     // sharded: a kernel's block partials are folded into this rank's slot of the packed scalar buffer (slot 0 sum, 1 min,
     // 2 max, 3 gamma) and all-gathered; the consumer then reduces `world` values (stride 4) in rank order instead of P block partials
@@ -2500,7 +2507,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const bool pipelined = ctx->pin != nullptr && ctx->ev0 != nullptr && ctx->ev1 != nullptr;
     long long batches = 0;
     bool done = false;
-    const bool tick_timing = getenv("B3C_KR_TIMING") != nullptr;
+    const bool tick_timing = CFG.on("B3C_KR_TIMING");
     std::vector<hipEvent_t> tev;
     auto tmark = [&]() { if (tick_timing && batches == 1) { hipEvent_t e = ctx->ev_get(); if (e) { (void)hipEventRecord(e, s); tev.push_back(e); } } };
     while (!done) {
@@ -2663,7 +2670,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         for (size_t e = 0; e + 1 < evs.size(); e += 2) {
             float f = 0.f;
             if (hipEventElapsedTime(&f, evs[e], evs[e + 1]) == hipSuccess) { dur.push_back(f); longest = f > longest ? f : longest; }
-            if (getenv("B3C_KR_DEBUG")) fprintf(stderr, "[b3c] SpMV launch of tick %lld: %.1f us\n", ev_tick[e / 2], f * 1e3);
+            if (CFG.on("B3C_KR_DEBUG")) fprintf(stderr, "[b3c] SpMV launch of tick %lld: %.1f us\n", ev_tick[e / 2], f * 1e3);
             ctx->ev_put(evs[e]);
             ctx->ev_put(evs[e + 1]);
         }

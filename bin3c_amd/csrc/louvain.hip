@@ -1860,8 +1860,10 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     if (n0 == 0) return B3C_OK;
     const double PL_MIN = 0.0000001;   // community_louvain.__MIN
 
+    const bool lv_debug = CFG.on("B3C_LV_DEBUG");
+    const bool shape_32x8 = CFG.str("B3C_LV_SHAPE") && !strcmp(CFG.str("B3C_LV_SHAPE"), "32x8");
     Events evs;
-    evs.on = getenv("B3C_PROFILE") != nullptr;
+    evs.on = CFG.on("B3C_PROFILE");
     evs.s = s;
     evs.ctx = ctx;
 
@@ -1869,7 +1871,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     // working copy; community ids, sub-round hashing and tie-breaks stay in the caller's numbering
     // through `ids`, so the labels are identical either way (tests/test_gpu_louvain.py).
     struct Guard { b3c_ctx *c; b3c_mat *m = nullptr; ~Guard() { if (m) b3c_mat_free(c, m); } } perm{ctx};
-    const bool reorder = !a->ordered && n0 >= 32768 && a->nnz >= (1 << 21) && getenv("B3C_NO_REORDER") == nullptr;
+    const bool reorder = !a->ordered && n0 >= 32768 && a->nnz >= (1 << 21) && !CFG.on("B3C_NO_REORDER");
     DevBuf<int32_t> new2old(ctx, reorder ? n0 : 1), old2new(ctx, reorder ? n0 : 1);
     int rc;
     if (reorder) {
@@ -1969,7 +1971,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int64_t need = 1ll << table_lg(maxdeg);
         // LDS table of the wave-per-node kernel: 12 bytes per slot and wave, four waves per workgroup -- 2048 slots are 96 KB, ONE
         // workgroup per CU.  B3C_LV_CAP_MAX clamps it (nodes beyond the cap use their global table): see DESIGN.md section 4
-        const int cap_max = getenv("B3C_LV_CAP_MAX") ? atoi(getenv("B3C_LV_CAP_MAX")) : 2048;
+        const int cap_max = (int)CFG.num("B3C_LV_CAP_MAX", 2048);
         const int cap0 = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
         const int cap = cap0 > cap_max ? cap_max : cap0;
         hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap, g.indptr, gsz.p);
@@ -1987,7 +1989,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // node lists of the grouped kernel: per sub-round, the nodes of this rank with at most `short_max` entries
         const double avgdeg = (double)g.nnz / (double)n;
         const int short_max = avgdeg * 1.3 <= 32 ? 32 : avgdeg * 1.3 <= 64 ? 64 : avgdeg * 1.3 <= 128 ? 128 : 256;
-        const bool grouped = n >= 4096 && getenv("B3C_LV_NO_GROUPED") == nullptr;
+        const bool grouped = n >= 4096 && !CFG.on("B3C_LV_NO_GROUPED");
         const int64_t nloc = r1 - r0;
         const bool need_wave_kernel = !grouped || maxdeg > short_max;
         // grouped lists and, behind them, the hubs the grouped kernel leaves out (usually a handful): one flag pass, one
@@ -2002,8 +2004,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         int64_t mega_auto = MEGA_DEG;
         if ((int64_t)hc[8] <= MEGA_FEW) mega_auto = 2048;
         else if ((int64_t)hc[9] <= MEGA_FEW) mega_auto = 4096;
-        const int mega_deg = (int)std::max<int64_t>(cap, getenv("B3C_LV_MEGA_DEG") ? atoll(getenv("B3C_LV_MEGA_DEG")) : mega_auto);
-        if (getenv("B3C_LV_DEBUG")) fprintf(stderr, "[b3c] level %d: %llu rows beyond 2048 entries, %llu beyond 4096, longest %lld: workgroup kernels from %d entries on\n",
+        const int mega_deg = (int)std::max<int64_t>(cap, CFG.num("B3C_LV_MEGA_DEG", mega_auto));
+        if (lv_debug) fprintf(stderr, "[b3c] level %d: %llu rows beyond 2048 entries, %llu beyond 4096, longest %lld: workgroup kernels from %d entries on\n",
                                             (int)info->n_levels, (unsigned long long)hc[8], (unsigned long long)hc[9], (long long)maxdeg, mega_deg);
         if (grouped) {
             const int n_seg = need_wave_kernel ? 3 * n_sub : n_sub;
@@ -2033,8 +2035,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // exact pruning of the neighbour scan (k_lv_prune): single GPU, grouped lists, during the sweeps that track the
         // internal weight through the movers' rows (the same pass keeps own[] current)
         // Row-sharded runs prune too (round 3): validity stamps replace the exchange the neighbours' own[] would need
-        const bool can_prune = grouped && getenv("B3C_LV_NO_PRUNE") == nullptr;
-        const bool use_side = getenv("B3C_LV_NO_SIDE") == nullptr;      // hubs / mega rows beside the grouped scan on side streams
+        const bool can_prune = grouped && !CFG.on("B3C_LV_NO_PRUNE");
+        const bool use_side = !CFG.on("B3C_LV_NO_SIDE");      // hubs / mega rows beside the grouped scan on side streams
         int64_t *own_p = can_prune ? own.p : nullptr;
         const bool stamps = can_prune && dist;
         DevBuf<int32_t> stamp(ctx, stamps ? n : 1), tstamp(ctx, stamps ? n : 1);
@@ -2059,7 +2061,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
             if (full) {
                 HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64), s));
-                const bool long_int = grouped && max_mega > 0 && getenv("B3C_LV_NO_INTERNAL_LONG") == nullptr;
+                const bool long_int = grouped && max_mega > 0 && !CFG.on("B3C_LV_NO_INTERNAL_LONG");
                 hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2, own_p,
                                    stamp_p, epoch + 1, long_int ? (int64_t)mega_deg : INT64_MAX);
                 if (long_int) {
@@ -2099,7 +2101,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if ((rc = modularity(&new_mod, false, nullptr))) { free_graph(ctx, g); return rc; }
         int sweep = 0;
         u64 prev_moved = ~0ull;
-        const int incr_div = getenv("B3C_LV_INCR_DIV") ? atoi(getenv("B3C_LV_INCR_DIV")) : 4;
+        const int incr_div = (int)CFG.num("B3C_LV_INCR_DIV", 4);
         for (;;) {
             cur_mod = new_mod;
             sweep++;
@@ -2107,7 +2109,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 1, 0, sizeof(u64), s));
             // few movers expected (the sweep before moved under a quarter of the nodes): track the internal weight through
             // the movers' rows instead of rescanning the whole graph after the sweep
-            const bool incr = grouped && prev_moved != ~0ull && prev_moved * (u64)incr_div < (u64)n && getenv("B3C_LV_NO_INCR") == nullptr;
+            const bool incr = grouped && prev_moved != ~0ull && prev_moved * (u64)incr_div < (u64)n && !CFG.on("B3C_LV_NO_INCR");
             for (int r = 0; r < n_sub; r++) {
                 epoch++;
                 evs.rec();
@@ -2144,7 +2146,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 #define LV_DECIDE_G(L, U)                                                                                                \
     hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, cnt_dev, lst, \
                        m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch)
-                    if (sweep == 1 && r == 0 && !incr && getenv("B3C_LV_NO_FIRST") == nullptr) {
+                    if (sweep == 1 && r == 0 && !incr && !CFG.on("B3C_LV_NO_FIRST")) {
                         // every node is still alone: the table-free form (k_lv_first_g)
 #define LV_FIRST_G(L, U)                                                                                                 \
     hipLaunchKernelGGL((k_lv_first_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, m2,     \
@@ -2159,7 +2161,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     } else
                     switch (short_max) {
                     case 256:      // C3 sweep of shapes, ms of delta-Q scan per step: 64x4 11.3, 32x8 12.2, 16x16 22.4
-                        if (getenv("B3C_LV_SHAPE") && !strcmp(getenv("B3C_LV_SHAPE"), "32x8")) { LV_DECIDE_G(32, 8); }
+                        if (shape_32x8) { LV_DECIDE_G(32, 8); }
                         else { LV_DECIDE_G(64, 4); }
                         break;
                     case 128: LV_DECIDE_G(16, 8); break;
@@ -2168,7 +2170,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     }
 #undef LV_DECIDE_G
                 }
-                const bool direct_level = !grouped && !dist && n <= LV_DIRECT_CAP && getenv("B3C_LV_NO_DIRECT") == nullptr;
+                const bool direct_level = !grouped && !dist && n <= LV_DIRECT_CAP && !CFG.on("B3C_LV_NO_DIRECT");
                 if (direct_level) {
                     // small level: direct community table in LDS
                     hipLaunchKernelGGL(k_lv_decide_direct<LV_DIRECT_CAP>, dim3(grid_for(n, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, n_sub, r, m2,
@@ -2243,7 +2245,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             u64 moved = 0;
             if ((rc = modularity(&new_mod, !incr, &moved))) { free_graph(ctx, g); return rc; }
             info->n_moves += (int64_t)moved;
-            if (getenv("B3C_LV_DEBUG")) fprintf(stderr, "[b3c] level %d sweep %d: %llu of %lld nodes moved\n", (int)info->n_levels, sweep, (unsigned long long)moved, (long long)n);
+            if (lv_debug) fprintf(stderr, "[b3c] level %d sweep %d: %llu of %lld nodes moved\n", (int)info->n_levels, sweep, (unsigned long long)moved, (long long)n);
             if (moved == 0) break;
             prev_moved = moved;
             if (new_mod - cur_mod < PL_MIN) break;
@@ -2271,7 +2273,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // ---- induced graph ----
         LvGraph h;
         GraphGuard next_guard{ctx, &h};               // an early return while h is under construction releases its blocks
-        if (kc <= AGG_BINS_KC && getenv("B3C_LV_AGG_SORT") == nullptr) {
+        if (kc <= AGG_BINS_KC && !CFG.on("B3C_LV_AGG_SORT")) {
             // few communities: exact integer sums straight into kc x kc bins (see k_agg_bins)
             const size_t nb = (size_t)kc * (size_t)kc;
             DevBuf<u64> bins(ctx, nb);
@@ -2288,9 +2290,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 const int nslot = kc <= 512 ? AGG_SLOTS : kc <= 2048 ? 2 : 1;
                 const int64_t rpb = std::max<int64_t>(64, std::min<int64_t>(512, n / (4 * (int64_t)ctx->n_cu)));   // at least four blocks per CU
                 const size_t lds = sizeof(u64) * (size_t)nslot * (size_t)kc;       // at most 32 KB
-                const bool long_rows = maxdeg > AGG_LONG && getenv("B3C_LV_NO_AGG_LONG") == nullptr;
+                const bool long_rows = maxdeg > AGG_LONG && !CFG.on("B3C_LV_NO_AGG_LONG");
                 // beyond the first level: rows in the order of their new community (one stable sort of n labels)
-                const bool by_com = !first && n >= 4096 && getenv("B3C_LV_NO_AGG_ORDER") == nullptr;
+                const bool by_com = !first && n >= 4096 && !CFG.on("B3C_LV_NO_AGG_ORDER");
                 DevBuf<int32_t> okey(ctx, by_com ? n : 1), oval(ctx, by_com ? n : 1), oiota(ctx, by_com ? n : 1);
                 if (by_com) {
                     if (!okey.p || !oval.p || !oiota.p) { free_graph(ctx, h); free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation order"); }

@@ -617,8 +617,8 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     const int64_t n = a->n;
     if (n == 0) return B3C_OK;
     int ROUNDS = 3;
-    if (const char *e = getenv("B3C_ORDER_ROUNDS")) ROUNDS = std::max(1, std::min(12, atoi(e)));
-    const int order_sample = getenv("B3C_ORDER_SAMPLE") ? atoi(getenv("B3C_ORDER_SAMPLE")) : 0;
+    if (CFG.on("B3C_ORDER_ROUNDS")) ROUNDS = std::max(1, std::min(12, (int)CFG.num("B3C_ORDER_ROUNDS", 3)));
+    const int order_sample = (int)CFG.num("B3C_ORDER_SAMPLE", 0);
     DevBuf<int32_t> p0(ctx, n), p1(ctx, n), lab(ctx, (size_t)n * ROUNDS), kin(ctx, n), kout(ctx, n), vout(ctx, n);
     DevBuf<unsigned long long> cbest(ctx, n);
     DevBuf<int> changed(ctx, 1);
@@ -631,7 +631,7 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     // sorts) is n-vector work every rank repeats.  Per-row results and max-folds do not depend on who computed them: the
     // order is bit for bit the single-GPU one.
     const b3c_dist &D = ctx->dist;
-    const bool dist = ctx->has_dist && D.world > 1 && (int64_t)D.world * D.chunk >= n && getenv("B3C_ORDER_REPLICATED") == nullptr;
+    const bool dist = ctx->has_dist && D.world > 1 && (int64_t)D.world * D.chunk >= n && !CFG.on("B3C_ORDER_REPLICATED");
     const int64_t r0 = dist ? std::min<int64_t>(n, (int64_t)D.rank * D.chunk) : 0;
     const int64_t r1 = dist ? std::min<int64_t>(n, (int64_t)(D.rank + 1) * D.chunk) : n;
     const int g16 = grid_for(r1 - r0, (BLK / 64) * 4, 16 * ctx->n_cu), g64 = grid_for(r1 - r0, BLK / 64, 16 * ctx->n_cu);
@@ -679,7 +679,7 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     }
     int bits = 1;
     while ((1ll << bits) < n) bits++;
-    if (ROUNDS * bits <= 64 && getenv("B3C_ORDER_LSD") == nullptr) {
+    if (ROUNDS * bits <= 64 && !CFG.on("B3C_ORDER_LSD")) {
         // ONE stable sort on the composite key (cluster_R, ..., cluster_2, cluster_1): the order the LSD passes below give, from a
         // third of the launches (1M keys go through rocPRIM's merge sort, ~20 small kernels per call; n up to 2^21 with three rounds)
         DevBuf<unsigned long long> k64(ctx, n), k64o(ctx, n);
@@ -741,8 +741,8 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
     constexpr int CAPR = 512;
     int nb = 1;
     while ((1ll << nb) < n) nb++;
-    const bool regs_ok = nnz && sort_cols && nb + 9 <= 32 && getenv("B3C_PERMUTE_GLOBAL_SORT") == nullptr &&
-                         getenv("B3C_PERMUTE_LDS") == nullptr;
+    const bool regs_ok = nnz && sort_cols && nb + 9 <= 32 && !CFG.on("B3C_PERMUTE_GLOBAL_SORT") &&
+                         !CFG.on("B3C_PERMUTE_LDS");
     if (regs_ok) {
         // rows of up to CAPR entries: bitonic network in registers on packed (new column, position) keys ...
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
@@ -795,7 +795,7 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
             HIP_TRY(ctx, hipStreamSynchronize(s));       // the scratch above goes back to the pool here
             }
         }
-    } else if (nnz && sort_cols && maxlen <= CAPR && getenv("B3C_PERMUTE_GLOBAL_SORT") == nullptr) {
+    } else if (nnz && sort_cols && maxlen <= CAPR && !CFG.on("B3C_PERMUTE_GLOBAL_SORT")) {
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
         int pb = 6;
         while ((1ull << pb) < maxlen) pb++;

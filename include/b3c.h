@@ -85,6 +85,10 @@ typedef struct {
  * its own non-blocking stream). */
 int b3c_ctx_create(int device, void *stream, b3c_ctx **out);
 int b3c_ctx_destroy(b3c_ctx *ctx);
+/* The B3C_* development switches of the process environment are read ONCE, by b3c_ctx_create; no other
+ * entry point looks at the environment.  A caller that changes them afterwards (the test suite, the profiling tools) calls this to
+ * have the context read them again. */
+int b3c_ctx_reload_env(b3c_ctx *ctx);
 const char *b3c_last_error(const b3c_ctx *ctx);
 int b3c_ctx_sync(b3c_ctx *ctx);
 /* HBM bytes currently held by the context's matrices and workspaces. */

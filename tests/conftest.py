@@ -29,3 +29,37 @@ def ctx():
     c = make_context(0)
     yield c
     c.close()
+
+
+class _EnvPatch(object):
+    """pytest's monkeypatch, with one addition: libb3c reads its B3C_* switches once per context (b3c_ctx_create), so a test
+    that flips one has every open context read them again (b3c_ctx_reload_env)."""
+
+    def __init__(self, mp):
+        self._mp = mp
+
+    def __getattr__(self, name):
+        return getattr(self._mp, name)
+
+    @staticmethod
+    def _reload():
+        from bin3c_amd import _native
+        _native.reload_env_all()
+
+    def setenv(self, name, value, prepend=None):
+        self._mp.setenv(name, value, prepend)
+        if name.startswith('B3C_'):
+            self._reload()
+
+    def delenv(self, name, raising=True):
+        self._mp.delenv(name, raising)
+        if name.startswith('B3C_'):
+            self._reload()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    mp = _EnvPatch(monkeypatch)
+    yield mp
+    monkeypatch.undo()
+    mp._reload()

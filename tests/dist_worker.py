@@ -63,6 +63,7 @@ def gpu_mode(rank, world):
             os.environ['B3C_KR_TCD_XT'] = '1'
         else:
             os.environ.pop('B3C_KR_TCD_XT', None)
+        ctx.reload_env()
         sm = make_synth(*args)
         counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
         single = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)            # before sharding is installed
@@ -72,11 +73,13 @@ def gpu_mode(rank, world):
             # the row sums are exact integers, so the layout cannot show in x
             os.environ['B3C_KR_XT_S'] = '12288'
             os.environ['B3C_KR_XT_CHUNKS'] = '16'
+            ctx.reload_env()
         try:
             res = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5)
         finally:
             os.environ.pop('B3C_KR_XT_S', None)
             os.environ.pop('B3C_KR_XT_CHUNKS', None)
+            ctx.reload_env()
         sess.check()
         # the map was SHARDED, not replicated: this rank formed and touched only its row block of the ordered map
         if sm.n >= 32768 and counts.nnz >= (1 << 21):

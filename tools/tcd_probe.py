@@ -26,6 +26,7 @@ for var in variants:
             k, v = kv.split('=')
             os.environ[k] = v
             keys.append(k)
+    ctx.reload_env()          # libb3c reads its switches once per context
     for rep in range(2):
         t = time.time(); rc, x, info = ctx.kr_balance_counts(work, sites, max_iter=30 if "PROBE" in var else 1000, check=False); dt = time.time() - t
     print('%-40s KR %.2f ms, spmv avg %.1f us over %d, n_iter %d; tiles %d dmax %d dmean %.0f tails %.1f%%' % (
@@ -37,3 +38,4 @@ for var in variants:
         print('    vs first: n_iter %s, max rel diff %.2e' % ('same' if info.n_iter == ref[1] else 'DIFFERENT', np.nanmax(np.abs(x - ref[0]) / ref[0])), flush=True)
     for k in keys:
         os.environ.pop(k, None)
+    ctx.reload_env()
