@@ -123,10 +123,13 @@ def main():
     ap.add_argument('--synth', default='default', choices=['default', 'survey'],
                     help="genome layout of the synthetic map: 'default' = G = n/500 genomes ~ rank^-0.5 (the headline workload, "
                          "DESIGN.md section 5); 'survey' = SURVEY.md 8(d) to the letter, G = n/200 genomes ~ Zipf(1.5)")
-    ap.add_argument('--c5-counts', default='unique', choices=['unique', 'summed-draws'],
-                    help="power-law maps: 'unique' = the stated number of UNIQUE edges, one count per pair (default); 'summed-draws' "
-                         "= that many DRAWS with duplicates summed, the host generator's rule (round 2's C5: 4.6e8 edges whose hub "
-                         "pairs carry counts of 10^5..10^6 -- about 2,450 KR iterations)")
+    ap.add_argument('--c5-counts', default='summed-draws', choices=['unique', 'summed-draws'],
+                    help="power-law maps: 'summed-draws' (default; SURVEY 8(d): duplicates summed) = the stated number of DRAWS with "
+                         "duplicates summed, the host generator's rule (C5: 4.6e8 edges whose hub pairs carry counts of 10^5..10^6 -- about "
+                         "2,450 KR iterations); 'unique' = the stated number of UNIQUE edges, one count per pair (an easier map for KR: "
+                         "report it as an additional, labelled line only)")
+    ap.add_argument('--no-survey-leg', action='store_true',
+                    help='skip the second leg on the workload as SURVEY 8(d) defines it (printed under "survey_workload")')
     ap.add_argument('--n-sub', type=int, default=0, help='sub-rounds per Louvain sweep (0: the library default, 4)')
     ap.add_argument('--hard', action='store_true',
                     help='a HARD clustering problem on the same contigs: 45 %% inter-genome noise, intra-genome counts not '
@@ -156,38 +159,53 @@ def main():
     from bin3c_amd.pipeline import make_context, run_hot_path
     from bin3c_amd.synth import CONFIGS, make_edges
 
-    n, n_edges, seed, law = CONFIGS[args.config]
     max_iter = args.max_iter if args.max_iter else (5000 if args.config == 'C5' else 1000)
     if args.config == 'C5':
         args.no_cpu_baseline = True          # the oracle would need hours on this map
     ctx = make_context(local_rank, pin=True)       # one process per GPU: stay on the CPUs of its NUMA node
-    # pair stream drawn on the host (numpy RandomState, deterministic), accumulated into the symmetric count matrix on
-    # the device (b3c_coo_symmetrise: the ingest tail, bit-identical to synth.symmetrise_to_csr).  Every rank builds
-    # the same map: the replica leg processes one copy per GPU, the sharded leg one copy over all GPUs.
-    genome_law = 'survey' if args.synth == 'survey' else 'sqrt'
-    noise, boost = (0.45, 1) if args.hard else (0.1, 5)
-    synth_note = ''
-    if law == 'powerlaw':
-        # the host generator sizes its draws for uniform endpoints; under the power law they collapse onto hub pairs (1e9 draws
-        # -> 4.6e8 unique edges at C5).  The device generator draws until the number of UNIQUE edges is the stated one.
-        from bin3c_amd.synth_device import make_counts_device
-        summed = args.c5_counts == 'summed-draws'
-        counts, e_true, lengths_h, sites_h, _genome, sinfo = make_counts_device(ctx, n, n_edges, seed, law, noise, boost,
-                                                                                genome_law=genome_law, dup='sum' if summed else 'first',
-                                                                                draws_only=summed)
-        synth_note = ', drawn on the device ({:.3g} intra-genome draws for {:.3g} unique intra-genome edges; {})'.format(
-            sinfo['intra_draws'], sinfo['intra_unique'], 'duplicate draws summed' if summed else 'one count per unique pair')
-    else:
-        lo, hi, cnt, diag, lengths_h, sites_h, _genome = make_edges(n, n_edges, seed, law, noise, boost, genome_law=genome_law)
-        counts, e_true = ctx.coo_symmetrise(n, lo, hi, cnt, diag)
-        del lo, hi, cnt
-    variant = ('' if args.synth == 'default' else ' [genomes as SURVEY 8(d): n/200, Zipf(1.5)]') + (
-        ' [hard: 45 % noise, no intra boost]' if args.hard else '')
-    # inputs resident in HBM before the timed region: the count matrix and the two per-contig tables
-    sites = torch.as_tensor(sites_h, device='cuda')
-    lengths = torch.as_tensor(lengths_h.astype(np.int64), device='cuda')
-    nnz = counts.nnz
     min_len, min_sig = 1000, 5
+
+    class Workload(object):
+        """one synthetic map resident in HBM: count matrix + the two per-contig tables, and what to call it"""
+
+    def build_workload(config, synth, hard):
+        # pair stream drawn on the host (numpy RandomState, deterministic), accumulated into the symmetric count matrix on
+        # the device (b3c_coo_symmetrise: the ingest tail, bit-identical to synth.symmetrise_to_csr).  Every rank builds
+        # the same map: the replica leg processes one copy per GPU, the sharded leg one copy over all GPUs.
+        w = Workload()
+        w.config = config
+        w.n, n_edges, w.seed, w.law = CONFIGS[config]
+        genome_law = 'survey' if synth == 'survey' else 'sqrt'
+        noise, boost = (0.45, 1) if hard else (0.1, 5)
+        synth_note = ''
+        if w.law == 'powerlaw':
+            # the host generator sizes its draws for uniform endpoints; under the power law they collapse onto hub pairs (1e9
+            # draws -> 4.6e8 unique edges at C5).  'summed-draws' (default: SURVEY 8(d)'s "duplicates summed") keeps that map;
+            # 'unique' draws on the device until the number of UNIQUE edges is the stated one, one count per pair.
+            from bin3c_amd.synth_device import make_counts_device
+            summed = args.c5_counts == 'summed-draws'
+            w.counts, w.e_true, w.lengths_h, w.sites_h, _genome, sinfo = make_counts_device(
+                ctx, w.n, n_edges, w.seed, w.law, noise, boost, genome_law=genome_law, dup='sum' if summed else 'first', draws_only=summed)
+            synth_note = ', drawn on the device ({:.3g} intra-genome draws for {:.3g} unique intra-genome edges; {})'.format(
+                sinfo['intra_draws'], sinfo['intra_unique'], 'duplicate draws summed' if summed else 'one count per unique pair')
+        else:
+            lo, hi, cnt, diag, w.lengths_h, w.sites_h, _genome = make_edges(w.n, n_edges, w.seed, w.law, noise, boost, genome_law=genome_law)
+            w.counts, w.e_true = ctx.coo_symmetrise(w.n, lo, hi, cnt, diag)
+            del lo, hi, cnt
+        # which genome-size law: the headline keeps the law rounds 1-3 were measured on, which DEVIATES from SURVEY 8(d);
+        # the surveyed law runs beside it under "survey_workload" (and alone with --synth survey)
+        variant = (' [genome sizes: G = n/500 ~ rank^-0.5 -- NOT SURVEY 8(d)\'s law, which is measured under "survey_workload"]'
+                   if synth == 'default' else ' [genome sizes as SURVEY 8(d): G = n/200 ~ Zipf(1.5)]') + (
+                   ' [hard: 45 % noise, no intra boost]' if hard else '')
+        w.label = '{}: hic-synth-v1{} n={} contigs, E={} undirected edges (nnz={}), seed={}{}{}'.format(
+            config, ' power law' if w.law == 'powerlaw' else '', w.n, w.e_true, w.counts.nnz, w.seed, variant, synth_note)
+        # inputs resident in HBM before the timed region: the count matrix and the two per-contig tables
+        w.sites = torch.as_tensor(w.sites_h, device='cuda')
+        w.lengths = torch.as_tensor(w.lengths_h.astype(np.int64), device='cuda')
+        w.nnz = w.counts.nnz
+        return w
+
+    W = build_workload(args.config, args.synth, args.hard)
 
     def barrier():
         if world > 1 or one_rank_group:
@@ -195,18 +213,19 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    def timed_leg():
+    def timed_leg(w, steps, warmup):
         """W warm-up steps, then exactly K timed steps between barriers; time = max over ranks."""
-        acc = {'stage': {}, 'spmv_ms': 0.0, 'spmv_n': 0, 'move_ms': 0.0, 'move_n': 0, 'move_nnz': 0, 'move_rows': 0}
+        acc = {'stage': {}, 'spmv_ms': 0.0, 'spmv_n': 0, 'move_ms': 0.0, 'move_n': 0, 'move_nnz': 0, 'move_rows': 0,
+               'first_ms': 0.0, 'first_n': 0}
         last = None
-        for _ in range(args.warmup):
-            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub)
+        for _ in range(warmup):
+            last = run_hot_path(ctx, w.counts, w.sites, w.lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub)
         gc.collect()
         gc.disable()            # a generation-2 collection in the middle of a step shows up as a 20 ms hole in the GPU timeline
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            last = run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub)
+        for _ in range(steps):
+            last = run_hot_path(ctx, w.counts, w.sites, w.lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub)
             for k, v in last.timings.items():
                 acc['stage'][k] = acc['stage'].get(k, 0.0) + v
             acc['spmv_ms'] += last.kr_info.spmv_ms
@@ -215,6 +234,8 @@ def main():
             acc['move_n'] += last.lv_info.n_move_launch
             acc['move_nnz'] += last.lv_info.move_nnz
             acc['move_rows'] += last.lv_info.move_rows
+            acc['first_ms'] += last.lv_info.first_sweep_ms
+            acc['first_n'] += last.lv_info.first_sweep_launches
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
@@ -225,85 +246,125 @@ def main():
             dt = float(tt.item())
         return dt, last, acc
 
-    def line(dt, last, acc, sharded, extra):
-        ms_per_step = dt / args.steps * 1e3
-        e_total = float(e_true) if (sharded or world == 1) else float(e_true) * world
-        value = e_total * args.steps / dt
-        spmv_ms, spmv_n, move_ms, move_n = acc['spmv_ms'], acc['spmv_n'], acc['move_ms'], acc['move_n']
+    def spmv_roofline(w, last, acc, share, sharded):
+        """The KR SpMV (all launches of one product).  `achieved` / `frac` are PHYSICAL: the HBM bytes one SpMV moves -- by the
+        counters when a pass over this kernel on this workload is on file (profiles/traffic.json), else the bytes the kernel's
+        encoding streams by construction -- over its mean duration, against the 8 TB/s peak.  SURVEY 8(d)'s algorithmic figure
+        (12 B per stored entry + 20 B per row: what a CSR fp64 SpMV would have to move) rides beside it as
+        `achieved_algorithmic_equiv` / `frac_algorithmic_equiv`: an equivalent rate, not a fraction of anything -- the
+        dictionary encoding streams fewer bytes than that, so it can pass 1."""
+        nnz, n = w.nnz, w.n
+        algorithmic = (12.0 * nnz + 20.0 * n) * share     # SURVEY 8(d): one KR SpMV
+        ki = last.kr_info
+        vb = ki.value_bits / 8.0                           # 2 when all counts fit 16 bits, else 4 (8: fp64 matrix)
+        streamed = ((4.0 + vb) * nnz + 36.0 * n) * share   # what the CSR count form physically reads / writes
+        tcd = getattr(ki, 'tcd_tiles', 0) > 0              # tile-dictionary layout (automatic from 4096 contigs on)
+        xt = getattr(ki, 'tcd_xt_tails', 0) > 0            # ... with the tails summed by their own pass (beyond 2^19 contigs)
+        if tcd:
+            # the dictionary form: 4 B per dictionary entry, 8 B per tail entry (word, or count + column), the dictionaries
+            # (ids in, operands gathered), row tables and the n-vectors of the epilogue
+            streamed = (4.0 * (nnz - ki.tcd_tail_entries) + 8.0 * ki.tcd_tail_entries + 12.0 * ki.tcd_dict_total + 52.0 * n) * share
+        kname = ('kr_kb_tails + kr_kb_tcd2 (ONE SpMV as two launches: tails summed in column order in fixed point, then dictionary '
+                 'rows + fused KR epilogue; times and bytes are those of the pair)' if xt
+                 else 'kr_kb_tcd2 (tile-dictionary SpMV on raw counts + fused KR epilogue)' if tcd
+                 else 'kr_kb_vec (CSR SpMV on raw counts + fused KR epilogue)')
+        avg_ms = acc['spmv_ms'] / max(acc['spmv_n'], 1)
+        traffic = measured_traffic(w.config if w is W and args.synth == 'default' and not args.hard else '-', kname) if not sharded else None
+        physical = traffic if traffic else streamed
+        rate = lambda b: b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        return {'bound': 'hbm', 'kernel': kname, 'achieved': rate(physical), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': rate(physical) / HBM_PEAK_GBS,
+                'frac_basis': 'HBM bytes per launch by the rocprofv3 counters (profiles/traffic.json)' if traffic
+                              else 'bytes the kernel streams by construction (no counter pass on file for this kernel and workload)',
+                'traffic': traffic, 'bytes_per_launch': physical, 'bytes_streamed_per_launch': streamed, 'avg_launch_ms': avg_ms,
+                'achieved_streamed': rate(streamed), 'frac_streamed': rate(streamed) / HBM_PEAK_GBS,
+                'bytes_algorithmic_per_launch': algorithmic, 'achieved_algorithmic_equiv': rate(algorithmic),
+                'frac_algorithmic_equiv': rate(algorithmic) / HBM_PEAK_GBS,
+                'tail_share': float(ki.tcd_tail_entries) / max(nnz * share, 1.0) if tcd else None}
+
+    def louvain_roofline(w, last, acc, share, n_acc):
+        """The delta-Q neighbour scan; one launch = one sub-round = 1/n_sub of a sweep.  SURVEY 8(d): 16 B per stored entry + 28 B
+        per node and sweep.  `achieved` / `frac` are those of the FIRST sweep of level 0, whose launches read every row (no
+        node can be settled without its row yet); the mean over all launches of a step is flattered by the pruned sub-rounds,
+        which skip most rows but are charged the full bytes, and rides beside it as `frac_mean_incl_pruned`."""
+        move_n = max(acc['move_n'], 1)
+        mean_bytes = (16.0 * acc['move_nnz'] + 28.0 * acc['move_rows']) / move_n
+        mean_ms = acc['move_ms'] / move_n
+        rate = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        nsub = args.n_sub if args.n_sub > 0 else 4
+        sub = last.sub_nnz if getattr(last, 'sub_nnz', None) else None
+        first_bytes = (16.0 * (sub if sub else w.nnz * share) + 28.0 * n_acc * share) / nsub
+        first_ms = acc['first_ms'] / max(acc['first_n'], 1)
+        use_first = acc['first_n'] > 0 and first_ms > 0
+        b, ms = (first_bytes, first_ms) if use_first else (mean_bytes, mean_ms)
+        return {'bound': 'hbm', 'kernel': 'k_lv_decide (Louvain delta-Q neighbour scan; one launch = one sub-round: 1/n_sub of a sweep)',
+                'achieved': rate(b, ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': rate(b, ms) / HBM_PEAK_GBS,
+                'frac_basis': 'SURVEY 8(d) bytes of the unpruned first sweep of level 0 over its mean launch' if use_first
+                              else 'SURVEY 8(d) bytes over the mean launch of the step',
+                'traffic': None, 'bytes_per_launch': b, 'avg_launch_ms': ms,
+                'frac_mean_incl_pruned': rate(mean_bytes, mean_ms) / HBM_PEAK_GBS, 'avg_launch_ms_all': mean_ms,
+                'launches_per_step': acc['move_n'] / max(1, acc.get('steps', 1))}
+
+    def line(w, dt, last, acc, steps, warmup, sharded, extra):
+        ms_per_step = dt / steps * 1e3
+        e_total = float(w.e_true) if (sharded or world == 1) else float(w.e_true) * world
+        value = e_total * steps / dt
+        acc['steps'] = steps
+        spmv_ms, spmv_n, move_ms = acc['spmv_ms'], acc['spmv_n'], acc['move_ms']
         n_acc = int(last.mask.sum())
         # dominant kernel by accumulated device time (this rank's launches: a row range of the map when sharded)
         share = 1.0 / world if sharded else 1.0
-        if spmv_ms >= move_ms:
-            per_launch = (12.0 * nnz + 20.0 * n) * share   # one KR SpMV
-            vb = last.kr_info.value_bits / 8.0             # 2 when all counts fit 16 bits, else 4 (8: fp64 matrix)
-            streamed = ((4.0 + vb) * nnz + 36.0 * n) * share   # what the SpMV kernel physically reads/writes
-            avg_ms = spmv_ms / max(spmv_n, 1)
-            ki = last.kr_info
-            tcd = getattr(ki, 'tcd_tiles', 0) > 0              # tile-dictionary layout (automatic from 4096 contigs on)
-            xt = getattr(ki, 'tcd_xt_tails', 0) > 0            # ... with the tails summed by their own pass (beyond 2^19 contigs)
-            if tcd:
-                # what the dictionary form physically moves: 4 B per dictionary entry, 8 B per tail entry (word, or count +
-                # column), the dictionaries (ids in, operands gathered), row tables and the n-vectors of the epilogue
-                streamed = (4.0 * (nnz - ki.tcd_tail_entries) + 8.0 * ki.tcd_tail_entries + 12.0 * ki.tcd_dict_total + 52.0 * n) * share
-            kname = ('kr_kb_tails + kr_kb_tcd2 (ONE SpMV as two launches: tails summed in column order in fixed point, then dictionary '
-                     'rows + fused KR epilogue; times and bytes are those of the pair)' if xt
-                     else 'kr_kb_tcd2 (tile-dictionary SpMV on raw counts + fused KR epilogue)' if tcd
-                     else 'kr_kb_vec (CSR SpMV on raw counts + fused KR epilogue)')
-        else:
-            per_launch = (16.0 * acc['move_nnz'] + 28.0 * acc['move_rows']) / max(move_n, 1)   # Louvain sweep / n_sub
-            streamed = per_launch
-            avg_ms = move_ms / max(move_n, 1)
-            kname = 'k_lv_decide (Louvain delta-Q neighbour scan)'
-        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        r_spmv = spmv_roofline(w, last, acc, share, sharded)
+        r_lv = louvain_roofline(w, last, acc, share, n_acc)
         out = {
             'metric': 'contact-graph edges/s through KR-normalise + Louvain',
-            'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if sharded else 'weak',
             'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '{}: hic-synth-v1{} n={} contigs, E={} undirected edges (nnz={}), seed={}{}{}'.format(
-                           args.config, ' power law' if law == 'powerlaw' else '', n, e_true, nnz, seed, variant, synth_note),
+            'config': {'workload': w.label,
                        'kr_max_iter': max_iter, 'kr_max_iter_reference_default': 1000,
                        'parallelism': 'single GPU' if world == 1 else (
                            'one map over {} GPUs by contig-row blocks (each rank forms and works on its rows of the ordered map); RCCL: 1 exchange per SpMV, 1 per Louvain sub-round'.format(world)
                            if sharded else 'replicas x{} (one map per GPU)'.format(world)),
-                       'accepted_contigs': n_acc, 'kr_spmv_per_step': int(spmv_n // args.steps),
+                       'accepted_contigs': n_acc, 'kr_spmv_per_step': int(spmv_n // steps),
                        'louvain_sweeps_per_step': int(last.lv_info.n_sweeps), 'louvain_levels': int(last.lv_info.n_levels),
+                       'communities_level0': int(last.lv_info.n_comm_level0),
                        'communities': int(last.lv_info.n_comm), 'modularity': last.lv_info.modularity,
-                       'stage_ms': {k: v / args.steps * 1e3 for k, v in acc['stage'].items()},
-                       'kernel_ms': {'kr_spmv_total': spmv_ms / args.steps, 'louvain_decide_total': move_ms / args.steps}},
-            'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': measured_traffic(args.config, kname) if not sharded else None,
-                         'bytes_per_launch': per_launch, 'bytes_streamed_per_launch': streamed, 'avg_launch_ms': avg_ms,
-                         # `achieved` / `frac` are on SURVEY 8(d)'s ALGORITHMIC bytes (12 B per stored entry), as the bench
-                         # contract defines them; the kernel's encoding streams fewer bytes than that, so the figure is an
-                         # equivalent rate and can pass the physical peak.  The physical rates sit beside it:
-                         'achieved_streamed': streamed / (avg_ms * 1e-3) / 1e9,
-                         'frac_streamed': streamed / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                       'stage_ms': {k: v / steps * 1e3 for k, v in acc['stage'].items()},
+                       'kernel_ms': {'kr_spmv_total': spmv_ms / steps, 'louvain_decide_total': move_ms / steps}},
+            'roofline': r_spmv if spmv_ms >= move_ms else r_lv,
+            # the same figure for the kernel family that is NOT the dominant one
+            'roofline_other': r_lv if spmv_ms >= move_ms else r_spmv,
         }
-        # the same figure for the kernel family that is NOT the dominant one (a roofline-style line for the
-        # Louvain scan beside the SpMV's, and vice versa on maps where the scan dominates)
-        if spmv_ms >= move_ms:
-            o_bytes = (16.0 * acc['move_nnz'] + 28.0 * acc['move_rows']) / max(move_n, 1)
-            o_ms, o_name = move_ms / max(move_n, 1), 'k_lv_decide (Louvain delta-Q neighbour scan; one launch = one sub-round: 1/n_sub of a sweep)'
-        else:
-            o_bytes = (12.0 * nnz + 20.0 * n) * share
-            o_ms, o_name = spmv_ms / max(spmv_n, 1), 'KR SpMV (all launches of one product)'
-        if o_ms > 0:
-            o_ach = o_bytes / (o_ms * 1e-3) / 1e9
-            out['roofline_other'] = {'bound': 'hbm', 'kernel': o_name, 'achieved': o_ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                     'frac': o_ach / HBM_PEAK_GBS, 'bytes_per_launch': o_bytes, 'avg_launch_ms': o_ms}
         out.update(extra)
         return out
 
+    def survey_leg():
+        """the workload as SURVEY 8(d) writes it (G = n/200 genomes ~ Zipf(1.5): one genome holds 38 % of
+        the contigs) on the same GPU right after the headline leg, 3 steps, its own stage times and dominant-kernel roofline."""
+        ws = build_workload(args.config, 'survey', False)
+        try:
+            dt, last, acc = timed_leg(ws, 3, 1)
+            o = line(ws, dt, last, acc, 3, 1, False, {})
+        finally:
+            ws.counts.free()
+        keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'roofline', 'roofline_other')
+        res = {'workload': o['config']['workload']}
+        res.update({k: o[k] for k in keep})
+        res.update({k: o['config'][k] for k in ('accepted_contigs', 'kr_spmv_per_step', 'louvain_sweeps_per_step', 'louvain_levels',
+                                                'communities_level0', 'communities', 'modularity', 'stage_ms', 'kernel_ms')})
+        return res
+
     def emit(out):
         if rank == 0:
+            counts, n, nnz, e_true = W.counts, W.n, W.nnz, W.e_true
+            sites_h, lengths_h, seed = W.sites_h, W.lengths_h, W.seed
             if world == 1:
-                out['roofline']['copy_gbs'] = measured_copy_gbs()     # what a plain copy reaches on this box, beside `peak`
-                tr = out['roofline'].get('traffic')
-                if tr:
-                    out['roofline']['frac_traffic'] = tr / (out['roofline']['avg_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                copy = measured_copy_gbs()                            # what a plain copy reaches on this box, beside `peak`
+                for key in ('roofline', 'roofline_other'):
+                    if key in out:
+                        out[key]['copy_gbs'] = copy
             if world == 1 and not args.no_cpu_baseline:
                 nthr = min(64, len(os.sched_getaffinity(0))) if hasattr(os, 'sched_getaffinity') else 1
                 if args.cpu_baseline == 'same' or args.config != 'C3':
@@ -329,9 +390,12 @@ def main():
     want_sharded = (world > 1 or one_rank_group) and args.mode in ('auto', 'sharded')
     rep = None
     if want_replicas:
-        dt, last, acc = timed_leg()
-        rep = line(dt, last, acc, False, {})
+        dt, last, acc = timed_leg(W, args.steps, args.warmup)
+        rep = line(W, dt, last, acc, args.steps, args.warmup, False, {})
         rep_ref = last
+        # the surveyed workload beside the headline (single GPU, the default C3 / C2 legs only: C5 has no surveyed counterpart run)
+        if world == 1 and args.synth == 'default' and not args.hard and args.config in ('C2', 'C3') and not args.no_survey_leg:
+            rep['survey_workload'] = survey_leg()
     if not want_sharded:
         emit(rep)
     else:
@@ -358,10 +422,10 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
-            sess = DistSession(ctx, n)
+            sess = DistSession(ctx, W.n)
             if os.environ.get('B3C_BENCH_FAIL_SHARDED'):          # test hook (tests/test_dist.py)
                 raise RuntimeError('sharded leg disabled by B3C_BENCH_FAIL_SHARDED')
-            dt, last, acc = timed_leg()
+            dt, last, acc = timed_leg(W, args.steps, args.warmup)
             sess.check()
             n_exchanges = sess.n_exchanges
             sess.close()
@@ -377,7 +441,7 @@ def main():
                 extra['agrees_with_single_gpu'] = bool(
                     last.kr_info.n_iter == rep_ref.kr_info.n_iter and np.allclose(last.x, rep_ref.x, rtol=1e-9, atol=0)
                     and last.lv_info.n_comm == rep_ref.lv_info.n_comm and np.array_equal(last.mask, rep_ref.mask))
-        emit(line(dt, last, acc, True, extra))
+        emit(line(W, dt, last, acc, args.steps, args.warmup, True, extra))
     if world > 1 or one_rank_group:
         dist.destroy_process_group()
     ctx.close()

@@ -35,7 +35,8 @@ class LouvainInfo(C.Structure):
     _fields_ = [('n_comm', C.c_int32), ('n_levels', C.c_int32), ('n_sweeps', C.c_int64), ('n_moves', C.c_int64),
                 ('quant_shift', C.c_int32), ('reserved', C.c_int32), ('modularity', C.c_double),
                 ('move_ms', C.c_double), ('n_move_launch', C.c_int64), ('move_nnz', C.c_int64),
-                ('move_rows', C.c_int64), ('n_comm_level0', C.c_int64), ('agg_gathered_runs', C.c_int64)]
+                ('move_rows', C.c_int64), ('n_comm_level0', C.c_int64), ('agg_gathered_runs', C.c_int64),
+                ('first_sweep_ms', C.c_double), ('first_sweep_launches', C.c_int64)]
 
 
 class B3CDist(C.Structure):

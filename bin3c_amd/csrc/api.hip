@@ -22,7 +22,8 @@ extern "C" int b3c_abi_layout(int which, int32_t *out, int cap)
                                  F(b3c_louvain_info, n_moves), F(b3c_louvain_info, quant_shift), F(b3c_louvain_info, reserved),
                                  F(b3c_louvain_info, modularity), F(b3c_louvain_info, move_ms), F(b3c_louvain_info, n_move_launch),
                                  F(b3c_louvain_info, move_nnz), F(b3c_louvain_info, move_rows), F(b3c_louvain_info, n_comm_level0),
-                                 F(b3c_louvain_info, agg_gathered_runs)};
+                                 F(b3c_louvain_info, agg_gathered_runs), F(b3c_louvain_info, first_sweep_ms),
+                                 F(b3c_louvain_info, first_sweep_launches)};
     static const int32_t ds[] = {(int32_t)sizeof(b3c_dist), 0,
                                  F(b3c_dist, rank), F(b3c_dist, world), F(b3c_dist, chunk), F(b3c_dist, vec), F(b3c_dist, scal),
                                  F(b3c_dist, labels), F(b3c_dist, isum), F(b3c_dist, allgather), F(b3c_dist, user),

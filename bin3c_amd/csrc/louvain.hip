@@ -18,6 +18,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
@@ -597,6 +598,200 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval(const NodeRec *__restr
     }
 }
 
+// Rows between the grouped kernel's reach and the mega rows: one WORKGROUP per node (round 4).  The induced graph of a level
+// that ended with 10^5 communities (the surveyed genome-size law at C3: 185,559 nodes, ~1000 entries per row) is made of such rows,
+// and one WAVE per node with a 2048-slot table of its own (96 KB per four waves: one workgroup per CU, four waves to hide the
+// community gathers of a 1000-entry row) took 1.9 ms per sub-round there.  Here the NT threads of a workgroup share ONE table of
+// 2^LGS slots in LDS (12 bytes per slot): 12 / 48 / 96 KB for rows of up to 819 / 3276 / 6553 entries, i.e. 8 / 3 / 1 workgroups
+// per CU with every lane holding four gathers in flight.  Same protocol as k_lv_decide -- insert by compare-and-swap, evaluate and
+// clear every slot of the node's table size, exact 128-bit gains, order-free arg-max (ties to the lowest community id) -- hence
+// the same result.
+constexpr int LV_WG_CLASSES = 3;
+__host__ __device__ __forceinline__ int lv_wg_max_deg(int cls) { return cls == 0 ? 819 : cls == 1 ? 3276 : 6553; }   // table_lg() <= 10 / 12 / 13
+
+template <int LGS, int NT>
+__global__ void __launch_bounds__(NT) k_lv_decide_wg(int64_t cnt_max, const int64_t *__restrict__ cnt_dev, const NodeRec *__restrict__ list, u64 m2,
+                                                      const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
+                                                      const int64_t *__restrict__ kdeg, const int64_t *__restrict__ tot,
+                                                      const int32_t *__restrict__ com, const int32_t *__restrict__ csize,
+                                                      int32_t *__restrict__ nxt)
+{
+    constexpr int SLOTS = 1 << LGS;
+    constexpr int NW = NT / 64;
+    extern __shared__ __align__(16) unsigned char lv_wg_smem[];
+    u64 *vals = (u64 *)lv_wg_smem;
+    int32_t *keys = (int32_t *)(vals + SLOTS);
+    long long *red_hi = (long long *)(keys + SLOTS);
+    u64 *red_lo = (u64 *)(red_hi + NW);
+    long long *red_own = (long long *)(red_lo + NW);
+    int32_t *red_com = (int32_t *)(red_own + NW);
+    int32_t *red_have = red_com + NW;
+    const int64_t cnt = cnt_dev ? (*cnt_dev < cnt_max ? *cnt_dev : cnt_max) : cnt_max;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int t = tid; t < SLOTS; t += NT) { keys[t] = EMPTY; vals[t] = 0; }
+    __syncthreads();
+    for (int64_t pos = blockIdx.x; pos < cnt; pos += gridDim.x) {
+        const NodeRec rec = list[pos];
+        const int32_t i = rec.node;
+        const int32_t a = com[i];
+        const long long ki = kdeg[i];
+        const int lg = table_lg(rec.deg);
+        const uint32_t mask = (1u << lg) - 1u;
+        const int32_t *__restrict__ ci = indices + rec.start;
+        const int64_t *__restrict__ qi = q + rec.start;
+        long long own = 0;
+        for (int base = tid; base < rec.deg; base += 4 * NT) {
+            int32_t j[4];
+            u64 qv[4];
+            int32_t c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = base + u * NT;
+                const bool ok = k < rec.deg;
+                j[u] = ok ? ci[k] : i;
+                qv[u] = ok ? (u64)qi[k] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) c[u] = j[u] != i ? com[j[u]] : EMPTY;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (c[u] == EMPTY) continue;
+                if (c[u] == a) { own += (long long)qv[u]; continue; }
+                uint32_t slot = hash_slot(c[u], lg);
+                for (;;) {
+                    const int32_t prev = atomicCAS(&keys[slot], EMPTY, c[u]);
+                    if (prev == EMPTY || prev == c[u]) { atomicAdd(&vals[slot], qv[u]); break; }
+                    slot = (slot + 1) & mask;
+                }
+            }
+        }
+        __syncthreads();
+        Best b;
+        b.gain = 0; b.com = a; b.have = 0;
+        for (uint32_t t0 = tid; t0 <= mask; t0 += 4 * NT) {
+            int32_t c[4];
+            u64 d[4];
+            long long tc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t t = t0 + u * NT;
+                c[u] = t <= mask ? keys[t] : EMPTY;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t t = t0 + u * NT;
+                d[u] = c[u] != EMPTY ? vals[t] : 0;
+                tc[u] = c[u] != EMPTY ? tot[c[u]] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (c[u] == EMPTY) continue;
+                const uint32_t t = t0 + u * NT;
+                keys[t] = EMPTY;
+                vals[t] = 0;
+                const i128 g = (i128)d[u] * (i128)m2 - (i128)tc[u] * (i128)ki;
+                best_take(b, g, c[u]);
+            }
+        }
+        b = best_wave_reduce(b);
+        own = wave_sum_ll(own);
+        if (lane == 0) {
+            red_hi[wv] = (long long)(b.gain >> 64);
+            red_lo[wv] = (u64)b.gain;
+            red_com[wv] = b.com;
+            red_have[wv] = b.have;
+            red_own[wv] = own;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long o = 0;
+            Best r;
+            r.gain = 0; r.com = a; r.have = 0;
+            for (int w = 0; w < NW; w++) {
+                o += red_own[w];
+                const i128 g = ((i128)red_hi[w] << 64) | (i128)red_lo[w];
+                if (red_have[w] && (!r.have || g > r.gain || (g == r.gain && red_com[w] < r.com))) { r.gain = g; r.com = red_com[w]; r.have = 1; }
+            }
+            // staying: i removed from its own community first (python-louvain __remove)
+            const i128 g = (i128)o * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            best_take(r, g, a);
+            int32_t best = r.have ? r.com : a;
+            if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
+            nxt[i] = best;
+        }
+        __syncthreads();          // the table is clear again and the reduction slots are free
+    }
+}
+template <int LGS, int NT>
+constexpr size_t lv_wg_lds() { return (size_t)(1 << LGS) * 12 + (size_t)(NT / 64) * 32; }
+
+// pass 1 of the mega rows with the chunk's entries summed per community in LDS first (round 4): from the second sweep on most
+// entries of a mega row point into a few large communities, and 4096 lanes adding to the same few slots of the node's table in
+// global memory serialise in the L2 (the surveyed law, level 1: 0.3 ms per sub-round in the first sweep, 1.2 ms in the last ones).
+// One compare-and-swap insertion per DISTINCT community of the chunk reaches the global table.  Integer sums: same table content.
+constexpr int MEGA_LDS_LG = 13;            // table_lg(MEGA_CHUNK)
+__global__ void __launch_bounds__(MEGA_NT) k_lv_mega_insert_lds(const NodeRec *__restrict__ list, int chunks, const int32_t *__restrict__ indices,
+                                                                 const int64_t *__restrict__ q, const int32_t *__restrict__ com,
+                                                                 const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
+                                                                 u64 *__restrict__ gvals, u64 *__restrict__ own_acc)
+{
+    constexpr int SLOTS = 1 << MEGA_LDS_LG;
+    extern __shared__ __align__(16) unsigned char lv_wg_smem[];
+    u64 *lvals = (u64 *)lv_wg_smem;
+    int32_t *lkeys = (int32_t *)(lvals + SLOTS);
+    long long *red = (long long *)(lkeys + SLOTS);
+    const int m = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const NodeRec rec = list[m];
+    if ((int64_t)ch * MEGA_CHUNK >= rec.deg) return;                 // (uniform per workgroup)
+    for (int t = threadIdx.x; t < SLOTS; t += MEGA_NT) { lkeys[t] = EMPTY; lvals[t] = 0; }
+    __syncthreads();
+    const int32_t i = rec.node;
+    const int32_t a = com[i];
+    const int64_t end = rec.start + rec.deg;
+    const int64_t base = rec.start + (int64_t)ch * MEGA_CHUNK + threadIdx.x;
+    int32_t j[4];
+    u64 qv[4];
+    int32_t c[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int64_t k = base + (int64_t)t * MEGA_NT;
+        const bool ok = k < end;
+        j[t] = ok ? indices[k] : i;
+        qv[t] = ok ? (u64)q[k] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = j[t] != i ? com[j[t]] : EMPTY;
+    long long own = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (c[t] == EMPTY) continue;
+        if (c[t] == a) { own += (long long)qv[t]; continue; }
+        uint32_t slot = hash_slot(c[t], MEGA_LDS_LG);
+        for (;;) {
+            const int32_t prev = atomicCAS(&lkeys[slot], EMPTY, c[t]);
+            if (prev == EMPTY || prev == c[t]) { atomicAdd(&lvals[slot], qv[t]); break; }
+            slot = (slot + 1) & (SLOTS - 1);
+        }
+    }
+    __syncthreads();
+    const int lg = table_lg(rec.deg);
+    const uint32_t mask = (1u << lg) - 1u;
+    int32_t *keys = gkeys + goff[i];
+    u64 *vals = gvals + goff[i];
+    for (int t = threadIdx.x; t < SLOTS; t += MEGA_NT) {
+        const int32_t cc = lkeys[t];
+        if (cc == EMPTY) continue;
+        const u64 d = lvals[t];
+        uint32_t slot = hash_slot(cc, lg);
+        for (;;) {
+            const int32_t prev = atomicCAS(&keys[slot], EMPTY, cc);
+            if (prev == EMPTY || prev == cc) { atomicAdd(&vals[slot], d); break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+    block_atomic_add_u64(own, own_acc + m, red);
+}
+
 // Small levels (the induced graphs: n <= CAPD nodes, often dense rows): the weight towards every community goes into a
 // DIRECT table indexed by the community id in the wave's LDS -- no hashing, no compare-and-swap, and no global-memory
 // tables for rows of more than CAP/2 entries.  Same gains, same arg-max (ties to the lowest id) as k_lv_decide.
@@ -679,40 +874,47 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_direct(int64_t n, int n_sub, 
 // summed in registers; only groups that saw a foreign community take turns on the wave's LDS table.
 // The node list of a sub-round is fixed for a level (the bucket depends on the id only), so it is built once.
 // ---------------------------------------------------------------------------------------------
-// Node lists of one level, all at once.  Without hubs: segment r = the nodes of sub-round r.  With hubs: segment 3r = the nodes of
-// sub-round r with at most max_deg entries (grouped kernel), 3r + 1 = those with more (wave-per-node kernel), 3r + 2 = the MEGA rows
-// (workgroup-per-node kernel) -- adjacent, so that the passes that treat them alike (apply, internal-weight delta) cover a
-// sub-round in ONE launch.  A node sets the flag of its segment; ONE exclusive
-// scan over the n_seg * nloc flags gives every listed node its position in the common list and, at the segment starts,
-// the list boundaries.  Inside a segment the nodes ascend, as they did when every segment had its own scan.
-__device__ __forceinline__ int lv_list_segment(int64_t i, int n_sub, int max_deg, int with_hubs, const int64_t *__restrict__ indptr,
+// Node lists of one level, all at once.  Without hubs: segment r = the nodes of sub-round r.  With hubs every sub-round has
+// LV_SEGS adjacent segments by row length: [0] at most thr[0] entries (grouped kernel), [1] at most thr[1] (wave-per-node kernel),
+// [2 .. 4] at most thr[2 .. 4] (workgroup-per-node kernel with a table of 1024 / 4096 / 8192 slots), [5] the MEGA rows beyond
+// (workgroups per node, table in global memory) -- adjacent, so that the passes that treat them alike (apply, internal-weight
+// delta) cover a sub-round in ONE launch.  A node sets the flag of its segment; ONE exclusive scan over the n_seg * nloc flags
+// gives every listed node its position in the common list and, at the segment starts, the list boundaries.  Inside a segment
+// the nodes ascend, as they did when every segment had its own scan.
+constexpr int LV_SEGS = 6;
+struct LvThr { int t[LV_SEGS - 1]; };
+__device__ __forceinline__ int lv_list_segment(int64_t i, int n_sub, LvThr thr, int with_hubs, const int64_t *__restrict__ indptr,
                                                const int32_t *__restrict__ ids, const int64_t *__restrict__ kdeg)
 {
     if (kdeg[i] == 0) return -1;
     const int64_t deg = indptr[i + 1] - indptr[i];
     const int32_t id = ids ? ids[i] : (int32_t)i;
     const int b = (int)bucket_of(id, n_sub);
-    if (deg <= max_deg) return with_hubs ? 3 * b : b;
-    return with_hubs ? (deg > with_hubs ? 3 * b + 2 : 3 * b + 1) : -1;     // with_hubs = the entry count beyond which a row is a MEGA row
+    if (deg <= thr.t[0]) return with_hubs ? LV_SEGS * b : b;
+    if (!with_hubs) return -1;
+    int c = 1;
+#pragma unroll
+    for (int k = 1; k < LV_SEGS - 1; k++) c += deg > thr.t[k] ? 1 : 0;
+    return LV_SEGS * b + c;
 }
 
-__global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, int max_deg, int with_hubs,
+__global__ void k_lv_list_flags(int64_t r0, int64_t r1, int n_sub, LvThr thr, int with_hubs,
                                 const int64_t *__restrict__ indptr, const int32_t *__restrict__ ids,
                                 const int64_t *__restrict__ kdeg, int64_t *__restrict__ flag)     // zeroed by the caller
 {
     const int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r1) return;
-    const int seg = lv_list_segment(i, n_sub, max_deg, with_hubs, indptr, ids, kdeg);
+    const int seg = lv_list_segment(i, n_sub, thr, with_hubs, indptr, ids, kdeg);
     if (seg >= 0) flag[(int64_t)seg * (r1 - r0) + (i - r0)] = 1;
 }
 
-__global__ void k_lv_list_fill(int64_t r0, int64_t r1, int n_sub, int max_deg, int with_hubs,
+__global__ void k_lv_list_fill(int64_t r0, int64_t r1, int n_sub, LvThr thr, int with_hubs,
                                const int64_t *__restrict__ indptr, const int32_t *__restrict__ ids,
                                const int64_t *__restrict__ kdeg, const int64_t *__restrict__ pos, NodeRec *__restrict__ list)
 {
     const int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r1) return;
-    const int seg = lv_list_segment(i, n_sub, max_deg, with_hubs, indptr, ids, kdeg);
+    const int seg = lv_list_segment(i, n_sub, thr, with_hubs, indptr, ids, kdeg);
     if (seg < 0) return;
     NodeRec rec;
     rec.node = (int32_t)i;
@@ -733,7 +935,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
                                                       const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
                                                       const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
                                                       const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
-                                                      int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out, int32_t epoch)
+                                                      int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out, int32_t epoch, int xcd)
 {
     constexpr int CAP = 512;                       // >= 1.25 * LPR * UN + 1
     constexpr int LG = 9;
@@ -751,15 +953,26 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
     for (int t = lane; t < CAP; t += 64) { keys[t] = EMPTY; vals[t] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
-    const int64_t step = (int64_t)gridDim.x * WPB * RPW;
+    // XCD-aware numbering (round 4): workgroup b runs on XCD b mod 8, and every XCD has its own 4 MB L2.  With xcd set (a grid of a
+    // multiple of eight workgroups) XCD k walks the k-th EIGHTH of the list -- the list is in row order, i.e. in locality order, so
+    // the labels, degrees and totals its gathers touch are one slice of those vectors, which its L2 can hold -- instead of every
+    // XCD seeing all of all three (FETCH_SIZE of an unpruned sub-round at C3: 2.0 GB against 0.69 GB algorithmic).
+    int64_t step = (int64_t)gridDim.x * WPB * RPW;
     int64_t pos = ((int64_t)blockIdx.x * WPB + wib) * RPW + sub;
+    int64_t cnt_end = cnt;
+    if (xcd) {
+        const int64_t k = blockIdx.x & 7, per = (cnt + 7) >> 3;
+        step = (int64_t)(gridDim.x >> 3) * WPB * RPW;
+        pos = k * per + ((int64_t)(blockIdx.x >> 3) * WPB + wib) * RPW + sub;
+        cnt_end = (k + 1) * per < cnt ? (k + 1) * per : cnt;
+    }
     // current node
     int32_t i = -1, a = 0;
     int deg = 0;
     long long ki = 0;
     int64_t start = 0;
     int32_t j[UN];
-    if (pos < cnt) {
+    if (pos < cnt_end) {
         const NodeRec rec = list[pos];
         i = rec.node;
         deg = rec.deg;
@@ -779,7 +992,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
         const int64_t posn = pos + step;
         NodeRec recn;
         recn.node = -1; recn.deg = 0; recn.start = 0;
-        if (i >= 0 && posn < cnt) recn = list[posn];
+        if (i >= 0 && posn < cnt_end) recn = list[posn];
         // 2. community gathers and weights of the current node, own-community total
         int32_t cm[UN];
         u64 qv[UN];
@@ -909,13 +1122,19 @@ template <int LPR, int UN>
 __global__ void __launch_bounds__(BLK) k_lv_first_g(int64_t cnt, const NodeRec *__restrict__ list, u64 m2,
                                                      const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
                                                      const int64_t *__restrict__ kdeg, const int32_t *__restrict__ com,
-                                                     const int32_t *__restrict__ csize, int32_t *__restrict__ nxt)
+                                                     const int32_t *__restrict__ csize, int32_t *__restrict__ nxt, int xcd)
 {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, sl = lane % LPR;
-    const int64_t step = (int64_t)gridDim.x * WPB * RPW;
+    int64_t step = (int64_t)gridDim.x * WPB * RPW;
     int64_t pos = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * RPW + sub;
+    if (xcd) {                                   // XCD k walks the k-th eighth of the list (see k_lv_decide_g)
+        const int64_t k = blockIdx.x & 7, per = (cnt + 7) >> 3;
+        step = (int64_t)(gridDim.x >> 3) * WPB * RPW;
+        pos = k * per + ((int64_t)(blockIdx.x >> 3) * WPB + (threadIdx.x >> 6)) * RPW + sub;
+        cnt = (k + 1) * per < cnt ? (k + 1) * per : cnt;
+    }
     // software pipeline as in k_lv_decide_g: record, entries and own label of the group's NEXT node are requested while the
     // gathers of the current one are in flight
     int32_t i = -1, a = 0;
@@ -1716,12 +1935,15 @@ struct Events {
         hipEvent_t e = ctx->ev_get();
         if (e) { (void)hipEventRecord(e, s); ev.push_back(e); }
     }
-    double total_ms()
+    double total_ms(size_t first_pairs = 0, double *first_ms = nullptr)
     {
         double ms = 0;
         for (size_t i = 0; i + 1 < ev.size(); i += 2) {
             float f = 0;
-            if (hipEventElapsedTime(&f, ev[i], ev[i + 1]) == hipSuccess) ms += f;
+            if (hipEventElapsedTime(&f, ev[i], ev[i + 1]) == hipSuccess) {
+                ms += f;
+                if (first_ms && i / 2 < first_pairs) *first_ms += f;
+            }
         }
         for (auto e : ev) ctx->ev_put(e);
         ev.clear();
@@ -1967,14 +2189,26 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int64_t maxdeg = (int64_t)hc[7];
         if (m2 == 0) break;   // no links: every node alone (generate_dendrogram special case)
 
-        // LDS table capacity per wave for this level; nodes beyond it use the global table
-        const int64_t need = 1ll << table_lg(maxdeg);
+        // ---- row-length classes of this level (see lv_list_segment) ----
+        const double avgdeg = (double)g.nnz / (double)n;
+        const int short_max = avgdeg * 1.3 <= 32 ? 32 : avgdeg * 1.3 <= 64 ? 64 : avgdeg * 1.3 <= 128 ? 128 : 256;
+        const bool grouped = n >= 4096 && !CFG.on("B3C_LV_NO_GROUPED");
+        const int64_t nloc = r1 - r0;
+        const bool need_wave_kernel = !grouped || maxdeg > short_max;
+        // round 4: rows beyond the grouped kernel's reach get one WORKGROUP each with a table in LDS (k_lv_decide_wg: up to 6553
+        // entries); the wave-per-node kernel keeps the rows of up to 409 entries (512-slot tables: six workgroups per CU) and the
+        // levels that have no node lists.  B3C_LV_NO_WG=1: round 3's split (wave kernel up to the mega threshold).
+        const bool use_wg = grouped && !CFG.on("B3C_LV_NO_WG");
         // LDS table of the wave-per-node kernel: 12 bytes per slot and wave, four waves per workgroup -- 2048 slots are 96 KB, ONE
         // workgroup per CU.  B3C_LV_CAP_MAX clamps it (nodes beyond the cap use their global table): see DESIGN.md section 4
+        const int64_t wave_max = use_wg ? std::min<int64_t>(maxdeg, 409) : maxdeg;
+        const int64_t need = 1ll << table_lg(wave_max);
         const int cap_max = (int)CFG.num("B3C_LV_CAP_MAX", 2048);
         const int cap0 = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
         const int cap = cap0 > cap_max ? cap_max : cap0;
-        hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap, g.indptr, gsz.p);
+        // rows whose table does not fit the LDS of the kernel that takes them use a table in global memory (goff / gkeys / gvals)
+        const int cap_tbl = use_wg ? (1 << 13) : cap;
+        hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap_tbl, g.indptr, gsz.p);
         if ((rc = b3c_exclusive_scan_i64(ctx, gsz.p, goff.p, n + 1))) { free_graph(ctx, g); return rc; }
         int64_t gtab = 0;
         { const int rb_ = b3c_readback(ctx, &gtab, goff.p + n, sizeof(int64_t)); if (rb_) return rb_; }
@@ -1986,48 +2220,56 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(gvals.p, 0, sizeof(u64) * (size_t)gtab, s));
         }
 
-        // node lists of the grouped kernel: per sub-round, the nodes of this rank with at most `short_max` entries
-        const double avgdeg = (double)g.nnz / (double)n;
-        const int short_max = avgdeg * 1.3 <= 32 ? 32 : avgdeg * 1.3 <= 64 ? 64 : avgdeg * 1.3 <= 128 ? 128 : 256;
-        const bool grouped = n >= 4096 && !CFG.on("B3C_LV_NO_GROUPED");
-        const int64_t nloc = r1 - r0;
-        const bool need_wave_kernel = !grouped || maxdeg > short_max;
-        // grouped lists and, behind them, the hubs the grouped kernel leaves out (usually a handful): one flag pass, one
-        // scan, one fill, one read-back of the boundaries for all sub-rounds
+        // node lists: per sub-round, the nodes of this rank by row-length class: one flag pass, one scan, one fill, one read-back
+        // of the boundaries for all sub-rounds
         DevBuf<NodeRec> lists(ctx, grouped ? nloc + 1 : 1);
         const NodeRec *nlist_p = lists.p;
-        std::vector<int64_t> loff(n_sub + 1, 0), hoff(n_sub + 1, 0), moff(n_sub + 1, 0), lend(n_sub + 1, 0);
-        // rows beyond mega_deg entries get workgroups (k_lv_mega_*); they need the node's global table, i.e. more entries than the LDS table
-        // From how many entries on?  The wave kernel copes with long rows as long as there are enough of them to fill the chip (C5:
-        // thousands of hub contigs; handing those to the workgroup kernels and their global tables cost the stage 309 -> 346 ms);
-        // a FEW long rows are the tail everybody waits for (the surveyed genome-size law at level 1: 146 -> 141 ms with 2048).
+        // off[r][k] .. off[r][k + 1]: segment k of sub-round r in the common list (k = 0 grouped, 1 wave kernel, 2 .. 4 workgroup
+        // kernel, 5 mega rows)
+        std::vector<std::array<int64_t, LV_SEGS + 1>> off(n_sub);
+        for (auto &o : off) o.fill(0);
+        // rows beyond mega_deg entries get workgroups and the node's table in global memory (k_lv_mega_*).  With the workgroup
+        // kernel: whatever its largest LDS table cannot hold.  Without it (round 3's rule): the wave kernel copes with long rows as
+        // long as there are enough of them to fill the chip (C5: thousands of hub contigs), a FEW long rows are the tail everybody
+        // waits for.
         int64_t mega_auto = MEGA_DEG;
         if ((int64_t)hc[8] <= MEGA_FEW) mega_auto = 2048;
         else if ((int64_t)hc[9] <= MEGA_FEW) mega_auto = 4096;
-        const int mega_deg = (int)std::max<int64_t>(cap, CFG.num("B3C_LV_MEGA_DEG", mega_auto));
-        if (lv_debug) fprintf(stderr, "[b3c] level %d: %llu rows beyond 2048 entries, %llu beyond 4096, longest %lld: workgroup kernels from %d entries on\n",
-                                            (int)info->n_levels, (unsigned long long)hc[8], (unsigned long long)hc[9], (long long)maxdeg, mega_deg);
+        const int mega_deg = use_wg ? (int)std::min<int64_t>(lv_wg_max_deg(2), std::max<int64_t>(short_max, CFG.num("B3C_LV_MEGA_DEG", lv_wg_max_deg(2))))
+                                    : (int)std::max<int64_t>(cap, CFG.num("B3C_LV_MEGA_DEG", mega_auto));
+        LvThr thr;
+        thr.t[0] = short_max;
+        if (use_wg) {
+            thr.t[1] = std::min(mega_deg, std::max(short_max, 409));
+            thr.t[2] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(0)));
+            thr.t[3] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(1)));
+            thr.t[4] = mega_deg;
+        } else {
+            thr.t[1] = thr.t[2] = thr.t[3] = thr.t[4] = mega_deg;
+        }
+        if (lv_debug) fprintf(stderr, "[b3c] level %d: %lld nodes, %lld entries; %llu rows beyond 2048 entries, %llu beyond 4096, longest %lld: classes <= %d | %d | %d | %d | %d | mega\n",
+                              (int)info->n_levels, (long long)n, (long long)g.nnz, (unsigned long long)hc[8], (unsigned long long)hc[9], (long long)maxdeg,
+                              thr.t[0], thr.t[1], thr.t[2], thr.t[3], thr.t[4]);
         if (grouped) {
-            const int n_seg = need_wave_kernel ? 3 * n_sub : n_sub;
+            const int n_seg = need_wave_kernel ? LV_SEGS * n_sub : n_sub;
             const int64_t tot = (int64_t)n_seg * nloc + 1;
             DevBuf<int64_t> lflag(ctx, tot), lpos(ctx, tot), bnd(ctx, n_seg + 1);
             if (!lists.p || !lflag.p || !lpos.p || !bnd.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: node lists"); }
             const unsigned gl = (unsigned)((nloc + 255) / 256);
             HIP_TRY(ctx, hipMemsetAsync(lflag.p, 0, sizeof(int64_t) * (size_t)tot, s));
-            if (nloc) hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, short_max, need_wave_kernel ? mega_deg : 0, g.indptr, ids, kdeg.p, lflag.p);
+            if (nloc) hipLaunchKernelGGL(k_lv_list_flags, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, thr, need_wave_kernel ? 1 : 0, g.indptr, ids, kdeg.p, lflag.p);
             if ((rc = b3c_exclusive_scan_i64(ctx, lflag.p, lpos.p, tot))) { free_graph(ctx, g); return rc; }
-            if (nloc) hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, short_max, need_wave_kernel ? mega_deg : 0, g.indptr, ids, kdeg.p, lpos.p, lists.p);
+            if (nloc) hipLaunchKernelGGL(k_lv_list_fill, dim3(gl), dim3(256), 0, s, r0, r1, n_sub, thr, need_wave_kernel ? 1 : 0, g.indptr, ids, kdeg.p, lpos.p, lists.p);
             hipLaunchKernelGGL(k_lv_list_bounds, dim3(1), dim3(64), 0, s, n_seg, nloc, lpos.p, bnd.p);
             std::vector<int64_t> hb(n_seg + 1, 0);
             { const int rb_ = b3c_readback(ctx, hb.data(), bnd.p, sizeof(int64_t) * hb.size()); if (rb_) return rb_; }
-            // [loff[r], hoff[r]) grouped nodes of sub-round r, [hoff[r], moff[r]) its hubs, [moff[r], lend[r]) its mega rows
-            for (int r = 0; r < n_sub; r++) {
-                loff[r] = need_wave_kernel ? hb[3 * r] : hb[r];
-                hoff[r] = need_wave_kernel ? hb[3 * r + 1] : hb[r + 1];
-                moff[r] = need_wave_kernel ? hb[3 * r + 2] : hb[r + 1];
-                lend[r] = need_wave_kernel ? hb[3 * r + 3] : hb[r + 1];
-            }
+            for (int r = 0; r < n_sub; r++)
+                for (int k = 0; k <= LV_SEGS; k++)
+                    off[r][k] = need_wave_kernel ? hb[LV_SEGS * r + k] : hb[r + (k > 0 ? 1 : 0)];
         }
+        // [loff[r], hoff[r]) grouped nodes of sub-round r, [hoff[r], moff[r]) its hubs (by class: off[r][1 .. 5]), [moff[r], lend[r]) its mega rows
+        std::vector<int64_t> loff(n_sub + 1, 0), hoff(n_sub + 1, 0), moff(n_sub + 1, 0), lend(n_sub + 1, 0);
+        for (int r = 0; r < n_sub; r++) { loff[r] = off[r][0]; hoff[r] = off[r][1]; moff[r] = off[r][LV_SEGS - 1]; lend[r] = off[r][LV_SEGS]; }
 
         // full: recount the internal weight; otherwise ctr[2] was kept up to date by k_lv_delta_internal.  The sums are
         // launched before the move count of the sweep is known and come back with it in ONE read-back (a host round
@@ -2037,6 +2279,14 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // Row-sharded runs prune too (round 3): validity stamps replace the exchange the neighbours' own[] would need
         const bool can_prune = grouped && !CFG.on("B3C_LV_NO_PRUNE");
         const bool use_side = !CFG.on("B3C_LV_NO_SIDE");      // hubs / mega rows beside the grouped scan on side streams
+        const bool mega_lds = use_wg && !CFG.on("B3C_LV_NO_MEGA_LDS");
+        const bool xcd_lists = !CFG.on("B3C_LV_NO_XCD");
+        const size_t mega_lds_bytes = (size_t)(1 << MEGA_LDS_LG) * 12 + (MEGA_NT / 64) * 8;
+        if (use_wg) {
+            // tables beyond 64 KB of LDS are dynamic shared memory that a kernel must be allowed first (per device: set on every call)
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_lv_decide_wg<13, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv_wg_lds<13, 1024>()));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_lv_mega_insert_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mega_lds_bytes));
+        }
         int64_t *own_p = can_prune ? own.p : nullptr;
         const bool stamps = can_prune && dist;
         DevBuf<int32_t> stamp(ctx, stamps ? n : 1), tstamp(ctx, stamps ? n : 1);
@@ -2055,7 +2305,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if (!mega_own.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: mega rows");
         HIP_TRY(ctx, hipMemsetAsync(mega_own.p, 0, sizeof(u64) * (size_t)(max_mega + 1), s));
         DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1), plist_h(ctx, can_prune ? max_hlist + 1 : 1);
-        DevBuf<unsigned long long> pcnt(ctx, 2);          // [0] grouped nodes left after pruning, [1] hubs left
+        DevBuf<unsigned long long> pcnt(ctx, LV_SEGS);    // [0] grouped nodes left after pruning, [1 .. 4] hubs left, by class
         if (!plist.p || !plist_h.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
         auto modularity = [&](double *out, bool full, u64 *moved) -> int {
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
@@ -2114,7 +2364,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 epoch++;
                 evs.rec();
                 // (both pruned-list counters are cleared BEFORE the fork below: the side stream only waits for what precedes it)
-                if (incr && can_prune) HIP_TRY(ctx, hipMemsetAsync(pcnt.p, 0, sizeof(unsigned long long) * 2, s));
+                if (incr && can_prune) HIP_TRY(ctx, hipMemsetAsync(pcnt.p, 0, sizeof(unsigned long long) * LV_SEGS, s));
                 // many hub nodes or any mega row: they run on side streams BESIDE the grouped scan (both read the state of the
                 // sub-round's start and write nxt[] of their own nodes).  A handful of hubs (C3: 17 us of work) stays on the main
                 // stream: forking and joining costs as much as it hides (A/B at C3: 14.80 ms with, 14.70 without)
@@ -2143,14 +2393,19 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                         lst = plist.p;
                         cnt_dev = (const int64_t *)pcnt.p;
                     }
+                    // grids of a multiple of eight workgroups number their list positions XCD by XCD (see the kernel)
+#define LV_GRID_G(L) ([&]() { int g_ = grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu); if (xcd_lists && g_ >= 64) g_ = (g_ + 7) & ~7; return g_; }())
 #define LV_DECIDE_G(L, U)                                                                                                \
-    hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, cnt_dev, lst, \
-                       m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch)
+    { const int g_ = LV_GRID_G(L);                                                                                       \
+      hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(g_), dim3(BLK), 0, s, cntr, cnt_dev, lst,                            \
+                       m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch, \
+                       (xcd_lists && g_ >= 64) ? 1 : 0); }
                     if (sweep == 1 && r == 0 && !incr && !CFG.on("B3C_LV_NO_FIRST")) {
                         // every node is still alone: the table-free form (k_lv_first_g)
 #define LV_FIRST_G(L, U)                                                                                                 \
-    hipLaunchKernelGGL((k_lv_first_g<L, U>), dim3(grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, m2,     \
-                       g.indices, g.q, kdeg.p, com.p, csize.p, nxt_p)
+    { const int g_ = LV_GRID_G(L);                                                                                       \
+      hipLaunchKernelGGL((k_lv_first_g<L, U>), dim3(g_), dim3(BLK), 0, s, cntr, lst, m2,                                  \
+                       g.indices, g.q, kdeg.p, com.p, csize.p, nxt_p, (xcd_lists && g_ >= 64) ? 1 : 0); }
                         switch (short_max) {
                         case 256: LV_FIRST_G(64, 4); break;
                         case 128: LV_FIRST_G(16, 8); break;
@@ -2169,6 +2424,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     default: LV_DECIDE_G(4, 8); break;
                     }
 #undef LV_DECIDE_G
+#undef LV_GRID_G
                 }
                 const bool direct_level = !grouped && !dist && n <= LV_DIRECT_CAP && !CFG.on("B3C_LV_NO_DIRECT");
                 if (direct_level) {
@@ -2179,8 +2435,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (grouped && lend[r] > moff[r]) {       // mega rows: workgroups per node (side stream, beside the others)
                     const int64_t nm = lend[r] - moff[r];
                     const int chunks = (int)((maxdeg + MEGA_CHUNK - 1) / MEGA_CHUNK);
-                    hipLaunchKernelGGL(k_lv_mega_insert, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], chunks, g.indices, g.q,
-                                       com.p, goff.p, gkeys.p, gvals.p, mega_own.p);
+                    // from the second sweep on the chunk's entries are summed per community in LDS before they reach the node's table
+                    if (mega_lds && sweep > 1)
+                        hipLaunchKernelGGL(k_lv_mega_insert_lds, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), mega_lds_bytes, ms, nlist_p + moff[r], chunks, g.indices, g.q,
+                                           com.p, goff.p, gkeys.p, gvals.p, mega_own.p);
+                    else
+                        hipLaunchKernelGGL(k_lv_mega_insert, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], chunks, g.indices, g.q,
+                                           com.p, goff.p, gkeys.p, gvals.p, mega_own.p);
                     hipLaunchKernelGGL(k_lv_mega_eval, dim3((unsigned)nm), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], m2, kdeg.p, tot.p, com.p, csize.p,
                                        nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p);
                     if (ms != s && ms != hs) {
@@ -2189,31 +2450,52 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     }
                 }
                 if (!direct_level && need_wave_kernel && (!grouped || moff[r] > hoff[r])) {
-                    // all rows of this rank (small levels), or just the hubs the grouped kernel left out
-                    const NodeRec *hubs = grouped ? nlist_p + hoff[r] : nullptr;
-                    const int64_t w0 = grouped ? 0 : r0, w1 = grouped ? moff[r] - hoff[r] : r1;
-                    const int64_t *hcnt_dev = nullptr;
-                    if (grouped && incr && can_prune && !stamps && w1 >= PRUNE_MIN_HUBS) {
-                        // the hubs are pruned like the grouped nodes (round 3: on a heavy-tailed map with hundreds of entries per
-                        // row -- C5 -- most of the WEIGHT sits in rows beyond the grouped kernel's 256 entries, and scanning all of
-                        // them in every late sweep was 85 % of the stage).  Row-sharded runs keep scanning them: this kernel
-                        // does not refresh own[] / stamp[] (see k_lv_prune)
-                        hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(w1, BLK, 8 * ctx->n_cu)), dim3(BLK), 0, hs, w1, hubs, m2, kdeg.p,
-                                           wnl.p, own.p, tot.p, com.p, nxt_p, plist_h.p, pcnt.p + 1, stamp_p, tstamp_p);
-                        hubs = plist_h.p;
-                        hcnt_dev = (const int64_t *)(pcnt.p + 1);
+#define LV_DECIDE(C, W0, W1, HUBS, HCNT)                                                                                 \
+    hipLaunchKernelGGL(k_lv_decide<C>, dim3(grid_for((W1) - (W0), WPB, 16 * ctx->n_cu)), dim3(BLK), 0, hs, W0, W1, HUBS, -1, n_sub, r, m2, g.indptr, \
+                       g.indices, g.q, ids, kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p, HCNT)
+#define LV_DECIDE_CAP(W0, W1, HUBS, HCNT)                                                                                \
+    switch (cap) {                                                                                                       \
+    case 128: LV_DECIDE(128, W0, W1, HUBS, HCNT); break;                                                                 \
+    case 256: LV_DECIDE(256, W0, W1, HUBS, HCNT); break;                                                                 \
+    case 512: LV_DECIDE(512, W0, W1, HUBS, HCNT); break;                                                                 \
+    case 1024: LV_DECIDE(1024, W0, W1, HUBS, HCNT); break;                                                               \
+    default: LV_DECIDE(2048, W0, W1, HUBS, HCNT); break;                                                                 \
+    }
+                    if (!grouped) {
+                        // all rows of this rank (small levels)
+                        LV_DECIDE_CAP(r0, r1, (const NodeRec *)nullptr, (const int64_t *)nullptr);
+                    } else {
+                        // the hubs the grouped kernel left out, class by class: [1] one wave per node, [2 .. 4] one workgroup per node
+                        for (int k = 1; k < LV_SEGS - 1; k++) {
+                            const int64_t w1 = off[r][k + 1] - off[r][k];
+                            if (w1 <= 0) continue;
+                            const NodeRec *hubs = nlist_p + off[r][k];
+                            const int64_t *hcnt_dev = nullptr;
+                            if (incr && can_prune && !stamps && w1 >= PRUNE_MIN_HUBS) {
+                                // the hubs are pruned like the grouped nodes (round 3: on a heavy-tailed map with hundreds of entries per
+                                // row -- C5 -- most of the WEIGHT sits in rows beyond the grouped kernel's 256 entries, and scanning all of
+                                // them in every late sweep was 85 % of the stage).  Row-sharded runs keep scanning them: these kernels
+                                // do not refresh own[] / stamp[] (see k_lv_prune)
+                                NodeRec *pl = plist_h.p + (off[r][k] - off[r][1]);
+                                hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(w1, BLK, 8 * ctx->n_cu)), dim3(BLK), 0, hs, w1, hubs, m2, kdeg.p,
+                                                   wnl.p, own.p, tot.p, com.p, nxt_p, pl, pcnt.p + k, stamp_p, tstamp_p);
+                                hubs = pl;
+                                hcnt_dev = (const int64_t *)(pcnt.p + k);
+                            }
+                            if (k == 1 || !use_wg) {
+                                LV_DECIDE_CAP((int64_t)0, w1, hubs, hcnt_dev);
+                            } else {
+#define LV_DECIDE_WG(LGS, NT, MAXG)                                                                                      \
+    hipLaunchKernelGGL((k_lv_decide_wg<LGS, NT>), dim3((unsigned)std::min<int64_t>(w1, MAXG)), dim3(NT), (lv_wg_lds<LGS, NT>()), hs, w1, hcnt_dev,  \
+                       hubs, m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p)
+                                if (k == 2) LV_DECIDE_WG(10, 256, 16 * (int64_t)ctx->n_cu);
+                                else if (k == 3) LV_DECIDE_WG(12, 256, 6 * (int64_t)ctx->n_cu);
+                                else LV_DECIDE_WG(13, 1024, 2 * (int64_t)ctx->n_cu);
+#undef LV_DECIDE_WG
+                            }
+                        }
                     }
-                    const int gwh = grid_for(w1 - w0, WPB, 16 * ctx->n_cu);
-#define LV_DECIDE(C)                                                                                                     \
-    hipLaunchKernelGGL(k_lv_decide<C>, dim3(gwh), dim3(BLK), 0, hs, w0, w1, hubs, -1, n_sub, r, m2, g.indptr, g.indices, g.q, ids, \
-                       kdeg.p, tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p, hcnt_dev)
-                    switch (cap) {
-                    case 128: LV_DECIDE(128); break;
-                    case 256: LV_DECIDE(256); break;
-                    case 512: LV_DECIDE(512); break;
-                    case 1024: LV_DECIDE(1024); break;
-                    default: LV_DECIDE(2048); break;
-                    }
+#undef LV_DECIDE_CAP
 #undef LV_DECIDE
                 }
                 if (hub_side) {
@@ -2425,7 +2707,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     }
     free_graph(ctx, g);
     info->modularity = mod;
-    info->move_ms = evs.total_ms();
+    info->first_sweep_launches = evs.on ? std::min<int64_t>(n_sub, info->n_move_launch) : 0;
+    info->move_ms = evs.total_ms((size_t)info->first_sweep_launches, &info->first_sweep_ms);
     HIP_TRY(ctx, hipGetLastError());
     if (reorder) {
         DevBuf<int32_t> lo(ctx, n0);

@@ -89,6 +89,7 @@ class HotPathResult(object):
         self._n2o = self._o2n = None  # locality ordering on the device (int32 new2old, old2new), or None
         self.row_block = None       # (r0, r1): rows of the ordered map this rank formed and worked on (sharded run), else None
         self.work_nnz = None        # stored entries of the map this rank worked on
+        self.sub_nnz = None         # stored entries of the masked sub-map Louvain's level 0 ran on (this rank's rows when sharded)
 
     @property
     def perm(self):
@@ -137,7 +138,7 @@ STRICT_KR_ITER = 100      # strict_kr: balance again in the reference's own form
 
 
 def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=0, cluster=True, keep=False,
-                 reorder=True, mask=None, adopt_counts=False, max_iter=1000, strict_kr=False):
+                 reorder=True, mask=None, adopt_counts=False, max_iter=1000, strict_kr=None):
     """
     :param ctx: context from :func:`make_context`
     :param counts: _native.Mat (B3C_U32) raw symmetric contact counts, already in HBM
@@ -148,13 +149,19 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
     :param mask: bool[n] acceptance mask decided by the caller (ContactMap.primary_acceptance_mask); when
                  None it is computed here from lengths / min_len / min_sig
     :param max_iter: iteration limit of the balancing (sparse_utils.py:90, default 1000 like the reference)
-    :param strict_kr: when the balancing needed STRICT_KR_ITER iterations or more (an ill-conditioned map), repeat it on the
-                      explicitly normalised fp64 matrix -- the reference's own formulation (contact_map.py:933 then
-                      sparse_utils.py:90), 12 bytes per entry instead of 6 -- and return THAT x.  The count form perturbs the
-                      matrix entries by an ulp (1/s_i * 1/s_j against 1/(s_i s_j)); on tiny maps with ~2 contacts per row that
-                      has moved x by 3e-6 once in 1700 (tests/golden/illcond_kr_counts.npz), next to a spread of the reference
-                      against itself of up to 9e-4 on such maps (tests/test_kr_spread.py).  Off by default: it doubles the
-                      balancing time exactly where that is longest, for digits the algorithm does not determine.
+    :param strict_kr: which formulation of the balancing returns x.  The count form (b3c_kr_balance_counts: raw counts, the two
+                      1/s factors folded into operand and epilogue, 6 bytes per entry) perturbs every matrix entry by an ulp
+                      (1/s_i * 1/s_j against 1/(s_i s_j)); on a tiny ill-conditioned map that has moved x by 3e-6 once in 1700
+                      (tests/golden/illcond_kr_counts.npz: the reference's two environments agree to 8e-9 there), beyond the
+                      1e-6 contract.  The reference's own formulation (contact_map.py:933 then sparse_utils.py:90: explicit
+                      fp64 matrix, 12 bytes per entry, b3c_site_norm + b3c_kr_balance) stays within 4.3e-7 on all 1715 stable
+                      maps of the campaign (tools/fuzz_ill.py).
+                      None (default): maps below REORDER_MIN_NNZ entries -- where the count form buys nothing: the whole
+                      balancing is launch latency -- are balanced in the reference's formulation; larger maps in the count form
+                      (x within 1e-9 of the reference on every fixture and at C2 / C3).
+                      True: in addition, a larger map that needed STRICT_KR_ITER iterations or more is balanced AGAIN in the
+                      reference's formulation and that x is returned (doubles the balancing time where it is longest).
+                      False: the count form whatever the size.
     :param adopt_counts: the result takes `counts` over (frees it with res.free()); with keep=True the balanced map can then
                          still be formed on demand when no ordered copy was made
     :return: HotPathResult (device matrices freed unless keep=True)
@@ -207,9 +214,18 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
             # mirror lookups; otherwise exactly as scipy does.
             t0 = time.perf_counter()
             x_w = torch.empty(n, dtype=torch.float64, device=dev)
-            rc, _, res.kr_info = ctx.kr_balance_counts(work, sites_t, tol=tol, max_iter=max_iter, x_out=x_w, check=False)
             res.kr_strict = False
-            if strict_kr and rc in (0, _native.E_NOCONV) and res.kr_info.n_iter >= STRICT_KR_ITER:
+            if strict_kr is not False and block is None and work.nnz < REORDER_MIN_NNZ:
+                # small map: the reference's own formulation (explicit fp64 matrix) -- see strict_kr
+                nm = ctx.site_norm(work, sites_t)
+                try:
+                    rc, _, res.kr_info = ctx.kr_balance(nm, tol=tol, max_iter=max_iter, x_out=x_w, check=False)
+                finally:
+                    nm.free()
+                res.kr_strict = True
+            else:
+                rc, _, res.kr_info = ctx.kr_balance_counts(work, sites_t, tol=tol, max_iter=max_iter, x_out=x_w, check=False)
+            if strict_kr is True and not res.kr_strict and rc in (0, _native.E_NOCONV) and res.kr_info.n_iter >= STRICT_KR_ITER:
                 first = res.kr_info
                 nm = ctx.site_norm(work, sites_t)
                 try:
@@ -349,6 +365,7 @@ def _cluster_stage(ctx, res, mask_w, n_sub=0):
         res.sub = sub
     # a rank of a row-sharded run decides from the GLOBAL entry count: its own block may be empty (all its rows masked) while
     # the others still cluster, and the calls below are collective over the ranks
+    res.sub_nnz = sub.nnz
     nnz_all = sub.nnz if res.row_block is None else int(ctx.dist_max(float(sub.nnz)))
     if sub.n == 0 or nnz_all == 0:
         # nothing passed the acceptance mask: the reference raises NoneAcceptedException one level up

@@ -77,6 +77,9 @@ typedef struct {
     int64_t n_comm_level0; /* communities level 0 ended with (later levels merge them: n_comm is the final count) */
     int64_t agg_gathered_runs; /* row blocks, levels with more communities than the bin table holds: (community pair,
                                 * weight) runs gathered over the ranks for the second reduction; 0 otherwise */
+    double first_sweep_ms;     /* the part of move_ms spent in the FIRST sweep of level 0: its n_sub launches scan every row
+                                * (no node can be settled without its row yet), the honest figure for a roofline */
+    int64_t first_sweep_launches;
 } b3c_louvain_info;
 
 /* ---- context ------------------------------------------------------------------------------- */

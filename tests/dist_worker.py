@@ -169,6 +169,7 @@ def gpu_many_mode(rank, world):
     single2 = run_hot_path(ctx, c2, sm2.sites, sm2.lengths, 1000, 5)
     for env in ({'B3C_LV_AGG_SORT': '1'}, {'B3C_LV_NO_PRUNE': '1'}, {}):
         os.environ.update(env)
+        ctx.reload_env()
         sess = DistSession(ctx, sm2.n)
         res2 = run_hot_path(ctx, c2, sm2.sites, sm2.lengths, 1000, 5)
         sess.check()
@@ -178,6 +179,7 @@ def gpu_many_mode(rank, world):
         sess.close()
         for k in env:
             os.environ.pop(k)
+        ctx.reload_env()
     c2.free()
     counts.free()
     assert res.lv_info.n_comm_level0 == single.lv_info.n_comm_level0

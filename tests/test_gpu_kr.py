@@ -321,11 +321,13 @@ def test_kr_4d_wrapper(ctx):
     np.testing.assert_allclose(np.asarray(back.sum(axis=1)).ravel(), 1.0, atol=5e-6)
 
 
-def test_ill_conditioned_map_count_form_and_strict_mode(ctx):
+def test_ill_conditioned_map_count_form_and_default_path(ctx):
     """tests/golden/illcond_kr_counts.npz (tools/make_golden3.py): 64 contigs, 126 entries, 262 iterations, 20 bound cuts.  The
     reference's two environments agree on x to 8e-9; the count form of the device balance was recorded 3.2e-6 away, the explicit
-    fp64 form 6e-9.  (1) Both device forms reproduce the iteration count and balance the map; (2) run_hot_path(strict_kr=True)
-    returns the fp64 form's x -- inside the reference's 1e-6 contract -- because the map needed >= 100 iterations."""
+    fp64 form 6e-9.  (1) Both device forms reproduce the iteration count and balance the map; (2) the DEFAULT product path --
+    run_hot_path with default arguments, and ContactMap.prepare_seq_map over it -- balances a map of this size in the
+    reference's own formulation and returns x inside the 1e-6 contract; the count form stays
+    available (strict_kr=False) and, on maps too large for the default rule, strict_kr=True repeats the balance in fp64."""
     import scipy.sparse as sp
     from bin3c_amd.pipeline import run_hot_path
     z = np.load(os.path.join(GOLDEN, 'illcond_kr_counts.npz'))
@@ -347,12 +349,21 @@ def test_ill_conditioned_map_count_form_and_strict_mode(ctx):
     assert rc == 0 and info_f.n_iter == int(z['n_iter_ref'])
     assert rel(x_f, z['x_ref_a']) < 1e-6 and rel(x_f, z['x_ref_b']) < 1e-6
     lengths = np.full(n, 5000)
-    loose = run_hot_path(ctx, counts, sites, lengths, 1000, 0, cluster=False, max_iter=400)
+    loose = run_hot_path(ctx, counts, sites, lengths, 1000, 0, cluster=False, max_iter=400, strict_kr=False)
+    default = run_hot_path(ctx, counts, sites, lengths, 1000, 0, cluster=False, max_iter=400)
     strict = run_hot_path(ctx, counts, sites, lengths, 1000, 0, cluster=False, max_iter=400, strict_kr=True)
-    assert not loose.kr_strict and strict.kr_strict
-    assert np.array_equal(loose.x, x_c) and np.array_equal(strict.x, x_f)
-    assert rel(strict.x, z['x_ref_a']) < 1e-6
+    assert not loose.kr_strict and default.kr_strict and strict.kr_strict
+    assert np.array_equal(loose.x, x_c) and np.array_equal(default.x, x_f) and np.array_equal(strict.x, x_f)
+    assert default.kr_info.n_iter == int(z['n_iter_ref']) and default.kr_info.bitwise_symmetric == 1
+    assert rel(default.x, z['x_ref_a']) < 1e-6 and rel(default.x, z['x_ref_b']) < 1e-6
     counts.free()
+    # ... and through the reference's own call surface: ContactMap.prepare_seq_map(norm=True, bisto=True) (contact_map.py:911-945)
+    from bin3c_amd.mzd.contact_map import ContactMap
+    cm = ContactMap.from_arrays(sp.csr_matrix((cnt, ix, ip), shape=(n, n)), lengths, sites, min_len=1000, min_sig=1)
+    cm._ctx = ctx
+    cm.primary_acceptance_mask = np.ones(n, dtype=bool)
+    cm.prepare_seq_map(norm=True, bisto=True)
+    assert rel(cm.bisto_scale, z['x_ref_a']) < 1e-6 and rel(cm.bisto_scale, z['x_ref_b']) < 1e-6
 
 
 def test_reference_spread_maps_device_balances_them(ctx):

@@ -164,8 +164,30 @@ def test_mega_rows_take_the_workgroup_kernel(ctx, oracle_lib):
     _assert_same(ref, labels, info)
 
 
+def test_rows_of_every_length_class(ctx, oracle_lib):
+    """Round 4: rows beyond the grouped kernel's reach get one workgroup each with a table of 1024 / 4096 / 8192 slots in LDS
+    (k_lv_decide_wg), rows of up to 409 entries stay with the wave-per-node kernel, rows beyond 6553 are mega rows whose chunks
+    are summed per community in LDS before they reach the node's global table (k_lv_mega_insert_lds, from the second sweep on).
+    Stars on either side of every class boundary on a noisy ring of cliques (several levels, so the classes also meet the rows of
+    the induced graphs): labels, sweep and level counts and the exact modularity equal the scalar schedule's."""
+    rs = np.random.RandomState(17)
+    n, edges = graphs.ring_of_cliques(4000, 6, 1.0, 0.2)
+    m = len(edges)
+    a = rs.randint(0, n, m // 2)
+    b = rs.randint(0, n, m // 2)
+    edges += [(int(i), int(j), float(rs.uniform(0.2, 1.0))) for i, j in zip(a, b) if i != j]
+    degs = (300, 409, 410, 700, 819, 820, 1500, 3276, 3277, 5000, 6553, 6554, 9000, 23000)
+    for t, deg in enumerate(degs):
+        edges += [(n + t, int(v), float(rs.uniform(0.01, 0.5))) for v in rs.choice(n, deg, replace=False)]
+    ip, ix, w = graphs.csr_from_edges(n + len(degs), edges)
+    ref, labels, info = _run_both(ctx, oracle_lib, ip, ix, w, 1.0 / w.max())
+    _assert_same(ref, labels, info)
+    assert info.n_levels >= 2 and info.n_sweeps >= 6
+
+
 @pytest.mark.parametrize('env', [{'B3C_LV_NO_FIRST': '1'}, {'B3C_LV_NO_AGG_ORDER': '1', 'B3C_LV_NO_AGG_LONG': '1'},
-                                 {'B3C_LV_MEGA_DEG': '2048'}, {'B3C_LV_MEGA_DEG': '100000'}, {'B3C_LV_NO_INTERNAL_LONG': '1'}])
+                                 {'B3C_LV_MEGA_DEG': '2048'}, {'B3C_LV_MEGA_DEG': '100000'}, {'B3C_LV_NO_INTERNAL_LONG': '1'},
+                                 {'B3C_LV_NO_WG': '1'}, {'B3C_LV_NO_WG': '1', 'B3C_LV_MEGA_DEG': '2048'}, {'B3C_LV_NO_MEGA_LDS': '1'}])
 def test_kernel_choices_do_not_show_in_the_result(ctx, oracle_lib, monkeypatch, env):
     """Round 3's per-level kernel choices -- the table-free first sub-round, the bin aggregation in community order and its
     long rows by workgroups, the entry count from which a row gets workgroups (automatic: by the number of such rows), the
