@@ -42,7 +42,8 @@ class LouvainInfo(C.Structure):
 class B3CDist(C.Structure):
     _fields_ = [('rank', C.c_int32), ('world', C.c_int32), ('chunk', C.c_int64), ('vec', C.c_void_p),
                 ('scal', C.c_void_p), ('labels', C.c_void_p), ('isum', C.c_void_p), ('allgather', C.c_void_p),
-                ('user', C.c_void_p), ('comm', C.c_void_p), ('allreduce', C.c_void_p)]
+                ('user', C.c_void_p), ('comm', C.c_void_p), ('allreduce', C.c_void_p), ('starts', C.c_void_p),
+                ('allgatherv', C.c_void_p)]
 
 
 # structs that cross the ABI, by the `which` of b3c_abi_layout
@@ -86,6 +87,7 @@ SYMBOLS = [
     ('b3c_mat_upload', C.c_int, [_VP, C.c_int64, C.c_int64, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]),
     ('b3c_mat_free', C.c_int, [_VP, _VP]),
     ('b3c_mat_info', C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ('b3c_mat_row_nnz', C.c_int, [_VP, _VP, _VP, _VP]),
     ('b3c_mat_download', C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     ('b3c_mat_device_ptrs', C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     ('b3c_max_offdiag_u32', C.c_int, [_VP, _VP, C.c_int, _VP]),
@@ -364,6 +366,13 @@ class Context(object):
         n = idx.numel() if hasattr(idx, 'numel') else len(idx)
         esz = src.element_size() if hasattr(src, 'element_size') else src.dtype.itemsize
         self._check(self.lib.b3c_vec_permute(self.h, int(n), int(esz), _ptr(src), _ptr(idx), _ptr(out), 1 if scatter else 0))
+        return out
+
+    def row_nnz(self, mat, idx=None, out=None):
+        """stored entries of the rows of `mat`, in the order idx (int32 tensor / array) or row order -> out (int64)"""
+        if out is None:
+            out = np.empty(mat.n, dtype=np.int64)
+        self._check(self.lib.b3c_mat_row_nnz(self.h, mat.h, _ptr(idx) if idx is not None else None, _ptr(out)))
         return out
 
     def site_norm(self, counts, sites):

@@ -27,7 +27,7 @@ extern "C" int b3c_abi_layout(int which, int32_t *out, int cap)
     static const int32_t ds[] = {(int32_t)sizeof(b3c_dist), 0,
                                  F(b3c_dist, rank), F(b3c_dist, world), F(b3c_dist, chunk), F(b3c_dist, vec), F(b3c_dist, scal),
                                  F(b3c_dist, labels), F(b3c_dist, isum), F(b3c_dist, allgather), F(b3c_dist, user),
-                                 F(b3c_dist, comm), F(b3c_dist, allreduce)};
+                                 F(b3c_dist, comm), F(b3c_dist, allreduce), F(b3c_dist, starts), F(b3c_dist, allgatherv)};
 #undef F
     const int32_t *src = which == B3C_ABI_KR_INFO ? kr : which == B3C_ABI_LOUVAIN_INFO ? lv : which == B3C_ABI_DIST ? ds : nullptr;
     const int len = which == B3C_ABI_KR_INFO ? (int)(sizeof(kr) / 4) : which == B3C_ABI_LOUVAIN_INFO ? (int)(sizeof(lv) / 4)
@@ -131,6 +131,20 @@ extern "C" int b3c_ctx_set_dist(b3c_ctx *ctx, const b3c_dist *dist)
         !dist->vec || !dist->scal || !dist->labels || !dist->isum)
         return ctx->fail(B3C_E_ARG, "b3c_ctx_set_dist: bad argument");
     ctx->dist = *dist;
+    ctx->dist_starts.clear();
+    if (dist->starts) {
+        // the caller's array is copied (the library never retains caller memory) and checked: ascending, from 0, inside the buffers
+        ctx->dist_starts.assign(dist->starts, dist->starts + dist->world + 1);
+        bool ok = ctx->dist_starts[0] == 0 && ctx->dist_starts[dist->world] <= (int64_t)dist->world * dist->chunk;
+        for (int r = 0; r < dist->world; r++) ok = ok && ctx->dist_starts[r] <= ctx->dist_starts[r + 1];
+        if (!ok || (!dist->comm && !dist->allgatherv)) {
+            ctx->dist_starts.clear();
+            ctx->dist.starts = nullptr;
+            ctx->has_dist = false;
+            return ctx->fail(B3C_E_ARG, "b3c_ctx_set_dist: bad row ranges");
+        }
+        ctx->dist.starts = ctx->dist_starts.data();
+    }
     // B3C_DIST_FORCE: run the sharded code path (callbacks, exchange buffers) with a single rank too -- a test hook that
     // lets one GPU exercise the RCCL plumbing of the caller
     ctx->has_dist = dist->world > 1 || (dist->world == 1 && CFG.on("B3C_DIST_FORCE"));

@@ -78,6 +78,19 @@ struct b3c_ctx {
     }
     void *pin = nullptr;      // pinned host staging for small read-backs (a pageable destination costs a staged copy)
     b3c_dist dist;            // row-sharded multi-GPU execution (b3c_ctx_set_dist); world <= 1: off
+    std::vector<int64_t> dist_starts;   // the library's copy of b3c_dist.starts (dist.starts points here), empty: equal ranges
+    // rows [*r0, *r1) of rank `rank` of an n-row matrix under the installed sharding
+    void dist_rows(int64_t n, int rank, int64_t *r0, int64_t *r1) const
+    {
+        if (dist.starts) {
+            *r0 = dist.starts[rank] < n ? dist.starts[rank] : n;
+            *r1 = dist.starts[rank + 1] < n ? dist.starts[rank + 1] : n;
+            if (rank == dist.world - 1) *r1 = n;
+        } else {
+            *r0 = (int64_t)rank * dist.chunk < n ? (int64_t)rank * dist.chunk : n;
+            *r1 = *r0 + dist.chunk < n ? *r0 + dist.chunk : n;
+        }
+    }
     bool has_dist = false;
     int64_t n_exchanges = 0;  // collectives issued (b3c_dist_exchange)
 
@@ -285,6 +298,7 @@ __device__ __forceinline__ void block_atomic_add_u64(long long v, unsigned long 
 int b3c_dist_exchange(b3c_ctx *ctx, int buf);   // in-place all-gather of an exchange buffer: RCCL or the caller's callback
 int b3c_dist_allreduce_u64(b3c_ctx *ctx, void *dev, int64_t count);
 int b3c_dist_allgather_rows(b3c_ctx *ctx, void *full, int esz, const int64_t *starts_host, const int64_t *starts_dev);
+int b3c_dist_allgatherv(b3c_ctx *ctx, void *base, int esz, const int64_t *starts_host);   // ragged, in place
 // ragged gather of (key, value) pairs of 64-bit words; *out: pooled block of 2 * *total words (keys of all ranks in rank
 // order, then the values), released by the caller with ctx->release
 int b3c_dist_gather_pairs(b3c_ctx *ctx, const int64_t *keys, const int64_t *vals, int64_t cnt, int64_t **out, int64_t *total);

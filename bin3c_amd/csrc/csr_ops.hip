@@ -348,6 +348,33 @@ extern "C" int b3c_vec_permute(b3c_ctx *ctx, int64_t n, int elem_bytes, const vo
     return b3c_copy_out_lazy(ctx, dst, dd.p, (size_t)n * elem_bytes);
 }
 
+namespace {
+__global__ void k_row_nnz(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ idx, int64_t *__restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t r = idx ? idx[k] : k;
+    out[k] = indptr[r + 1] - indptr[r];
+}
+}  // namespace
+
+extern "C" int b3c_mat_row_nnz(b3c_ctx *ctx, const b3c_mat *m, const int32_t *idx, int64_t *out)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!m || !out) return ctx->fail(B3C_E_ARG, "b3c_mat_row_nnz: bad argument");
+    const int64_t n = m->n;
+    if (n == 0) return B3C_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<int64_t> dd(ctx, n);
+    DevBuf<int32_t> di(ctx, idx ? n : 1);
+    if (!dd.p || !di.p) return ctx->fail(B3C_E_NOMEM, "b3c_mat_row_nnz");
+    int rc;
+    if (idx && (rc = b3c_copy_in(ctx, di.p, idx, sizeof(int32_t) * (size_t)n))) return rc;
+    hipLaunchKernelGGL(k_row_nnz, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, m->indptr, idx ? di.p : nullptr, dd.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return b3c_copy_out(ctx, out, dd.p, sizeof(int64_t) * (size_t)n);
+}
+
 extern "C" int b3c_site_norm(b3c_ctx *ctx, const b3c_mat *counts, const double *sites, b3c_mat **out)
 {
     if (!ctx) return B3C_E_ARG;

@@ -20,6 +20,7 @@ typedef int (*fn_comm_init_rank)(void **, int, unsigned char[128], int);   // nc
 typedef int (*fn_comm_destroy)(void *);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_group)(void);
 typedef const char *(*fn_err)(int);
 
@@ -33,12 +34,13 @@ struct Rccl {
     fn_comm_destroy comm_destroy = nullptr;
     fn_all_gather all_gather = nullptr;
     fn_all_reduce all_reduce = nullptr;
+    fn_broadcast broadcast = nullptr;
     fn_group group_start = nullptr, group_end = nullptr;
     fn_err err = nullptr;
     bool ok = false;
 };
 
-constexpr int NCCL_INT32 = 2, NCCL_INT64 = 4, NCCL_UINT64 = 5, NCCL_FLOAT64 = 8;
+constexpr int NCCL_INT8 = 0, NCCL_INT32 = 2, NCCL_INT64 = 4, NCCL_UINT64 = 5, NCCL_FLOAT64 = 8;
 constexpr int NCCL_SUM = 0;
 
 Rccl *rccl()
@@ -56,10 +58,11 @@ Rccl *rccl()
     r.comm_destroy = (fn_comm_destroy)dlsym(r.h, "ncclCommDestroy");
     r.all_gather = (fn_all_gather)dlsym(r.h, "ncclAllGather");
     r.all_reduce = (fn_all_reduce)dlsym(r.h, "ncclAllReduce");
+    r.broadcast = (fn_broadcast)dlsym(r.h, "ncclBroadcast");
     r.group_start = (fn_group)dlsym(r.h, "ncclGroupStart");
     r.group_end = (fn_group)dlsym(r.h, "ncclGroupEnd");
     r.err = (fn_err)dlsym(r.h, "ncclGetErrorString");
-    r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_gather && r.all_reduce && r.group_start && r.group_end;
+    r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_gather && r.all_reduce && r.broadcast && r.group_start && r.group_end;
     return &r;
 }
 
@@ -118,27 +121,84 @@ extern "C" int b3c_dist_comm_destroy(b3c_ctx *ctx, void *comm)
     return rc == 0 ? B3C_OK : rccl_fail(ctx, "ncclCommDestroy", rc);
 }
 
-// All-gather exchange buffer `buf` in place (B3C_BUF_SCAL_VEC: the scalar and the vector buffer, one grouped launch).
-int b3c_dist_exchange(b3c_ctx *ctx, int buf)
+namespace {
+// RCCL calls of a ragged in-place all-gather: rank r broadcasts its bytes [starts[r], starts[r + 1]) * esz of `base` to everybody.
+// Inside a group these are ONE launch (RCCL has no all-gather with per-rank counts; a group of broadcasts is its documented
+// equivalent).  The caller opens and closes the group.
+int ragged_calls(b3c_ctx *ctx, Rccl *r, void *base, int esz, const int64_t *starts)
+{
+    const b3c_dist &D = ctx->dist;
+    for (int k = 0; k < D.world; k++) {
+        const int64_t len = starts[k + 1] - starts[k];
+        if (len <= 0) continue;
+        char *p = (char *)base + starts[k] * esz;
+        const int rc = r->broadcast(p, p, (size_t)len * esz, NCCL_INT8, k, D.comm, ctx->stream);
+        if (rc != 0) return rccl_fail(ctx, "ncclBroadcast", rc);
+    }
+    return B3C_OK;
+}
+}  // namespace
+
+// Ragged in-place all-gather of a row-indexed vector: rank r owns elements [starts[r], starts[r + 1]) of `base` (esz 4 or 8).
+int b3c_dist_allgatherv(b3c_ctx *ctx, void *base, int esz, const int64_t *starts)
 {
     const b3c_dist &D = ctx->dist;
     ctx->n_exchanges++;
     if (!D.comm) {
+        if (!D.allgatherv) return ctx->fail(B3C_E_ARG, "ragged multi-GPU exchange without communicator or callback");
+        if (D.allgatherv(D.user, base, esz, starts, D.world) != 0) return ctx->fail(B3C_E_RCCL, "ragged all-gather callback failed");
+        return B3C_OK;
+    }
+    Rccl *r = rccl();
+    if (!r->ok) return ctx->fail(B3C_E_RCCL, "librccl.so.1 could not be loaded");
+    int rc = 0;
+    if ((rc = r->group_start()) != 0) return rccl_fail(ctx, "ncclGroupStart", rc);
+    if ((rc = ragged_calls(ctx, r, base, esz, starts))) return rc;
+    if ((rc = r->group_end()) != 0) return rccl_fail(ctx, "ncclGroupEnd", rc);
+    return B3C_OK;
+}
+
+// All-gather exchange buffer `buf` in place (B3C_BUF_SCAL_VEC: the scalar and the vector buffer, one grouped launch).  The scalar
+// and integer buffers are `world` equal slices; the vector and label buffers are indexed by contig row, every rank's slice being
+// its row range: equal slices of `chunk`, or -- with b3c_dist.starts -- the ragged ranges the caller balanced by stored entries.
+int b3c_dist_exchange(b3c_ctx *ctx, int buf)
+{
+    const b3c_dist &D = ctx->dist;
+    const bool ragged = D.starts != nullptr;
+    if (!D.comm) {
+        if (ragged && buf != B3C_BUF_SCAL && buf != B3C_BUF_ISUM) {
+            // callback transport with ragged ranges: the scalars by the slice callback, the row-indexed buffer by the ragged one
+            int rc = B3C_OK;
+            if (buf == B3C_BUF_SCAL_VEC) {
+                ctx->n_exchanges++;
+                if (!D.allgather || D.allgather(D.user, B3C_BUF_SCAL) != 0) return ctx->fail(B3C_E_RCCL, "all-gather callback failed (buffer %d)", B3C_BUF_SCAL);
+                ctx->n_exchanges--;               // (the pair counts as ONE exchange, as on the RCCL transport)
+            }
+            const bool lab = buf == B3C_BUF_LABELS;
+            rc = b3c_dist_allgatherv(ctx, lab ? (void *)D.labels : (void *)D.vec, lab ? 4 : 8, D.starts);
+            return rc;
+        }
+        ctx->n_exchanges++;
         if (!D.allgather) return ctx->fail(B3C_E_ARG, "multi-GPU exchange without communicator or callback");
         if (D.allgather(D.user, buf) != 0) return ctx->fail(B3C_E_RCCL, "all-gather callback failed (buffer %d)", buf);
         return B3C_OK;
     }
+    ctx->n_exchanges++;
     Rccl *r = rccl();
     if (!r->ok) return ctx->fail(B3C_E_RCCL, "librccl.so.1 could not be loaded");
     int ids[2] = {buf, -1};
     if (buf == B3C_BUF_SCAL_VEC) { ids[0] = B3C_BUF_SCAL; ids[1] = B3C_BUF_VEC; }
     int rc = 0;
-    const bool grouped = ids[1] >= 0;
+    const bool grouped = ids[1] >= 0 || (ragged && buf != B3C_BUF_SCAL && buf != B3C_BUF_ISUM);
     if (grouped && (rc = r->group_start()) != 0) return rccl_fail(ctx, "ncclGroupStart", rc);
     for (int k = 0; k < 2 && ids[k] >= 0; k++) {
         BufDesc d;
         if (!describe(D, ids[k], &d)) return ctx->fail(B3C_E_ARG, "unknown exchange buffer %d", ids[k]);
         const size_t esz = d.type == NCCL_INT32 ? 4 : 8;
+        if (ragged && (ids[k] == B3C_BUF_VEC || ids[k] == B3C_BUF_LABELS)) {
+            if ((rc = ragged_calls(ctx, r, d.p, (int)esz, D.starts))) return rc;
+            continue;
+        }
         // in place: the send buffer is this rank's slice of the receive buffer (NCCL/RCCL define this case)
         rc = r->all_gather((const char *)d.p + (size_t)D.rank * d.count * esz, d.p, d.count, d.type, D.comm, ctx->stream);
         if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
@@ -186,6 +246,8 @@ __global__ void k_unpack_slots(int world, int skip, int64_t slot_bytes, int esz,
 int b3c_dist_allgather_rows(b3c_ctx *ctx, void *full, int esz, const int64_t *starts_host, const int64_t *starts_dev)
 {
     const b3c_dist &D = ctx->dist;
+    // a transport that moves ragged slices gathers the vector where it stands
+    if (D.comm || D.allgatherv) return b3c_dist_allgatherv(ctx, full, esz, starts_host);
     const int64_t slot_bytes = D.chunk * 8;
     const int64_t mine = (starts_host[D.rank + 1] - starts_host[D.rank]) * esz;
     for (int r = 0; r < D.world; r++)
@@ -258,7 +320,7 @@ extern "C" int b3c_dist_max_f64(b3c_ctx *ctx, double *value)
     return B3C_OK;
 }
 
-// All-gather of a row-indexed int32 vector whose rank r owns [rank*chunk, (rank+1)*chunk) (clipped to n): `vec` (device or
+// All-gather of a row-indexed int32 vector of which rank r owns its row range (b3c_ctx::dist_rows): `vec` (device or
 // host, n elements) holds this rank's part on entry and everything on return.  Used for the per-contig signal of the mask.
 extern "C" int b3c_dist_allgather_i32(b3c_ctx *ctx, int32_t *vec, int64_t n)
 {
@@ -267,7 +329,8 @@ extern "C" int b3c_dist_allgather_i32(b3c_ctx *ctx, int32_t *vec, int64_t n)
     const b3c_dist &D = ctx->dist;
     if ((int64_t)D.world * D.chunk < n) return ctx->fail(B3C_E_ARG, "b3c_dist_allgather_i32: vector longer than the exchange buffers");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int64_t r0 = std::min<int64_t>(n, (int64_t)D.rank * D.chunk), r1 = std::min<int64_t>(n, r0 + D.chunk);
+    int64_t r0 = 0, r1 = 0;
+    ctx->dist_rows(n, D.rank, &r0, &r1);
     if (r1 > r0)
         HIP_TRY(ctx, hipMemcpyAsync(D.labels + r0, vec + r0, sizeof(int32_t) * (size_t)(r1 - r0), hipMemcpyDefault, ctx->stream));
     int rc = b3c_dist_exchange(ctx, B3C_BUF_LABELS);

@@ -1168,6 +1168,49 @@ __global__ void __launch_bounds__(256) kr_tails_emit(int64_t r0, int64_t r1, int
     }
 }
 
+// The sorted tail words once more, as 32-bit words (round 4).  kr_kb_tails streams 8 bytes per tail, and on a map where the
+// tails are most of the matrix -- the surveyed genome-size law: the five largest genomes hold 67 % of the contigs and a tile's
+// columns inside such a genome never repeat -- the pass runs at the rate HBM delivers those bytes (1.1 GB in 0.28 ms).  Inside
+// a group of 64 consecutive sorted words the columns lie close together, so a word shrinks to
+//      column - (smallest column of the group) << (rbits + 8) | row inside the super-tile << 8 | count
+// with one 32-bit base column per group; a word whose column is too far from the base (11 | 10 bits) or whose count needs more
+// than 8 bits stays a 64-bit word in a short residual list (its slot in the stream becomes a zero: no contribution), which the
+// kernel adds straight into the global row sums.  All sums are integer sums: x stays bit for bit what the 64-bit stream gives.
+constexpr int XT_PACK_CB = 8;           // count bits of a packed word
+__global__ void __launch_bounds__(256) kr_tails_pack(int64_t n_tails, int rbits, int cshift, uint32_t cmask,
+                                                      const unsigned long long *__restrict__ words, uint32_t *__restrict__ cw,
+                                                      uint32_t *__restrict__ hdr, unsigned long long *__restrict__ rwords,
+                                                      unsigned long long *__restrict__ n_res)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t groups = (n_tails + 63) >> 6;
+    const int db = 32 - rbits - XT_PACK_CB;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += (int64_t)gridDim.x * 4) {
+        const int64_t k = g * 64 + lane;
+        const bool valid = k < n_tails;
+        const unsigned long long w = valid ? words[k] : 0ull;
+        const uint32_t col = (uint32_t)(w >> cshift) & cmask;
+        uint32_t base = valid ? col : 0xFFFFFFFFu;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)base, o, 64);
+            base = t < base ? t : base;
+        }
+        const uint32_t c = (uint32_t)(w & 0xFFFFu), r = (uint32_t)(w >> 16) & ((1u << rbits) - 1u), d = col - base;
+        const bool fits = valid && c != 0 && d < (1u << db) && c < (1u << XT_PACK_CB);
+        const bool res = valid && c != 0 && !fits;
+        if (valid) cw[k] = fits ? (d << (rbits + XT_PACK_CB)) | (r << XT_PACK_CB) | c : 0u;
+        if (lane == 0) hdr[g] = base;
+        const unsigned long long m = __ballot(res);
+        if (m) {
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(n_res, (unsigned long long)__popcll(m));
+            at = (unsigned long long)__shfl((long long)at, 0, 64);
+            if (res) rwords[at + __popcll(m & ((1ull << lane) - 1ull))] = w;
+        }
+    }
+}
+
 template <int NT>
 __device__ double reduce_max_n(const double *__restrict__ part, int P, double *lds)
 {
@@ -1189,7 +1232,9 @@ __device__ double reduce_max_n(const double *__restrict__ part, int P, double *l
 __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__ sin, const double *__restrict__ pumax, int PU,
                                                       int lg_bound, int lo_bits, int chunks, int64_t n_tails, const int64_t *__restrict__ toff, int64_t r0, int64_t n,
                                                       int S, int rbits, uint32_t cmask, const unsigned long long *__restrict__ words, const double *__restrict__ u,
-                                                      unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex)
+                                                      unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex,
+                                                      const uint32_t *__restrict__ cw, const uint32_t *__restrict__ hdr,
+                                                      const unsigned long long *__restrict__ rwords, int64_t n_res, int st_shift)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long xt_lds[];
     unsigned long long *acc = xt_lds;                 // S 64-bit sums
@@ -1221,6 +1266,43 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
     const int64_t a = toff[ra - r0], b = rb >= n ? n_tails : toff[rb - r0];
     const int64_t len = (b - a + chunks - 1) / chunks;
     const int64_t s0 = a + ch * len, e0 = s0 + len < b ? s0 + len : b;
+    if (cw) {
+        // packed stream (kr_tails_pack): 4 bytes per tail + one base column per 64
+        for (int64_t k0 = s0 + threadIdx.x; k0 < e0; k0 += 4 * XT_NT) {
+            uint32_t w[4], hb[4];
+            double g[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t k = k0 + q * XT_NT;
+                w[q] = k < e0 ? cw[k] : 0u;
+                hb[q] = k < e0 ? hdr[k >> 6] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) g[q] = u[(hb[q] + (w[q] >> (rbits + XT_PACK_CB))) & cmask];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t c = w[q] & ((1u << XT_PACK_CB) - 1u);
+                if (c) {
+                    const double ps = (g[q] * (double)c) * scale;
+                    const long long f = __double2ll_rn(ps);
+                    const int l = __double2int_rn((ps - (double)f) * lo_scale);       // |.| <= 2^(lo_bits - 1)
+                    const uint32_t r = (w[q] >> XT_PACK_CB) & rmask;
+                    atomicAdd(&acc[r], (unsigned long long)f);
+                    if (l) atomicAdd(&lo[r], l);
+                }
+            }
+        }
+        // the few words that did not fit: straight into the global row sums (integer atomics: order-free)
+        for (int64_t j = (int64_t)blockIdx.x * XT_NT + threadIdx.x; j < n_res; j += (int64_t)gridDim.x * XT_NT) {
+            const unsigned long long w = rwords[j];
+            const double ps = (u[(uint32_t)(w >> cshift) & cmask] * (double)(uint32_t)(w & 0xFFFFu)) * scale;
+            const long long f = __double2ll_rn(ps);
+            const int l = __double2int_rn((ps - (double)f) * lo_scale);
+            const int64_t row = (int64_t)(w >> st_shift) * S + ((uint32_t)(w >> 16) & rmask);
+            atomicAdd(&yhi[row], (unsigned long long)f);
+            if (l) atomicAdd(&ylo[row], l);
+        }
+    } else
     for (int64_t k0 = s0 + threadIdx.x; k0 < e0; k0 += 4 * XT_NT) {
         unsigned long long w[4];
         double g[4];
@@ -2098,8 +2180,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const bool dist = ctx->has_dist;
     const b3c_dist &D = ctx->dist;
     if (dist && (int64_t)D.world * D.chunk < n) return ctx->fail(B3C_E_ARG, "b3c_kr_balance: dist buffers too small for n");
-    const int64_t r0 = dist ? std::min<int64_t>(n, (int64_t)D.rank * D.chunk) : 0;
-    const int64_t r1 = dist ? std::min<int64_t>(n, r0 + D.chunk) : n;
+    int64_t r0 = 0, r1 = n;
+    if (dist) ctx->dist_rows(n, D.rank, &r0, &r1);
     const int64_t nloc = r1 - r0;
     // geometry: fixed for a given (n, nnz, world) so that reductions are reproducible
     const int G = grid_for(nloc, BLK * KV_E, 4 * ctx->n_cu);          // vector kernels over this rank's rows (KCD)
@@ -2395,6 +2477,12 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     DevBuf<int> ylo(ctx, tails_xt ? nloc : 1), tex(ctx, 2);
     DevBuf<int64_t> xt_off(ctx, tails_xt ? nloc + 2 : 1);
     int xt_lg_bound = 0, xt_lo_bits = 20;
+    // packed form of the sorted tail words (kr_tails_pack): 4 bytes per tail; B3C_KR_XT_PACK=0 keeps the 64-bit stream
+    struct PoolPtr32 { b3c_ctx *c; uint32_t *p = nullptr; ~PoolPtr32() { c->release(p); } } xt_cw{ctx}, xt_hdr{ctx};
+    struct PoolPtr64 { b3c_ctx *c; unsigned long long *p = nullptr; ~PoolPtr64() { c->release(p); } } xt_res{ctx};
+    const bool xt_pack_want = CFG.num("B3C_KR_XT_PACK", 1) != 0;
+    bool xt_packed = false;
+    int64_t xt_n_res = 0;
     const size_t xt_shmem = sizeof(unsigned long long) * (size_t)xt_S + sizeof(int) * (size_t)xt_S + sizeof(double) * XT_NT;
     if (tails_xt) {
         DevBuf<int64_t> tcnt(ctx, nloc + 2);
@@ -2434,7 +2522,24 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: tail sort workspace");
         e = hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, words_in.p, xt_words.p, (int64_t)n_tails, sort_lo, sort_hi, s);
         if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort of the tails failed");
-        { static bool xt_attr = false; if (!xt_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT))); xt_attr = true; } }
+        // (the attribute is per device: set on every call -- ADVICE round 3)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT)));
+        if (xt_pack_want && n_tails > 0) {
+            // the sorted words as 32-bit words + residual list (kr_tails_pack); not worth it when many words do not fit
+            xt_cw.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(n_tails + 64));
+            xt_hdr.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)((n_tails + 63) / 64 + 1));
+            xt_res.p = (unsigned long long *)ctx->alloc(sizeof(unsigned long long) * (size_t)(n_tails + 4));
+            if (!xt_cw.p || !xt_hdr.p || !xt_res.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: packed tails");
+            HIP_TRY(ctx, hipMemsetAsync(xst.p, 0, sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(kr_tails_pack, dim3((unsigned)std::min<int64_t>(((n_tails + 63) / 64 + 3) / 4, 16 * (int64_t)ctx->n_cu)), dim3(256), 0, s, n_tails, xt_rbits,
+                               16 + xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, xt_cw.p, xt_hdr.p, xt_res.p, xst.p);
+            unsigned long long nr = 0;
+            { const int rb_ = b3c_readback(ctx, &nr, xst.p, sizeof(nr)); if (rb_) return rb_; }
+            xt_n_res = (int64_t)nr;
+            xt_packed = xt_n_res * 8 <= n_tails;
+            if (CFG.on("B3C_KR_DEBUG"))
+                fprintf(stderr, "[b3c] tail pass: %lld of %lld words stay 64-bit (%s)\n", (long long)xt_n_res, (long long)n_tails, xt_packed ? "packed stream in use" : "too many: 64-bit stream kept");
+        }
         HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch above goes back to the pool here
         info->tcd_xt_tails = n_tails;
         if (CFG.on("B3C_KR_DEBUG"))
@@ -2539,7 +2644,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             if (tcd) {
                 if (tails_xt)
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
-                                       xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p);
+                                       xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p,
+                                       xt_packed ? xt_cw.p : nullptr, xt_hdr.p, xt_res.p, xt_n_res, xt_st_shift);
                 // dictionary waves and tail waves side by side (512-thread workgroups)
 #define KR_TCD2_ARGS                                                                                                         \
     dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \

@@ -928,14 +928,40 @@ __global__ void k_lv_list_bounds(int n_seg, int64_t nloc, const int64_t *__restr
     for (int t = threadIdx.x; t <= n_seg; t += blockDim.x) bnd[t] = pos[(int64_t)t * nloc];
 }
 
-template <int LPR, int UN>
+// Gather record of a node (round 4): its community and that community's total side by side, 16 bytes, in ROW order.  The grouped
+// scan asks for label AND total of every stored neighbour; with the totals indexed by community id -- the caller-side id of some
+// member, i.e. a random place in an n-vector of 8 bytes -- every entry costs two missed lines, the second one usually all the way
+// from the fabric (C3: 2.0 GB fetched per unpruned sub-round against 0.69 GB algorithmic).  One record per entry is one line, and
+// in a locality-ordered map mostly a line the L1 still holds.  The records are refreshed after every application of moves
+// (k_lv_rec_refresh: one gather per NODE instead of one per ENTRY).
+struct __align__(16) GRec {
+    int32_t com;
+    int32_t pad;
+    long long tot;
+};
+
+__global__ void __launch_bounds__(BLK) k_lv_rec_refresh(int64_t n, const int32_t *__restrict__ com, const int64_t *__restrict__ tot,
+                                                         GRec *__restrict__ rec)
+{
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+        GRec r;
+        r.com = com[i];
+        r.pad = 0;
+        r.tot = tot[r.com];
+        rec[i] = r;
+    }
+}
+
+template <int LPR, int UN, bool REC = false>
 __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int64_t *__restrict__ cnt_dev,
                                                       const NodeRec *__restrict__ list, u64 m2,
                                                       const int32_t *__restrict__ indices,
                                                       const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
                                                       const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
                                                       const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
-                                                      int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out, int32_t epoch, int xcd)
+                                                      int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out, int32_t epoch, int xcd,
+                                                      const GRec *__restrict__ grec)
 {
     constexpr int CAP = 512;                       // >= 1.25 * LPR * UN + 1
     constexpr int LG = 9;
@@ -996,11 +1022,20 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
         // 2. community gathers and weights of the current node, own-community total
         int32_t cm[UN];
         u64 qv[UN];
+        long long tv[UN];
         {
             const int64_t *__restrict__ qi = q + start;
 #pragma unroll
             for (int t = 0; t < UN; t++) {
-                cm[t] = j[t] != i ? com[j[t]] : EMPTY;
+                if (REC) {
+                    GRec r;
+                    r.com = EMPTY; r.pad = 0; r.tot = 0;
+                    if (j[t] != i) r = grec[j[t]];
+                    cm[t] = r.com;
+                    tv[t] = r.tot;
+                } else {
+                    cm[t] = j[t] != i ? com[j[t]] : EMPTY;
+                }
                 qv[t] = t * LPR + sl < deg ? (u64)qi[t * LPR + sl] : 0;
             }
         }
@@ -1008,9 +1043,10 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
         if (i >= 0 && sl == 0) ta = tot[a];
         // totals of the foreign communities, requested as soon as the labels are known: their round trip then runs under
         // the LDS insertions instead of after them (round 3; a community met twice costs a second, cached, request)
-        long long tv[UN];
+        if (!REC) {
 #pragma unroll
-        for (int t = 0; t < UN; t++) tv[t] = (cm[t] != EMPTY && cm[t] != a) ? tot[cm[t]] : 0;
+            for (int t = 0; t < UN; t++) tv[t] = (cm[t] != EMPTY && cm[t] != a) ? tot[cm[t]] : 0;
+        }
         // 3. neighbour ids and own community of the next node (its weights are fetched next to its gathers)
         int32_t an = 0;
         long long kin = 0;
@@ -1851,6 +1887,236 @@ __global__ void __launch_bounds__(BLK) k_bins_fill(int64_t kc, const u64 *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Aggregation by hashing, for levels that end with MORE communities than the bin table holds (round 4).  The pair sort moves
+// every foreign entry through five radix passes (the surveyed genome-size law at C3: level 0 ends with 185,559 communities of ~5
+// contigs, 2.0e8 pairs, 12.4 ms).  Here the rows of one new community are read once and their entries summed per target
+// community in a hash table -- in LDS for the communities whose rows hold at most 6553 entries together (one workgroup each,
+// tables of 1024 / 4096 / 8192 slots as in k_lv_decide_wg), in global memory for the others (one workgroup per member row
+// inserts, one per community emits).  The distinct (target, sum) pairs of community c land at ubpos[c] of a scratch area laid
+// out by the upper bounds ub[c] = entries of c's rows; a scan of the counts and one copy make the CSR of the next level.
+// Integer sums: the induced graph is the one the sort path builds, entry for entry -- only the ORDER of the entries inside a
+// row differs (slot order instead of ascending columns), which no kernel of the next level depends on.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_aggh_starts(int64_t n, int64_t kc, const int32_t *__restrict__ skey, int64_t *__restrict__ cstart)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { cstart[kc] = n; return; }
+    if (i == 0 || skey[i] != skey[i - 1]) cstart[skey[i]] = i;        // (every community 0 .. kc-1 has a member)
+}
+
+__global__ void k_aggh_ub(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ cn, unsigned long long *__restrict__ ub)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t d = indptr[i + 1] - indptr[i];
+    if (d) atomicAdd(&ub[cn[i]], (unsigned long long)d);
+}
+
+// class of every community by ub: 0 .. 2 = LDS tables of 1024 / 4096 / 8192 slots, 3 = global table; lists by atomic append (any
+// order), table sizes of class 3
+__global__ void k_aggh_classify(int64_t kc, const unsigned long long *__restrict__ ub, int32_t *__restrict__ lists, unsigned long long *__restrict__ lcnt,
+                                int64_t *__restrict__ tsz, int64_t *__restrict__ need)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > kc) return;
+    if (c == kc) { tsz[kc] = 0; need[kc] = 0; return; }
+    const long long u = (long long)ub[c];
+    need[c] = u + 1;                                  // scratch slots of the community: every entry a target of its own, plus the diagonal
+    const int cls = u <= lv_wg_max_deg(0) ? 0 : u <= lv_wg_max_deg(1) ? 1 : u <= lv_wg_max_deg(2) ? 2 : 3;
+    tsz[c] = cls == 3 ? (1ll << table_lg(u)) : 0;
+    const unsigned long long at = atomicAdd(&lcnt[cls], 1ull);
+    lists[(int64_t)cls * kc + at] = (int32_t)c;
+}
+
+// block-wide exclusive prefix of one count per thread (NT threads); returns the thread's offset, *total = the block's sum
+template <int NT>
+__device__ __forceinline__ int block_excl_scan(int v, int *lds, int *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) lds[wv] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < NT / 64; w++) {
+        const int t = lds[w];
+        if (w < wv) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+template <int LGS, int NT>
+__global__ void __launch_bounds__(NT) k_aggh_wg(int64_t cnt, const int32_t *__restrict__ list, const int64_t *__restrict__ cstart,
+                                                 const int32_t *__restrict__ ord, const int64_t *__restrict__ indptr,
+                                                 const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
+                                                 const int32_t *__restrict__ cn, const int64_t *__restrict__ ubpos,
+                                                 int32_t *__restrict__ tix, int64_t *__restrict__ tq, int64_t *__restrict__ dcnt)
+{
+    constexpr int SLOTS = 1 << LGS;
+    constexpr int NW = NT / 64;
+    extern __shared__ __align__(16) unsigned char lv_wg_smem[];
+    u64 *vals = (u64 *)lv_wg_smem;
+    int32_t *keys = (int32_t *)(vals + SLOTS);
+    int *sc = (int *)(keys + SLOTS);                   // NW ints of the scan, then NW 64-bit sums
+    long long *red = (long long *)(sc + NW + (NW & 1));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int t = tid; t < SLOTS; t += NT) { keys[t] = EMPTY; vals[t] = 0; }
+    __syncthreads();
+    for (int64_t pos = blockIdx.x; pos < cnt; pos += gridDim.x) {
+        const int32_t c1 = list[pos];
+        const int64_t m0 = cstart[c1], m1 = cstart[c1 + 1];
+        long long own = 0;
+        // wave w takes the member rows w, w + NW, ...; its lanes stride the row
+        for (int64_t m = m0 + wv; m < m1; m += NW) {
+            const int32_t i = ord[m];
+            const int64_t s = indptr[i], e = indptr[i + 1];
+            for (int64_t base = s; base < e; base += 4 * 64) {
+                int32_t j[4], c2[4];
+                u64 qv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int64_t k = base + u * 64 + lane;
+                    j[u] = k < e ? indices[k] : -1;
+                    qv[u] = k < e ? (u64)q[k] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) c2[u] = j[u] >= 0 ? cn[j[u]] : EMPTY;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (j[u] < 0) continue;
+                    if (c2[u] == c1) { own += j[u] == i ? 2 * (long long)qv[u] : (long long)qv[u]; continue; }   // loops doubled: the internal total halves exactly
+                    uint32_t slot = hash_slot(c2[u], LGS);
+                    for (;;) {
+                        const int32_t prev = atomicCAS(&keys[slot], EMPTY, c2[u]);
+                        if (prev == EMPTY || prev == c2[u]) { atomicAdd(&vals[slot], qv[u]); break; }
+                        slot = (slot + 1) & (SLOTS - 1);
+                    }
+                }
+            }
+        }
+        own = wave_sum_ll(own);
+        if (lane == 0) red[wv] = own;
+        __syncthreads();
+        // emit: the diagonal first, then every non-empty slot
+        int mine = 0;
+        for (int t = tid; t < SLOTS; t += NT) mine += keys[t] != EMPTY ? 1 : 0;
+        int total = 0;
+        int at = block_excl_scan<NT>(mine, sc, &total);
+        const int64_t o = ubpos[c1];
+        if (tid == 0) {
+            long long t = 0;
+            for (int w = 0; w < NW; w++) t += red[w];
+            tix[o] = c1;
+            tq[o] = t / 2;
+            dcnt[c1] = total + 1;
+        }
+        for (int t = tid; t < SLOTS; t += NT) {
+            const int32_t k = keys[t];
+            if (k == EMPTY) continue;
+            tix[o + 1 + at] = k;
+            tq[o + 1 + at] = (int64_t)vals[t];
+            at++;
+            keys[t] = EMPTY;
+            vals[t] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// communities beyond the LDS tables: one workgroup per MEMBER ROW inserts into the community's table in global memory ...
+__global__ void __launch_bounds__(BLK) k_aggh_big_insert(int64_t nrows, const int32_t *__restrict__ rows, const int64_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
+                                                          const int32_t *__restrict__ cn, const unsigned long long *__restrict__ ub,
+                                                          const int64_t *__restrict__ toff, int32_t *__restrict__ gkeys, u64 *__restrict__ gvals,
+                                                          unsigned long long *__restrict__ own_acc)
+{
+    __shared__ long long red[BLK / 64];
+    for (int64_t pos = blockIdx.x; pos < nrows; pos += gridDim.x) {
+        const int32_t i = rows[pos];
+        const int32_t c1 = cn[i];
+        const int lg = table_lg((int64_t)ub[c1]);
+        const uint32_t mask = (1u << lg) - 1u;
+        int32_t *keys = gkeys + toff[c1];
+        u64 *vals = gvals + toff[c1];
+        const int64_t s = indptr[i], e = indptr[i + 1];
+        long long own = 0;
+        for (int64_t k = s + threadIdx.x; k < e; k += BLK) {
+            const int32_t j = indices[k];
+            const u64 qv = (u64)q[k];
+            const int32_t c2 = cn[j];
+            if (c2 == c1) { own += j == i ? 2 * (long long)qv : (long long)qv; continue; }
+            uint32_t slot = hash_slot(c2, lg);
+            for (;;) {
+                const int32_t prev = atomicCAS(&keys[slot], EMPTY, c2);
+                if (prev == EMPTY || prev == c2) { atomicAdd(&vals[slot], qv); break; }
+                slot = (slot + 1) & mask;
+            }
+        }
+        block_atomic_add_u64(own, own_acc + c1, red);
+    }
+}
+
+// ... and one workgroup per community emits the diagonal and the non-empty slots of its table
+__global__ void __launch_bounds__(1024) k_aggh_big_emit(int64_t cnt, const int32_t *__restrict__ list, const unsigned long long *__restrict__ ub,
+                                                         const int64_t *__restrict__ toff, const int32_t *__restrict__ gkeys,
+                                                         const u64 *__restrict__ gvals, const unsigned long long *__restrict__ own_acc,
+                                                         const int64_t *__restrict__ ubpos, int32_t *__restrict__ tix, int64_t *__restrict__ tq,
+                                                         int64_t *__restrict__ dcnt)
+{
+    __shared__ int sc[16];
+    const int32_t c1 = list[blockIdx.x];
+    const int lg = table_lg((int64_t)ub[c1]);
+    const int64_t size = 1ll << lg;
+    const int32_t *keys = gkeys + toff[c1];
+    const u64 *vals = gvals + toff[c1];
+    const int64_t o = ubpos[c1];
+    int64_t done = 1;                                   // entries written so far (slot 0: the diagonal)
+    if (threadIdx.x == 0) { tix[o] = c1; tq[o] = (int64_t)(own_acc[c1] / 2); }
+    for (int64_t t0 = 0; t0 < size; t0 += 1024) {
+        const int64_t t = t0 + threadIdx.x;
+        const int32_t k = t < size ? keys[t] : EMPTY;
+        int total = 0;
+        const int at = block_excl_scan<1024>(k != EMPTY ? 1 : 0, sc, &total);
+        if (k != EMPTY) { tix[o + done + at] = k; tq[o + done + at] = (int64_t)vals[t]; }
+        done += total;
+    }
+    if (threadIdx.x == 0) dcnt[c1] = done;
+}
+
+__global__ void k_aggh_big_rows(int64_t n, const int32_t *__restrict__ cn, const int64_t *__restrict__ tsz, const int64_t *__restrict__ indptr,
+                                int32_t *__restrict__ rows, unsigned long long *__restrict__ nrows)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool big = i < n && indptr[i + 1] > indptr[i] && tsz[cn[i]] > 0;
+    const unsigned long long m = __ballot(big);
+    if (!m) return;
+    unsigned long long at = 0;
+    if ((threadIdx.x & 63) == 0) at = atomicAdd(nrows, (unsigned long long)__popcll(m));
+    at = (unsigned long long)__shfl((long long)at, 0, 64);
+    if (big) rows[at + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int32_t)i;
+}
+
+// copy the dcnt[c] pairs of community c from the scratch layout to row c of the next level's CSR (one wave per community)
+__global__ void __launch_bounds__(BLK) k_aggh_compact(int64_t kc, const int64_t *__restrict__ ubpos, const int64_t *__restrict__ hptr,
+                                                       const int32_t *__restrict__ tix, const int64_t *__restrict__ tq,
+                                                       int32_t *__restrict__ hix, int64_t *__restrict__ hq)
+{
+    const int lane = threadIdx.x & 63;
+    for (int64_t c = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); c < kc; c += (int64_t)gridDim.x * WPB) {
+        const int64_t src = ubpos[c], dst = hptr[c], len = hptr[c + 1] - dst;
+        for (int64_t t = lane; t < len; t += 64) { hix[dst + t] = tix[src + t]; hq[dst + t] = tq[src + t]; }
+    }
+}
+
 __global__ void k_rows_from_keys(int64_t kc, int64_t nu, const int64_t *__restrict__ ukeys,
                                  int64_t *__restrict__ indptr)
 {
@@ -2159,7 +2425,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 starts[D.world] = all[2 * (size_t)D.world - 1];
                 if (starts[0] != 0 || starts[D.world] != n) { free_graph(ctx, g); return ctx->fail(B3C_E_ARG, "b3c_louvain: the ranks' row blocks do not tile the matrix"); }
             } else {
-                for (int r = 0; r <= D.world; r++) starts[r] = std::min<int64_t>(n, (int64_t)r * D.chunk);
+                for (int r = 0; r < D.world; r++) { int64_t e_; ctx->dist_rows(n, r, &starts[r], &e_); }
+                starts[D.world] = n;
             }
             HIP_TRY(ctx, hipMemcpyAsync(starts_dev.p, starts.data(), sizeof(int64_t) * starts.size(), hipMemcpyHostToDevice, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -2201,7 +2468,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const bool use_wg = grouped && !CFG.on("B3C_LV_NO_WG");
         // LDS table of the wave-per-node kernel: 12 bytes per slot and wave, four waves per workgroup -- 2048 slots are 96 KB, ONE
         // workgroup per CU.  B3C_LV_CAP_MAX clamps it (nodes beyond the cap use their global table): see DESIGN.md section 4
-        const int64_t wave_max = use_wg ? std::min<int64_t>(maxdeg, 409) : maxdeg;
+        const int64_t wave_max = use_wg ? std::min<int64_t>(maxdeg, std::max<int64_t>(64, CFG.num("B3C_LV_WAVE_MAX", 409))) : maxdeg;
         const int64_t need = 1ll << table_lg(wave_max);
         const int cap_max = (int)CFG.num("B3C_LV_CAP_MAX", 2048);
         const int cap0 = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
@@ -2240,7 +2507,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         LvThr thr;
         thr.t[0] = short_max;
         if (use_wg) {
-            thr.t[1] = std::min(mega_deg, std::max(short_max, 409));
+            thr.t[1] = std::min(mega_deg, std::max(short_max, (int)CFG.num("B3C_LV_WAVE_MAX", 409)));
             thr.t[2] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(0)));
             thr.t[3] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(1)));
             thr.t[4] = mega_deg;
@@ -2281,6 +2548,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const bool use_side = !CFG.on("B3C_LV_NO_SIDE");      // hubs / mega rows beside the grouped scan on side streams
         const bool mega_lds = use_wg && !CFG.on("B3C_LV_NO_MEGA_LDS");
         const bool xcd_lists = !CFG.on("B3C_LV_NO_XCD");
+        // per-node gather records {community, its total} for the grouped scan (k_lv_decide_g<.., REC>), refreshed after every apply
+        const bool use_rec = grouped && CFG.num("B3C_LV_REC", 1) != 0;
+        DevBuf<GRec> grec(ctx, use_rec ? n : 1);
+        if (!grec.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: gather records");
+        if (use_rec) hipLaunchKernelGGL(k_lv_rec_refresh, dim3(gv), dim3(BLK), 0, s, n, com.p, tot.p, grec.p);
         const size_t mega_lds_bytes = (size_t)(1 << MEGA_LDS_LG) * 12 + (MEGA_NT / 64) * 8;
         if (use_wg) {
             // tables beyond 64 KB of LDS are dynamic shared memory that a kernel must be allowed first (per device: set on every call)
@@ -2395,11 +2667,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     }
                     // grids of a multiple of eight workgroups number their list positions XCD by XCD (see the kernel)
 #define LV_GRID_G(L) ([&]() { int g_ = grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu); if (xcd_lists && g_ >= 64) g_ = (g_ + 7) & ~7; return g_; }())
+#define LV_DECIDE_G_(L, U, REC)                                                                                          \
+      hipLaunchKernelGGL((k_lv_decide_g<L, U, REC>), dim3(g_), dim3(BLK), 0, s, cntr, cnt_dev, lst,                       \
+                       m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch, \
+                       (xcd_lists && g_ >= 64) ? 1 : 0, grec.p)
 #define LV_DECIDE_G(L, U)                                                                                                \
     { const int g_ = LV_GRID_G(L);                                                                                       \
-      hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(g_), dim3(BLK), 0, s, cntr, cnt_dev, lst,                            \
-                       m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch, \
-                       (xcd_lists && g_ >= 64) ? 1 : 0); }
+      if (use_rec) LV_DECIDE_G_(L, U, true); else LV_DECIDE_G_(L, U, false); }
                     if (sweep == 1 && r == 0 && !incr && !CFG.on("B3C_LV_NO_FIRST")) {
                         // every node is still alone: the table-free form (k_lv_first_g)
 #define LV_FIRST_G(L, U)                                                                                                 \
@@ -2424,6 +2698,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     default: LV_DECIDE_G(4, 8); break;
                     }
 #undef LV_DECIDE_G
+#undef LV_DECIDE_G_
 #undef LV_GRID_G
                 }
                 const bool direct_level = !grouped && !dist && n <= LV_DIRECT_CAP && !CFG.on("B3C_LV_NO_DIRECT");
@@ -2521,6 +2796,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt_p,
                                        csize.p, ctr.p + 1, r0, r1, tstamp_p, epoch);
                 }
+                if (use_rec) hipLaunchKernelGGL(k_lv_rec_refresh, dim3(gv), dim3(BLK), 0, s, n, com.p, tot.p, grec.p);
             }
             info->move_nnz += g.nnz;
             info->move_rows += g.n;
@@ -2629,6 +2905,84 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // the reduced runs of all ranks are gathered (b3c_dist_gather_pairs) and reduced once more: integer sums, so the
         // induced graph is bit for bit the single-GPU one whatever the split ("tuples keyed by community pair,
         // then local sort-reduce"; the graph of the next level is small against level 0 and stays replicated).
+        const bool agg_hash = !blk0 && !CFG.on("B3C_LV_NO_AGG_HASH");
+        if (agg_hash) {
+            // ---- by hashing: the rows of a community are read once, no pair ever sorted (see k_aggh_wg) ----
+            DevBuf<int32_t> skey(ctx, n), ord(ctx, n), iota(ctx, n), lists(ctx, 4 * (size_t)kc + 1), brows(ctx, n);
+            DevBuf<int64_t> cstart(ctx, kc + 1), tsz(ctx, kc + 1), toff(ctx, kc + 1), need(ctx, kc + 1), ubpos(ctx, kc + 1), dcnt(ctx, kc + 1);
+            DevBuf<unsigned long long> ub(ctx, kc + 1), lcnt(ctx, 5), own_acc(ctx, kc + 1);
+            DevBuf<int32_t> tix(ctx, (size_t)g.nnz + (size_t)kc + 1);
+            DevBuf<int64_t> tq(ctx, (size_t)g.nnz + (size_t)kc + 1);
+            if (!skey.p || !ord.p || !iota.p || !lists.p || !brows.p || !cstart.p || !tsz.p || !toff.p || !need.p || !ubpos.p || !dcnt.p || !ub.p ||
+                !lcnt.p || !own_acc.p || !tix.p || !tq.p)
+                return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hash aggregation");
+            hipLaunchKernelGGL(k_iota32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, iota.p);
+            {
+                int kb = 1;
+                while ((1ll << kb) < kc) kb++;
+                size_t tb = 0;
+                HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, cn.p, skey.p, iota.p, ord.p, n, 0, kb, s));
+                DevBuf<char> tmp(ctx, tb);
+                if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hash aggregation");
+                HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, cn.p, skey.p, iota.p, ord.p, n, 0, kb, s));
+                HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch goes back to the pool here
+            }
+            HIP_TRY(ctx, hipMemsetAsync(ub.p, 0, sizeof(unsigned long long) * (size_t)(kc + 1), s));
+            HIP_TRY(ctx, hipMemsetAsync(own_acc.p, 0, sizeof(unsigned long long) * (size_t)(kc + 1), s));
+            HIP_TRY(ctx, hipMemsetAsync(lcnt.p, 0, sizeof(unsigned long long) * 5, s));
+            hipLaunchKernelGGL(k_aggh_starts, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, kc, skey.p, cstart.p);
+            hipLaunchKernelGGL(k_aggh_ub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, cn.p, ub.p);
+            hipLaunchKernelGGL(k_aggh_classify, dim3((unsigned)((kc + 256) / 256)), dim3(256), 0, s, kc, ub.p, lists.p, lcnt.p, tsz.p, need.p);
+            if ((rc = b3c_exclusive_scan_i64(ctx, tsz.p, toff.p, kc + 1))) return rc;
+            if ((rc = b3c_exclusive_scan_i64(ctx, need.p, ubpos.p, kc + 1))) return rc;
+            hipLaunchKernelGGL(k_aggh_big_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, cn.p, tsz.p, g.indptr, brows.p, lcnt.p + 4);
+            unsigned long long hl[5];
+            int64_t gtot = 0;
+            { const int rb_ = b3c_readback(ctx, hl, lcnt.p, sizeof(hl)); if (rb_) return rb_; }
+            { const int rb_ = b3c_readback(ctx, &gtot, toff.p + kc, sizeof(int64_t)); if (rb_) return rb_; }
+            DevBuf<int32_t> hk(ctx, (size_t)gtot + 1);
+            DevBuf<u64> hv(ctx, (size_t)gtot + 1);
+            if (!hk.p || !hv.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hash aggregation tables");
+            if (gtot) {
+                HIP_TRY(ctx, hipMemsetAsync(hk.p, 0xFF, sizeof(int32_t) * (size_t)gtot, s));
+                HIP_TRY(ctx, hipMemsetAsync(hv.p, 0, sizeof(u64) * (size_t)gtot, s));
+            }
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_aggh_wg<13, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv_wg_lds<13, 1024>()));
+#define LV_AGGH(LGS, NT, CLS, MAXG)                                                                                      \
+    if (hl[CLS])                                                                                                         \
+        hipLaunchKernelGGL((k_aggh_wg<LGS, NT>), dim3((unsigned)std::min<int64_t>((int64_t)hl[CLS], MAXG)), dim3(NT), (lv_wg_lds<LGS, NT>()), s, (int64_t)hl[CLS], \
+                           lists.p + (int64_t)CLS * kc, cstart.p, ord.p, g.indptr, g.indices, g.q, cn.p, ubpos.p, tix.p, tq.p, dcnt.p)
+            LV_AGGH(10, 256, 0, 16 * (int64_t)ctx->n_cu);
+            LV_AGGH(12, 256, 1, 6 * (int64_t)ctx->n_cu);
+            LV_AGGH(13, 1024, 2, 2 * (int64_t)ctx->n_cu);
+#undef LV_AGGH
+            if (hl[3]) {
+                if (hl[4])
+                    hipLaunchKernelGGL(k_aggh_big_insert, dim3((unsigned)std::min<int64_t>((int64_t)hl[4], 32 * (int64_t)ctx->n_cu)), dim3(BLK), 0, s, (int64_t)hl[4], brows.p,
+                                       g.indptr, g.indices, g.q, cn.p, ub.p, toff.p, hk.p, hv.p, own_acc.p);
+                hipLaunchKernelGGL(k_aggh_big_emit, dim3((unsigned)hl[3]), dim3(1024), 0, s, (int64_t)hl[3], lists.p + 3 * kc, ub.p, toff.p, hk.p, hv.p,
+                                   own_acc.p, ubpos.p, tix.p, tq.p, dcnt.p);
+            }
+            HIP_TRY(ctx, hipMemsetAsync(dcnt.p + kc, 0, sizeof(int64_t), s));
+            h.n = kc; h.owned = true;
+            h.indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(kc + 1));
+            if (!h.indptr) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: next level");
+            if ((rc = b3c_exclusive_scan_i64(ctx, dcnt.p, h.indptr, kc + 1))) { free_graph(ctx, h); return rc; }
+            int64_t nu = 0;
+            { const int rb_ = b3c_readback(ctx, &nu, h.indptr + kc, sizeof(int64_t)); if (rb_) { free_graph(ctx, h); return rb_; } }
+            h.nnz = nu;
+            h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu > 0 ? nu : 1));
+            h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu > 0 ? nu : 1));
+            if (!h.indices || !h.q) { free_graph(ctx, h); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: next level"); }
+            hipLaunchKernelGGL(k_aggh_compact, dim3(grid_for(kc, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, kc, ubpos.p, h.indptr, tix.p, tq.p, h.indices, h.q);
+            {
+                const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(s);      // the scratch is read until here
+                if (e1 != hipSuccess || e2 != hipSuccess) {
+                    free_graph(ctx, h);
+                    return ctx->fail(B3C_E_HIP, "b3c_louvain: hash aggregation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+                }
+            }
+        } else {
         DevBuf<int64_t> pcnt(ctx, n + 1), ppos(ctx, n + 1);
         if (!pcnt.p || !ppos.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation counts");
         hipLaunchKernelGGL(k_pairs_count, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, cn.p, pcnt.p);
@@ -2698,6 +3052,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 free_graph(ctx, h);
                 return ctx->fail(B3C_E_HIP, "b3c_louvain: aggregation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
             }
+        }
         }
         }
         free_graph(ctx, g);

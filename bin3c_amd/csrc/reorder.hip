@@ -632,8 +632,8 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     // order is bit for bit the single-GPU one.
     const b3c_dist &D = ctx->dist;
     const bool dist = ctx->has_dist && D.world > 1 && (int64_t)D.world * D.chunk >= n && !CFG.on("B3C_ORDER_REPLICATED");
-    const int64_t r0 = dist ? std::min<int64_t>(n, (int64_t)D.rank * D.chunk) : 0;
-    const int64_t r1 = dist ? std::min<int64_t>(n, (int64_t)(D.rank + 1) * D.chunk) : n;
+    int64_t r0 = 0, r1 = n;
+    if (dist) ctx->dist_rows(n, D.rank, &r0, &r1);
     const int g16 = grid_for(r1 - r0, (BLK / 64) * 4, 16 * ctx->n_cu), g64 = grid_for(r1 - r0, BLK / 64, 16 * ctx->n_cu);
     const unsigned gn = (unsigned)((n + 255) / 256);
     const bool wide = avg >= 48;

@@ -1,8 +1,9 @@
 """
 Row-sharded multi-GPU execution of the hot path: one process per GPU (launched by torch.distributed.run).  Every rank
-holds the raw count map (the input); from the permutation on it forms and works on its ROW BLOCK
-[rank*chunk, (rank+1)*chunk) of the locality-ordered map only (b3c_mat_permute_rows; include/b3c.h "multi-GPU",
-DESIGN.md section 6).
+holds the raw count map (the input); from the permutation on it forms and works on its ROW BLOCK of the locality-ordered
+map only (b3c_mat_permute_rows; include/b3c.h "multi-GPU").  The blocks are contiguous row ranges
+balanced by STORED ENTRIES (:func:`balanced_starts`: a prefix sum over the ordered row lengths), not by row
+count: one genome may hold a third of the contigs and hub contigs carry 10^5..10^6 contacts.
 
 Transport.  On real multi-GPU runs (torch.distributed backend "nccl") the session creates an RCCL communicator INSIDE
 libb3c (b3c_dist_comm_create; the 128-byte unique id travels over torch.distributed once) and libb3c then issues every
@@ -10,9 +11,9 @@ collective itself on its stream -- ncclAllGather over xGMI, no Python in the loo
 CPU / one-GPU tests) libb3c calls back into :meth:`DistSession._allgather`, which moves the same buffers with
 torch.distributed.
 
-    KR, per SpMV     two exchanges: the partial of p.w | rk.rk after the SpMV, and after the vector step the slice of
-                     Z = rk*v together with the partials of min/max(ynew) and rk.Z (one grouped launch); every rank then
-                     advances p, y, x and the operand for all rows itself, so the operand is never exchanged
+    KR, per SpMV     ONE exchange (a grouped launch): the rank's partial of p.w | rk.rk together with its slice of w (inner
+                     iteration) or of v = x*(A x) (outer iteration); the vector steps on both sides of the SpMV run over all
+                     rows on every rank from the gathered slices, so nothing else travels
     Louvain level 0  all-gather of the decided labels per sub-round (4 n bytes), one integer partial sum per modularity
                      evaluation; moves are applied by every rank
 
@@ -36,6 +37,7 @@ B3CDist = _native.B3CDist      # b3c_dist, include/b3c.h (layout checked against
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int)
 
 
 def shard_range(n, rank, world, align=64):
@@ -44,6 +46,42 @@ def shard_range(n, rank, world, align=64):
     chunk = -(-chunk // align) * align
     r0 = min(n, rank * chunk)
     return r0, min(n, r0 + chunk), chunk
+
+
+def balanced_starts(row_nnz, world, align=64):
+    """Row ranges of `world` ranks over rows with `row_nnz` stored entries each (numpy or torch, in the order the ranks will
+    work in), balanced by entries: range r ends where the running sum first reaches (r + 1) / world of the total, rounded to a
+    multiple of `align` rows.  -> numpy int64[world + 1], ascending, starts[0] = 0, starts[world] = n.  Deterministic: every rank
+    computes the same ranges from the same lengths ("balanced by nnz (prefix-sum over indptr)")."""
+    import torch
+    t = torch.as_tensor(row_nnz).to(torch.int64)
+    n = int(t.shape[0])
+    cs = torch.cumsum(t, 0)
+    total = int(cs[-1].item()) if n else 0
+    starts = np.zeros(world + 1, dtype=np.int64)
+    starts[world] = n
+    if n and total > 0:
+        targets = torch.as_tensor([(total * (r + 1)) // world for r in range(world - 1)], dtype=torch.int64, device=cs.device)
+        cut = (torch.searchsorted(cs, targets, right=False) + 1).cpu().numpy() if world > 1 else np.zeros(0, dtype=np.int64)
+        cut = np.minimum(n, ((cut + align - 1) // align) * align)
+        starts[1:world] = np.maximum.accumulate(cut)
+    else:
+        starts[1:world] = np.minimum(n, (np.arange(1, world) * (-(-n // world))))
+    return starts
+
+
+def allgather_ragged(view, starts, rank, group=None):
+    """Ragged in-place all-gather of a row-indexed tensor: rank r owns view[starts[r]:starts[r+1]].  Done as a sum with zeros on
+    an INTEGER view (every element has exactly one non-zero contributor, so the all-reduce IS the gather, bit for bit, and raw
+    64-bit payloads survive); gloo and nccl alike."""
+    import torch
+    import torch.distributed as dist
+    v = view.view(torch.int64 if view.element_size() == 8 else torch.int32)
+    a, b = int(starts[rank]), int(starts[rank + 1])
+    keep = v[a:b].clone()
+    v.zero_()
+    v[a:b] = keep
+    dist.all_reduce(v, group=group)
 
 
 def allgather_inplace(full, rank, world, group=None):
@@ -95,6 +133,8 @@ class DistSession(object):
         self._error = None
         self._cb = ALLGATHER_FN(self._allgather)          # keep a reference: ctypes callbacks are not owned by C
         self._cb2 = ALLREDUCE_FN(self._allreduce)
+        self._cb3 = ALLGATHERV_FN(self._allgatherv)
+        self.starts = None                                # ragged row ranges (set_starts); None: equal chunks
         lib = ctx.lib
         # RCCL inside libb3c when the job runs on the nccl backend (or on request); the callback transport otherwise
         want = os.environ.get('B3C_DIST_TRANSPORT', 'auto')
@@ -116,13 +156,35 @@ class DistSession(object):
             self.comm = comm
         self.transport = 'rccl (in libb3c)' if self.comm else 'callback ({})'.format(dist.get_backend(group))
         self._x0 = int(lib.b3c_ctx_exchanges(ctx.h))
-        d = B3CDist(self.rank, self.world, self.chunk, self.vec.data_ptr(), self.scal.data_ptr(),
-                    self.labels.data_ptr(), self.isum.data_ptr(), C.cast(self._cb, C.c_void_p), None,
-                    self.comm.value if self.comm else None, C.cast(self._cb2, C.c_void_p))
-        self._struct = d
-        ctx._check(lib.b3c_ctx_set_dist(ctx.h, C.byref(d)))
+        self._install(None)
         torch.cuda.synchronize(dev)                       # the buffers were zero-filled on torch's stream, libb3c writes them on its own
         ctx.dist_session = self                           # pipeline.run_hot_path shards the map over the ranks when set
+
+    def _install(self, starts):
+        """(re)install the sharding description; `starts`: int64[world + 1] row ranges or None for equal chunks"""
+        self.starts = None if starts is None else np.ascontiguousarray(starts, dtype=np.int64)
+        sp = self.starts.ctypes.data_as(C.c_void_p) if self.starts is not None else None
+        d = B3CDist(self.rank, self.world, self.chunk, self.vec.data_ptr(), self.scal.data_ptr(),
+                    self.labels.data_ptr(), self.isum.data_ptr(), C.cast(self._cb, C.c_void_p), None,
+                    self.comm.value if self.comm else None, C.cast(self._cb2, C.c_void_p), sp, C.cast(self._cb3, C.c_void_p))
+        self._struct = d
+        self.ctx._check(self.ctx.lib.b3c_ctx_set_dist(self.ctx.h, C.byref(d)))
+        if self.starts is None:
+            self.r0, self.r1, _ = shard_range(self.n, self.rank, self.world)
+        else:
+            self.r0, self.r1 = int(self.starts[self.rank]), int(self.starts[self.rank + 1])
+
+    def set_starts(self, starts):
+        """Row ranges of the ranks from here on (all ranks must pass the same array), or None for equal chunks again.  The
+        pipeline balances them by stored entries once the locality order is known (balanced_starts) and returns to equal
+        chunks for the ordering passes of the next call, which run on the still un-ordered map."""
+        if starts is None and self.starts is None:
+            return
+        if starts is not None:
+            st = np.asarray(starts, dtype=np.int64)
+            assert st.shape == (self.world + 1,) and st[0] == 0 and st[-1] == self.n and np.all(np.diff(st) >= 0), st
+        self.ctx.sync()
+        self._install(starts)
 
     @property
     def n_exchanges(self):
@@ -137,6 +199,25 @@ class DistSession(object):
                     allgather_inplace(self._bufs[b], self.rank, self.world, self.group)
             return 0
         except Exception as ex:                                # never let an exception cross the C frame
+            self._error = ex
+            return 1
+
+    def _allgatherv(self, user, dev_ptr, esz, starts_p, world):
+        """callback transport: ragged in-place all-gather of the row-indexed vector at device pointer `dev_ptr`"""
+        import torch
+        try:
+            starts = [int(starts_p[r]) for r in range(world + 1)]
+            total = starts[world]
+
+            class _View(object):
+                __cuda_array_interface__ = {'shape': (total,), 'typestr': '<i8' if esz == 8 else '<i4', 'data': (int(dev_ptr), False),
+                                            'version': 2}
+            with torch.cuda.stream(self.ctx.torch_stream):
+                if total:
+                    t = torch.as_tensor(_View(), device=torch.device('cuda', self.ctx.device))
+                    allgather_ragged(t, starts, self.rank, self.group)
+            return 0
+        except Exception as ex:
             self._error = ex
             return 1
 

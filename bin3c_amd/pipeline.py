@@ -138,7 +138,7 @@ STRICT_KR_ITER = 100      # strict_kr: balance again in the reference's own form
 
 
 def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=0, cluster=True, keep=False,
-                 reorder=True, mask=None, adopt_counts=False, max_iter=1000, strict_kr=None):
+                 reorder=True, mask=None, adopt_counts=False, max_iter=1000, strict_kr=None, balance_rows=True):
     """
     :param ctx: context from :func:`make_context`
     :param counts: _native.Mat (B3C_U32) raw symmetric contact counts, already in HBM
@@ -162,6 +162,7 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
                       True: in addition, a larger map that needed STRICT_KR_ITER iterations or more is balanced AGAIN in the
                       reference's formulation and that x is returned (doubles the balancing time where it is longest).
                       False: the count form whatever the size.
+    :param balance_rows: row-sharded runs: row blocks balanced by stored entries (default) instead of equal row counts
     :param adopt_counts: the result takes `counts` over (frees it with res.free()); with keep=True the balanced map can then
                          still be formed on demand when no ordered copy was made
     :return: HotPathResult (device matrices freed unless keep=True)
@@ -186,12 +187,20 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
         # 1/world of the entries per rank
         sess = getattr(ctx, 'dist_session', None)
         block = None
+        if sess is not None:
+            sess.set_starts(None)                  # the ordering passes run on the un-ordered map: equal row ranges
         if reorder and n >= REORDER_MIN_N and counts.nnz >= REORDER_MIN_NNZ:
             try:
                 n2o = torch.empty(n, dtype=torch.int32, device=dev)
                 o2n = torch.empty(n, dtype=torch.int32, device=dev)
                 ctx._check(ctx.lib.b3c_locality_order(ctx.h, counts.h, _native._ptr(n2o), _native._ptr(o2n)))
                 if sess is not None and sess.world > 1 and sess.n == n:
+                    # row blocks of the ORDERED map, balanced by stored entries: every rank holds the whole raw
+                    # map, hence all row lengths, and the same order -- the ranges need no exchange
+                    if balance_rows:
+                        from .dist import balanced_starts
+                        lens = ctx.row_nnz(counts, n2o, torch.empty(n, dtype=torch.int64, device=dev))
+                        sess.set_starts(balanced_starts(lens, sess.world))
                     block = (sess.r0, sess.r1)
                 # canonical (columns re-sorted inside each row): unsorted rows cost the SpMV 12 % more than the sort saves
                 work = ctx.permute(counts, n2o, rows=block)

@@ -99,7 +99,8 @@ int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
 
 /* ---- multi-GPU: contig-row ranges of ONE map across ranks ---------------------------------- */
 
-/* One process per GPU.  Every rank WORKS on the rows [rank*chunk, (rank+1)*chunk) of the ordered matrix -- either of a
+/* One process per GPU.  Every rank WORKS on one contiguous range of rows of the ordered matrix (b3c_dist.starts; equal ranges
+ * [rank*chunk, (rank+1)*chunk) when none are given) -- either of a
  * whole matrix, or of a row block that holds only those rows (b3c_mat_permute_rows; the other rows are empty);
  * what the other ranks need is exchanged through four caller-owned device buffers, each laid out as `world` equal
  * slices, by an in-place all-gather ("my slice is already written").  All ranks reduce the gathered partials in rank
@@ -126,9 +127,12 @@ int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
 typedef int (*b3c_allgather_fn)(void *user, int buffer_id);
 /* comm == NULL only: sum `count` uint64 values at device pointer `dev` over all ranks, in place, on the context's stream */
 typedef int (*b3c_allreduce_fn)(void *user, void *dev, int64_t count);
+/* comm == NULL only: ragged in-place all-gather of a row-indexed vector at device pointer `dev` (elements of esz = 4 or 8 bytes):
+ * rank r owns elements [starts[r], starts[r + 1]) (starts: world + 1 host offsets); afterwards every rank holds [0, starts[world]) */
+typedef int (*b3c_allgatherv_fn)(void *user, void *dev, int esz, const int64_t *starts, int world);
 typedef struct {
     int32_t rank, world;
-    int64_t chunk;        /* rows per rank, world*chunk >= n */
+    int64_t chunk;        /* exchange buffers hold world*chunk >= n elements (vec, labels: indexed by contig row) */
     double *vec;
     double *scal;
     int32_t *labels;
@@ -137,6 +141,13 @@ typedef struct {
     void *user;
     void *comm;           /* ncclComm_t of b3c_dist_comm_create, or NULL */
     b3c_allreduce_fn allreduce;   /* used when comm == NULL (Louvain: community-pair bins of the sharded aggregation) */
+    /* Row ranges of the ranks: rank r works on rows [starts[r], starts[r + 1]) of the ordered map (world + 1 ascending host
+     * offsets, starts[0] = 0, starts[world] = n; copied by b3c_ctx_set_dist).  NULL: equal ranges [r*chunk, (r+1)*chunk).  The
+     * caller balances them by STORED ENTRIES -- a prefix sum over the ordered row lengths -- because the rows of a
+     * contact map are anything but equally long (one genome may hold a third of the contigs, hub contigs 10^5..10^6 contacts).
+     * The vector and label exchanges then move ragged slices (one grouped launch of per-rank broadcasts, or `allgatherv`). */
+    const int64_t *starts;
+    b3c_allgatherv_fn allgatherv; /* used when comm == NULL and starts != NULL */
 } b3c_dist;
 /* Install (or with NULL remove) the sharding description; it applies to b3c_kr_balance and b3c_louvain
  * calls on matrices with n <= world*chunk rows.  No reference counterpart (bin3C is single process). */
@@ -162,6 +173,9 @@ int b3c_mat_upload(b3c_ctx *ctx, int64_t n, int64_t nnz, const int64_t *indptr /
                    const int32_t *indices /*host|dev*/, const void *data /*host|dev*/, int kind, b3c_mat **out);
 int b3c_mat_free(b3c_ctx *ctx, b3c_mat *m);
 int b3c_mat_info(const b3c_mat *m, int64_t *n, int64_t *nnz, int *kind);
+/* Stored entries of the rows: out[k] = indptr[idx[k] + 1] - indptr[idx[k]] (idx == NULL: row k).  idx int32[n], out int64[n];
+ * host|dev.  What the sharded pipeline balances its row ranges by (np.diff(indptr) of the scipy object, in the working order). */
+int b3c_mat_row_nnz(b3c_ctx *ctx, const b3c_mat *m, const int32_t *idx /*host|dev, may be NULL*/, int64_t *out /*host|dev*/);
 /* Copy back; any of the three output pointers may be NULL. */
 int b3c_mat_download(b3c_ctx *ctx, const b3c_mat *m, int64_t *indptr, int32_t *indices, void *data);
 /* Raw device pointers of a matrix (for zero-copy consumers such as torch tensors).  Matrices are immutable once created;
@@ -198,7 +212,8 @@ int b3c_mat_permute(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old /*hos
 /* The same, but only the rows [row0, row1) of the result are formed; the others stay empty.  This is the ROW BLOCK a rank of
  * the sharded path owns: site_norm / max_offdiag / b3c_kr_balance_counts / b3c_normalise_scale_compress / b3c_louvain then
  * touch 1/world of the entries each, and combine what must be global (degrees, totals, checksums, community-pair sums)
- * through the exchange buffers of b3c_ctx_set_dist.  row0 / row1 must be this rank's [rank*chunk, (rank+1)*chunk). */
+ * through the exchange buffers of b3c_ctx_set_dist.  row0 / row1 must be this rank's range ([starts[rank], starts[rank+1]), or
+ * [rank*chunk, (rank+1)*chunk) without starts). */
 int b3c_mat_permute_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old /*host|dev*/, int flags, int64_t row0,
                          int64_t row1, b3c_mat **out);
 

@@ -42,6 +42,25 @@ def cpu_mode(rank, world):
     ref = out.clone()
     dist.broadcast(ref, 0)
     assert torch.equal(out, ref)
+    # ragged row ranges balanced by stored entries: every rank computes the same cuts; the ragged in-place gather
+    # moves each rank's slice to its place
+    from bin3c_amd.dist import allgather_ragged, balanced_starts
+    rs = np.random.RandomState(4)
+    lens = rs.randint(1, 50, 5000).astype(np.int64)
+    lens[:40] = 20000                                  # a few hub rows at the front: equal row counts would be 3x out of balance
+    st = balanced_starts(lens, world)
+    assert st[0] == 0 and st[-1] == lens.shape[0] and np.all(np.diff(st) >= 0) and np.all(st[1:-1] % 64 == 0)
+    per = np.add.reduceat(lens, st[:-1])
+    assert per.max() <= 1.10 * per.mean() + 64 * 20000 / world, (per, st)
+    ref = torch.as_tensor(st.copy())
+    dist.broadcast(ref, 0)
+    assert torch.equal(torch.as_tensor(st), ref)
+    for dtype in (torch.float64, torch.int32):
+        full = torch.full((int(st[-1]),), -7, dtype=dtype)
+        full[st[rank]:st[rank + 1]] = torch.arange(int(st[rank]), int(st[rank + 1])).to(dtype)
+        allgather_ragged(full, st, rank)
+        assert torch.equal(full, torch.arange(int(st[-1])).to(dtype)), dtype
+    assert np.array_equal(balanced_starts(np.zeros(300, dtype=np.int64), world)[[0, -1]], [0, 300])
     print('rank %d cpu ok' % rank)
 
 
@@ -55,7 +74,9 @@ def gpu_mode(rank, world):
     n_block = 0
     # a flat map, and a power-law one whose hub rows go through kr_kb_hub and the Louvain hub lists on both ranks
     # (the third is too small for the locality ordering: it runs the sharded kernels on a map every rank holds whole)
-    maps = ((40000, 1300000, 21), (70000, 4000000, 9, 'powerlaw'), (30000, 900000, 9, 'powerlaw'))
+    # ... and the workload as SURVEY 8(d) writes it (one genome holds 38 % of the contigs)
+    maps = ((40000, 1300000, 21), (70000, 4000000, 9, 'powerlaw'), (30000, 900000, 9, 'powerlaw'),
+            (60000, 3000000, 4, 'flat', 0.1, 5, None, 'survey'))
     maps = maps[:int(os.environ.get('B3C_DIST_WORKER_MAPS', len(maps)))]
     for k, args in enumerate(maps):
         # the second map also takes the tail pass of the KR SpMV (automatic only beyond 2^19 contigs) on both row blocks
@@ -87,6 +108,12 @@ def gpu_mode(rank, world):
             tot_nnz = torch.tensor([res.work_nnz], dtype=torch.int64)
             dist.all_reduce(tot_nnz)
             assert int(tot_nnz.item()) == counts.nnz
+            # the row blocks are balanced by STORED ENTRIES (round 4), whatever the row lengths: hub rows of the
+            # power-law maps, the giant genome of the surveyed law
+            most = torch.tensor([res.work_nnz], dtype=torch.int64)
+            dist.all_reduce(most, op=dist.ReduceOp.MAX)
+            assert int(most.item()) <= 1.10 * counts.nnz / world, (int(most.item()), counts.nnz, world, sess.starts)
+            assert sess.starts is not None and int(sess.starts[-1]) == sm.n
             n_block += 1
         # ONE exchange per KR tick (round 3: the rank partial of p.w | rk.rk travels with the slice of w | v, and the vector step
         # after it runs over all rows on every rank); ticks are enqueued in batches of 4 and the state is read one batch
@@ -204,7 +231,7 @@ def gpu_empty_mode(rank, world):
     single = run_hot_path(ctx, counts, sm.sites, lengths, 1000, 5)
     assert not single.mask[n2o[r0:r1]].any() and single.mask.sum() > 0
     sess = DistSession(ctx, sm.n)
-    res = run_hot_path(ctx, counts, sm.sites, lengths, 1000, 5, keep=True)
+    res = run_hot_path(ctx, counts, sm.sites, lengths, 1000, 5, keep=True, balance_rows=False)      # (equal row ranges: the block masked above)
     sess.check()
     if rank == world - 1:
         assert res.sub is not None and res.sub.nnz == 0, res.sub.nnz       # this rank's block of the sub-map is empty

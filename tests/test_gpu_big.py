@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _row_sums_are_one(counts, sites, x, rows, tol=1e-5):
-    ip, ix, data = counts.download()
+    ip, ix, data = counts if isinstance(counts, tuple) else counts.download()
     s = np.where(sites == 0, 1.0, sites)
     u = x / s
     for r in rows:
@@ -90,4 +90,36 @@ def test_c5_shaped_map_leaves_more_communities_than_the_bin_table(ctx):
     _row_sums_are_one(counts, sites, res.x, rs.randint(0, n, 1000).tolist())
     again = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=20000)
     assert np.array_equal(again.x, res.x) and np.array_equal(again.labels, res.labels)
+    counts.free()
+
+
+def test_c5_at_its_stated_size(ctx):
+    """BASELINE.json configs[4] at its STATED size on one GPU: 5,000,000 contigs, 1e9 unique power-law edges (nnz ~ 2.0e9, int64
+    entry offsets, 16 GB of counts), drawn on the device.  One pass of the whole hot path with the iteration limit the map needs
+    (the reference's default of 1000 would raise, sparse_utils.py:213), then the size-independent properties: sampled rows of the
+    balanced map -- the longest hub rows included -- sum to one, every accepted contig is labelled, level 0 of the Louvain ends
+    beyond the bin table (sort path), and the Knight-Ruiz vector of a repeat balance is bit for bit the same."""
+    from bin3c_amd.pipeline import run_hot_path
+    from bin3c_amd.synth import CONFIGS
+    from bin3c_amd.synth_device import make_counts_device
+    n, e, seed, law = CONFIGS['C5']
+    counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, seed, law)
+    assert abs(n_edges - e) < 0.01 * e, (n_edges, info)
+    assert counts.nnz > 2 ** 30 and counts.nnz * 8 > 2 ** 33
+    res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=5000)
+    assert 1000 < res.kr_info.n_iter < 5000, res.kr_info.n_iter       # (the reference's default limit would have raised)
+    assert res.kr_info.bitwise_symmetric == 1 and np.isfinite(res.x).all() and (res.x > 0).all()
+    assert res.labels.shape[0] == int(res.mask.sum()) and res.labels.min() >= 0
+    assert res.lv_info.n_comm_level0 > 4096, res.lv_info.n_comm_level0
+    assert res.lv_info.modularity > 0.8
+    # the five longest rows (the hub contigs) and 500 random ones
+    ip, ix, data = counts.download()
+    hubs = np.argsort(np.diff(ip))[-5:].tolist()
+    rs = np.random.RandomState(5)
+    longest = _row_sums_are_one((ip, ix, data), sites, res.x, hubs + rs.randint(0, n, 500).tolist())
+    del ip, ix, data
+    assert longest > 10000          # (one count per unique pair: the hub contigs of this law have 10^4 .. 10^5 partners)
+    # a repeat of the balance (the ~3000 dependent ticks are the bulk of the step): bit-identical x
+    again = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=5000, cluster=False)
+    assert again.kr_info.n_iter == res.kr_info.n_iter and np.array_equal(again.x, res.x)
     counts.free()
