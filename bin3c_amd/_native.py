@@ -76,6 +76,7 @@ SYMBOLS = [
     ('b3c_last_error', C.c_char_p, [_VP]),
     ('b3c_ctx_sync', C.c_int, [_VP]),
     ('b3c_ctx_bytes', C.c_int64, [_VP]),
+    ('b3c_ctx_trim', C.c_int, [_VP]),
     ('b3c_ctx_set_dist', C.c_int, [_VP, _VP]),
     ('b3c_dist_unique_id', C.c_int, [_VP]),
     ('b3c_dist_comm_create', C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
@@ -262,6 +263,10 @@ class Context(object):
 
     def bytes_in_use(self):
         return int(self.lib.b3c_ctx_bytes(self.h))
+
+    def trim(self):
+        """give the pooled (unused) HBM blocks of this context back to the driver"""
+        self._check(self.lib.b3c_ctx_trim(self.h))
 
     # ---- matrices ----
     def upload(self, indptr, indices, data, n=None, nnz=None):

@@ -153,6 +153,15 @@ extern "C" int b3c_ctx_set_dist(b3c_ctx *ctx, const b3c_dist *dist)
 
 extern "C" int64_t b3c_ctx_bytes(const b3c_ctx *ctx) { return ctx ? ctx->bytes : 0; }
 
+extern "C" int b3c_ctx_trim(b3c_ctx *ctx)
+{
+    if (!ctx) return B3C_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->trim();
+    return B3C_OK;
+}
+
 int b3c_copy_in(b3c_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return B3C_OK;

@@ -76,6 +76,10 @@ struct b3c_ctx {
         }
         return true;
     }
+    // hipFuncSetAttribute (dynamic LDS beyond 64 KB) is per DEVICE and costs ~150 us a call: every context -- one device each --
+    // sets each attribute once (a process-wide flag would leave the kernels of a second GPU without it: ADVICE round 3)
+    uint32_t attr_mask = 0;
+    bool attr_first(int bit) { const bool f = !(attr_mask & (1u << bit)); attr_mask |= 1u << bit; return f; }
     void *pin = nullptr;      // pinned host staging for small read-backs (a pageable destination costs a staged copy)
     b3c_dist dist;            // row-sharded multi-GPU execution (b3c_ctx_set_dist); world <= 1: off
     std::vector<int64_t> dist_starts;   // the library's copy of b3c_dist.starts (dist.starts points here), empty: equal ranges

@@ -2420,7 +2420,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         DevBuf<unsigned long long> stt(ctx, 16);           // [0..3] layout statistics, [8..11] phase clocks (development builds)
         if (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
         HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 16, s));
-        { static bool build_attr = false; if (!build_attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS)); build_attr = true; } }
+        if (ctx->attr_first(0)) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS));
         // (round 3 tried ONE pass per tile over a window of 2^18 columns centred on the tile, everything outside going to the tails
         // unseen: the build fell from 2.9 to 1.1 ms, but the SpMV rose from 0.289 to 0.375 ms at C3 -- the locality order keeps a
         // cluster together, not a genome: the pieces of a genome sit far apart and their columns DO repeat inside a tile)
@@ -2522,8 +2522,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: tail sort workspace");
         e = hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, words_in.p, xt_words.p, (int64_t)n_tails, sort_lo, sort_hi, s);
         if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort of the tails failed");
-        // (the attribute is per device: set on every call -- ADVICE round 3)
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT)));
+        if (ctx->attr_first(1)) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT)));
         if (xt_pack_want && n_tails > 0) {
             // the sorted words as 32-bit words + residual list (kr_tails_pack); not worth it when many words do not fit
             xt_cw.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(n_tails + 64));
@@ -2592,17 +2591,15 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int cP = dist ? D.world : 0, cS = dist ? 4 : 1;      // consumer view of gathered partials
     const size_t tcd_shmem2 = sizeof(double) * ((size_t)tcd_lds_d + 2 * (size_t)tcd_R + (size_t)tcd_R + 1 + TBK) + sizeof(int32_t) * (size_t)tcd_R;
     if (tcd) {
-        // dynamic LDS beyond 64 KB needs the attribute; set once per process to the device limit (the call is not cheap:
-        // fourteen of them per balance call cost over 2 ms)
-        static bool attr_done = false;
-        if (!attr_done) {
+        // dynamic LDS beyond 64 KB needs the attribute; set once per context (= device) to the device limit (the call is not
+        // cheap: fourteen of them per balance call cost over 2 ms)
+        if (ctx->attr_first(2)) {
             constexpr int LDS_MAX = 160 * 1024;
 #define KR_TCD2_ATTR(L, U, TL, T)                                                                                                             \
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX)); \
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
             KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
 #undef KR_TCD2_ATTR
-            attr_done = true;
         }
     }
     // The host looks at the state ONE BATCH BEHIND: the copy of batch b's final state is waited for after batch b + 1 has

@@ -1920,14 +1920,25 @@ __global__ void k_aggh_classify(int64_t kc, const unsigned long long *__restrict
                                 int64_t *__restrict__ tsz, int64_t *__restrict__ need)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > kc) return;
-    if (c == kc) { tsz[kc] = 0; need[kc] = 0; return; }
-    const long long u = (long long)ub[c];
-    need[c] = u + 1;                                  // scratch slots of the community: every entry a target of its own, plus the diagonal
-    const int cls = u <= lv_wg_max_deg(0) ? 0 : u <= lv_wg_max_deg(1) ? 1 : u <= lv_wg_max_deg(2) ? 2 : 3;
-    tsz[c] = cls == 3 ? (1ll << table_lg(u)) : 0;
-    const unsigned long long at = atomicAdd(&lcnt[cls], 1ull);
-    lists[(int64_t)cls * kc + at] = (int32_t)c;
+    const int lane = threadIdx.x & 63;
+    int cls = -1;
+    if (c == kc) { tsz[kc] = 0; need[kc] = 0; }
+    if (c < kc) {
+        const long long u = (long long)ub[c];
+        need[c] = u + 1;                                  // scratch slots of the community: every entry a target of its own, plus the diagonal
+        cls = u <= lv_wg_max_deg(0) ? 0 : u <= lv_wg_max_deg(1) ? 1 : u <= lv_wg_max_deg(2) ? 2 : 3;
+        tsz[c] = cls == 3 ? (1ll << table_lg(u)) : 0;
+    }
+    // one atomic per wave and class (185k communities appending one by one queue up on four addresses: 1.6 ms at C3's surveyed law)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long m = __ballot(cls == k);
+        if (!m) continue;
+        unsigned long long at = 0;
+        if (lane == 0) at = atomicAdd(&lcnt[k], (unsigned long long)__popcll(m));
+        at = (unsigned long long)__shfl((long long)at, 0, 64);
+        if (cls == k) lists[(int64_t)k * kc + at + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)c;
+    }
 }
 
 // block-wide exclusive prefix of one count per thread (NT threads); returns the thread's offset, *total = the block's sum
@@ -2032,12 +2043,16 @@ __global__ void __launch_bounds__(NT) k_aggh_wg(int64_t cnt, const int32_t *__re
     }
 }
 
-// communities beyond the LDS tables: one workgroup per MEMBER ROW inserts into the community's table in global memory ...
+// communities beyond the LDS tables: one workgroup per MEMBER ROW inserts into the community's table in global memory.  The lane
+// that turns an EMPTY slot into a target community CLAIMS it: it reserves the next output position of the community (dcnt) and
+// writes the target there at once -- so the emit pass below walks the community's DISTINCT targets (a few thousand) instead of
+// its table (sized by all entries of its rows, internal ones included: 2^19 slots for a genome of 2000 contigs) ...
 __global__ void __launch_bounds__(BLK) k_aggh_big_insert(int64_t nrows, const int32_t *__restrict__ rows, const int64_t *__restrict__ indptr,
                                                           const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
                                                           const int32_t *__restrict__ cn, const unsigned long long *__restrict__ ub,
                                                           const int64_t *__restrict__ toff, int32_t *__restrict__ gkeys, u64 *__restrict__ gvals,
-                                                          unsigned long long *__restrict__ own_acc)
+                                                          unsigned long long *__restrict__ own_acc, const int64_t *__restrict__ ubpos,
+                                                          int32_t *__restrict__ tix, unsigned long long *__restrict__ dcnt)
 {
     __shared__ long long red[BLK / 64];
     for (int64_t pos = blockIdx.x; pos < nrows; pos += gridDim.x) {
@@ -2047,7 +2062,7 @@ __global__ void __launch_bounds__(BLK) k_aggh_big_insert(int64_t nrows, const in
         const uint32_t mask = (1u << lg) - 1u;
         int32_t *keys = gkeys + toff[c1];
         u64 *vals = gvals + toff[c1];
-        const int64_t s = indptr[i], e = indptr[i + 1];
+        const int64_t s = indptr[i], e = indptr[i + 1], o = ubpos[c1];
         long long own = 0;
         for (int64_t k = s + threadIdx.x; k < e; k += BLK) {
             const int32_t j = indices[k];
@@ -2057,7 +2072,11 @@ __global__ void __launch_bounds__(BLK) k_aggh_big_insert(int64_t nrows, const in
             uint32_t slot = hash_slot(c2, lg);
             for (;;) {
                 const int32_t prev = atomicCAS(&keys[slot], EMPTY, c2);
-                if (prev == EMPTY || prev == c2) { atomicAdd(&vals[slot], qv); break; }
+                if (prev == EMPTY || prev == c2) {
+                    atomicAdd(&vals[slot], qv);
+                    if (prev == EMPTY) tix[o + 1 + (int64_t)atomicAdd(&dcnt[c1], 1ull)] = c2;      // (slot 0 of the community: its diagonal)
+                    break;
+                }
                 slot = (slot + 1) & mask;
             }
         }
@@ -2065,31 +2084,30 @@ __global__ void __launch_bounds__(BLK) k_aggh_big_insert(int64_t nrows, const in
     }
 }
 
-// ... and one workgroup per community emits the diagonal and the non-empty slots of its table
-__global__ void __launch_bounds__(1024) k_aggh_big_emit(int64_t cnt, const int32_t *__restrict__ list, const unsigned long long *__restrict__ ub,
-                                                         const int64_t *__restrict__ toff, const int32_t *__restrict__ gkeys,
-                                                         const u64 *__restrict__ gvals, const unsigned long long *__restrict__ own_acc,
-                                                         const int64_t *__restrict__ ubpos, int32_t *__restrict__ tix, int64_t *__restrict__ tq,
-                                                         int64_t *__restrict__ dcnt)
+// ... one workgroup per community: the diagonal, and the sum of every claimed target by probing the table once more
+__global__ void __launch_bounds__(BLK) k_aggh_big_emit(int64_t cnt, const int32_t *__restrict__ list, const unsigned long long *__restrict__ ub,
+                                                        const int64_t *__restrict__ toff, const int32_t *__restrict__ gkeys,
+                                                        const u64 *__restrict__ gvals, const unsigned long long *__restrict__ own_acc,
+                                                        const int64_t *__restrict__ ubpos, int32_t *__restrict__ tix, int64_t *__restrict__ tq,
+                                                        unsigned long long *__restrict__ dcnt)
 {
-    __shared__ int sc[16];
-    const int32_t c1 = list[blockIdx.x];
-    const int lg = table_lg((int64_t)ub[c1]);
-    const int64_t size = 1ll << lg;
-    const int32_t *keys = gkeys + toff[c1];
-    const u64 *vals = gvals + toff[c1];
-    const int64_t o = ubpos[c1];
-    int64_t done = 1;                                   // entries written so far (slot 0: the diagonal)
-    if (threadIdx.x == 0) { tix[o] = c1; tq[o] = (int64_t)(own_acc[c1] / 2); }
-    for (int64_t t0 = 0; t0 < size; t0 += 1024) {
-        const int64_t t = t0 + threadIdx.x;
-        const int32_t k = t < size ? keys[t] : EMPTY;
-        int total = 0;
-        const int at = block_excl_scan<1024>(k != EMPTY ? 1 : 0, sc, &total);
-        if (k != EMPTY) { tix[o + done + at] = k; tq[o + done + at] = (int64_t)vals[t]; }
-        done += total;
+    for (int64_t pos = blockIdx.x; pos < cnt; pos += gridDim.x) {
+        const int32_t c1 = list[pos];
+        const int lg = table_lg((int64_t)ub[c1]);
+        const uint32_t mask = (1u << lg) - 1u;
+        const int32_t *keys = gkeys + toff[c1];
+        const u64 *vals = gvals + toff[c1];
+        const int64_t o = ubpos[c1];
+        const int64_t nd = (int64_t)dcnt[c1];
+        for (int64_t t = threadIdx.x; t < nd; t += BLK) {
+            const int32_t c2 = tix[o + 1 + t];
+            uint32_t slot = hash_slot(c2, lg);
+            while (keys[slot] != c2) slot = (slot + 1) & mask;
+            tq[o + 1 + t] = (int64_t)vals[slot];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { tix[o] = c1; tq[o] = (int64_t)(own_acc[c1] / 2); dcnt[c1] = (unsigned long long)nd + 1; }
     }
-    if (threadIdx.x == 0) dcnt[c1] = done;
 }
 
 __global__ void k_aggh_big_rows(int64_t n, const int32_t *__restrict__ cn, const int64_t *__restrict__ tsz, const int64_t *__restrict__ indptr,
@@ -2554,8 +2572,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if (!grec.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: gather records");
         if (use_rec) hipLaunchKernelGGL(k_lv_rec_refresh, dim3(gv), dim3(BLK), 0, s, n, com.p, tot.p, grec.p);
         const size_t mega_lds_bytes = (size_t)(1 << MEGA_LDS_LG) * 12 + (MEGA_NT / 64) * 8;
-        if (use_wg) {
-            // tables beyond 64 KB of LDS are dynamic shared memory that a kernel must be allowed first (per device: set on every call)
+        if (use_wg && ctx->attr_first(3)) {
+            // tables beyond 64 KB of LDS are dynamic shared memory that a kernel must be allowed first (once per context = device)
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_lv_decide_wg<13, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv_wg_lds<13, 1024>()));
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_lv_mega_insert_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mega_lds_bytes));
         }
@@ -2618,6 +2636,12 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             return B3C_OK;
         };
 
+        // every exit from here on -- an early return between a fork onto the side streams and its join included -- waits for the side
+        // streams BEFORE the blocks their kernels read and write (declared above: tables, lists, nxt, mega_own) go back to the pool
+        struct SideJoin {
+            b3c_ctx *c;
+            ~SideJoin() { if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(c->side2); } }
+        } side_join{ctx};
         double cur_mod, new_mod;
         // all nodes alone: k_lv_init has left the self-loop weight in ctr[2], no scan of the graph needed
         if ((rc = modularity(&new_mod, false, nullptr))) { free_graph(ctx, g); return rc; }
@@ -2930,6 +2954,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ub.p, 0, sizeof(unsigned long long) * (size_t)(kc + 1), s));
             HIP_TRY(ctx, hipMemsetAsync(own_acc.p, 0, sizeof(unsigned long long) * (size_t)(kc + 1), s));
             HIP_TRY(ctx, hipMemsetAsync(lcnt.p, 0, sizeof(unsigned long long) * 5, s));
+            HIP_TRY(ctx, hipMemsetAsync(dcnt.p, 0, sizeof(int64_t) * (size_t)(kc + 1), s));      // (class 3 counts its claims in it)
             hipLaunchKernelGGL(k_aggh_starts, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, kc, skey.p, cstart.p);
             hipLaunchKernelGGL(k_aggh_ub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.indptr, cn.p, ub.p);
             hipLaunchKernelGGL(k_aggh_classify, dim3((unsigned)((kc + 256) / 256)), dim3(256), 0, s, kc, ub.p, lists.p, lcnt.p, tsz.p, need.p);
@@ -2947,7 +2972,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 HIP_TRY(ctx, hipMemsetAsync(hk.p, 0xFF, sizeof(int32_t) * (size_t)gtot, s));
                 HIP_TRY(ctx, hipMemsetAsync(hv.p, 0, sizeof(u64) * (size_t)gtot, s));
             }
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_aggh_wg<13, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv_wg_lds<13, 1024>()));
+            if (ctx->attr_first(4)) HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_aggh_wg<13, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv_wg_lds<13, 1024>()));
 #define LV_AGGH(LGS, NT, CLS, MAXG)                                                                                      \
     if (hl[CLS])                                                                                                         \
         hipLaunchKernelGGL((k_aggh_wg<LGS, NT>), dim3((unsigned)std::min<int64_t>((int64_t)hl[CLS], MAXG)), dim3(NT), (lv_wg_lds<LGS, NT>()), s, (int64_t)hl[CLS], \
@@ -2959,11 +2984,10 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             if (hl[3]) {
                 if (hl[4])
                     hipLaunchKernelGGL(k_aggh_big_insert, dim3((unsigned)std::min<int64_t>((int64_t)hl[4], 32 * (int64_t)ctx->n_cu)), dim3(BLK), 0, s, (int64_t)hl[4], brows.p,
-                                       g.indptr, g.indices, g.q, cn.p, ub.p, toff.p, hk.p, hv.p, own_acc.p);
-                hipLaunchKernelGGL(k_aggh_big_emit, dim3((unsigned)hl[3]), dim3(1024), 0, s, (int64_t)hl[3], lists.p + 3 * kc, ub.p, toff.p, hk.p, hv.p,
-                                   own_acc.p, ubpos.p, tix.p, tq.p, dcnt.p);
+                                       g.indptr, g.indices, g.q, cn.p, ub.p, toff.p, hk.p, hv.p, own_acc.p, ubpos.p, tix.p, (unsigned long long *)dcnt.p);
+                hipLaunchKernelGGL(k_aggh_big_emit, dim3((unsigned)std::min<int64_t>((int64_t)hl[3], 16 * (int64_t)ctx->n_cu)), dim3(BLK), 0, s, (int64_t)hl[3], lists.p + 3 * kc,
+                                   ub.p, toff.p, hk.p, hv.p, own_acc.p, ubpos.p, tix.p, tq.p, (unsigned long long *)dcnt.p);
             }
-            HIP_TRY(ctx, hipMemsetAsync(dcnt.p + kc, 0, sizeof(int64_t), s));
             h.n = kc; h.owned = true;
             h.indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(kc + 1));
             if (!h.indptr) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: next level");

@@ -13,7 +13,13 @@
  *    hipMemcpyDefault); the library never retains or frees caller memory.
  *  - Every call returns B3C_OK or a negative error code; b3c_last_error() gives the text.  Calls are
  *    synchronous with respect to their outputs unless the name ends in _async.
- *  - One b3c_ctx per host thread and device; a ctx is not re-entrant.
+ *  - One b3c_ctx per host thread and device; a ctx is not re-entrant.  A b3c_mat belongs to the context that created it and must
+ *    not be passed to two calls at once: calls leave by-products with the (otherwise immutable) matrix -- its largest value, the
+ *    largest off-diagonal count of every row -- which later calls answer from.
+ *  - Completion: a call has finished all its work when it returns, with ONE exception: b3c_acceptance_mask and b3c_vec_permute
+ *    with a DEVICE destination return once the result is enqueued on the context's stream (they are the per-contig plumbing
+ *    between stages; a host destination is complete on return).  A caller that reads such a device result on another stream, or
+ *    from the host, orders itself behind the context's stream first (an event on it, or b3c_ctx_sync).
  */
 #ifndef B3C_H
 #define B3C_H
@@ -96,6 +102,10 @@ const char *b3c_last_error(const b3c_ctx *ctx);
 int b3c_ctx_sync(b3c_ctx *ctx);
 /* HBM bytes currently held by the context's matrices and workspaces. */
 int64_t b3c_ctx_bytes(const b3c_ctx *ctx);
+/* Return the context's cached (pooled, currently unused) HBM blocks to the driver.  Workspaces are recycled between calls so that
+ * a warm step issues no hipMalloc; a caller about to need the memory for something else (a 16 GB map next to a pool sized by the
+ * last one) trims first.  Matrices and blocks in use are not touched. */
+int b3c_ctx_trim(b3c_ctx *ctx);
 
 /* ---- multi-GPU: contig-row ranges of ONE map across ranks ---------------------------------- */
 

@@ -104,6 +104,24 @@ def test_max_offdiag_integer_dtypes_and_refusal(ctx):
         sparse_utils.max_offdiag(sp.csr_matrix(-d.astype(np.int64)), ctx=ctx)
 
 
+
+def test_row_maxima_left_by_the_balance_and_their_invalidation(ctx, oracle_lib):
+    """b3c_kr_balance_counts leaves the largest off-diagonal count of every row with the matrix (kr_prep_counts) and
+    b3c_max_offdiag_u32(assume_symmetric) answers from it; b3c_mat_device_ptrs hands out writable pointers and must drop that
+    by-product, after which the call makes its own pass again -- same answer either way."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(20000, 600000, 13)
+    ref = oracle_lib.max_offdiag_u32(sm.indptr, sm.indices, sm.counts)
+    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    assert np.array_equal(ctx.max_offdiag_u32(cm, assume_symmetric=True), ref)      # own pass
+    ctx.kr_balance_counts(cm, sm.sites)
+    assert np.array_equal(ctx.max_offdiag_u32(cm, assume_symmetric=True), ref)      # by-product of the balance
+    cm.device_ptrs()                                                                # writable pointers: by-products dropped
+    assert np.array_equal(ctx.max_offdiag_u32(cm, assume_symmetric=True), ref)      # own pass again
+    assert np.array_equal(ctx.max_offdiag_u32(cm, assume_symmetric=False), ref)
+    cm.free()
+
+
 @pytest.mark.parametrize('graph_form', [False, True])
 def test_fused_sub_map_is_bit_identical(ctx, graph_form):
     """b3c_normalise_scale_compress == b3c_normalise_scale followed by b3c_compress, on a permuted (id-carrying) matrix"""
