@@ -598,6 +598,110 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval(const NodeRec *__restr
     }
 }
 
+// pass 2 of the mega rows, split over the table (round 4): one workgroup per node walked the node's whole table -- 2^18 slots for
+// the 147k-entry row of the surveyed law's level 1, 134 us per sub-round with the rest of the chip idle.  Workgroup (node m, chunk
+// ch) evaluates and clears MEGA_ESL slots and leaves its best candidate in part[]; the LAST workgroup of a node to finish (a ticket
+// per node) folds the partial results in chunk order with the same order-free arg-max (ties to the lowest community id) and
+// settles the node.  Same candidates, same comparisons: the same decision as k_lv_mega_eval.
+constexpr int MEGA_ESL = 16384;            // table slots per workgroup of the split evaluation
+struct MegaPart { u64 hi, lo, com_have; };
+__global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval_split(const NodeRec *__restrict__ list, int echunks, u64 m2, const int64_t *__restrict__ kdeg,
+                                                                 const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
+                                                                 const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
+                                                                 const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
+                                                                 u64 *__restrict__ gvals, u64 *__restrict__ own_acc, MegaPart *__restrict__ part,
+                                                                 unsigned int *__restrict__ ticket)
+{
+    __shared__ long long red_hi[MEGA_NT / 64];
+    __shared__ u64 red_lo[MEGA_NT / 64];
+    __shared__ int32_t red_com[MEGA_NT / 64], red_have[MEGA_NT / 64];
+    __shared__ int last;
+    const int m = blockIdx.x / echunks, ch = blockIdx.x % echunks;
+    const NodeRec rec = list[m];
+    const int lg = table_lg(rec.deg);
+    const uint32_t size = 1u << lg;
+    const int nch = (int)((size + MEGA_ESL - 1) / MEGA_ESL);
+    if (ch >= nch) return;                                            // (uniform per workgroup)
+    const int32_t i = rec.node;
+    const long long ki = kdeg[i];
+    const int32_t a = com[i];
+    int32_t *keys = gkeys + goff[i];
+    u64 *vals = gvals + goff[i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    Best b;
+    b.gain = 0; b.com = a; b.have = 0;
+    const uint32_t s0 = (uint32_t)ch * MEGA_ESL, s1 = s0 + MEGA_ESL < size ? s0 + MEGA_ESL : size;
+    for (uint32_t t0 = s0 + threadIdx.x; t0 < s1; t0 += 4 * MEGA_NT) {
+        int32_t c[4];
+        u64 d[4];
+        long long tc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t t = t0 + u * MEGA_NT;
+            c[u] = t < s1 ? keys[t] : EMPTY;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t t = t0 + u * MEGA_NT;
+            d[u] = c[u] != EMPTY ? vals[t] : 0;
+            tc[u] = c[u] != EMPTY ? tot[c[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (c[u] == EMPTY) continue;
+            const uint32_t t = t0 + u * MEGA_NT;
+            keys[t] = EMPTY;
+            vals[t] = 0;
+            const i128 g = (i128)d[u] * (i128)m2 - (i128)tc[u] * (i128)ki;
+            best_take(b, g, c[u]);
+        }
+    }
+    b = best_wave_reduce(b);
+    if (lane == 0) {
+        red_hi[wv] = (long long)(b.gain >> 64);
+        red_lo[wv] = (u64)b.gain;
+        red_com[wv] = b.com;
+        red_have[wv] = b.have;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Best r;
+        r.gain = 0; r.com = a; r.have = 0;
+        for (int w = 0; w < MEGA_NT / 64; w++) {
+            const i128 g = ((i128)red_hi[w] << 64) | (i128)red_lo[w];
+            if (red_have[w] && (!r.have || g > r.gain || (g == r.gain && red_com[w] < r.com))) { r.gain = g; r.com = red_com[w]; r.have = 1; }
+        }
+        // the partial result travels through agent-scope atomics: the workgroups of a node run on different XCDs, each with its own L2
+        u64 *slot = (u64 *)&part[(int64_t)m * echunks + ch];
+        __hip_atomic_store(slot + 0, (u64)(long long)(r.gain >> 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 1, (u64)r.gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 2, (u64)(uint32_t)r.com | ((u64)(uint32_t)r.have << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(&ticket[m], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nch - 1);
+        if (last) {
+            __hip_atomic_store(&ticket[m], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next sub-round
+            Best f;
+            f.gain = 0; f.com = a; f.have = 0;
+            for (int k = 0; k < nch; k++) {
+                u64 *q = (u64 *)&part[(int64_t)m * echunks + k];
+                const u64 qh = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 ql = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 qc = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const i128 g = ((i128)(long long)qh << 64) | (i128)ql;
+                const int32_t qcom = (int32_t)(uint32_t)qc, qhave = (int32_t)(qc >> 32);
+                if (qhave && (!f.have || g > f.gain || (g == f.gain && qcom < f.com))) { f.gain = g; f.com = qcom; f.have = 1; }
+            }
+            const long long o = (long long)own_acc[m];
+            own_acc[m] = 0;
+            // staying: i removed from its own community first (python-louvain __remove)
+            const i128 g = (i128)o * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            best_take(f, g, a);
+            int32_t best = f.have ? f.com : a;
+            if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
+            nxt[i] = best;
+        }
+    }
+}
+
 // Rows between the grouped kernel's reach and the mega rows: one WORKGROUP per node (round 4).  The induced graph of a level
 // that ended with 10^5 communities (the surveyed genome-size law at C3: 185,559 nodes, ~1000 entries per row) is made of such rows,
 // and one WAVE per node with a 2048-slot table of its own (96 KB per four waves: one workgroup per CU, four waves to hide the
@@ -1898,12 +2002,19 @@ __global__ void __launch_bounds__(BLK) k_bins_fill(int64_t kc, const u64 *__rest
 // Integer sums: the induced graph is the one the sort path builds, entry for entry -- only the ORDER of the entries inside a
 // row differs (slot order instead of ascending columns), which no kernel of the next level depends on.
 // ---------------------------------------------------------------------------------------------
+// sort key of a node: its new community; the nodes that are in no community (empty rows of level 0: cn = -1) go behind all of them
+__global__ void k_aggh_keys(int64_t n, int64_t kc, const int32_t *__restrict__ cn, int32_t *__restrict__ key)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = cn[i] >= 0 ? cn[i] : (int32_t)kc;
+}
+
 __global__ void k_aggh_starts(int64_t n, int64_t kc, const int32_t *__restrict__ skey, int64_t *__restrict__ cstart)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
-    if (i == n) { cstart[kc] = n; return; }
-    if (i == 0 || skey[i] != skey[i - 1]) cstart[skey[i]] = i;        // (every community 0 .. kc-1 has a member)
+    if (i == n) { if (n == 0 || skey[n - 1] < kc) cstart[kc] = n; return; }
+    if (i == 0 || skey[i] != skey[i - 1]) cstart[skey[i] < kc ? skey[i] : kc] = i;        // (every community 0 .. kc-1 has a member)
 }
 
 __global__ void k_aggh_ub(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ cn, unsigned long long *__restrict__ ub)
@@ -2175,13 +2286,15 @@ __global__ void k_init_labels(int64_t n, const int64_t *__restrict__ indptr, int
     if (i < n) labels[i] = indptr[i + 1] > indptr[i] ? (int32_t)i : -1;
 }
 
-__global__ void k_big_table_sizes(int64_t n, int cap, const int64_t *__restrict__ indptr, int64_t *__restrict__ sz)
+// table in global memory for the rows whose table does not fit `cap` slots of LDS, and for every row beyond deg_thr entries (the
+// mega rows, whatever the threshold: k_lv_mega_* work on global tables only)
+__global__ void k_big_table_sizes(int64_t n, int cap, int64_t deg_thr, const int64_t *__restrict__ indptr, int64_t *__restrict__ sz)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const int64_t deg = indptr[i + 1] - indptr[i];
         const int lg = table_lg(deg);
-        sz[i] = (1ll << lg) > cap ? (1ll << lg) : 0;
+        sz[i] = ((1ll << lg) > cap || deg > deg_thr) ? (1ll << lg) : 0;
     }
     if (i == n) sz[i] = 0;
 }
@@ -2491,9 +2604,19 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int cap_max = (int)CFG.num("B3C_LV_CAP_MAX", 2048);
         const int cap0 = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
         const int cap = cap0 > cap_max ? cap_max : cap0;
+        // rows beyond mega_deg entries get workgroups and the node's table in global memory (k_lv_mega_*).  With the workgroup
+        // kernel: whatever its largest LDS table cannot hold (or fewer: B3C_LV_MEGA_DEG).  Without it (round 3's rule): the wave kernel
+        // copes with long rows as long as there are enough of them to fill the chip (C5: thousands of hub contigs), a FEW long rows are
+        // the tail everybody waits for.
+        int64_t mega_auto = MEGA_DEG;
+        if ((int64_t)hc[8] <= MEGA_FEW) mega_auto = 2048;
+        else if ((int64_t)hc[9] <= MEGA_FEW) mega_auto = 4096;
+        const int mega_deg = use_wg ? (int)std::min<int64_t>(lv_wg_max_deg(2), std::max<int64_t>(short_max, CFG.num("B3C_LV_MEGA_DEG", lv_wg_max_deg(2))))
+                                    : (int)std::max<int64_t>(cap, CFG.num("B3C_LV_MEGA_DEG", mega_auto));
         // rows whose table does not fit the LDS of the kernel that takes them use a table in global memory (goff / gkeys / gvals)
         const int cap_tbl = use_wg ? (1 << 13) : cap;
-        hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap_tbl, g.indptr, gsz.p);
+        hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap_tbl, use_wg ? (int64_t)mega_deg : INT64_MAX,
+                           g.indptr, gsz.p);
         if ((rc = b3c_exclusive_scan_i64(ctx, gsz.p, goff.p, n + 1))) { free_graph(ctx, g); return rc; }
         int64_t gtab = 0;
         { const int rb_ = b3c_readback(ctx, &gtab, goff.p + n, sizeof(int64_t)); if (rb_) return rb_; }
@@ -2513,15 +2636,6 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // kernel, 5 mega rows)
         std::vector<std::array<int64_t, LV_SEGS + 1>> off(n_sub);
         for (auto &o : off) o.fill(0);
-        // rows beyond mega_deg entries get workgroups and the node's table in global memory (k_lv_mega_*).  With the workgroup
-        // kernel: whatever its largest LDS table cannot hold.  Without it (round 3's rule): the wave kernel copes with long rows as
-        // long as there are enough of them to fill the chip (C5: thousands of hub contigs), a FEW long rows are the tail everybody
-        // waits for.
-        int64_t mega_auto = MEGA_DEG;
-        if ((int64_t)hc[8] <= MEGA_FEW) mega_auto = 2048;
-        else if ((int64_t)hc[9] <= MEGA_FEW) mega_auto = 4096;
-        const int mega_deg = use_wg ? (int)std::min<int64_t>(lv_wg_max_deg(2), std::max<int64_t>(short_max, CFG.num("B3C_LV_MEGA_DEG", lv_wg_max_deg(2))))
-                                    : (int)std::max<int64_t>(cap, CFG.num("B3C_LV_MEGA_DEG", mega_auto));
         LvThr thr;
         thr.t[0] = short_max;
         if (use_wg) {
@@ -2592,6 +2706,13 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         int64_t max_hlist = 0, max_mega = 0;
         for (int r = 0; r < n_sub; r++) { max_hlist = std::max(max_hlist, moff[r] - hoff[r]); max_mega = std::max(max_mega, lend[r] - moff[r]); }
         DevBuf<u64> mega_own(ctx, max_mega + 1);            // own-community weight of the mega rows of a sub-round (cleared by the eval pass)
+        // split evaluation of the mega rows' tables (k_lv_mega_eval_split): partial results and tickets
+        const bool mega_split = !CFG.on("B3C_LV_NO_MEGA_SPLIT") && max_mega > 0;
+        const int mega_echunks = mega_split ? (int)(((1ll << table_lg(maxdeg)) + MEGA_ESL - 1) / MEGA_ESL) : 1;
+        DevBuf<MegaPart> mega_part(ctx, mega_split ? (size_t)max_mega * mega_echunks + 1 : 1);
+        DevBuf<unsigned int> mega_ticket(ctx, max_mega + 1);
+        if (!mega_part.p || !mega_ticket.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: mega rows");
+        HIP_TRY(ctx, hipMemsetAsync(mega_ticket.p, 0, sizeof(unsigned int) * (size_t)(max_mega + 1), s));
         if (!mega_own.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: mega rows");
         HIP_TRY(ctx, hipMemsetAsync(mega_own.p, 0, sizeof(u64) * (size_t)(max_mega + 1), s));
         DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1), plist_h(ctx, can_prune ? max_hlist + 1 : 1);
@@ -2741,8 +2862,12 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     else
                         hipLaunchKernelGGL(k_lv_mega_insert, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], chunks, g.indices, g.q,
                                            com.p, goff.p, gkeys.p, gvals.p, mega_own.p);
-                    hipLaunchKernelGGL(k_lv_mega_eval, dim3((unsigned)nm), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], m2, kdeg.p, tot.p, com.p, csize.p,
-                                       nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p);
+                    if (mega_split)
+                        hipLaunchKernelGGL(k_lv_mega_eval_split, dim3((unsigned)(nm * mega_echunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], mega_echunks, m2, kdeg.p,
+                                           tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p, mega_part.p, mega_ticket.p);
+                    else
+                        hipLaunchKernelGGL(k_lv_mega_eval, dim3((unsigned)nm), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], m2, kdeg.p, tot.p, com.p, csize.p,
+                                           nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p);
                     if (ms != s && ms != hs) {
                         HIP_TRY(ctx, hipEventRecord(ctx->ev_join2, ms));
                         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join2, 0));
@@ -2942,13 +3067,16 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hash aggregation");
             hipLaunchKernelGGL(k_iota32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, iota.p);
             {
+                DevBuf<int32_t> key_in(ctx, n);
+                if (!key_in.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hash aggregation");
+                hipLaunchKernelGGL(k_aggh_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, kc, cn.p, key_in.p);
                 int kb = 1;
-                while ((1ll << kb) < kc) kb++;
+                while ((1ll << kb) <= kc) kb++;                // (keys 0 .. kc: kc = "in no community")
                 size_t tb = 0;
-                HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, cn.p, skey.p, iota.p, ord.p, n, 0, kb, s));
+                HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key_in.p, skey.p, iota.p, ord.p, n, 0, kb, s));
                 DevBuf<char> tmp(ctx, tb);
                 if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: hash aggregation");
-                HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, cn.p, skey.p, iota.p, ord.p, n, 0, kb, s));
+                HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key_in.p, skey.p, iota.p, ord.p, n, 0, kb, s));
                 HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch goes back to the pool here
             }
             HIP_TRY(ctx, hipMemsetAsync(ub.p, 0, sizeof(unsigned long long) * (size_t)(kc + 1), s));

@@ -65,6 +65,29 @@ def test_loops_empty_rows_and_no_edges(ctx, oracle_lib):
     assert (labels == -1).all() and info.n_levels == 0
 
 
+def test_aggregation_by_hashing_with_nodes_in_no_community(ctx, oracle_lib, monkeypatch):
+    """The many-communities branch of the aggregation (forced: B3C_LV_AGG_SORT=1), by hashing and by the pair sort, on a graph
+    with empty rows scattered through it: such nodes are in NO community (label -1; never added to the graph, cluster.py:321)
+    and must stay out of the member lists the hash path builds (round 4: their -1 used to be a sort key)."""
+    rs = np.random.RandomState(8)
+    n, edges = graphs.ring_of_cliques(300, 5, 1.0, 0.3)
+    # renumber onto a larger id space: every seventh id keeps an empty row
+    ids = np.array([i for i in range(int(n * 1.2) + 8) if i % 7 != 3][:n])
+    edges = [(int(ids[i]), int(ids[j]), w) for i, j, w in edges]
+    m = len(edges)
+    a, b = rs.randint(0, n, m // 3), rs.randint(0, n, m // 3)
+    edges += [(int(ids[i]), int(ids[j]), float(rs.uniform(0.2, 1.0))) for i, j in zip(a, b) if i != j]
+    nn = int(ids.max()) + 3
+    ip, ix, w = graphs.csr_from_edges(nn, edges)
+    assert (np.diff(ip) == 0).sum() > 100
+    for env in ({'B3C_LV_AGG_SORT': '1'}, {'B3C_LV_AGG_SORT': '1', 'B3C_LV_NO_AGG_HASH': '1'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ref, labels, info = _run_both(ctx, oracle_lib, ip, ix, w, 1.0 / w.max())
+        _assert_same(ref, labels, info)
+        assert info.n_levels >= 2 and (labels[np.diff(ip) == 0] == -1).all()
+
+
 @pytest.mark.parametrize('n_sub', [1, 2, 4, 8])
 def test_pipeline_golden_graph(ctx, oracle_lib, n_sub):
     """The compressed, balanced map of the reference pipeline fixture (cluster.py:310-321)."""
@@ -189,7 +212,7 @@ def test_rows_of_every_length_class(ctx, oracle_lib):
                                  {'B3C_LV_MEGA_DEG': '2048'}, {'B3C_LV_MEGA_DEG': '100000'}, {'B3C_LV_NO_INTERNAL_LONG': '1'},
                                  {'B3C_LV_NO_WG': '1'}, {'B3C_LV_NO_WG': '1', 'B3C_LV_MEGA_DEG': '2048'}, {'B3C_LV_NO_MEGA_LDS': '1'},
                                  {'B3C_LV_AGG_SORT': '1'}, {'B3C_LV_AGG_SORT': '1', 'B3C_LV_NO_AGG_HASH': '1'}, {'B3C_LV_REC': '0'},
-                                 {'B3C_LV_NO_XCD': '1'}, {'B3C_LV_WAVE_MAX': '256'}])
+                                 {'B3C_LV_NO_XCD': '1'}, {'B3C_LV_WAVE_MAX': '256'}, {'B3C_LV_NO_MEGA_SPLIT': '1'}])
 def test_kernel_choices_do_not_show_in_the_result(ctx, oracle_lib, monkeypatch, env):
     """Round 3's and round 4's per-level kernel choices -- the table-free first sub-round, the bin aggregation in community order and its
     long rows by workgroups, the entry count from which a row gets workgroups (automatic: by the number of such rows), the
