@@ -38,15 +38,19 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def measured_traffic(config, kernel):
+def measured_traffic(config, kernel, algorithmic=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes on this workload); None when no measurement is on file."""
+    FETCH_SIZE and WRITE_SIZE collected in separate passes on this workload); None when no measurement is on file -- or when
+    the record on file is for another map of the same config name (its algorithmic byte count differs from this run's)."""
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
     try:
         with open(path) as fh:
             rec = json.load(fh).get(config, {})
         base = lambda name: name.replace('<', ' ').split()[0] if name else ''
         if rec and base(rec.get('kernel', '')) == base(kernel):
+            ref = rec.get('algorithmic_bytes_per_launch')
+            if ref and algorithmic and abs(ref - algorithmic) > 0.02 * ref:
+                return None
             return rec.get('hbm_bytes_per_launch')
     except (IOError, ValueError):
         pass
@@ -114,7 +118,7 @@ def main():
     ap.add_argument('--config', default='C3', choices=['C1', 'C2', 'C3', 'C5'],
                     help="C5: 5M contigs / 1e9 edge draws, power law (BASELINE.json's largest map; fits ONE GPU; no CPU baseline)")
     ap.add_argument('--max-iter', type=int, default=None,
-                    help='KR iteration limit (the reference default 1000; C5 defaults to 5000: its heavy-tailed degrees need ~2450)')
+                    help='KR iteration limit (the reference default 1000; C5 defaults to 20000 | 5000 by --c5-counts: its heavy-tailed degrees need 10,903 | 2,967 SpMVs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline', default='same', choices=['same', 'sample'],
                     help="'same': the oracle on the very map the GPU ran (about two minutes at C3); 'sample': on a bounded "
@@ -159,7 +163,9 @@ def main():
     from bin3c_amd.pipeline import make_context, run_hot_path
     from bin3c_amd.synth import CONFIGS, make_edges
 
-    max_iter = args.max_iter if args.max_iter else (5000 if args.config == 'C5' else 1000)
+    # C5: the reference's default of 1000 would raise on either map; the device-drawn one with duplicate draws summed (hub pairs
+    # of 10^5..10^6 contacts beside tail pairs of 5) takes 10,903 SpMVs, the one with one count per unique pair 2,967
+    max_iter = args.max_iter if args.max_iter else ((20000 if args.c5_counts == 'summed-draws' else 5000) if args.config == 'C5' else 1000)
     if args.config == 'C5':
         args.no_cpu_baseline = True          # the oracle would need hours on this map
     ctx = make_context(local_rank, pin=True)       # one process per GPU: stay on the CPUs of its NUMA node
@@ -269,7 +275,7 @@ def main():
                  else 'kr_kb_tcd2 (tile-dictionary SpMV on raw counts + fused KR epilogue)' if tcd
                  else 'kr_kb_vec (CSR SpMV on raw counts + fused KR epilogue)')
         avg_ms = acc['spmv_ms'] / max(acc['spmv_n'], 1)
-        traffic = measured_traffic(w.config if w is W and args.synth == 'default' and not args.hard else '-', kname) if not sharded else None
+        traffic = measured_traffic(w.config if w is W and args.synth == 'default' and not args.hard else '-', kname, algorithmic) if not sharded else None
         physical = traffic if traffic else streamed
         rate = lambda b: b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         return {'bound': 'hbm', 'kernel': kname, 'achieved': rate(physical), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -345,8 +351,8 @@ def main():
         the contigs) on the same GPU right after the headline leg, 3 steps, its own stage times and dominant-kernel roofline."""
         ws = build_workload(args.config, 'survey', False)
         try:
-            dt, last, acc = timed_leg(ws, 3, 1)
-            o = line(ws, dt, last, acc, 3, 1, False, {})
+            dt, last, acc = timed_leg(ws, 3, 2)
+            o = line(ws, dt, last, acc, 3, 2, False, {})
         finally:
             ws.counts.free()
         keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'roofline', 'roofline_other')

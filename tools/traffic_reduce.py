@@ -89,9 +89,25 @@ if 'kr_kb_tails' in kernels:
         'kr_kb_tails': {'FETCH_SIZE_raw_bytes_per_launch': ft, 'WRITE_SIZE_raw_bytes_per_launch': wt},
         'kr_kb_tcd2': {'FETCH_SIZE_raw_bytes_per_launch': fd, 'WRITE_SIZE_raw_bytes_per_launch': wd},
         'hbm_bytes_per_launch': 2.0 * (ft + fd) + wt + wd,
+        'algorithmic_bytes_per_launch': 12.0 * NNZ + 20.0 * N,      # bench.py uses a record only for the map it was taken on
         'launches_counted': na, 'launches_total': nt, 'correction': correction, 'source': source}
+    # the Louvain neighbour scan beside it: raw FETCH_SIZE of the launches of the first three sweeps of level 0 (unpruned: every row
+    # is read), in launch order -- k_lv_first_g, then eleven launches of k_lv_decide_g
+    lv = [r for r in csv.DictReader(open('profiles/%s_c3_FETCH_SIZE.csv' % rnd)) if r['Kernel'].startswith('k_lv_decide_g') or r['Kernel'].startswith('k_lv_first_g')]
+    lv.sort(key=lambda r: int(r['Dispatch_Id']))
+    if lv:
+        out['C3_k_lv_scan'] = {
+            'kernel': 'k_lv_first_g + k_lv_decide_g (Louvain delta-Q neighbour scan, one launch per sub-round)',
+            'FETCH_SIZE_raw_bytes_first_12_launches': [float(r['Counter_Value']) * 1024.0 for r in lv[:12]],
+            'duration_ns_first_12_launches': [int(r['Duration_ns']) for r in lv[:12]],
+            'algorithmic_bytes_per_launch': (16.0 * NNZ + 28.0 * N) / 4.0,
+            'note': 'raw counter values (FETCH_SIZE tallies 128-byte fabric requests at 64 bytes: double them for bytes); round 3: '
+                    '2.18 / 2.02 / 1.80 GB raw in the three general sub-rounds of sweep 1',
+            'source': source}
     json.dump(out, open('profiles/traffic.json', 'w'), indent=1)
     print(json.dumps(out['C3'], indent=1))
+    if lv:
+        print(json.dumps(out['C3_k_lv_scan'], indent=1))
     sys.exit(0)
 fv, na, nt = active('FETCH_SIZE', 'kr_kb_vec')
 wv, _, _ = active('WRITE_SIZE', 'kr_kb_vec')
