@@ -156,8 +156,14 @@ class DistSession(object):
             self.comm = comm
         self.transport = 'rccl (in libb3c)' if self.comm else 'callback ({})'.format(dist.get_backend(group))
         self._x0 = int(lib.b3c_ctx_exchanges(ctx.h))
-        self._install(None)
         torch.cuda.synchronize(dev)                       # the buffers were zero-filled on torch's stream, libb3c writes them on its own
+        self._install(None)
+        # Ragged row ranges need a transport that moves unequal slices (a group of broadcasts on RCCL).  One small exchange on
+        # deliberately uneven ranges tells whether it does on THIS stack; if not, the session keeps equal row ranges (the plain
+        # in-place all-gather of rounds 1-3) instead of failing the run.
+        self.ragged_ok = self.world == 1 or self._selftest_ragged(dev)
+        torch.cuda.synchronize(dev)
+        self._x0 = int(lib.b3c_ctx_exchanges(ctx.h))       # (the self-test's exchange is not the caller's)
         ctx.dist_session = self                           # pipeline.run_hot_path shards the map over the ranks when set
 
     def _install(self, starts):
@@ -174,12 +180,40 @@ class DistSession(object):
         else:
             self.r0, self.r1 = int(self.starts[self.rank]), int(self.starts[self.rank + 1])
 
+    def _selftest_ragged(self, dev):
+        import torch
+        import torch.distributed as dist
+        n, w = self.n, self.world
+        st = np.array([n * r * (r + 1) // (w * (w + 1)) for r in range(w + 1)], dtype=np.int64)      # rank r holds r + 1 shares
+        ok = 1
+        try:
+            self._install(st)
+            v = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            v[int(st[self.rank]):int(st[self.rank + 1])] = self.rank
+            torch.cuda.synchronize(dev)
+            self.ctx.dist_allgather_i32(v)
+            want = torch.repeat_interleave(torch.arange(w, dtype=torch.int32, device=dev), torch.as_tensor(np.diff(st), device=dev))
+            ok = int(torch.equal(v, want))
+        except Exception:
+            ok = 0
+        finally:
+            try:
+                self._install(None)
+            except Exception:
+                ok = 0
+        red_dev = dev if dist.get_backend(self.group) == 'nccl' else 'cpu'
+        t = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
     def set_starts(self, starts):
         """Row ranges of the ranks from here on (all ranks must pass the same array), or None for equal chunks again.  The
         pipeline balances them by stored entries once the locality order is known (balanced_starts) and returns to equal
         chunks for the ordering passes of the next call, which run on the still un-ordered map."""
         if starts is None and self.starts is None:
             return
+        if starts is not None and not getattr(self, 'ragged_ok', True):
+            return                                        # this stack's transport does not move ragged slices: equal ranges stay
         if starts is not None:
             st = np.asarray(starts, dtype=np.int64)
             assert st.shape == (self.world + 1,) and st[0] == 0 and st[-1] == self.n and np.all(np.diff(st) >= 0), st
