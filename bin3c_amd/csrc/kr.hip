@@ -1042,6 +1042,7 @@ __device__ void block_partial_at(double v, double *__restrict__ part, int64_t at
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 
 
 // The same with the two kinds of entries on DIFFERENT waves of a 512-thread workgroup: waves 0-3 stream the dictionary
@@ -1328,6 +1329,59 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The dictionary entries once more, as 24-bit words (round 4).  With the tails gone to their own pass kr_kb_tcd2 is a stream of
+// 32-bit words `dictionary index << 16 | count` at the rate a device copy reaches (0.72 GB in 0.18 ms at C3): what is left
+// is the byte count.  A dictionary holds at most 8192 columns here (13 bits) and the counts of a Hi-C map are small, so an
+// entry fits `index << 11 | count`; four of them are three 32-bit words, and a row's dictionary entries become
+// ceil(n1 / 4) such 12-byte groups in a stream of their own (the 32-bit layout interleaves them with the rows' tail slots).
+// Used when every dictionary entry's count fits 11 bits (C3: largest count 472; a map with larger ones keeps the 32-bit words).
+// ---------------------------------------------------------------------------------------------
+constexpr int TCD24_CB = 11;            // count bits of a 24-bit dictionary word
+__global__ void kr_tcd24_groups(int64_t r0, int64_t r1, int hub_len, const int64_t *__restrict__ indptr, const int32_t *__restrict__ n1v,
+                                int64_t *__restrict__ grp)
+{
+    const int64_t row = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row > r1) return;
+    int64_t g = 0;
+    if (row < r1) {
+        const int64_t len = indptr[row + 1] - indptr[row];
+        g = len > hub_len ? 0 : (n1v[row - r0] + 3) >> 2;
+    }
+    grp[row - r0] = g;
+}
+
+// one wave per row: lane l packs entries 4l .. 4l + 3 of the row's dictionary part into words 3l .. 3l + 2 of its groups
+__global__ void __launch_bounds__(256) kr_tcd24_pack(int64_t r0, int64_t r1, int hub_len, const int64_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ n1v, const uint32_t *__restrict__ packed,
+                                                      const int64_t *__restrict__ goff, uint32_t *__restrict__ p24,
+                                                      unsigned long long *__restrict__ overflow)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
+    bool bad = false;
+    for (int64_t row = r0 + wave; row < r1; row += nwave) {
+        const int64_t s0 = indptr[row];
+        if (indptr[row + 1] - s0 > hub_len) continue;
+        const int n1 = n1v[row - r0];
+        uint32_t *__restrict__ dst = p24 + goff[row - r0] * 3;
+        for (int g = lane; g * 4 < n1; g += 64) {
+            uint32_t e[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t w = g * 4 + j < n1 ? packed[s0 + g * 4 + j] : 0u;
+                const uint32_t c = w & 0xFFFFu, idx = w >> 16;
+                bad |= c >= (1u << TCD24_CB) || idx >= (1u << (24 - TCD24_CB));
+                e[j] = (idx << TCD24_CB) | (c & ((1u << TCD24_CB) - 1u));
+            }
+            dst[g * 3 + 0] = e[0] | (e[1] << 24);
+            dst[g * 3 + 1] = (e[1] >> 8) | (e[2] << 16);
+            dst[g * 3 + 2] = (e[2] >> 16) | (e[3] << 8);
+        }
+    }
+    if (__ballot(bad) && lane == 0) atomicAdd(overflow, 1ull);
+}
+
 template <int NT>
 __device__ double reduce_sum_n(const double *__restrict__ part, int P, int stride, double *lds)
 {
@@ -1356,7 +1410,7 @@ __device__ double reduce_sum_n(const double *__restrict__ part, int P, int strid
     return r;
 }
 
-template <int LPR, int UN, int TLPR, int TU, bool XT>
+template <int LPR, int UN, int TLPR, int TU, bool XT, bool P24 = false>
 __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_t ncols, int R, int dlds, int dstride, int ntiles,
                                                    int swz, const KRState *__restrict__ sin, KRState *__restrict__ sout,
                                                    const double *__restrict__ partA, int PA, int PS,
@@ -1370,7 +1424,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                                                    double *__restrict__ part_out, int hub_len, int probe, uint32_t probe_mask,
                                                    unsigned long long *__restrict__ tlog,
                                                    unsigned long long *__restrict__ yhi, int *__restrict__ ylo, const int *__restrict__ tex,
-                                                   const double *__restrict__ corr)
+                                                   const double *__restrict__ corr, const uint32_t *__restrict__ p24, const int64_t *__restrict__ g24)
 {
     // XT: the tails are summed by kr_kb_tails beforehand (fixed point in yhi / ylo, exponent tex[0]); all eight waves run
     // dictionary rows here and the epilogue converts the row's tail sum and clears it for the next SpMV
@@ -1381,6 +1435,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     int64_t *ipl = (int64_t *)(ot + R);       // R + 1 row pointers
     double *lds = (double *)(ipl + R + 1);    // TBK doubles for the reductions
     int32_t *n1l = (int32_t *)(lds + TBK);    // R dictionary-entry counts
+    int32_t *g24l = n1l + R;                  // P24: R + 1 group offsets of the rows in the 24-bit stream, relative to the tile's first
     int64_t tile = blockIdx.x;
     if (swz) {
         const int per = (ntiles + 7) / 8;
@@ -1395,6 +1450,8 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     const int D1 = live ? dict_cnt[tile] : 0;
     for (int i = tid; i <= nrows && live; i += TBK) ipl[i] = indptr[ra + i];
     for (int i = tid; i < nrows; i += TBK) n1l[i] = n1v[ra + i - r0];
+    const int64_t g24_0 = P24 && live ? g24[ra - r0] : 0;
+    if (P24) for (int i = tid; i <= nrows && live; i += TBK) g24l[i] = (int32_t)(g24[ra - r0 + i] - g24_0);
     // the epilogue operands of "my" row (thread i < nrows owns row ra + i at the end)
     double ex = 0.0, ed = 0.0, er = 1.0, ep = 0.0, ev = 0.0;
     if (tid < nrows) {
@@ -1438,7 +1495,28 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)pahi << 32) | palo), 0, (int)ebytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)cahi << 32) | calo), 0, (int)ebytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, (int)(ncols * 8), 0x00020000);
+    // P24: the tile's groups of the 24-bit dictionary stream (12 bytes each)
+    const uint64_t qa = (uint64_t)(p24 + (P24 ? g24_0 : 0) * 3);
+    const uint32_t qalo = __builtin_amdgcn_readfirstlane((uint32_t)qa), qahi = __builtin_amdgcn_readfirstlane((uint32_t)(qa >> 32));
+    const uint32_t qbytes = __builtin_amdgcn_readfirstlane(P24 ? (uint32_t)g24l[nrows] * 12u : 0u);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)qahi << 32) | qalo), 0, (int)qbytes, 0x00020000);
     constexpr uint32_t NOLOAD = 0xFFFFFFFFu;
+    // four dictionary entries of a row from entry index i (a multiple of four) on: four 32-bit words, or -- P24 -- three
+    auto ld4 = [&](uint32_t so32, uint32_t so24, int i, int n1) -> u32x4 {
+        if constexpr (P24) {
+            const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rq, i < n1 ? so24 + (uint32_t)(i >> 2) * 12u : NOLOAD, 0, 0);
+            u32x4 r;
+            r[0] = t[0] & 0xFFFFFFu;
+            r[1] = (t[0] >> 24) | ((t[1] & 0xFFFFu) << 8);
+            r[2] = (t[1] >> 16) | ((t[2] & 0xFFu) << 16);
+            r[3] = t[2] >> 8;
+            return r;
+        } else {
+            return __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1 ? so32 + (uint32_t)i * 4u : NOLOAD, 0, 0);
+        }
+    };
+    constexpr int EB = P24 ? TCD24_CB : 16;      // count bits of a dictionary word
+    constexpr uint32_t EM = (1u << EB) - 1u;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int DW = XT ? 8 : 4;            // waves on dictionary rows
@@ -1449,32 +1527,28 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
         constexpr int CH = LPR * UN * 4;
         const int sub = lane / LPR, sl = lane % LPR;
         int rl = wv * RPW + sub;
-        uint32_t so = 0;
+        uint32_t so = 0, sq = 0;
         int n1 = 0;
         if (rl < nrows) {
             so = (uint32_t)((ipl[rl] - e0) * 4);
+            if (P24) sq = (uint32_t)g24l[rl] * 12u;
             n1 = (ipl[rl + 1] - ipl[rl] > hub_len || (probe & 8)) ? 0 : n1l[rl];
         }
         u32x4 c[UN];
 #pragma unroll
-        for (int q = 0; q < UN; q++) {
-            const int i = (q * LPR + sl) * 4;
-            c[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1 ? so + (uint32_t)i * 4u : NOLOAD, 0, 0);
-        }
+        for (int q = 0; q < UN; q++) c[q] = ld4(so, sq, (q * LPR + sl) * 4, n1);
         while (rl < nrows) {
             const int rln = rl + RPP;
-            uint32_t son = 0;
+            uint32_t son = 0, sqn = 0;
             int n1n = 0;
             if (rln < nrows) {
                 son = (uint32_t)((ipl[rln] - e0) * 4);
+                if (P24) sqn = (uint32_t)g24l[rln] * 12u;
                 n1n = (ipl[rln + 1] - ipl[rln] > hub_len || (probe & 8)) ? 0 : n1l[rln];
             }
             u32x4 c2[UN];
 #pragma unroll
-            for (int q = 0; q < UN; q++) {
-                const int i = (q * LPR + sl) * 4;
-                c2[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1n ? son + (uint32_t)i * 4u : NOLOAD, 0, 0);
-            }
+            for (int q = 0; q < UN; q++) c2[q] = ld4(son, sqn, (q * LPR + sl) * 4, n1n);
             double acc = 0.0;
 #pragma unroll
             for (int q = 0; q < UN; q++) {
@@ -1482,18 +1556,18 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t e = i + j < n1 ? c[q][j] : 0u;
-                    acc += (double)(e & 0xFFFFu) * xl[e >> 16];
+                    acc += (double)(e & EM) * xl[e >> EB];
                 }
             }
             for (int base = CH; base < n1; base += CH) {          // more dictionary entries than one chunk
 #pragma unroll
                 for (int q = 0; q < UN; q++) {
                     const int i = base + (q * LPR + sl) * 4;
-                    const u32x4 cc = __builtin_amdgcn_raw_buffer_load_b128(rp, i < n1 ? so + (uint32_t)i * 4u : NOLOAD, 0, 0);
+                    const u32x4 cc = ld4(so, sq, i, n1);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t e = i + j < n1 ? cc[j] : 0u;
-                        acc += (double)(e & 0xFFFFu) * xl[e >> 16];
+                        acc += (double)(e & EM) * xl[e >> EB];
                     }
                 }
             }
@@ -1502,6 +1576,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
             if (sl == 0) od[rl] = acc;
             rl = rln;
             so = son;
+            sq = sqn;
             n1 = n1n;
 #pragma unroll
             for (int q = 0; q < UN; q++) c[q] = c2[q];
@@ -2545,6 +2620,31 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             fprintf(stderr, "[b3c] tail pass: %lld tails in %lld super-tiles of %d rows, largest count %llu, longest tail %llu\n",
                     (long long)n_tails, (long long)xt_super, xt_S, hx[0], hx[1]);
     }
+    // ---- 24-bit dictionary words (kr_tcd24_pack): the dictionary kernel then streams 3 bytes per entry instead of 4 ----
+    struct PoolPtr24 { b3c_ctx *c; uint32_t *p = nullptr; ~PoolPtr24() { c->release(p); } } tcd_p24{ctx};
+    DevBuf<int64_t> g24cnt(ctx, tails_xt ? nloc + 2 : 1), g24off(ctx, tails_xt ? nloc + 2 : 1);
+    bool tcd_24 = false;
+    if (tails_xt && tcd_dcap <= (1 << (24 - TCD24_CB)) && vmax_counts < (1ull << 16) && CFG.num("B3C_KR_TCD_P24", 1) != 0) {
+        if (!g24cnt.p || !g24off.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: 24-bit dictionary words");
+        hipLaunchKernelGGL(kr_tcd24_groups, dim3((unsigned)((nloc + 256) / 256)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, n1v.p, g24cnt.p);
+        int rcg;
+        if ((rcg = b3c_exclusive_scan_i64(ctx, g24cnt.p, g24off.p, nloc + 1))) return rcg;
+        int64_t ngrp = 0;
+        { const int rb_ = b3c_readback(ctx, &ngrp, g24off.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
+        if (ngrp > 0 && ngrp * 12 < (int64_t)0x7FFFFFFF * 64) {
+            tcd_p24.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * 3 * (size_t)ngrp + 16);
+            DevBuf<unsigned long long> ovf(ctx, 1);
+            if (!tcd_p24.p || !ovf.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: 24-bit dictionary words");
+            HIP_TRY(ctx, hipMemsetAsync(ovf.p, 0, sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(kr_tcd24_pack, dim3((unsigned)std::min<int64_t>((nloc + 3) / 4, 32 * (int64_t)ctx->n_cu)), dim3(256), 0, s, r0, r1, hub_len, a->indptr,
+                               n1v.p, packed.p, g24off.p, tcd_p24.p, ovf.p);
+            unsigned long long hov = 0;
+            { const int rb_ = b3c_readback(ctx, &hov, ovf.p, sizeof(hov)); if (rb_) return rb_; }
+            tcd_24 = hov == 0;                   // a count beyond 11 bits (or an index beyond 13) somewhere: the 32-bit words stay
+            if (CFG.on("B3C_KR_DEBUG"))
+                fprintf(stderr, "[b3c] dictionary words: %lld groups of four 24-bit words (%s)\n", (long long)ngrp, tcd_24 ? "in use" : "a count needs more than 11 bits: 32-bit words kept");
+        }
+    }
     const int GS = tcd ? (int)tcd_tiles : GS_rows;
     // partials the SpMV step leaves behind: row groups / tiles + hub rows.  EVERY block of KCD reduces all of them, so many
     // hub rows (a power-law map: 10^5) are first summed in chunks by their own launch (fixed order: deterministic)
@@ -2589,7 +2689,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     double *my_scal = dist ? D.scal + 4 * D.rank : nullptr;
     auto xchg = [&](int buf) -> int { return b3c_dist_exchange(ctx, buf); };
     const int cP = dist ? D.world : 0, cS = dist ? 4 : 1;      // consumer view of gathered partials
-    const size_t tcd_shmem2 = sizeof(double) * ((size_t)tcd_lds_d + 2 * (size_t)tcd_R + (size_t)tcd_R + 1 + TBK) + sizeof(int32_t) * (size_t)tcd_R;
+    const size_t tcd_shmem2 = sizeof(double) * ((size_t)tcd_lds_d + 2 * (size_t)tcd_R + (size_t)tcd_R + 1 + TBK) + sizeof(int32_t) * (size_t)tcd_R +
+                              (tcd_24 ? sizeof(int32_t) * ((size_t)tcd_R + 2) : 0);
     if (tcd) {
         // dynamic LDS beyond 64 KB needs the attribute; set once per context (= device) to the device limit (the call is not
         // cheap: fourteen of them per balance call cost over 2 ms)
@@ -2597,7 +2698,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             constexpr int LDS_MAX = 160 * 1024;
 #define KR_TCD2_ATTR(L, U, TL, T)                                                                                                             \
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX)); \
-    HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX)); \
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tcd2<L, U, TL, T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX))
             KR_TCD2_ATTR(16, 4, 8, 2); KR_TCD2_ATTR(8, 4, 4, 2); KR_TCD2_ATTR(4, 4, 4, 1);
 #undef KR_TCD2_ATTR
         }
@@ -2648,10 +2750,12 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \
         kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len,     \
         tcd_probe, tcd_probe_mask,                                                                                                            \
-        want_tlog ? tlog.p : nullptr, tails_xt ? yhi.p : nullptr, tails_xt ? ylo.p : nullptr, tails_xt ? tex.p : nullptr, corr_p
+        want_tlog ? tlog.p : nullptr, tails_xt ? yhi.p : nullptr, tails_xt ? ylo.p : nullptr, tails_xt ? tex.p : nullptr, corr_p,       \
+        tcd_24 ? tcd_p24.p : nullptr, tcd_24 ? g24off.p : nullptr
 #define KR_TCD2(L, U, TL, T)                                                                                                 \
     do {                                                                                                                     \
-        if (tails_xt) hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, true>), KR_TCD2_ARGS);                                    \
+        if (tails_xt && tcd_24) hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, true, true>), KR_TCD2_ARGS);                     \
+        else if (tails_xt) hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, true>), KR_TCD2_ARGS);                               \
         else hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, false>), KR_TCD2_ARGS);                                            \
     } while (0)
                 if (avg > 128) KR_TCD2(16, 4, 8, 2);       // (tail shapes 8x1, 4x2, 4x4 within 5 % of this one at C3, 2x4 17 % slower)

@@ -133,6 +133,29 @@ def test_kr_locality_reordered_path_matches_oracle(ctx, oracle_lib, monkeypatch)
     np.testing.assert_allclose(xv, xc, rtol=1e-11)
 
 
+@pytest.mark.parametrize('scale', [1, 100])
+def test_dictionary_words_of_24_bits(ctx, oracle_lib, monkeypatch, scale):
+    """With the tails in their own pass the dictionary kernel streams 24-bit words (13-bit dictionary index, 11-bit count) when every
+    dictionary entry's count fits (round 4; kr_tcd24_pack): same products in the same order, so x is BIT FOR BIT that of the
+    32-bit words (B3C_KR_TCD_P24=0).  scale = 100 pushes counts beyond 2047: the pack kernel reports it and the 32-bit words stay."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(40000, 1300000, 41)
+    cnt = (sm.counts.astype(np.uint64) * scale).astype(np.uint32)
+    assert cnt.max() < 65536 and (cnt.max() > 2047) == (scale > 1)
+    nd = oracle_lib.site_norm(sm.indptr, sm.indices, cnt.astype(np.float64), sm.sites)
+    rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
+    assert rc == oracle_lib.OK
+    cm = ctx.upload(sm.indptr, sm.indices, cnt)
+    monkeypatch.setenv('B3C_KR_TCD_XT', '1')
+    _, x24, i24 = ctx.kr_balance_counts(cm, sm.sites)
+    assert i24.tcd_xt_tails > 0 and i24.n_iter == st.n_iter
+    np.testing.assert_allclose(x24, xo, rtol=1e-9)
+    monkeypatch.setenv('B3C_KR_TCD_P24', '0')
+    _, x32, i32 = ctx.kr_balance_counts(cm, sm.sites)
+    assert i32.n_iter == i24.n_iter and np.array_equal(x24, x32)
+    cm.free()
+
+
 def test_tail_pass_with_long_tails(ctx, monkeypatch):
     """Tail pass of the dictionary SpMV on a power-law map whose hub rows stay in the tiles (B3C_KR_NO_HUB): tails of
     thousands of entries narrow the 32-bit remainder sums of the fixed-point accumulation; x must agree with the CSR
