@@ -66,7 +66,8 @@ def balanced_starts(row_nnz, world, align=64):
         cut = np.minimum(n, ((cut + align - 1) // align) * align)
         starts[1:world] = np.maximum.accumulate(cut)
     else:
-        starts[1:world] = np.minimum(n, (np.arange(1, world) * (-(-n // world))))
+        chunk = -(-(-(-n // world)) // align) * align          # no entries at all: equal row counts, aligned like shard_range
+        starts[1:world] = np.minimum(n, np.arange(1, world) * chunk)
     return starts
 
 

@@ -145,3 +145,24 @@ def test_bench_one_rank_over_rccl():
     d = json.loads(lines[0])
     assert d['scaling'] == 'strong' and d['exchanges_per_step'] > 100 and d['agrees_with_single_gpu'] is True
     assert 'sharded' not in d and d['replicas']['value'] > 0
+
+
+def test_balanced_starts_host_logic():
+    """dist.balanced_starts (row ranges 'balanced by nnz (prefix-sum over indptr)'): ascending cuts aligned to 64 rows
+    that start at 0, end at n and leave no rank with more than its share plus one alignment block of rows -- on flat rows, on hub
+    rows at the front (equal row counts would be 3x out of balance) and on degenerate inputs."""
+    import numpy as np
+    from bin3c_amd.dist import balanced_starts
+    rs = np.random.RandomState(11)
+    for world in (1, 2, 3, 8):
+        for lens in (rs.randint(1, 400, 100000), np.concatenate((np.full(50, 500000), rs.randint(1, 50, 20000))),
+                     np.zeros(1000, dtype=np.int64), np.ones(5, dtype=np.int64), np.zeros(0, dtype=np.int64)):
+            lens = lens.astype(np.int64)
+            st = balanced_starts(lens, world)
+            n = lens.shape[0]
+            assert st.shape == (world + 1,) and st[0] == 0 and st[-1] == n and np.all(np.diff(st) >= 0)
+            assert np.all(st[1:-1] % 64 == 0) or n < 64 * world
+            if lens.sum() > 0 and n >= 64 * world:
+                per = np.array([lens[st[r]:st[r + 1]].sum() for r in range(world)])
+                slack = max(int(lens[a:a + 64].sum()) for a in range(0, n, 64))       # one alignment block of rows
+                assert per.max() <= lens.sum() / world + slack + 1, (world, per, slack)
