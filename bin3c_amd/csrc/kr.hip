@@ -1230,6 +1230,19 @@ __device__ double reduce_max_n(const double *__restrict__ part, int P, double *l
     return r;
 }
 
+// ps -> (f, l): f = ps rounded to the nearest integer (ties to even), l = (ps - f) * lo_scale rounded likewise.  |ps| < 2^51 (the
+// host bounds the exponent E accordingly), so adding 1.5 * 2^52 leaves rint(ps) in the low mantissa bits of the sum: the integer and
+// its exact double come out of one add and two subtractions instead of the emulated f64 -> i64 -> f64 conversions (a dozen
+// instructions each).  At C3 the pass sits on its L1 misses and does not notice; where the tails are most of the matrix (the
+// surveyed genome-size law: 145 M words per SpMV) it is the ~30 vector instructions per word that bound it (round 4).
+__device__ __forceinline__ void xt_split(double ps, double lo_scale, long long &f, int &l)
+{
+    constexpr double MAGIC = 6755399441055744.0;          // 1.5 * 2^52
+    const double t = ps + MAGIC;
+    f = __double_as_longlong(t) - __double_as_longlong(MAGIC);
+    l = __double2int_rn((ps - (t - MAGIC)) * lo_scale);     // |.| <= 2^(lo_bits - 1)
+}
+
 __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__ sin, const double *__restrict__ pumax, int PU,
                                                       int lg_bound, int lo_bits, int chunks, int64_t n_tails, const int64_t *__restrict__ toff, int64_t r0, int64_t n,
                                                       int S, int rbits, uint32_t cmask, const unsigned long long *__restrict__ words, const double *__restrict__ u,
@@ -1285,8 +1298,9 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
                 const uint32_t c = w[q] & ((1u << XT_PACK_CB) - 1u);
                 if (c) {
                     const double ps = (g[q] * (double)c) * scale;
-                    const long long f = __double2ll_rn(ps);
-                    const int l = __double2int_rn((ps - (double)f) * lo_scale);       // |.| <= 2^(lo_bits - 1)
+                    long long f;
+                    int l;
+                    xt_split(ps, lo_scale, f, l);
                     const uint32_t r = (w[q] >> XT_PACK_CB) & rmask;
                     atomicAdd(&acc[r], (unsigned long long)f);
                     if (l) atomicAdd(&lo[r], l);
@@ -1297,8 +1311,9 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
         for (int64_t j = (int64_t)blockIdx.x * XT_NT + threadIdx.x; j < n_res; j += (int64_t)gridDim.x * XT_NT) {
             const unsigned long long w = rwords[j];
             const double ps = (u[(uint32_t)(w >> cshift) & cmask] * (double)(uint32_t)(w & 0xFFFFu)) * scale;
-            const long long f = __double2ll_rn(ps);
-            const int l = __double2int_rn((ps - (double)f) * lo_scale);
+            long long f;
+            int l;
+            xt_split(ps, lo_scale, f, l);
             const int64_t row = (int64_t)(w >> st_shift) * S + ((uint32_t)(w >> 16) & rmask);
             atomicAdd(&yhi[row], (unsigned long long)f);
             if (l) atomicAdd(&ylo[row], l);
@@ -1315,8 +1330,9 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
         for (int q = 0; q < 4; q++)
             if (k0 + q * XT_NT < e0) {
                 const double ps = (g[q] * (double)(uint32_t)(w[q] & 0xFFFFu)) * scale;
-                const long long f = __double2ll_rn(ps);
-                const int l = __double2int_rn((ps - (double)f) * lo_scale);       // |.| <= 2^(lo_bits - 1)
+                long long f;
+                int l;
+                xt_split(ps, lo_scale, f, l);
                 const uint32_t r = (uint32_t)(w[q] >> 16) & rmask;
                 atomicAdd(&acc[r], (unsigned long long)f);
                 if (l) atomicAdd(&lo[r], l);
@@ -2582,7 +2598,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         int lgc = 0, lgt = 0;
         while ((1ull << lgc) < hx[0] + 1) lgc++;
         while ((1ull << lgt) < hx[1] + 1) lgt++;
-        xt_lg_bound = lgc + lgt;
+        xt_lg_bound = lgc + std::max(lgt, 10);      // every product below 2^51 (xt_split), every row sum below 2^61
         // the 32-bit remainder sums: a tail of T terms of at most 2^(lo_bits - 1) each must stay below 2^31
         xt_lo_bits = std::max(4, std::min(20, 31 - lgt));
         // column order inside every super-tile: sort on (super-tile, column / 8) -- the words of a 64-byte line of u stay in
