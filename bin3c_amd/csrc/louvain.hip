@@ -8,13 +8,17 @@
 // lanes, waves or atomics happen to run.
 //
 // Kernels (all HBM/L2-bound integer work; no MFMA):
-//   lv_decide   one wave per node: neighbour-community weights accumulated in an LDS hash table
-//               (open addressing, ds_cmpst + ds_add_u64), own-community weight in registers, exact
-//               128-bit gain per candidate, wave arg-max by shuffles.  Hubs whose table does not fit
-//               LDS use a global-memory table.
+//   lv_decide   neighbour-community weights accumulated in an LDS hash table (open addressing, ds_cmpst +
+//               ds_add_u64), own-community weight in registers, exact 128-bit gain per candidate, order-free
+//               arg-max.  By row length: k_lv_decide_g (several nodes per wave, entries in registers, one 16-byte
+//               {community, total} record gathered per neighbour, list positions dealt XCD by XCD),
+//               k_lv_decide (one wave per node), k_lv_decide_wg (one workgroup per node, table of 1024 /
+//               4096 / 8192 slots), k_lv_mega_* (rows beyond 6553 entries: table in global memory, chunks
+//               pre-summed in LDS, evaluation split over the table), k_lv_decide_direct (levels of <= 2048 nodes)
 //   lv_apply    moves of one sub-round: integer atomics on the community totals
 //   lv_modularity / lv_tot2   exact modularity numerator
-//   aggregation: (community pair, weight) keys -> radix sort + reduce-by-key (hipcub) -> next level CSR
+//   aggregation: kc x kc integer bins (few communities); else per-community hashing (k_aggh_*); on row blocks
+//               (community pair, weight) keys -> radix sort + reduce-by-key (hipcub) -> next level CSR
 #include "common.hpp"
 
 #include <algorithm>
