@@ -214,6 +214,38 @@ def gpu_many_mode(rank, world):
     ctx.close()
 
 
+def gpu_large_mode(rank, world):
+    """the sharded path beyond a million contigs.  A C5-shaped map (power law, 6000 genomes) of 1.2M contigs
+    / 4.8e7 edges, drawn on the device by every rank (same seed, same stack: the same map): row blocks balanced by stored entries,
+    level 0 beyond the bin table on row blocks (pair runs gathered over the ranks), same iteration count, x, mask and partition as
+    one rank, bitwise equal results on all ranks."""
+    from bin3c_amd.dist import DistSession
+    from bin3c_amd.pipeline import make_context, run_hot_path
+    from bin3c_amd.synth_device import make_counts_device
+    ctx = make_context(0)
+    n, e = 1200000, 48000000
+    counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, 11, 'powerlaw', genomes=6000)
+    chk = torch.tensor([counts.nnz, n_edges], dtype=torch.int64)
+    ref = chk.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(chk, ref), 'the ranks drew different maps'
+    single = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=20000)
+    assert single.lv_info.n_comm_level0 > 4096
+    sess = DistSession(ctx, n)
+    res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=20000)
+    sess.check()
+    assert res.row_block == (sess.r0, sess.r1) and sess.starts is not None
+    most = torch.tensor([res.work_nnz], dtype=torch.int64)
+    dist.all_reduce(most, op=dist.ReduceOp.MAX)
+    assert int(most.item()) <= 1.10 * counts.nnz / world, (int(most.item()), counts.nnz)
+    _agree(res, single, rank)
+    assert res.lv_info.agg_gathered_runs > 4096 and res.lv_info.n_comm_level0 == single.lv_info.n_comm_level0
+    sess.close()
+    counts.free()
+    print('rank %d gpu-large ok (%d contigs, %d stored entries, %d communities after level 0)' % (rank, n, counts.nnz, single.lv_info.n_comm_level0))
+    ctx.close()
+
+
 def gpu_empty_mode(rank, world):
     """One rank's row block is masked out completely (all its contigs shorter than min_len): that rank still has to take part
     in every collective of the cluster stage (maximum, degrees, label gathers, bins) with an empty sub-map."""
@@ -250,6 +282,6 @@ if __name__ == '__main__':
     dist.init_process_group(backend='gloo')
     print('rank %d rendezvous done' % dist.get_rank(), flush=True)
     r, w = dist.get_rank(), dist.get_world_size()
-    {'cpu': cpu_mode, 'gpu': gpu_mode, 'gpu-many': gpu_many_mode, 'gpu-empty': gpu_empty_mode}[sys.argv[1]](r, w)
+    {'cpu': cpu_mode, 'gpu': gpu_mode, 'gpu-many': gpu_many_mode, 'gpu-empty': gpu_empty_mode, 'gpu-large': gpu_large_mode}[sys.argv[1]](r, w)
     dist.barrier()
     dist.destroy_process_group()

@@ -79,6 +79,13 @@ def test_sharded_aggregation_beyond_the_bin_table_two_ranks_one_gpu():
 
 
 @pytest.mark.gpu
+def test_sharded_hot_path_beyond_a_million_contigs_two_ranks_one_gpu():
+    """the sharded path on a C5-shaped map of 1.2M contigs / 4.8e7 edges: balanced row blocks, level 0 beyond the bin table"""
+    text = _launch('gpu-large', 900)
+    assert 'rank 0 gpu-large ok' in text and 'rank 1 gpu-large ok' in text
+
+
+@pytest.mark.gpu
 def test_a_rank_with_an_empty_block_takes_part_two_ranks_one_gpu():
     text = _launch('gpu-empty', 900)
     assert 'rank 0 gpu-empty ok' in text and 'rank 1 gpu-empty ok' in text
