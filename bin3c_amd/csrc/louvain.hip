@@ -1071,8 +1071,8 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
                                                       int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out, int32_t epoch, int xcd,
                                                       const GRec *__restrict__ grec)
 {
-    constexpr int CAP = 512;                       // >= 1.25 * LPR * UN + 1
-    constexpr int LG = 9;
+    constexpr int CAP = LPR * UN > 384 ? 1024 : 512;       // >= 1.25 * LPR * UN + 1
+    constexpr int LG = LPR * UN > 384 ? 10 : 9;
     static_assert(LPR * UN * 5 / 4 + 1 <= CAP, "table too small");
     // the list may have been thinned on the device (k_lv_prune): its length then sits in device memory
     const int64_t cnt = cnt_dev ? (*cnt_dev < cnt_max ? *cnt_dev : cnt_max) : cnt_max;
@@ -2643,7 +2643,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         LvThr thr;
         thr.t[0] = short_max;
         if (use_wg) {
-            thr.t[1] = std::min(mega_deg, std::max(short_max, (int)CFG.num("B3C_LV_WAVE_MAX", 409)));
+            thr.t[1] = std::min(mega_deg, std::max(short_max, (int)CFG.num("B3C_LV_WAVE_MAX", short_max == 256 && CFG.num("B3C_LV_WIDE_G", 1) != 0 ? 512 : 409)));
             thr.t[2] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(0)));
             thr.t[3] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(1)));
             thr.t[4] = mega_deg;
@@ -2684,6 +2684,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const bool use_side = !CFG.on("B3C_LV_NO_SIDE");      // hubs / mega rows beside the grouped scan on side streams
         const bool mega_lds = use_wg && !CFG.on("B3C_LV_NO_MEGA_LDS");
         const bool xcd_lists = !CFG.on("B3C_LV_NO_XCD");
+        const bool wide_g = short_max == 256 && CFG.num("B3C_LV_WIDE_G", 1) != 0;      // rows of 257 .. 512 entries by k_lv_decide_g<64, 8>
         // per-node gather records {community, its total} for the grouped scan (k_lv_decide_g<.., REC>), refreshed after every apply
         const bool use_rec = grouped && CFG.num("B3C_LV_REC", 1) != 0;
         DevBuf<GRec> grec(ctx, use_rec ? n : 1);
@@ -2910,7 +2911,18 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                                 hubs = pl;
                                 hcnt_dev = (const int64_t *)(pcnt.p + k);
                             }
-                            if (k == 1 || !use_wg) {
+                            if (k == 1 && use_wg && wide_g && thr.t[1] <= 512) {
+                                // rows of 257 .. 512 entries (15 % of the rows at C3, a quarter of the entries): the grouped kernel
+                                // with eight entries per lane -- entries in registers, claims instead of a scan of the table -- on
+                                // the hub stream, instead of the wave-per-node kernel
+                                const int g_ = grid_for(w1, WPB, 16 * ctx->n_cu);
+                                if (use_rec)
+                                    hipLaunchKernelGGL((k_lv_decide_g<64, 8, true>), dim3(g_), dim3(BLK), 0, hs, w1, hcnt_dev, hubs, m2, g.indices, g.q, kdeg.p, tot.p,
+                                                       com.p, csize.p, nxt_p, (int64_t *)nullptr, (int32_t *)nullptr, epoch, 0, grec.p);
+                                else
+                                    hipLaunchKernelGGL((k_lv_decide_g<64, 8, false>), dim3(g_), dim3(BLK), 0, hs, w1, hcnt_dev, hubs, m2, g.indices, g.q, kdeg.p, tot.p,
+                                                       com.p, csize.p, nxt_p, (int64_t *)nullptr, (int32_t *)nullptr, epoch, 0, grec.p);
+                            } else if (k == 1 || !use_wg) {
                                 LV_DECIDE_CAP((int64_t)0, w1, hubs, hcnt_dev);
                             } else {
 #define LV_DECIDE_WG(LGS, NT, MAXG)                                                                                      \

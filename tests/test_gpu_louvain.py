@@ -212,7 +212,7 @@ def test_rows_of_every_length_class(ctx, oracle_lib):
                                  {'B3C_LV_MEGA_DEG': '2048'}, {'B3C_LV_MEGA_DEG': '100000'}, {'B3C_LV_NO_INTERNAL_LONG': '1'},
                                  {'B3C_LV_NO_WG': '1'}, {'B3C_LV_NO_WG': '1', 'B3C_LV_MEGA_DEG': '2048'}, {'B3C_LV_NO_MEGA_LDS': '1'},
                                  {'B3C_LV_AGG_SORT': '1'}, {'B3C_LV_AGG_SORT': '1', 'B3C_LV_NO_AGG_HASH': '1'}, {'B3C_LV_REC': '0'},
-                                 {'B3C_LV_NO_XCD': '1'}, {'B3C_LV_WAVE_MAX': '256'}, {'B3C_LV_NO_MEGA_SPLIT': '1'}])
+                                 {'B3C_LV_NO_XCD': '1'}, {'B3C_LV_WAVE_MAX': '256'}, {'B3C_LV_NO_MEGA_SPLIT': '1'}, {'B3C_LV_WIDE_G': '0'}])
 def test_kernel_choices_do_not_show_in_the_result(ctx, oracle_lib, monkeypatch, env):
     """Round 3's and round 4's per-level kernel choices -- the table-free first sub-round, the bin aggregation in community order and its
     long rows by workgroups, the entry count from which a row gets workgroups (automatic: by the number of such rows), the
