@@ -794,7 +794,7 @@ constexpr size_t TCD_BUILD_LDS = sizeof(uint32_t) * 2 * TCD_WORDS + sizeof(uint1
 // pass starts where the one before stopped (rdone) and stops at the first slice that leaves its column range -- each entry
 // is read once per sweep, whatever the number of passes.  The row pointers of the tile sit in LDS, and a wave has the first
 // slice of its NEXT row in flight while it works on the current one.
-__global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap, int sorted,
+__global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap, int sorted, uint32_t cfront,
                                                         const int64_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices,
                                                         const uint32_t *__restrict__ counts, uint32_t *__restrict__ packed,
@@ -989,7 +989,7 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
                             if ((wk >> (c & 31)) & 1u) {
                                 r = a1 + pre1[g] + (k > 0 ? __popc(m.x) : 0) + (k > 1 ? __popc(m.y) : 0) + (k > 2 ? __popc(m.z) : 0) +
                                     __popc(wk & ((1u << (c & 31)) - 1u));
-                                front = r < d1cap;
+                                front = r < d1cap && cv[t] < cfront;      // (a count the 24-bit words cannot hold: to the tails)
                             }
                         }
                         const unsigned long long mf = __ballot(in && front), mb = __ballot(in && !front);
@@ -1240,7 +1240,9 @@ __device__ __forceinline__ void xt_split(double ps, double lo_scale, long long &
     constexpr double MAGIC = 6755399441055744.0;          // 1.5 * 2^52
     const double t = ps + MAGIC;
     f = __double_as_longlong(t) - __double_as_longlong(MAGIC);
-    l = __double2int_rn((ps - (t - MAGIC)) * lo_scale);     // |.| <= 2^(lo_bits - 1)
+    // the remainder likewise: (ps - f) * lo_scale is exact (a power of two), |.| <= 2^(lo_bits - 1), and MAGIC is even, so the sum
+    // rounds it to the nearest integer with ties to even -- the value __double2int_rn gave -- and leaves it in the low word
+    l = (int)(uint32_t)__double_as_longlong(fma(ps - (t - MAGIC), lo_scale, MAGIC));
 }
 
 __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__ sin, const double *__restrict__ pumax, int PU,
@@ -1248,7 +1250,7 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
                                                       int S, int rbits, uint32_t cmask, const unsigned long long *__restrict__ words, const double *__restrict__ u,
                                                       unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex,
                                                       const uint32_t *__restrict__ cw, const uint32_t *__restrict__ hdr,
-                                                      const unsigned long long *__restrict__ rwords, int64_t n_res, int st_shift)
+                                                      const unsigned long long *__restrict__ rwords, int64_t n_res, int st_shift, int pipe)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long xt_lds[];
     unsigned long long *acc = xt_lds;                 // S 64-bit sums
@@ -1281,16 +1283,76 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
     const int64_t len = (b - a + chunks - 1) / chunks;
     const int64_t s0 = a + ch * len, e0 = s0 + len < b ? s0 + len : b;
     if (cw) {
-        // packed stream (kr_tails_pack): 4 bytes per tail + one base column per 64
+        // packed stream (kr_tails_pack): 4 bytes per tail + one base column per 64.
+        // Where the tails are most of the matrix and their operands L2 hits (the surveyed genome-size law: 145 M words per SpMV) this
+        // loop is bound by the instructions it issues, ~40 per word in its first form (round 4, from the ISA).  Now ~17:
+        //  * the words come through a buffer descriptor over [s0, e0): a lane outside it -- the lanes below s0 of the first,
+        //    64-ALIGNED group as well, their offset wraps -- reads a zero word, which adds nothing; no per-word bounds, no branch;
+        //  * a wave's 64 words are one aligned group of the stream, so their base column is ONE scalar load;
+        //  * the operand gather is a buffer load as well (two address instructions);
+        //  * no branch around a zero count or a zero remainder (both add zero);
+        //  * software pipeline: the words of the NEXT step are requested right after the gathers of this one, so a step waits for one
+        //    round trip instead of two dependent ones (four waves per SIMD: 0.407 -> 0.368 ms per SpMV on the surveyed law by itself).
+        if (pipe) {
+            const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const int B = (int)(s0 & 63);
+            const int64_t nw = e0 > s0 ? e0 - s0 : 0;                       // (< 2^29 words: the host checks the longest chunk)
+            const int64_t hlast = (n_tails + 63) >> 6;                     // hdr[] has hlast + 1 entries
+            const int64_t g0 = ((s0 - B) >> 6) + wave;
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(cw + s0), 0, (int)(nw * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, (int)(((int64_t)cmask + 1) * 8), 0x00020000);
+            const int steps = (int)((B + nw + 4 * XT_NT - 1) / (4 * XT_NT));
+            const int csh = rbits + XT_PACK_CB;
+            uint32_t voff = (uint32_t)((int)threadIdx.x - B) * 4u;
+            uint32_t wn[4], hn[4];
+            auto fetch = [&](int st) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    wn[q] = __builtin_amdgcn_raw_buffer_load_b32(rw, voff + (uint32_t)q * (XT_NT * 4u), 0, 0);
+                    int64_t gi = g0 + 16 * q + 64 * (int64_t)st;
+                    gi = gi < hlast ? gi : hlast;
+                    hn[q] = hdr[gi];
+                }
+                voff += 4u * XT_NT * 4u;
+            };
+            fetch(0);
+            for (int st = 0; st < steps; st++) {
+                uint32_t w[4];
+                u32x2 gw[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    w[q] = wn[q];
+                    gw[q] = __builtin_amdgcn_raw_buffer_load_b64(ru, ((w[q] >> csh) + hn[q]) << 3, 0, 0);
+                }
+                fetch(st + 1);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double g = __hiloint2double((int)gw[q][1], (int)gw[q][0]);
+                    const double ps = (g * (double)(w[q] & ((1u << XT_PACK_CB) - 1u))) * scale;
+                    long long f;
+                    int l;
+                    xt_split(ps, lo_scale, f, l);
+                    const uint32_t r = (w[q] >> XT_PACK_CB) & rmask;
+                    atomicAdd(&acc[r], (unsigned long long)f);
+                    atomicAdd(&lo[r], l);
+                }
+            }
+        } else {
+        uint32_t wn[4], hn[4];
+        auto fetch = [&](int64_t kb) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t k = kb + q * XT_NT;
+                wn[q] = k < e0 ? cw[k] : 0u;
+                hn[q] = k < e0 ? hdr[k >> 6] : 0u;
+            }
+        };
         for (int64_t k0 = s0 + threadIdx.x; k0 < e0; k0 += 4 * XT_NT) {
             uint32_t w[4], hb[4];
             double g[4];
+            fetch(k0);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int64_t k = k0 + q * XT_NT;
-                w[q] = k < e0 ? cw[k] : 0u;
-                hb[q] = k < e0 ? hdr[k >> 6] : 0u;
-            }
+            for (int q = 0; q < 4; q++) { w[q] = wn[q]; hb[q] = hn[q]; }
 #pragma unroll
             for (int q = 0; q < 4; q++) g[q] = u[(hb[q] + (w[q] >> (rbits + XT_PACK_CB))) & cmask];
 #pragma unroll
@@ -1306,6 +1368,7 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
                     if (l) atomicAdd(&lo[r], l);
                 }
             }
+        }
         }
         // the few words that did not fit: straight into the global row sums (integer atomics: order-free)
         for (int64_t j = (int64_t)blockIdx.x * XT_NT + threadIdx.x; j < n_res; j += (int64_t)gridDim.x * XT_NT) {
@@ -2515,8 +2578,14 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         // (round 3 tried ONE pass per tile over a window of 2^18 columns centred on the tile, everything outside going to the tails
         // unseen: the build fell from 2.9 to 1.1 ms, but the SpMV rose from 0.289 to 0.375 ms at C3 -- the locality order keeps a
         // cluster together, not a genome: the pieces of a genome sit far apart and their columns DO repeat inside a tile)
+        // With the tails in their own pass the dictionary kernel wants 24-bit words (kr_tcd24_pack): an entry whose count needs more
+        // than 11 bits -- a handful of contig pairs inside an abundant genome -- goes to the tails instead of keeping the whole map on
+        // 32-bit words (the surveyed genome-size law at C3: largest count 3395; its dictionary kernel streamed 800 MB per SpMV, tail
+        // slots included, for 56 M dictionary entries).  The tail pass takes any 16-bit count (packed word or residual list).
+        const uint32_t tcd_cfront = xt_want && tcd_dcap <= (1 << (24 - TCD24_CB)) && vmax_counts < (1ull << 16) && CFG.num("B3C_KR_TCD_DEMOTE", 1) != 0
+                                        ? (1u << TCD24_CB) : (1u << 16);
         hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
-                           a->sorted_cols ? 1 : 0, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
+                           a->sorted_cols ? 1 : 0, tcd_cfront, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
         unsigned long long hst[16];
         { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
 #ifdef B3C_PROBES
@@ -2572,6 +2641,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     struct PoolPtr32 { b3c_ctx *c; uint32_t *p = nullptr; ~PoolPtr32() { c->release(p); } } xt_cw{ctx}, xt_hdr{ctx};
     struct PoolPtr64 { b3c_ctx *c; unsigned long long *p = nullptr; ~PoolPtr64() { c->release(p); } } xt_res{ctx};
     const bool xt_pack_want = CFG.num("B3C_KR_XT_PACK", 1) != 0;
+    const int xt_pipe = (int)CFG.num("B3C_KR_XT_PIPE", 1);
     bool xt_packed = false;
     int64_t xt_n_res = 0;
     const size_t xt_shmem = sizeof(unsigned long long) * (size_t)xt_S + sizeof(int) * (size_t)xt_S + sizeof(double) * XT_NT;
@@ -2760,7 +2830,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                 if (tails_xt)
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
                                        xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p,
-                                       xt_packed ? xt_cw.p : nullptr, xt_hdr.p, xt_res.p, xt_n_res, xt_st_shift);
+                                       xt_packed ? xt_cw.p : nullptr, xt_hdr.p, xt_res.p, xt_n_res, xt_st_shift,
+                                       xt_pipe && n_tails < (1ll << 29) ? 1 : 0);       // (32-bit byte offsets inside a chunk of the packed stream)
                 // dictionary waves and tail waves side by side (512-thread workgroups)
 #define KR_TCD2_ARGS                                                                                                         \
     dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \

@@ -135,9 +135,11 @@ def test_kr_locality_reordered_path_matches_oracle(ctx, oracle_lib, monkeypatch)
 
 @pytest.mark.parametrize('scale', [1, 100])
 def test_dictionary_words_of_24_bits(ctx, oracle_lib, monkeypatch, scale):
-    """With the tails in their own pass the dictionary kernel streams 24-bit words (13-bit dictionary index, 11-bit count) when every
-    dictionary entry's count fits (round 4; kr_tcd24_pack): same products in the same order, so x is BIT FOR BIT that of the
-    32-bit words (B3C_KR_TCD_P24=0).  scale = 100 pushes counts beyond 2047: the pack kernel reports it and the 32-bit words stay."""
+    """With the tails in their own pass the dictionary kernel streams 24-bit words (13-bit dictionary index, 11-bit count;
+    kr_tcd24_pack): same products in the same order, so x is BIT FOR BIT that of the 32-bit words (B3C_KR_TCD_P24=0).  scale = 100
+    pushes counts beyond 2047: those entries are handed to the tail pass by the dictionary build (kr_tcd_build, `cfront`), so the
+    24-bit words stay in use; without that rule (B3C_KR_TCD_DEMOTE=0) the pack kernel reports the overflow and the 32-bit words stay
+    -- same x up to the order of the sums."""
     from bin3c_amd.synth import make_synth
     sm = make_synth(40000, 1300000, 41)
     cnt = (sm.counts.astype(np.uint64) * scale).astype(np.uint32)
@@ -153,6 +155,17 @@ def test_dictionary_words_of_24_bits(ctx, oracle_lib, monkeypatch, scale):
     monkeypatch.setenv('B3C_KR_TCD_P24', '0')
     _, x32, i32 = ctx.kr_balance_counts(cm, sm.sites)
     assert i32.n_iter == i24.n_iter and np.array_equal(x24, x32)
+    monkeypatch.delenv('B3C_KR_TCD_P24')
+    monkeypatch.setenv('B3C_KR_TCD_DEMOTE', '0')
+    _, xk, ik = ctx.kr_balance_counts(cm, sm.sites)
+    assert ik.n_iter == i24.n_iter
+    np.testing.assert_allclose(xk, x24, rtol=1e-12)
+    n_big = int((cnt >= 2048).sum())
+    assert ik.tcd_xt_tails <= i24.tcd_xt_tails <= ik.tcd_xt_tails + n_big
+    if scale > 1:
+        assert i24.tcd_xt_tails > ik.tcd_xt_tails          # (entries with large counts did move)
+    else:
+        assert np.array_equal(xk, x24)
     cm.free()
 
 
