@@ -275,11 +275,53 @@ __device__ __forceinline__ void max_row_len_body(int64_t n, const int64_t *__res
     if ((threadIdx.x & 63) == 0 && (unsigned long long)d > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, (unsigned long long)d);
 }
 
+// Wave reductions by DPP (round 4): row_shr 1 / 2 / 4 / 8 leave every row's result in its lane 15, row_bcast:15 (rows 1, 3) and
+// row_bcast:31 (rows 2, 3) carry it on to lane 63, v_readlane makes it uniform.  Six VALU instructions per 32-bit word instead of
+// six ds_bpermute round trips and their address arithmetic; ALL 64 lanes must be active (wave-uniform control flow).  A lane the
+// shift has no source for, or whose row the mask leaves out, reads the identity (`old` = 0).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, dpp_u32<0x111, 0xf>(v));
+    v = max(v, dpp_u32<0x112, 0xf>(v));
+    v = max(v, dpp_u32<0x114, 0xf>(v));
+    v = max(v, dpp_u32<0x118, 0xf>(v));
+    v = max(v, dpp_u32<0x142, 0xa>(v));
+    v = max(v, dpp_u32<0x143, 0xc>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int CTRL, int ROWS>
+__device__ __forceinline__ long long dpp_add_ll(long long v)
+{
+    const uint32_t lo = dpp_u32<CTRL, ROWS>((uint32_t)v), hi = dpp_u32<CTRL, ROWS>((uint32_t)((unsigned long long)v >> 32));
+    return v + (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
+}
+
+// sum over the wave, in every lane (integers: the order of the additions is immaterial); all 64 lanes active
+__device__ __forceinline__ long long wave_sum_ll_all(long long v)
+{
+    v = dpp_add_ll<0x111, 0xf>(v);
+    v = dpp_add_ll<0x112, 0xf>(v);
+    v = dpp_add_ll<0x114, 0xf>(v);
+    v = dpp_add_ll<0x118, 0xf>(v);
+    v = dpp_add_ll<0x142, 0xa>(v);
+    v = dpp_add_ll<0x143, 0xc>(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), 63);
+    return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 // A sum every wave of the grid contributes to: ONE atomic per block.  Thousands of waves that finish together queue up

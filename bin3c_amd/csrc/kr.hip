@@ -787,14 +787,14 @@ constexpr int TCD_L2_LG = 19;                         // operand vectors up to 2
 constexpr int TCD_WORDS = 1 << (TCD_CHUNK_LG - 5);    // 16384 words = 64 KB per bitmap
 constexpr int TCD_GROUPS = TCD_WORDS / 4;             // one 16-bit prefix per 128 columns
 constexpr int TCD_RMAX = 256;                         // rows per tile at most
-constexpr size_t TCD_BUILD_LDS = sizeof(uint32_t) * 2 * TCD_WORDS + sizeof(uint16_t) * TCD_GROUPS + sizeof(uint32_t) * (32 + 4 * TCD_RMAX) +
+constexpr size_t TCD_BUILD_LDS = sizeof(uint32_t) * 2 * TCD_WORDS + sizeof(uint16_t) * TCD_GROUPS + sizeof(uint32_t) * (64 + 4 * TCD_RMAX) +
                                  sizeof(int64_t) * (TCD_RMAX + 2);
 
 // Columns ascend inside a row (`sorted` != 0), so the entries of one bitmap pass are a contiguous piece of the row: every
 // pass starts where the one before stopped (rdone) and stops at the first slice that leaves its column range -- each entry
 // is read once per sweep, whatever the number of passes.  The row pointers of the tile sit in LDS, and a wave has the first
 // slice of its NEXT row in flight while it works on the current one.
-__global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap, int sorted, uint32_t cfront,
+__global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap, int sorted, uint32_t cfront, int minuse8,
                                                         const int64_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices,
                                                         const uint32_t *__restrict__ counts, uint32_t *__restrict__ packed,
@@ -806,8 +806,8 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
     uint32_t *bm1 = tsm;                              // column seen
     uint32_t *bm2 = tsm + TCD_WORDS;                  // column seen more than once
     uint16_t *pre1 = (uint16_t *)(tsm + 2 * TCD_WORDS);   // dictionary columns of this pass before the group
-    uint32_t *wsum = tsm + 2 * TCD_WORDS + TCD_GROUPS / 2;    // 16 wave sums
-    uint32_t *nfront = wsum + 32;                     // per row: entries placed from the front / from the back so far
+    uint32_t *wsum = tsm + 2 * TCD_WORDS + TCD_GROUPS / 2;    // 16 wave sums; [16 .. 31] columns seen per wave, [32 .. 47] entries of the pass per wave
+    uint32_t *nfront = wsum + 64;                     // per row: entries placed from the front / from the back so far
     uint32_t *nback = nfront + TCD_RMAX;
     uint32_t *rdone = nback + TCD_RMAX;               // per row: entries consumed by the passes before
     uint32_t *rcnt = rdone + TCD_RMAX;                // per row: entries of this pass
@@ -884,11 +884,20 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
         // phase clocks of a development build showed this stretch at 33 of a tile's 137 us.  So the bitmap is always read with
         // consecutive lanes on consecutive words (groups tid, tid + TB, ...), the per-group counts go through pre1, and only
         // the scan itself walks a thread's contiguous groups (8 bytes per thread).
+        uint32_t seen = 0;
 #pragma unroll
         for (int k = 0; k < GPT; k++) {
             const int g = tid + k * TCD_TB;
             const uint4 m2 = b24[g];
             pre1[g] = (uint16_t)(__popc(m2.x) + __popc(m2.y) + __popc(m2.z) + __popc(m2.w));
+            if (minuse8) { const uint4 m1 = b14[g]; seen += __popc(m1.x) + __popc(m1.y) + __popc(m1.z) + __popc(m1.w); }
+        }
+        if (minuse8) {
+            // is the dictionary of this pass worth its staging?  entries on columns seen more than once / such columns
+            uint32_t ent = tid < nrows ? rcnt[tid] : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { seen += __shfl_xor(seen, o, 64); ent += __shfl_xor(ent, o, 64); }
+            if (lane == 0) { wsum[16 + wv] = seen; wsum[32 + wv] = ent; }
         }
         __syncthreads();
         uint32_t e1[GPT], run1 = 0;
@@ -912,6 +921,18 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
             if (q < wv) base1 += t1;
             tot1 += t1;
         }
+        // A dictionary column costs a gather and an LDS slot per SpMV and tile, a tail word one gather in column order (kr_kb_tails):
+        // with fewer than minuse8 / 8 entries per dictionary column the pass leaves ALL its entries to the tails (round 4; the large
+        // genomes of the surveyed genome-size law: two uses per column, thousands of columns per tile)
+        bool skip = false;
+        if (minuse8) {
+            uint32_t seen_all = 0, ent_all = 0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) { seen_all += wsum[16 + q]; ent_all += wsum[32 + q]; }
+            const uint32_t singles = seen_all - tot1;                      // columns seen exactly once
+            const uint64_t fr = ent_all - singles;                           // entries on columns seen more than once
+            skip = fr * 8u < (uint64_t)tot1 * (uint32_t)minuse8;
+        }
 #pragma unroll
         for (int g = 0; g < GPT; g++) {
             const uint32_t pv = base1 + e1[g];
@@ -923,7 +944,7 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
         for (int k = 0; k < GPT; k++) {
             const int g = tid + k * TCD_TB;
             int64_t p1 = a1 + pre1[g];
-            if (p1 >= d1cap) continue;
+            if (p1 >= d1cap || skip) continue;
             const uint4 m2 = b24[g];
             const uint32_t wds[4] = {m2.x, m2.y, m2.z, m2.w};
 #pragma unroll
@@ -989,7 +1010,7 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
                             if ((wk >> (c & 31)) & 1u) {
                                 r = a1 + pre1[g] + (k > 0 ? __popc(m.x) : 0) + (k > 1 ? __popc(m.y) : 0) + (k > 2 ? __popc(m.z) : 0) +
                                     __popc(wk & ((1u << (c & 31)) - 1u));
-                                front = r < d1cap && cv[t] < cfront;      // (a count the 24-bit words cannot hold: to the tails)
+                                front = r < d1cap && cv[t] < cfront && !skip;      // (a count the 24-bit words cannot hold: to the tails)
                             }
                         }
                         const unsigned long long mf = __ballot(in && front), mb = __ballot(in && !front);
@@ -1007,7 +1028,7 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
                 if (lane == 0) { nfront[rl] = nf; nback[rl] = nb; rdone[rl] += rcnt[rl]; }
             }
         }
-        a1 += tot1;
+        if (!skip) a1 += tot1;
         __syncthreads();
         TCD_PH(3);
     }
@@ -2584,8 +2605,13 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         // slots included, for 56 M dictionary entries).  The tail pass takes any 16-bit count (packed word or residual list).
         const uint32_t tcd_cfront = xt_want && tcd_dcap <= (1 << (24 - TCD24_CB)) && vmax_counts < (1ull << 16) && CFG.num("B3C_KR_TCD_DEMOTE", 1) != 0
                                         ? (1u << TCD24_CB) : (1u << 16);
+        // (the tails must have their own pass for the rule below: inside the dictionary kernel a tail is a gather in ROW order)
+        // Default 3.5 entries per dictionary column, measured: the surveyed law at C3 0.327 -> 0.311 ms per SpMV for any threshold from 2.5 to
+        // 8 (and 0.318 with NO dictionary at all: on that map the dictionary is worth nothing), the headline map unchanged up to 5 and
+        // slower from 8 on (0.241 -> 0.253 ms).
+        const int tcd_minuse8 = xt_want ? std::max(0, (int)CFG.num("B3C_KR_TCD_MINUSE8", 28)) : 0;      // (in eighths of an entry per column)
         hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
-                           a->sorted_cols ? 1 : 0, tcd_cfront, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
+                           a->sorted_cols ? 1 : 0, tcd_cfront, tcd_minuse8, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
         unsigned long long hst[16];
         { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
 #ifdef B3C_PROBES

@@ -278,6 +278,14 @@ constexpr int LV_DIRECT_CAP = 2048;     // levels of at most this many nodes: k_
 
 __device__ __forceinline__ uint32_t hash_slot(int32_t c, int lg) { return ((uint32_t)c * 0x9E3779B1u) >> (32 - lg); }
 
+// gain of a move as an exact 128-bit integer: d * 2m - tot * k_i.  All four factors are non-negative and below 2^64, so both
+// products are UNSIGNED 64 x 64 -> 128 multiplications (four v_mad_u64_u32 each); written with signed 128-bit operands the
+// second one carried a dozen instructions of sign handling per evaluation (round 4, from the ISA of k_lv_decide_g).
+__device__ __forceinline__ i128 gain128(u64 d, u64 m2, u64 t, u64 k)
+{
+    return (i128)((unsigned __int128)d * (unsigned __int128)m2) - (i128)((unsigned __int128)t * (unsigned __int128)k);
+}
+
 struct Best {
     i128 gain;
     int32_t com;
@@ -293,22 +301,29 @@ __device__ __forceinline__ void best_take(Best &b, i128 g, int32_t c)
     }
 }
 
+// Arg-max of the lanes' candidates over the wave: largest gain, ties to the lowest community id.  A candidate's gain is positive
+// (best_take), a lane without one holds gain 0, so the 128-bit gains compare as unsigned integers word by word: four 32-bit
+// maxima, each among the lanes that matched the words above, then the minimum id among the lanes that hold the maximum -- five
+// DPP reductions (wave_max_u32, common.hpp: six v_max_u32_dpp and a v_readlane each), the result in scalar registers.  The same
+// arg-max as six rounds of __shfl_down over (gain, id, have) -- 24 ds_bpermute and six 128-bit compare-and-select blocks, 375 of
+// the ~1400 instructions of k_lv_decide_g's loop body (round 4, from its ISA) -- and uniform over the wave instead of lane 0 only.
 __device__ __forceinline__ Best best_wave_reduce(Best b)
 {
+    const u64 hi = (u64)(b.gain >> 64), lo = (u64)b.gain;
+    const uint32_t w[4] = {(uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(lo >> 32), (uint32_t)lo};
+    uint32_t m[4];
+    bool cand = b.have != 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        long long hi = __shfl_down((long long)(b.gain >> 64), o, 64);
-        u64 lo = (u64)__shfl_down((long long)(u64)b.gain, o, 64);
-        int32_t c = __shfl_down(b.com, o, 64);
-        int32_t hv = __shfl_down(b.have, o, 64);
-        i128 g = ((i128)hi << 64) | (i128)lo;
-        if (hv && (!b.have || g > b.gain || (g == b.gain && c < b.com))) {
-            b.gain = g;
-            b.com = c;
-            b.have = 1;
-        }
+    for (int k = 0; k < 4; k++) {
+        m[k] = wave_max_u32(cand ? w[k] : 0u);
+        cand = cand && w[k] == m[k];
     }
-    return b;
+    const uint32_t mc = wave_max_u32(cand ? ~(uint32_t)b.com : 0u);      // ids are >= 0: ~id has the top bit set, 0 = no candidate
+    Best r;
+    r.have = (m[0] | m[1] | m[2] | m[3]) != 0u ? 1 : 0;
+    r.gain = (i128)(((unsigned __int128)(((u64)m[0] << 32) | m[1]) << 64) | (unsigned __int128)(((u64)m[2] << 32) | m[3]));
+    r.com = r.have ? (int32_t)~mc : b.com;
+    return r;
 }
 
 struct NodeRec {
@@ -421,7 +436,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
                     const u64 d = vals[claim[t]];
                     keys[claim[t]] = EMPTY;
                     vals[claim[t]] = 0;
-                    const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
+                    const i128 g = gain128((u64)d, m2, (u64)tot[c], (u64)ki);
                     best_take(b, g, c);
                 }
             }
@@ -449,14 +464,14 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
                     const uint32_t t = t0 + u * 64;
                     keys[t] = EMPTY;
                     vals[t] = 0;
-                    const i128 g = (i128)d[u] * (i128)m2 - (i128)tc[u] * (i128)ki;
+                    const i128 g = gain128((u64)d[u], m2, (u64)tc[u], (u64)ki);
                     best_take(b, g, c[u]);
                 }
             }
         }
         if (lane == 0) {
             // staying: i removed from its own community first (python-louvain __remove)
-            const i128 g = (i128)own * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            const i128 g = gain128((u64)own, m2, (u64)(tot[a] - ki), (u64)ki);
             best_take(b, g, a);
         }
         b = best_wave_reduce(b);
@@ -572,7 +587,7 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval(const NodeRec *__restr
             const uint32_t t = t0 + u * MEGA_NT;
             keys[t] = EMPTY;
             vals[t] = 0;
-            const i128 g = (i128)d[u] * (i128)m2 - (i128)tc[u] * (i128)ki;
+            const i128 g = gain128((u64)d[u], m2, (u64)tc[u], (u64)ki);
             best_take(b, g, c[u]);
         }
     }
@@ -594,7 +609,7 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval(const NodeRec *__restr
             if (red_have[w] && (!r.have || g > r.gain || (g == r.gain && red_com[w] < r.com))) { r.gain = g; r.com = red_com[w]; r.have = 1; }
         }
         // staying: i removed from its own community first (python-louvain __remove)
-        const i128 g = (i128)o * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+        const i128 g = gain128((u64)o, m2, (u64)(tot[a] - ki), (u64)ki);
         best_take(r, g, a);
         int32_t best = r.have ? r.com : a;
         if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
@@ -656,7 +671,7 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval_split(const NodeRec *_
             const uint32_t t = t0 + u * MEGA_NT;
             keys[t] = EMPTY;
             vals[t] = 0;
-            const i128 g = (i128)d[u] * (i128)m2 - (i128)tc[u] * (i128)ki;
+            const i128 g = gain128((u64)d[u], m2, (u64)tc[u], (u64)ki);
             best_take(b, g, c[u]);
         }
     }
@@ -697,7 +712,7 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval_split(const NodeRec *_
             const long long o = (long long)own_acc[m];
             own_acc[m] = 0;
             // staying: i removed from its own community first (python-louvain __remove)
-            const i128 g = (i128)o * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            const i128 g = gain128((u64)o, m2, (u64)(tot[a] - ki), (u64)ki);
             best_take(f, g, a);
             int32_t best = f.have ? f.com : a;
             if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
@@ -797,7 +812,7 @@ __global__ void __launch_bounds__(NT) k_lv_decide_wg(int64_t cnt_max, const int6
                 const uint32_t t = t0 + u * NT;
                 keys[t] = EMPTY;
                 vals[t] = 0;
-                const i128 g = (i128)d[u] * (i128)m2 - (i128)tc[u] * (i128)ki;
+                const i128 g = gain128((u64)d[u], m2, (u64)tc[u], (u64)ki);
                 best_take(b, g, c[u]);
             }
         }
@@ -821,7 +836,7 @@ __global__ void __launch_bounds__(NT) k_lv_decide_wg(int64_t cnt_max, const int6
                 if (red_have[w] && (!r.have || g > r.gain || (g == r.gain && red_com[w] < r.com))) { r.gain = g; r.com = red_com[w]; r.have = 1; }
             }
             // staying: i removed from its own community first (python-louvain __remove)
-            const i128 g = (i128)o * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            const i128 g = gain128((u64)o, m2, (u64)(tot[a] - ki), (u64)ki);
             best_take(r, g, a);
             int32_t best = r.have ? r.com : a;
             if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
@@ -956,12 +971,12 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_direct(int64_t n, int n_sub, 
             const u64 d = lv[c];
             if (d) {
                 lv[c] = 0;
-                const i128 g = (i128)d * (i128)m2 - (i128)tot[c] * (i128)ki;
+                const i128 g = gain128((u64)d, m2, (u64)tot[c], (u64)ki);
                 best_take(b, g, c);
             }
         }
         if (lane == 0) {
-            const i128 g = (i128)own * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            const i128 g = gain128((u64)own, m2, (u64)(tot[a] - ki), (u64)ki);
             best_take(b, g, a);
         }
         b = best_wave_reduce(b);
@@ -1178,8 +1193,11 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
             if (cm[t] == a) own += (long long)qv[t];
             else foreign = true;
         }
+        if constexpr (LPR == 64) own = wave_sum_ll_all(own);
+        else {
 #pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) own += __shfl_down(own, o, LPR);
+            for (int o = LPR / 2; o > 0; o >>= 1) own += __shfl_down(own, o, LPR);
+        }
         const u64 fmask = __ballot(foreign);
         Best b;
         b.gain = 0; b.com = a; b.have = 0;
@@ -1214,7 +1232,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
                     const u64 d = vals[j[t]];
                     keys[j[t]] = EMPTY;
                     vals[j[t]] = 0;
-                    const i128 g = (i128)d * (i128)m2 - (i128)tv[t] * (i128)ki;
+                    const i128 g = gain128((u64)d, m2, (u64)tv[t], (u64)ki);
                     best_take(b, g, cm[t]);
                 }
             }
@@ -1222,11 +1240,13 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
         }
         if (i >= 0 && sl == 0) {
             // staying: i removed from its own community first (python-louvain __remove)
-            const i128 g = (i128)own * (i128)m2 - (i128)(ta - ki) * (i128)ki;
+            const i128 g = gain128((u64)own, m2, (u64)(ta - ki), (u64)ki);
             best_take(b, g, a);
             if (own_out) { own_out[i] = own; stamp_out[i] = epoch; }      // row-sharded pruning: own_i as of this sub-round's start
         }
         // arg-max inside the group
+        if constexpr (LPR == 64) b = best_wave_reduce(b);
+        else
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) {
             long long hi = __shfl_down((long long)(b.gain >> 64), o, LPR);
@@ -1331,7 +1351,7 @@ __global__ void __launch_bounds__(BLK) k_lv_first_g(int64_t cnt, const NodeRec *
 #pragma unroll
         for (int t = 0; t < UN; t++) {
             if (cm[t] == EMPTY) continue;
-            const i128 g = (i128)qv[t] * (i128)m2 - (i128)tv[t] * (i128)ki;
+            const i128 g = gain128((u64)qv[t], m2, (u64)tv[t], (u64)ki);
             best_take(b, g, cm[t]);
         }
 #pragma unroll
@@ -1429,7 +1449,7 @@ __global__ void __launch_bounds__(BLK) k_lv_prune(int64_t cnt, const NodeRec *__
             const int32_t i = rec.node;
             const int32_t a = com[i];
             const long long ki = kdeg[i], o = own[i], f = wnl[i] - o;
-            const i128 stay = (i128)o * (i128)m2 - (i128)(tot[a] - ki) * (i128)ki;
+            const i128 stay = gain128((u64)o, m2, (u64)(tot[a] - ki), (u64)ki);
             bool stays = f <= 0 || (stay > 0 && (i128)f * (i128)m2 < stay);
             if (stamp && !(tstamp[a] < stamp[i])) stays = false;      // own_i may miss a foreign mover: rescan
             if (stays) nxt[i] = a;

@@ -169,6 +169,32 @@ def test_dictionary_words_of_24_bits(ctx, oracle_lib, monkeypatch, scale):
     cm.free()
 
 
+def test_dictionaries_not_worth_their_staging_are_dropped(ctx, monkeypatch):
+    """kr_tcd_build leaves a pass of a tile whose dictionary columns are used fewer than B3C_KR_TCD_MINUSE8 / 8 times on average to
+    the tail pass (round 4; default 3.5).  Forced for every tile (a huge threshold) and switched off (0): the same balance up to the
+    order of the sums, more tails with the rule than without, bit-identical repeats."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(40000, 1300000, 43)
+    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    monkeypatch.setenv('B3C_KR_TCD_XT', '1')
+    res = {}
+    for thr in ('0', '28', '1000000'):
+        monkeypatch.setenv('B3C_KR_TCD_MINUSE8', thr)
+        _, x, info = ctx.kr_balance_counts(cm, sm.sites)
+        _, x2, _ = ctx.kr_balance_counts(cm, sm.sites)
+        assert np.array_equal(x, x2)
+        res[thr] = (x, info)
+    x0, i0 = res['0']
+    for thr in ('28', '1000000'):
+        x, info = res[thr]
+        assert info.n_iter == i0.n_iter
+        np.testing.assert_allclose(x, x0, rtol=1e-11)
+        assert info.tcd_xt_tails >= i0.tcd_xt_tails
+    assert res['1000000'][1].tcd_xt_tails > i0.tcd_xt_tails
+    assert res['1000000'][1].tcd_dict_total == 0          # no dictionary column anywhere
+    cm.free()
+
+
 def test_tail_pass_with_long_tails(ctx, monkeypatch):
     """Tail pass of the dictionary SpMV on a power-law map whose hub rows stay in the tiles (B3C_KR_NO_HUB): tails of
     thousands of entries narrow the 32-bit remainder sums of the fixed-point accumulation; x must agree with the CSR
