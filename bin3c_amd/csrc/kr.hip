@@ -1329,7 +1329,9 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
             auto fetch = [&](int st) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    wn[q] = __builtin_amdgcn_raw_buffer_load_b32(rw, voff + (uint32_t)q * (XT_NT * 4u), 0, 0);
+                    uint32_t off = voff + (uint32_t)q * (XT_NT * 4u);
+                    if (st == 0 && (int32_t)off < 0) off = 0x80000000u;      // lanes before the chunk (first step only): beyond any descriptor, no wrap-around in its range test
+                    wn[q] = __builtin_amdgcn_raw_buffer_load_b32(rw, off, 0, 0);
                     int64_t gi = g0 + 16 * q + 64 * (int64_t)st;
                     gi = gi < hlast ? gi : hlast;
                     hn[q] = hdr[gi];
