@@ -6,6 +6,10 @@ One "step" = one pass of the cluster hot path over one synthetic contact map tha
 resident in HBM: acceptance mask -> site normalisation -> Knight-Ruiz balancing -> X A X ->
 mask compaction -> weight scaling -> Louvain labels on the host (bin3c_amd/pipeline.py).
 
+The headline leg (`value`, `roofline`, `cpu_baseline`) runs the workload as SURVEY.md 8(d) defines it (hic-synth-v1,
+G = n/200 genomes ~ Zipf(1.5)); the rank^-0.5 genome-size variant rounds 1-4 were tuned on follows as a labelled extra leg
+("variant_workload").
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3|C5]
 
 N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  `--mode`:
@@ -38,20 +42,21 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def measured_traffic(config, kernel, algorithmic=None):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes on this workload); None when no measurement is on file -- or when
-    the record on file is for another map of the same config name (its algorithmic byte count differs from this run's)."""
+def measured_traffic(key, kernel, algorithmic=None, field='hbm_bytes_per_launch'):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate passes on this workload, corrected as MI355X_MICROARCH.md prescribes); None when no
+    measurement is on file -- or when the record on file is for another map of the same name (its algorithmic byte count
+    differs from this run's)."""
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
     try:
         with open(path) as fh:
-            rec = json.load(fh).get(config, {})
+            rec = json.load(fh).get(key, {})
         base = lambda name: name.replace('<', ' ').split()[0] if name else ''
         if rec and base(rec.get('kernel', '')) == base(kernel):
             ref = rec.get('algorithmic_bytes_per_launch')
             if ref and algorithmic and abs(ref - algorithmic) > 0.02 * ref:
                 return None
-            return rec.get('hbm_bytes_per_launch')
+            return rec.get(field)
     except (IOError, ValueError):
         pass
     return None
@@ -124,16 +129,17 @@ def main():
                     help="'same': the oracle on the very map the GPU ran (about two minutes at C3); 'sample': on a bounded "
                          "sample of the same generator (n = 200k, E = 10M)")
     ap.add_argument('--mode', default='auto', choices=['auto', 'sharded', 'replicas'], help='N > 1 only')
-    ap.add_argument('--synth', default='default', choices=['default', 'survey'],
-                    help="genome layout of the synthetic map: 'default' = G = n/500 genomes ~ rank^-0.5 (the headline workload, "
-                         "DESIGN.md section 5); 'survey' = SURVEY.md 8(d) to the letter, G = n/200 genomes ~ Zipf(1.5)")
+    ap.add_argument('--synth', default='survey', choices=['survey', 'sqrt'],
+                    help="genome layout of the synthetic map: 'survey' (default, the contract workload) = SURVEY.md 8(d) to the letter, "
+                         "G = n/200 genomes ~ Zipf(1.5); 'sqrt' = the variant rounds 1-4 were tuned on, G = n/500 genomes ~ rank^-0.5 "
+                         "(runs as a labelled extra leg, \"variant_workload\", after the headline)")
     ap.add_argument('--c5-counts', default='summed-draws', choices=['unique', 'summed-draws'],
                     help="power-law maps: 'summed-draws' (default; SURVEY 8(d): duplicates summed) = the stated number of DRAWS with "
                          "duplicates summed, the host generator's rule (C5: 4.6e8 edges whose hub pairs carry counts of 10^5..10^6 -- about "
                          "2,450 KR iterations); 'unique' = the stated number of UNIQUE edges, one count per pair (an easier map for KR: "
                          "report it as an additional, labelled line only)")
-    ap.add_argument('--no-survey-leg', action='store_true',
-                    help='skip the second leg on the workload as SURVEY 8(d) defines it (printed under "survey_workload")')
+    ap.add_argument('--no-variant-leg', action='store_true',
+                    help='skip the second leg on the rank^-0.5 genome-size variant (printed under "variant_workload")')
     ap.add_argument('--n-sub', type=int, default=0, help='sub-rounds per Louvain sweep (0: the library default, 4)')
     ap.add_argument('--hard', action='store_true',
                     help='a HARD clustering problem on the same contigs: 45 %% inter-genome noise, intra-genome counts not '
@@ -198,11 +204,12 @@ def main():
             lo, hi, cnt, diag, w.lengths_h, w.sites_h, _genome = make_edges(w.n, n_edges, w.seed, w.law, noise, boost, genome_law=genome_law)
             w.counts, w.e_true = ctx.coo_symmetrise(w.n, lo, hi, cnt, diag)
             del lo, hi, cnt
-        # which genome-size law: the headline keeps the law rounds 1-3 were measured on, which DEVIATES from SURVEY 8(d);
-        # the surveyed law runs beside it under "survey_workload" (and alone with --synth survey)
-        variant = (' [genome sizes: G = n/500 ~ rank^-0.5 -- NOT SURVEY 8(d)\'s law, which is measured under "survey_workload"]'
-                   if synth == 'default' else ' [genome sizes as SURVEY 8(d): G = n/200 ~ Zipf(1.5)]') + (
+        # which genome-size law: the headline is the workload as SURVEY 8(d) defines it; the law rounds 1-4 were tuned on
+        # DEVIATES from it and runs beside it as a labelled extra leg, "variant_workload" (alone with --synth sqrt)
+        variant = (' [genome sizes: G = n/500 ~ rank^-0.5 -- a VARIANT, not SURVEY 8(d)\'s law]'
+                   if synth != 'survey' else ' [genome sizes as SURVEY 8(d): G = n/200 ~ Zipf(1.5)]') + (
                    ' [hard: 45 % noise, no intra boost]' if hard else '')
+        w.synth, w.hard = synth, hard
         w.label = '{}: hic-synth-v1{} n={} contigs, E={} undirected edges (nnz={}), seed={}{}{}'.format(
             config, ' power law' if w.law == 'powerlaw' else '', w.n, w.e_true, w.counts.nnz, w.seed, variant, synth_note)
         # inputs resident in HBM before the timed region: the count matrix and the two per-contig tables
@@ -252,30 +259,33 @@ def main():
             dt = float(tt.item())
         return dt, last, acc
 
+    def traffic_key(w):
+        """name of this workload's records in profiles/traffic.json: '<config>' for the contract workload, '<config>_variant' for
+        the rank^-0.5 genome-size variant; none for the hard map and the power-law draws"""
+        if w.hard or w.law == 'powerlaw':
+            return '-'
+        return w.config if w.synth == 'survey' else w.config + '_variant'
+
     def spmv_roofline(w, last, acc, share, sharded):
         """The KR SpMV (all launches of one product).  `achieved` / `frac` are PHYSICAL: the HBM bytes one SpMV moves -- by the
         counters when a pass over this kernel on this workload is on file (profiles/traffic.json), else the bytes the kernel's
-        encoding streams by construction -- over its mean duration, against the 8 TB/s peak.  SURVEY 8(d)'s algorithmic figure
-        (12 B per stored entry + 20 B per row: what a CSR fp64 SpMV would have to move) rides beside it as
-        `achieved_algorithmic_equiv` / `frac_algorithmic_equiv`: an equivalent rate, not a fraction of anything -- the
-        dictionary encoding streams fewer bytes than that, so it can pass 1."""
+        encoding streams by construction (b3c_kr_info.spmv_stream_bytes: the library prices its own layout -- 3 or 4 bytes per
+        dictionary entry, 4 per packed tail word, 8 per residual word, the dictionaries, row tables and epilogue vectors) --
+        over its mean duration, against the 8 TB/s peak.  SURVEY 8(d)'s algorithmic figure (12 B per stored entry + 20 B per
+        row: what a CSR fp64 SpMV would have to move) rides beside it as `achieved_algorithmic_equiv` /
+        `frac_algorithmic_equiv`: an equivalent rate, not a fraction of anything -- the encodings stream fewer bytes than that."""
         nnz, n = w.nnz, w.n
         algorithmic = (12.0 * nnz + 20.0 * n) * share     # SURVEY 8(d): one KR SpMV
         ki = last.kr_info
-        vb = ki.value_bits / 8.0                           # 2 when all counts fit 16 bits, else 4 (8: fp64 matrix)
-        streamed = ((4.0 + vb) * nnz + 36.0 * n) * share   # what the CSR count form physically reads / writes
+        streamed = float(ki.spmv_stream_bytes)             # this rank's rows, as the library laid them out
         tcd = getattr(ki, 'tcd_tiles', 0) > 0              # tile-dictionary layout (automatic from 4096 contigs on)
         xt = getattr(ki, 'tcd_xt_tails', 0) > 0            # ... with the tails summed by their own pass (beyond 2^19 contigs)
-        if tcd:
-            # the dictionary form: 4 B per dictionary entry, 8 B per tail entry (word, or count + column), the dictionaries
-            # (ids in, operands gathered), row tables and the n-vectors of the epilogue
-            streamed = (4.0 * (nnz - ki.tcd_tail_entries) + 8.0 * ki.tcd_tail_entries + 12.0 * ki.tcd_dict_total + 52.0 * n) * share
         kname = ('kr_kb_tails + kr_kb_tcd2 (ONE SpMV as two launches: tails summed in column order in fixed point, then dictionary '
                  'rows + fused KR epilogue; times and bytes are those of the pair)' if xt
                  else 'kr_kb_tcd2 (tile-dictionary SpMV on raw counts + fused KR epilogue)' if tcd
                  else 'kr_kb_vec (CSR SpMV on raw counts + fused KR epilogue)')
         avg_ms = acc['spmv_ms'] / max(acc['spmv_n'], 1)
-        traffic = measured_traffic(w.config if w is W and args.synth == 'default' and not args.hard else '-', kname, algorithmic) if not sharded else None
+        traffic = measured_traffic(traffic_key(w), kname, algorithmic) if not sharded else None
         physical = traffic if traffic else streamed
         rate = lambda b: b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         return {'bound': 'hbm', 'kernel': kname, 'achieved': rate(physical), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -286,13 +296,16 @@ def main():
                 'achieved_streamed': rate(streamed), 'frac_streamed': rate(streamed) / HBM_PEAK_GBS,
                 'bytes_algorithmic_per_launch': algorithmic, 'achieved_algorithmic_equiv': rate(algorithmic),
                 'frac_algorithmic_equiv': rate(algorithmic) / HBM_PEAK_GBS,
-                'tail_share': float(ki.tcd_tail_entries) / max(nnz * share, 1.0) if tcd else None}
+                'tail_share': float(ki.tcd_tail_entries) / max(nnz * share, 1.0) if tcd else None,
+                'word_bytes': {'dictionary': int(ki.tcd_word_bytes), 'tail': int(ki.xt_word_bytes),
+                               'residual_words': int(ki.xt_residual_words)} if tcd else None}
 
-    def louvain_roofline(w, last, acc, share, n_acc):
+    def louvain_roofline(w, last, acc, share, n_acc, sharded):
         """The delta-Q neighbour scan; one launch = one sub-round = 1/n_sub of a sweep.  SURVEY 8(d): 16 B per stored entry + 28 B
         per node and sweep.  `achieved` / `frac` are those of the FIRST sweep of level 0, whose launches read every row (no
         node can be settled without its row yet); the mean over all launches of a step is flattered by the pruned sub-rounds,
-        which skip most rows but are charged the full bytes, and rides beside it as `frac_mean_incl_pruned`."""
+        which skip most rows but are charged the full bytes, and rides beside it as `frac_mean_incl_pruned`.  `traffic`: the
+        counters' HBM bytes of a first-sweep launch when a pass on this workload is on file."""
         move_n = max(acc['move_n'], 1)
         mean_bytes = (16.0 * acc['move_nnz'] + 28.0 * acc['move_rows']) / move_n
         mean_ms = acc['move_ms'] / move_n
@@ -303,13 +316,31 @@ def main():
         first_ms = acc['first_ms'] / max(acc['first_n'], 1)
         use_first = acc['first_n'] > 0 and first_ms > 0
         b, ms = (first_bytes, first_ms) if use_first else (mean_bytes, mean_ms)
-        return {'bound': 'hbm', 'kernel': 'k_lv_decide (Louvain delta-Q neighbour scan; one launch = one sub-round: 1/n_sub of a sweep)',
+        kname = 'k_lv_decide (Louvain delta-Q neighbour scan; one launch = one sub-round: 1/n_sub of a sweep)'
+        traffic = measured_traffic(traffic_key(w) + '_k_lv_scan', 'k_lv_decide', None, 'first_sweep_hbm_bytes_per_launch') if (use_first and not sharded) else None
+        return {'bound': 'hbm', 'kernel': kname,
                 'achieved': rate(b, ms), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': rate(b, ms) / HBM_PEAK_GBS,
                 'frac_basis': 'SURVEY 8(d) bytes of the unpruned first sweep of level 0 over its mean launch' if use_first
                               else 'SURVEY 8(d) bytes over the mean launch of the step',
-                'traffic': None, 'bytes_per_launch': b, 'avg_launch_ms': ms,
+                'traffic': traffic, 'frac_traffic': rate(traffic, ms) / HBM_PEAK_GBS if traffic else None,
+                'bytes_per_launch': b, 'avg_launch_ms': ms,
                 'frac_mean_incl_pruned': rate(mean_bytes, mean_ms) / HBM_PEAK_GBS, 'avg_launch_ms_all': mean_ms,
                 'launches_per_step': acc['move_n'] / max(1, acc.get('steps', 1))}
+
+    def step_algorithmic(w, last, n_acc):
+        """SURVEY 8(d)'s algorithmic bytes of the WHOLE step (what a CSR fp64 implementation of every stage would move), so that the
+        stage-level fraction is on record every round: max_offdiag 8 nnz + 8 n; site norm 20 nnz + 8 n; KR (n_iter + 1) SpMVs of
+        12 nnz + 20 n, n_iter vector steps of 96 n, the final X A X 20 nnz + 8 n (the step forms only its masked part: see
+        "processed_map"); compress 12 nnz + 12 nnz' + n; Louvain 16 nnz_l + 28 n_l per sweep, 2 * 16 nnz_l per aggregation."""
+        nnz, n = float(w.nnz), float(w.n)
+        it = float(last.kr_info.n_iter)
+        sub = float(last.sub_nnz or 0)
+        lv = last.lv_info
+        parts = {'max_offdiag': 8 * nnz + 8 * n, 'site_norm': 20 * nnz + 8 * n,
+                 'kr': (it + 1) * (12 * nnz + 20 * n) + it * 96 * n + 20 * nnz + 8 * n,
+                 'compress': 12 * nnz + 12 * sub + n,
+                 'louvain': 16.0 * lv.move_nnz + 28.0 * lv.move_rows + 32.0 * lv.agg_nnz}
+        return parts
 
     def line(w, dt, last, acc, steps, warmup, sharded, extra):
         ms_per_step = dt / steps * 1e3
@@ -321,7 +352,9 @@ def main():
         # dominant kernel by accumulated device time (this rank's launches: a row range of the map when sharded)
         share = 1.0 / world if sharded else 1.0
         r_spmv = spmv_roofline(w, last, acc, share, sharded)
-        r_lv = louvain_roofline(w, last, acc, share, n_acc)
+        r_lv = louvain_roofline(w, last, acc, share, n_acc, sharded)
+        alg = step_algorithmic(w, last, n_acc)
+        alg_total = sum(alg.values())
         out = {
             'metric': 'contact-graph edges/s through KR-normalise + Louvain',
             'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
@@ -333,6 +366,9 @@ def main():
                        'parallelism': 'single GPU' if world == 1 else (
                            'one map over {} GPUs by contig-row blocks (each rank forms and works on its rows of the ordered map); RCCL: 1 exchange per SpMV, 1 per Louvain sub-round'.format(world)
                            if sharded else 'replicas x{} (one map per GPU)'.format(world)),
+                       # what the step does NOT write: the full balanced map the reference caches (contact_map.py:945) is formed on
+                       # first access; the step computes its masked part straight from the counts (bit for bit the same values)
+                       'processed_map': 'lazy',
                        'accepted_contigs': n_acc, 'kr_spmv_per_step': int(spmv_n // steps),
                        'louvain_sweeps_per_step': int(last.lv_info.n_sweeps), 'louvain_levels': int(last.lv_info.n_levels),
                        'communities_level0': int(last.lv_info.n_comm_level0),
@@ -342,20 +378,26 @@ def main():
             'roofline': r_spmv if spmv_ms >= move_ms else r_lv,
             # the same figure for the kernel family that is NOT the dominant one
             'roofline_other': r_lv if spmv_ms >= move_ms else r_spmv,
+            # SURVEY 8(d)'s algorithmic bytes of the whole step over its wall time: an EQUIVALENT rate (the encodings stream fewer
+            # bytes than a CSR fp64 implementation would), printed so that the stage-level figure is on record every round
+            'step_algorithmic': {'bytes': alg_total * share, 'GB_per_s_equiv': alg_total * share / (ms_per_step * 1e-3) / 1e9,
+                                 'frac_of_peak_equiv': alg_total * share / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 'by_stage_GB': {k: v * share / 1e9 for k, v in alg.items()}},
         }
         out.update(extra)
         return out
 
-    def survey_leg():
-        """the workload as SURVEY 8(d) writes it (G = n/200 genomes ~ Zipf(1.5): one genome holds 38 % of
-        the contigs) on the same GPU right after the headline leg, 3 steps, its own stage times and dominant-kernel roofline."""
-        ws = build_workload(args.config, 'survey', False)
+    def variant_leg():
+        """The genome-size law rounds 1-4 were tuned on (G = n/500 genomes ~ rank^-0.5: an easy planted structure, one Louvain
+        level) on the same GPU right after the headline leg, 3 steps, its own stage times and rooflines: a labelled extra, NOT the
+        contract workload."""
+        ws = build_workload(args.config, 'sqrt', False)
         try:
             dt, last, acc = timed_leg(ws, 3, 2)
             o = line(ws, dt, last, acc, 3, 2, False, {})
         finally:
             ws.counts.free()
-        keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'roofline', 'roofline_other')
+        keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'roofline', 'roofline_other', 'step_algorithmic')
         res = {'workload': o['config']['workload']}
         res.update({k: o[k] for k in keep})
         res.update({k: o['config'][k] for k in ('accepted_contigs', 'kr_spmv_per_step', 'louvain_sweeps_per_step', 'louvain_levels',
@@ -376,13 +418,15 @@ def main():
                 if args.cpu_baseline == 'same' or args.config != 'C3':
                     # like for like: the same map, downloaded from HBM (SURVEY 8(d) ii and iii)
                     hip_, hix_, hcnt_ = counts.download()
-                    what = '{} (the map the GPU ran: n={} E={} nnz={})'.format(args.config, n, e_true, nnz)
+                    what = '{} (the map the GPU ran: n={} E={} nnz={}, {})'.format(
+                        args.config, n, e_true, nnz, 'genome sizes as SURVEY 8(d)' if W.synth == 'survey' else 'rank^-0.5 genome-size variant')
                     base_args = (hip_, hix_, hcnt_, sites_h, lengths_h, e_true, what)
                 else:
                     from bin3c_amd.synth import make_synth
-                    sm = make_synth(200000, 10000000, seed)
+                    sm = make_synth(200000, 10000000, seed, genome_law='survey' if W.synth == 'survey' else 'sqrt')
                     base_args = (sm.indptr, sm.indices, sm.counts, sm.sites, sm.lengths, sm.n_edges,
-                                 'hic-synth-v1 sample n=200000 E={} seed={}'.format(sm.n_edges, seed))
+                                 'hic-synth-v1 sample n=200000 E={} seed={} ({})'.format(
+                                     sm.n_edges, seed, 'genome sizes as SURVEY 8(d)' if W.synth == 'survey' else 'rank^-0.5 variant'))
                 if nthr > 1:
                     # the multi-thread figure first: it also tells how long the one-thread run will take
                     out['cpu_baseline_mt'] = cpu_baseline(*base_args, threads=nthr)
@@ -399,9 +443,9 @@ def main():
         dt, last, acc = timed_leg(W, args.steps, args.warmup)
         rep = line(W, dt, last, acc, args.steps, args.warmup, False, {})
         rep_ref = last
-        # the surveyed workload beside the headline (single GPU, the default C3 / C2 legs only: C5 has no surveyed counterpart run)
-        if world == 1 and args.synth == 'default' and not args.hard and args.config in ('C2', 'C3') and not args.no_survey_leg:
-            rep['survey_workload'] = survey_leg()
+        # the variant law beside the headline (single GPU, the default C3 / C2 legs only)
+        if world == 1 and args.synth == 'survey' and not args.hard and args.config in ('C2', 'C3') and not args.no_variant_leg:
+            rep['variant_workload'] = variant_leg()
     if not want_sharded:
         emit(rep)
     else:

@@ -28,7 +28,9 @@ class KRInfo(C.Structure):
                 ('hit_Delta', C.c_int64), ('rout', C.c_double), ('spmv_ms', C.c_double), ('n_spmv', C.c_int64),
                 ('bitwise_symmetric', C.c_int32), ('value_bits', C.c_int32),
                 ('tcd_tiles', C.c_int64), ('tcd_dict_max', C.c_int64), ('tcd_dict_total', C.c_int64),
-                ('tcd_tail_entries', C.c_int64), ('tcd_xt_tails', C.c_int64), ('big_counts', C.c_int64)]
+                ('tcd_tail_entries', C.c_int64), ('tcd_xt_tails', C.c_int64), ('big_counts', C.c_int64),
+                ('tcd_word_bytes', C.c_int64), ('xt_word_bytes', C.c_int64), ('xt_residual_words', C.c_int64),
+                ('spmv_stream_bytes', C.c_int64)]
 
 
 class LouvainInfo(C.Structure):
@@ -36,7 +38,7 @@ class LouvainInfo(C.Structure):
                 ('quant_shift', C.c_int32), ('reserved', C.c_int32), ('modularity', C.c_double),
                 ('move_ms', C.c_double), ('n_move_launch', C.c_int64), ('move_nnz', C.c_int64),
                 ('move_rows', C.c_int64), ('n_comm_level0', C.c_int64), ('agg_gathered_runs', C.c_int64),
-                ('first_sweep_ms', C.c_double), ('first_sweep_launches', C.c_int64)]
+                ('first_sweep_ms', C.c_double), ('first_sweep_launches', C.c_int64), ('agg_nnz', C.c_int64)]
 
 
 class B3CDist(C.Structure):

@@ -16,14 +16,15 @@ extern "C" int b3c_abi_layout(int which, int32_t *out, int cap)
                                  F(b3c_kr_info, hit_Delta), F(b3c_kr_info, rout), F(b3c_kr_info, spmv_ms), F(b3c_kr_info, n_spmv),
                                  F(b3c_kr_info, bitwise_symmetric), F(b3c_kr_info, value_bits), F(b3c_kr_info, tcd_tiles),
                                  F(b3c_kr_info, tcd_dict_max), F(b3c_kr_info, tcd_dict_total), F(b3c_kr_info, tcd_tail_entries),
-                                 F(b3c_kr_info, tcd_xt_tails), F(b3c_kr_info, big_counts)};
+                                 F(b3c_kr_info, tcd_xt_tails), F(b3c_kr_info, big_counts), F(b3c_kr_info, tcd_word_bytes),
+                                 F(b3c_kr_info, xt_word_bytes), F(b3c_kr_info, xt_residual_words), F(b3c_kr_info, spmv_stream_bytes)};
     static const int32_t lv[] = {(int32_t)sizeof(b3c_louvain_info), 0,
                                  F(b3c_louvain_info, n_comm), F(b3c_louvain_info, n_levels), F(b3c_louvain_info, n_sweeps),
                                  F(b3c_louvain_info, n_moves), F(b3c_louvain_info, quant_shift), F(b3c_louvain_info, reserved),
                                  F(b3c_louvain_info, modularity), F(b3c_louvain_info, move_ms), F(b3c_louvain_info, n_move_launch),
                                  F(b3c_louvain_info, move_nnz), F(b3c_louvain_info, move_rows), F(b3c_louvain_info, n_comm_level0),
                                  F(b3c_louvain_info, agg_gathered_runs), F(b3c_louvain_info, first_sweep_ms),
-                                 F(b3c_louvain_info, first_sweep_launches)};
+                                 F(b3c_louvain_info, first_sweep_launches), F(b3c_louvain_info, agg_nnz)};
     static const int32_t ds[] = {(int32_t)sizeof(b3c_dist), 0,
                                  F(b3c_dist, rank), F(b3c_dist, world), F(b3c_dist, chunk), F(b3c_dist, vec), F(b3c_dist, scal),
                                  F(b3c_dist, labels), F(b3c_dist, isum), F(b3c_dist, allgather), F(b3c_dist, user),

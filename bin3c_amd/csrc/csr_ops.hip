@@ -349,11 +349,17 @@ extern "C" int b3c_vec_permute(b3c_ctx *ctx, int64_t n, int elem_bytes, const vo
 }
 
 namespace {
-__global__ void k_row_nnz(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ idx, int64_t *__restrict__ out)
+__global__ void k_row_nnz(int64_t n, const int64_t *__restrict__ indptr, const int32_t *__restrict__ idx, int64_t *__restrict__ out,
+                          int *__restrict__ bad)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int64_t r = idx ? idx[k] : k;
+    if ((uint64_t)r >= (uint64_t)n) {        // a caller-supplied row id outside the matrix: reported, never dereferenced
+        out[k] = 0;
+        *bad = 1;
+        return;
+    }
     out[k] = indptr[r + 1] - indptr[r];
 }
 }  // namespace
@@ -366,12 +372,16 @@ extern "C" int b3c_mat_row_nnz(b3c_ctx *ctx, const b3c_mat *m, const int32_t *id
     if (n == 0) return B3C_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf<int64_t> dd(ctx, n);
-    DevBuf<int32_t> di(ctx, idx ? n : 1);
-    if (!dd.p || !di.p) return ctx->fail(B3C_E_NOMEM, "b3c_mat_row_nnz");
+    DevBuf<int32_t> di(ctx, idx ? n : 1), bad(ctx, 1);
+    if (!dd.p || !di.p || !bad.p) return ctx->fail(B3C_E_NOMEM, "b3c_mat_row_nnz");
     int rc;
     if (idx && (rc = b3c_copy_in(ctx, di.p, idx, sizeof(int32_t) * (size_t)n))) return rc;
-    hipLaunchKernelGGL(k_row_nnz, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, m->indptr, idx ? di.p : nullptr, dd.p);
+    HIP_TRY(ctx, hipMemsetAsync(bad.p, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_row_nnz, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, m->indptr, idx ? di.p : nullptr, dd.p, bad.p);
     HIP_TRY(ctx, hipGetLastError());
+    int32_t hbad = 0;
+    if ((rc = b3c_readback(ctx, &hbad, bad.p, sizeof(hbad)))) return rc;
+    if (hbad) return ctx->fail(B3C_E_ARG, "b3c_mat_row_nnz: idx holds a row id outside [0, %lld)", (long long)n);
     return b3c_copy_out(ctx, out, dd.p, sizeof(int64_t) * (size_t)n);
 }
 

@@ -153,7 +153,7 @@ int b3c_dist_allgatherv(b3c_ctx *ctx, void *base, int esz, const int64_t *starts
     if (!r->ok) return ctx->fail(B3C_E_RCCL, "librccl.so.1 could not be loaded");
     int rc = 0;
     if ((rc = r->group_start()) != 0) return rccl_fail(ctx, "ncclGroupStart", rc);
-    if ((rc = ragged_calls(ctx, r, base, esz, starts))) return rc;
+    if ((rc = ragged_calls(ctx, r, base, esz, starts))) { (void)r->group_end(); return rc; }   // (never leave a group open)
     if ((rc = r->group_end()) != 0) return rccl_fail(ctx, "ncclGroupEnd", rc);
     return B3C_OK;
 }
@@ -193,15 +193,15 @@ int b3c_dist_exchange(b3c_ctx *ctx, int buf)
     if (grouped && (rc = r->group_start()) != 0) return rccl_fail(ctx, "ncclGroupStart", rc);
     for (int k = 0; k < 2 && ids[k] >= 0; k++) {
         BufDesc d;
-        if (!describe(D, ids[k], &d)) return ctx->fail(B3C_E_ARG, "unknown exchange buffer %d", ids[k]);
+        if (!describe(D, ids[k], &d)) { if (grouped) (void)r->group_end(); return ctx->fail(B3C_E_ARG, "unknown exchange buffer %d", ids[k]); }
         const size_t esz = d.type == NCCL_INT32 ? 4 : 8;
         if (ragged && (ids[k] == B3C_BUF_VEC || ids[k] == B3C_BUF_LABELS)) {
-            if ((rc = ragged_calls(ctx, r, d.p, (int)esz, D.starts))) return rc;
+            if ((rc = ragged_calls(ctx, r, d.p, (int)esz, D.starts))) { if (grouped) (void)r->group_end(); return rc; }
             continue;
         }
         // in place: the send buffer is this rank's slice of the receive buffer (NCCL/RCCL define this case)
         rc = r->all_gather((const char *)d.p + (size_t)D.rank * d.count * esz, d.p, d.count, d.type, D.comm, ctx->stream);
-        if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
+        if (rc != 0) { if (grouped) (void)r->group_end(); return rccl_fail(ctx, "ncclAllGather", rc); }
     }
     if (grouped && (rc = r->group_end()) != 0) return rccl_fail(ctx, "ncclGroupEnd", rc);
     return B3C_OK;
@@ -246,8 +246,10 @@ __global__ void k_unpack_slots(int world, int skip, int64_t slot_bytes, int esz,
 int b3c_dist_allgather_rows(b3c_ctx *ctx, void *full, int esz, const int64_t *starts_host, const int64_t *starts_dev)
 {
     const b3c_dist &D = ctx->dist;
-    // a transport that moves ragged slices gathers the vector where it stands
-    if (D.comm || D.allgatherv) return b3c_dist_allgatherv(ctx, full, esz, starts_host);
+    // a transport that moves ragged slices gathers the vector where it stands.  Only a session that INSTALLED ragged ranges has
+    // shown that its stack can (DistSession's self-test gates set_starts: ADVICE round 4); one that fell back to equal ranges keeps
+    // the staged equal-slice path below for Louvain's row-block gathers too
+    if (D.starts && (D.comm || D.allgatherv)) return b3c_dist_allgatherv(ctx, full, esz, starts_host);
     const int64_t slot_bytes = D.chunk * 8;
     const int64_t mine = (starts_host[D.rank + 1] - starts_host[D.rank]) * esz;
     for (int r = 0; r < D.world; r++)
@@ -328,6 +330,8 @@ extern "C" int b3c_dist_allgather_i32(b3c_ctx *ctx, int32_t *vec, int64_t n)
     if (!ctx->has_dist) return B3C_OK;
     const b3c_dist &D = ctx->dist;
     if ((int64_t)D.world * D.chunk < n) return ctx->fail(B3C_E_ARG, "b3c_dist_allgather_i32: vector longer than the exchange buffers");
+    if (D.starts && D.starts[D.world] != n)
+        return ctx->fail(B3C_E_ARG, "b3c_dist_allgather_i32: the installed row ranges end at %lld, the vector has %lld elements", (long long)D.starts[D.world], (long long)n);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int64_t r0 = 0, r1 = 0;
     ctx->dist_rows(n, D.rank, &r0, &r1);

@@ -1271,7 +1271,7 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
                                                       int S, int rbits, uint32_t cmask, const unsigned long long *__restrict__ words, const double *__restrict__ u,
                                                       unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex,
                                                       const uint32_t *__restrict__ cw, const uint32_t *__restrict__ hdr,
-                                                      const unsigned long long *__restrict__ rwords, int64_t n_res, int st_shift, int pipe)
+                                                      const unsigned long long *__restrict__ rwords, int64_t n_res, int st_shift, int pipe, int64_t ncols)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long xt_lds[];
     unsigned long long *acc = xt_lds;                 // S 64-bit sums
@@ -1321,7 +1321,8 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
             const int64_t hlast = (n_tails + 63) >> 6;                     // hdr[] has hlast + 1 entries
             const int64_t g0 = ((s0 - B) >> 6) + wave;
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(cw + s0), 0, (int)(nw * 4), 0x00020000);
-            const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, (int)(((int64_t)cmask + 1) * 8), 0x00020000);
+            // (the operand vector holds ncols doubles -- not 2^cbits: a gather beyond it reads zero instead of the next pooled block)
+            const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, (int)(ncols * 8), 0x00020000);
             const int steps = (int)((B + nw + 4 * XT_NT - 1) / (4 * XT_NT));
             const int csh = rbits + XT_PACK_CB;
             uint32_t voff = (uint32_t)((int)threadIdx.x - B) * 4u;
@@ -2357,6 +2358,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const bool dist = ctx->has_dist;
     const b3c_dist &D = ctx->dist;
     if (dist && (int64_t)D.world * D.chunk < n) return ctx->fail(B3C_E_ARG, "b3c_kr_balance: dist buffers too small for n");
+    // ragged row ranges must tile THIS matrix: the exchanges move [starts[r], starts[r + 1]) only, rows beyond starts[world] would be
+    // computed by the last rank and never reach the others
+    if (dist && D.starts && D.starts[D.world] != n)
+        return ctx->fail(B3C_E_ARG, "b3c_kr_balance: the installed row ranges end at %lld, the matrix has %lld rows", (long long)D.starts[D.world], (long long)n);
     int64_t r0 = 0, r1 = n;
     if (dist) ctx->dist_rows(n, D.rank, &r0, &r1);
     const int64_t nloc = r1 - r0;
@@ -2719,6 +2724,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             xt_res.p = (unsigned long long *)ctx->alloc(sizeof(unsigned long long) * (size_t)(n_tails + 4));
             if (!xt_cw.p || !xt_hdr.p || !xt_res.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: packed tails");
             HIP_TRY(ctx, hipMemsetAsync(xst.p, 0, sizeof(unsigned long long), s));
+            // the sentinel hdr[groups]: lanes past the end of the stream clamp their group index to it (kr_kb_tails) -- it must be a
+            // column, not whatever the pooled block held before
+            HIP_TRY(ctx, hipMemsetAsync(xt_hdr.p + (n_tails + 63) / 64, 0, sizeof(uint32_t), s));
             hipLaunchKernelGGL(kr_tails_pack, dim3((unsigned)std::min<int64_t>(((n_tails + 63) / 64 + 3) / 4, 16 * (int64_t)ctx->n_cu)), dim3(256), 0, s, n_tails, xt_rbits,
                                16 + xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, xt_cw.p, xt_hdr.p, xt_res.p, xst.p);
             unsigned long long nr = 0;
@@ -2757,6 +2765,29 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             tcd_24 = hov == 0;                   // a count beyond 11 bits (or an index beyond 13) somewhere: the 32-bit words stay
             if (CFG.on("B3C_KR_DEBUG"))
                 fprintf(stderr, "[b3c] dictionary words: %lld groups of four 24-bit words (%s)\n", (long long)ngrp, tcd_24 ? "in use" : "a count needs more than 11 bits: 32-bit words kept");
+        }
+    }
+    // ---- what one SpMV streams by construction in this layout (b3c_kr_info.spmv_stream_bytes; this rank's rows) ----
+    {
+        const int64_t ent = a->nnz;
+        const int vbytes = counts ? (v16 ? 2 : 4) : 8;
+        if (tcd) {
+            // (entries of hub rows -- kr_kb_hub reads them from the CSR arrays -- are priced as dictionary entries: a handful of rows)
+            const int64_t tails = info->tcd_tail_entries, dent = ent - tails;
+            info->tcd_word_bytes = tcd_24 ? 3 : 4;
+            info->xt_word_bytes = tails_xt && xt_packed ? 4 : 8;
+            info->xt_residual_words = tails_xt && xt_packed ? xt_n_res : 0;
+            int64_t b = dent * info->tcd_word_bytes;                                    // dictionary words
+            if (tails_xt && xt_packed) b += 4 * n_tails + 4 * ((n_tails + 63) / 64) + 8 * xt_n_res + 8 * (tails - n_tails);
+            else b += 8 * tails;                                                        // count + column, or one 64-bit word
+            b += 12 * info->tcd_dict_total;                                             // dictionaries: column ids in, operands gathered
+            // per row: indptr 8, n1v 4, x / p / v / 1/s / dfix 40, w | v + rk out 8; with the tail pass its fixed-point row sums
+            // (read + cleared by the row kernel 24, flushed by xt_chunks workgroups per super-tile 12 each), 24-bit words: group offsets 8
+            b += nloc * (int64_t)(60 + (tails_xt ? 24 + 12 * xt_chunks : 0) + (tcd_24 ? 8 : 0));
+            if (tails > 0) b += n * 8;                                                  // the tails' operands: the vector at least once
+            info->spmv_stream_bytes = b;
+        } else {
+            info->spmv_stream_bytes = ent * (4 + vbytes) + nloc * 56 + n * 8;             // CSR: column + value per entry; per row indptr, x / p / v / 1/s / dfix, out; the operand vector once
         }
     }
     const int GS = tcd ? (int)tcd_tiles : GS_rows;
@@ -2859,7 +2890,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
                                        xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p,
                                        xt_packed ? xt_cw.p : nullptr, xt_hdr.p, xt_res.p, xt_n_res, xt_st_shift,
-                                       xt_pipe && n_tails < (1ll << 29) ? 1 : 0);       // (32-bit byte offsets inside a chunk of the packed stream)
+                                       xt_pipe && n_tails < (1ll << 29) ? 1 : 0, n);    // (32-bit byte offsets inside a chunk of the packed stream)
                 // dictionary waves and tail waves side by side (512-thread workgroups)
 #define KR_TCD2_ARGS                                                                                                         \
     dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \

@@ -758,7 +758,8 @@ __global__ void __launch_bounds__(NT) k_lv_decide_wg(int64_t cnt_max, const int6
         const int32_t i = rec.node;
         const int32_t a = com[i];
         const long long ki = kdeg[i];
-        const int lg = table_lg(rec.deg);
+        const int lgt = table_lg(rec.deg);
+        const int lg = lgt < LGS ? lgt : LGS;        // (the host's classes guarantee lgt <= LGS; never index past the LDS table)
         const uint32_t mask = (1u << lg) - 1u;
         const int32_t *__restrict__ ci = indices + rec.start;
         const int64_t *__restrict__ qi = q + rec.start;
@@ -2623,7 +2624,10 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const bool use_wg = grouped && !CFG.on("B3C_LV_NO_WG");
         // LDS table of the wave-per-node kernel: 12 bytes per slot and wave, four waves per workgroup -- 2048 slots are 96 KB, ONE
         // workgroup per CU.  B3C_LV_CAP_MAX clamps it (nodes beyond the cap use their global table): see DESIGN.md section 4
-        const int64_t wave_max = use_wg ? std::min<int64_t>(maxdeg, std::max<int64_t>(64, CFG.num("B3C_LV_WAVE_MAX", 409))) : maxdeg;
+        // (the class bound of the wave kernel, wave_thr, is derived further down from the same numbers: one source for both)
+        const bool wide_g = short_max == 256 && CFG.num("B3C_LV_WIDE_G", 1) != 0;      // rows of 257 .. 512 entries by k_lv_decide_g<64, 8>
+        const int wave_thr = use_wg ? std::min(lv_wg_max_deg(0), std::max(short_max, (int)CFG.num("B3C_LV_WAVE_MAX", wide_g ? 512 : 409))) : 0;
+        const int64_t wave_max = use_wg ? std::min<int64_t>(maxdeg, std::max<int64_t>(64, wave_thr)) : maxdeg;
         const int64_t need = 1ll << table_lg(wave_max);
         const int cap_max = (int)CFG.num("B3C_LV_CAP_MAX", 2048);
         const int cap0 = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
@@ -2663,10 +2667,12 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         LvThr thr;
         thr.t[0] = short_max;
         if (use_wg) {
-            thr.t[1] = std::min(mega_deg, std::max(short_max, (int)CFG.num("B3C_LV_WAVE_MAX", short_max == 256 && CFG.num("B3C_LV_WIDE_G", 1) != 0 ? 512 : 409)));
+            // ascending by construction (lv_list_segment counts the bounds a row exceeds): the wave kernel's bound never passes the
+            // first workgroup class -- a row of the 1024-slot class with a longer table would write past its LDS
             thr.t[2] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(0)));
             thr.t[3] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(1)));
             thr.t[4] = mega_deg;
+            thr.t[1] = std::min(thr.t[2], std::max(short_max, wave_thr));
         } else {
             thr.t[1] = thr.t[2] = thr.t[3] = thr.t[4] = mega_deg;
         }
@@ -2704,7 +2710,6 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const bool use_side = !CFG.on("B3C_LV_NO_SIDE");      // hubs / mega rows beside the grouped scan on side streams
         const bool mega_lds = use_wg && !CFG.on("B3C_LV_NO_MEGA_LDS");
         const bool xcd_lists = !CFG.on("B3C_LV_NO_XCD");
-        const bool wide_g = short_max == 256 && CFG.num("B3C_LV_WIDE_G", 1) != 0;      // rows of 257 .. 512 entries by k_lv_decide_g<64, 8>
         // per-node gather records {community, its total} for the grouped scan (k_lv_decide_g<.., REC>), refreshed after every apply
         const bool use_rec = grouped && CFG.num("B3C_LV_REC", 1) != 0;
         DevBuf<GRec> grec(ctx, use_rec ? n : 1);
@@ -3014,6 +3019,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if (info->n_levels == 1) info->n_comm_level0 = kc;
 
         // ---- induced graph ----
+        info->agg_nnz += g.nnz;
         LvGraph h;
         GraphGuard next_guard{ctx, &h};               // an early return while h is under construction releases its blocks
         if (kc <= AGG_BINS_KC && !CFG.on("B3C_LV_AGG_SORT")) {

@@ -66,6 +66,12 @@ typedef struct {
     int64_t tcd_xt_tails;
     /* counts beyond 65535 handled by the correction list beside the 16-bit forms (0: none, or too many: 32-bit values) */
     int64_t big_counts;
+    /* what ONE SpMV streams BY CONSTRUCTION in the layout this call ran on (this rank's rows), for the roofline: bytes of a
+     * dictionary entry (4, or 3 as 24-bit words; 0: no dictionary form), bytes of a tail entry (8: count + column or a 64-bit
+     * word; 4: packed words of the tail pass), tail words that stayed 64-bit beside the packed stream, and the total over all
+     * streams of the product -- entry words, group bases, dictionaries (ids in, operands gathered), row tables, the n-vectors of
+     * the fused epilogue, the fixed-point row sums of the tail pass (read, cleared, flushed) */
+    int64_t tcd_word_bytes, xt_word_bytes, xt_residual_words, spmv_stream_bytes;
 } b3c_kr_info;
 
 typedef struct {
@@ -86,6 +92,8 @@ typedef struct {
     double first_sweep_ms;     /* the part of move_ms spent in the FIRST sweep of level 0: its n_sub launches scan every row
                                 * (no node can be settled without its row yet), the honest figure for a roofline */
     int64_t first_sweep_launches;
+    int64_t agg_nnz;      /* stored entries of the graphs that were aggregated into a next level, summed over the levels (for the
+                           * whole-step algorithmic byte count of the bench line: SURVEY 8(d) charges 2 * 16 bytes per entry) */
 } b3c_louvain_info;
 
 /* ---- context ------------------------------------------------------------------------------- */

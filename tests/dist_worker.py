@@ -246,6 +246,46 @@ def gpu_large_mode(rank, world):
     ctx.close()
 
 
+def gpu_c4_mode(rank, world):
+    """BASELINE.json configs[3] -- C4: the 1M-contig / 100M-edge map of bench.py's headline (the contract generator, G = n/200 genomes
+    ~ Zipf(1.5)) row-sharded -- through the sharded code with the ranks sharing one GPU: row blocks balanced by stored entries (one
+    genome holds 38 % of the contigs), 162 SpMVs with one exchange each, three Louvain levels of which the first ends beyond the bin
+    table (185k communities: pair runs gathered over the ranks), identical results to one rank and on all ranks.  The 8-GPU form
+    (xGMI) is the driver's; what can differ there is the transport, not the arithmetic."""
+    from bin3c_amd.dist import DistSession
+    from bin3c_amd.pipeline import make_context, run_hot_path
+    from bin3c_amd.synth import CONFIGS, make_edges
+    ctx = make_context(0)
+    n, e, seed, law = CONFIGS['C3']
+    lo, hi, c, diag, lengths, sites, genome = make_edges(n, e, seed, law, genome_law='survey')
+    counts, n_edges = ctx.coo_symmetrise(n, lo, hi, c, diag)
+    del lo, hi, c
+    chk = torch.tensor([counts.nnz, n_edges], dtype=torch.int64)
+    ref = chk.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(chk, ref), 'the ranks built different maps'
+    single = run_hot_path(ctx, counts, sites, lengths, 1000, 5)
+    assert single.kr_info.n_iter > 100 and single.lv_info.n_levels >= 3 and single.lv_info.n_comm_level0 > 4096
+    bytes_single = ctx.bytes_in_use()
+    sess = DistSession(ctx, n)
+    res = run_hot_path(ctx, counts, sites, lengths, 1000, 5)
+    sess.check()
+    assert res.row_block == (sess.r0, sess.r1) and sess.starts is not None
+    most = torch.tensor([res.work_nnz], dtype=torch.int64)
+    dist.all_reduce(most, op=dist.ReduceOp.MAX)
+    assert int(most.item()) <= 1.10 * counts.nnz / world, (int(most.item()), counts.nnz)
+    _agree(res, single, rank)
+    assert res.lv_info.n_comm_level0 == single.lv_info.n_comm_level0 and res.lv_info.n_comm == single.lv_info.n_comm
+    n_spmv = res.kr_info.n_iter + 1
+    cuts = res.kr_info.hit_delta + res.kr_info.hit_Delta
+    assert n_spmv <= sess.n_exchanges <= (n_spmv + cuts + 12) + 5 * (res.lv_info.n_sweeps + 1) + 14 + 8 * res.lv_info.n_levels, (sess.n_exchanges, n_spmv)
+    sess.close()
+    counts.free()
+    print('rank %d gpu-c4 ok (%d contigs, %d stored entries, %d SpMVs, %d communities after level 0 -> %d, %d exchanges; pool %d MB single)' % (
+        rank, n, counts.nnz, n_spmv, single.lv_info.n_comm_level0, single.lv_info.n_comm, sess._final, bytes_single >> 20))
+    ctx.close()
+
+
 def gpu_empty_mode(rank, world):
     """One rank's row block is masked out completely (all its contigs shorter than min_len): that rank still has to take part
     in every collective of the cluster stage (maximum, degrees, label gathers, bins) with an empty sub-map."""
@@ -282,6 +322,7 @@ if __name__ == '__main__':
     dist.init_process_group(backend='gloo')
     print('rank %d rendezvous done' % dist.get_rank(), flush=True)
     r, w = dist.get_rank(), dist.get_world_size()
-    {'cpu': cpu_mode, 'gpu': gpu_mode, 'gpu-many': gpu_many_mode, 'gpu-empty': gpu_empty_mode, 'gpu-large': gpu_large_mode}[sys.argv[1]](r, w)
+    {'cpu': cpu_mode, 'gpu': gpu_mode, 'gpu-many': gpu_many_mode, 'gpu-empty': gpu_empty_mode, 'gpu-large': gpu_large_mode,
+     'gpu-c4': gpu_c4_mode}[sys.argv[1]](r, w)
     dist.barrier()
     dist.destroy_process_group()

@@ -86,6 +86,14 @@ def test_sharded_hot_path_beyond_a_million_contigs_two_ranks_one_gpu():
 
 
 @pytest.mark.gpu
+def test_c4_workload_through_the_sharded_code_two_ranks_one_gpu():
+    """BASELINE.json configs[3] (1M contigs / 100M edges on the contract generator, row-sharded) with two ranks on one GPU: identical
+    to the single-rank run"""
+    text = _launch('gpu-c4', 900)
+    assert 'rank 0 gpu-c4 ok' in text and 'rank 1 gpu-c4 ok' in text
+
+
+@pytest.mark.gpu
 def test_a_rank_with_an_empty_block_takes_part_two_ranks_one_gpu():
     text = _launch('gpu-empty', 900)
     assert 'rank 0 gpu-empty ok' in text and 'rank 1 gpu-empty ok' in text

@@ -20,10 +20,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(ctx, cfg, reorder=True, keep=False):
+    """cfg: a BASELINE.json config on the rank^-0.5 genome-size variant ('C2', 'C3'), or -- '-survey' appended -- on the contract
+    generator as SURVEY 8(d) writes it (G = n/200 genomes ~ Zipf(1.5)), the map bench.py's headline runs"""
     from bin3c_amd.pipeline import run_hot_path
     from bin3c_amd.synth import CONFIGS, make_edges
-    n, e, seed, law = CONFIGS[cfg]
-    lo, hi, c, diag, lengths, sites, genome = make_edges(n, e, seed, law)
+    n, e, seed, law = CONFIGS[cfg.split('-')[0]]
+    lo, hi, c, diag, lengths, sites, genome = make_edges(n, e, seed, law, genome_law='survey' if cfg.endswith('-survey') else 'sqrt')
     counts, n_edges = ctx.coo_symmetrise(n, lo, hi, c, diag)
     res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, reorder=reorder, keep=keep)
     return counts, n_edges, sites, lengths, genome, res
@@ -79,7 +81,17 @@ def compare_with_oracle(ctx, orc, counts, sites, lengths, res, max_iter=1000, se
         assert np.array_equal(res.labels, ref['labels'])
         assert (res.lv_info.modularity, res.lv_info.n_sweeps, res.lv_info.n_levels, res.lv_info.n_comm) == \
                (ref['Q'], ref['n_sweeps'], ref['n_levels'], ref['n_comm'])
-        if seq:
+        if seq == 'quality':
+            # where the two schedules CAN differ (a flat modularity landscape: the giant genome of the surveyed law is a uniform
+            # random graph) they end in different optima: how far apart is asserted and reported
+            sq = orc.louvain_seq(sip, six, w)
+            ari = graphs.adjusted_rand(res.labels, sq['labels'])
+            print('BSP (device) vs sequential (python-louvain style): Q {:.6f} / {:.6f}, communities {} / {}, sweeps {} / {}, ARI {:.4f}'.format(
+                ref['Q'], sq['Q'], ref['n_comm'], sq['n_comm'], ref['n_sweeps'], sq['n_sweeps'], ari))
+            assert ref['Q'] >= sq['Q'] - 0.01
+            assert ari > 0.5
+            ref = dict(ref, seq_Q=sq['Q'], ari=ari)
+        elif seq:
             sq = orc.louvain_seq(sip, six, w)
             assert graphs.same_partition(res.labels, sq['labels'])
             assert abs(sq['Q'] - ref['Q']) < 1e-9
@@ -88,11 +100,18 @@ def compare_with_oracle(ctx, orc, counts, sites, lengths, res, max_iter=1000, se
         orc.set_threads(1)
 
 
-@pytest.mark.parametrize('cfg', ['C2', 'C3'])
+@pytest.mark.parametrize('cfg', ['C2', 'C3', 'C3-survey'])
 def test_full_size_matches_the_oracle(ctx, oracle_lib, cfg):
+    """'C3-survey' is the map bench.py's headline runs (the contract generator at 1M contigs / 100M edges: 162 SpMVs of which 87 % of
+    the entries take the tail pass, three Louvain levels, 26 sweeps, mega rows, hash aggregation): every stage against the oracle
+    at ITS size.  Its sequential-Louvain comparison is made at C2's size below (the python-louvain-style oracle needs minutes on the
+    185k-node induced graph)."""
     counts, n_edges, sites, lengths, genome, res = _run(ctx, cfg, keep=True)
     try:
-        compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res)
+        st, ref = compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res, seq=not cfg.endswith('-survey'))
+        if cfg == 'C3-survey':
+            assert st.n_iter > 100 and ref['n_levels'] >= 3 and ref['n_sweeps'] >= 20, (st.n_iter, ref['n_levels'], ref['n_sweeps'])
+            assert res.kr_info.tcd_xt_tails > 0.5 * counts.nnz          # the tail pass carries most of this map
     finally:
         res.free()
         counts.free()
@@ -111,7 +130,9 @@ def test_c2_on_other_workload_definitions_matches_the_oracle(ctx, oracle_lib, va
     counts, n_edges = ctx.coo_symmetrise(100000, lo, hi, c, diag)
     res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, keep=True)
     try:
-        st, ref = compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res, seq=False)
+        # the device's schedule against the sequential python-louvain-style sweep: not the same partition on these maps (by design,
+        # DESIGN.md section 2) -- the modularity within 0.01 and the agreement of the two partitions are asserted and printed
+        st, ref = compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res, seq='quality')
         assert ref['n_sweeps'] >= 15 and (ref['n_levels'] >= 2 or variant == 'hard')
     finally:
         res.free()

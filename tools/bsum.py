@@ -15,8 +15,8 @@ for line in sys.stdin:
         print('   other    %s: %.0f GB/s (%.1f%%) avg %.3f ms' % (o['kernel'][:12], o['achieved'], 100 * o['frac'], o['avg_launch_ms']))
     if 'cpu_baseline' in d:
         print('   cpu', d['cpu_baseline']['value'], d['cpu_baseline']['sample'][:100])
-    sv = d.get('survey_workload')
+    sv = d.get('variant_workload')
     if sv:
-        print('   SURVEY leg: %.2f ms/step  %.3g edges/s  stage_ms %s  spmv/step %s sweeps %s levels %s' % (
+        print('   VARIANT leg: %.2f ms/step  %.3g edges/s  stage_ms %s  spmv/step %s sweeps %s levels %s' % (
             sv['ms_per_step'], sv['value'], {k: round(v, 2) for k, v in sv['stage_ms'].items()}, sv['kr_spmv_per_step'],
             sv['louvain_sweeps_per_step'], sv['louvain_levels']))

@@ -11,7 +11,7 @@ i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $group --kernel-include-regex "${B3C_PMC_KERNEL:-kr_kb_}" --output-format csv -d $out/pmc_$i -- python bench.py --config C3 --steps 1 --warmup 0 --no-cpu-baseline --no-survey-leg > $out/pmc_$i.log 2>&1
+  timeout 150 rocprofv3 --pmc $group --kernel-include-regex "${B3C_PMC_KERNEL:-kr_kb_}" --output-format csv -d $out/pmc_$i -- python bench.py --config C3 --steps 1 --warmup 0 --no-cpu-baseline --no-variant-leg > $out/pmc_$i.log 2>&1
   echo "group $i: $group -> rc $?"
 done <<'GROUPS'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
