@@ -1623,7 +1623,14 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int DW = XT ? 8 : 4;            // waves on dictionary rows
-    if (wv < DW) {
+    // A tile WITHOUT a dictionary (round 5): every pass of its build left its entries to the tail pass (kr_tcd_build: `skip`, or no
+    // column seen twice), so no row has a dictionary entry and the row loop below would walk 192 rows of nothing -- on the contract
+    // workload (the surveyed genome-size law at C3) four tiles in five are such tiles, and the kernel is then the fused epilogue and
+    // little else.  Block-uniform: D1 comes from one scalar load.
+    const bool no_dict = XT && D1 == 0;
+    if (no_dict) {
+        if (tid < nrows) od[tid] = 0.0;
+    } else if (wv < DW) {
         // ---- dictionary entries: LPR lanes per row, UN 16-byte vectors per lane, next row prefetched ----
         constexpr int RPW = 64 / LPR;
         constexpr int RPP = RPW * DW;
