@@ -414,7 +414,7 @@ __global__ void kr_max_degree(int64_t n, const int64_t *__restrict__ indptr, uns
 // wait behind the indptr -> entries -> gather chain of the row before.  Measured at C3 (ordered matrix): 0.72 ms per
 // SpMV = 3.37 TB/s algorithmic, against 0.88 ms un-pipelined; non-temporal loads of the matrix stream made it slower.
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int UN, typename VT, bool NOGATHER = false>
+template <int LPR, int UN, typename VT>
 __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const KRState *__restrict__ sin,
                                                    KRState *__restrict__ sout, const double *__restrict__ partA, int PA,
                                                    int PS, const int64_t *__restrict__ indptr,
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_pipe(int64_t r0, int64_t n, const K
         }
         double g[UN];
 #pragma unroll
-        for (int q = 0; q < UN; q++) g[q] = NOGATHER ? u[row + (c[q] & 1)] : u[(uint32_t)c[q]];   // NOGATHER: timing probe only
+        for (int q = 0; q < UN; q++) g[q] = u[(uint32_t)c[q]];
         // 3. first chunk of the next row
         int32_t c2[UN];
         VT m2[UN];
@@ -824,17 +824,9 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
     int32_t *__restrict__ dc = dict_cols + tile * (int64_t)d1cap;
     int64_t a1 = 0;                                   // dictionary columns of the passes before (uncapped)
     const int64_t CHUNK = (int64_t)1 << TCD_CHUNK_LG;
-#ifdef B3C_PROBES
-    long long tph[6] = {0, 0, 0, 0, 0, 0};               // phase clocks of this tile (development builds: B3C_KR_TCD_BLOG)
-    long long tq = wall_clock64();
-#define TCD_PH(k) do { __syncthreads(); const long long tn_ = wall_clock64(); tph[k] += tn_ - tq; tq = tn_; } while (0)
-#else
-#define TCD_PH(k) do { } while (0)
-#endif
     for (int64_t c0 = 0; c0 < ncols; c0 += CHUNK) {
         for (int i = tid; i < TCD_WORDS / 4; i += TCD_TB) { b14[i] = make_uint4(0, 0, 0, 0); b24[i] = make_uint4(0, 0, 0, 0); }
         __syncthreads();
-        TCD_PH(0);
         // ---- sweep 1: which columns does the tile use, which more than once ----
         {
             int rl = wv;
@@ -878,7 +870,6 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
             }
         }
         __syncthreads();
-        TCD_PH(1);
         // Prefix popcounts of bm2 per group of 128 columns, free of LDS bank conflicts (round 3): a thread that walks ITS
         // contiguous groups reads 16-byte words 64 bytes apart from its neighbours' -- every lane on the same two banks; the
         // phase clocks of a development build showed this stretch at 33 of a tile's 137 us.  So the bitmap is always read with
@@ -957,7 +948,6 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
                 }
             }
         }
-        TCD_PH(2);
         // ---- sweep 2: the rows, dictionary entries to the front (index << 16 | count), the others to the back ----
         {
             int rl = wv;
@@ -1030,11 +1020,7 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
         }
         if (!skip) a1 += tot1;
         __syncthreads();
-        TCD_PH(3);
     }
-#ifdef B3C_PROBES
-    if (tid == 0) for (int k = 0; k < 4; k++) atomicAdd(&stats[8 + k], (unsigned long long)tph[k]);
-#endif
     for (int i = tid; i < nrows; i += TCD_TB) n1_out[ra + i - r0] = (int32_t)nfront[i];
     if (tid == 0) {
         const int d1 = (int)(a1 < d1cap ? a1 : d1cap);
@@ -1129,7 +1115,7 @@ __global__ void __launch_bounds__(256) kr_big_fix(const KRState *__restrict__ si
 // can overflow) and a 32-bit one that takes what every product leaves below that grid, on a grid 2^20 times finer (fewer bits for
 // tails of more than 2048 entries, so that the 32-bit sums cannot overflow either): the sum is exact to 2^-(E+20), about
 // 2^-70 of the largest term, i.e. more accurate than the fp64 sum it replaces.
-// Stand-alone measurement (tools/probes/tails_probe.hip): 26 M gathers in row order 273 us, this way 100 us.
+// Stand-alone measurement (round 2): 26 M gathers in row order 273 us, this way 100 us.
 // ---------------------------------------------------------------------------------------------
 constexpr int XT_S = 8192;           // rows per super-tile (13 bits of a tail word) ...
 constexpr int XT_S_BIG = 12288;      // ... or, on maps whose operand vector is beyond the L2s, all the row sums the LDS holds (14 bits)
@@ -1524,14 +1510,13 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                                                    const double *__restrict__ u, const double *__restrict__ x,
                                                    const double *__restrict__ p, double *__restrict__ v,
                                                    double *__restrict__ rk, double *__restrict__ w,
-                                                   double *__restrict__ part_out, int hub_len, int probe, uint32_t probe_mask,
+                                                   double *__restrict__ part_out, int hub_len,
                                                    unsigned long long *__restrict__ tlog,
                                                    unsigned long long *__restrict__ yhi, int *__restrict__ ylo, const int *__restrict__ tex,
                                                    const double *__restrict__ corr, const uint32_t *__restrict__ p24, const int64_t *__restrict__ g24)
 {
     // XT: the tails are summed by kr_kb_tails beforehand (fixed point in yhi / ylo, exponent tex[0]); all eight waves run
     // dictionary rows here and the epilogue converts the row's tail sum and clears it for the next SpMV
-    // probe (timing only, wrong results): 1 no tail gathers, 2 no tail work at all, 4 no dictionary staging, 8 no dictionary work
     extern __shared__ __attribute__((aligned(16))) double ksm[];
     double *xl = ksm;                         // dlds operands of the tile's dictionary
     double *od = xl + dlds, *ot = od + R;     // row sums over the dictionary entries / over the tails
@@ -1575,7 +1560,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     const long long tl1 = tlog ? wall_clock64() : 0;
     {
         const int32_t *__restrict__ dc1 = dict_cols + (live ? tile : 0) * (int64_t)dstride;
-        for (int base = 0; base < D1 && !(probe & 4); base += TBK * 4) {
+        for (int base = 0; base < D1; base += TBK * 4) {
             int32_t cc[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) { const int i = base + q * TBK + tid; cc[q] = i < D1 ? dc1[i] : 0; }
@@ -1642,7 +1627,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
         if (rl < nrows) {
             so = (uint32_t)((ipl[rl] - e0) * 4);
             if (P24) sq = (uint32_t)g24l[rl] * 12u;
-            n1 = (ipl[rl + 1] - ipl[rl] > hub_len || (probe & 8)) ? 0 : n1l[rl];
+            n1 = ipl[rl + 1] - ipl[rl] > hub_len ? 0 : n1l[rl];
         }
         u32x4 c[UN];
 #pragma unroll
@@ -1654,7 +1639,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
             if (rln < nrows) {
                 son = (uint32_t)((ipl[rln] - e0) * 4);
                 if (P24) sqn = (uint32_t)g24l[rln] * 12u;
-                n1n = (ipl[rln + 1] - ipl[rln] > hub_len || (probe & 8)) ? 0 : n1l[rln];
+                n1n = ipl[rln + 1] - ipl[rln] > hub_len ? 0 : n1l[rln];
             }
             u32x4 c2[UN];
 #pragma unroll
@@ -1705,7 +1690,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
             so = (uint32_t)((ipl[rl] - e0) * 4);
             len = (int)(ipl[rl + 1] - ipl[rl]);
             t0 = n1l[rl];
-            if (len > hub_len || (probe & 2)) { len = 0; t0 = 0; }
+            if (len > hub_len) { len = 0; t0 = 0; }
         }
         u32x4 tc[TU], tcol[TU];
 #pragma unroll
@@ -1723,7 +1708,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                 son = (uint32_t)((ipl[rln] - e0) * 4);
                 lenn = (int)(ipl[rln + 1] - ipl[rln]);
                 t0n = n1l[rln];
-                if (lenn > hub_len || (probe & 2)) { lenn = 0; t0n = 0; }
+                if (lenn > hub_len) { lenn = 0; t0n = 0; }
             }
             double tg[TU][4];
 #pragma unroll
@@ -1731,7 +1716,7 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                 const int t = t0 + (k * TLPR + sl) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len && !(probe & 1) ? (tcol[k][j] & probe_mask) * 8u : NOLOAD, 0, 0);
+                    const u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(ru, t + j < len ? tcol[k][j] * 8u : NOLOAD, 0, 0);
                     tg[k][j] = __hiloint2double((int)gw.y, (int)gw.x);
                 }
             }
@@ -2299,22 +2284,12 @@ __global__ void kr_site_scale(int64_t n, double *__restrict__ sites, double *__r
     }
 }
 
-#ifdef B3C_PROBES
-static bool g_probe_nogather = false;      // B3C_KR_NOGATHER of the calling context (development builds only)
-#endif
-
 template <int LPR, int UN>
 void launch_kb_pipe(hipStream_t s, int grid, int64_t r0, int64_t n, const KRState *sin, KRState *sout, const double *partA,
                     int PA, int PS, const b3c_mat *m, const uint16_t *v16, const double *rs, const double *dfix, const double *u,
                     const double *x, const double *p, double *v, double *rk, double *w, double *part_out, int hub_len,
                     const double *corr = nullptr)
 {
-#ifdef B3C_PROBES      // timing probe with WRONG RESULTS (the kernel without its random gathers): development builds only, never in the shipped library
-    if (m->kind == B3C_U32 && g_probe_nogather)
-        hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint32_t, true>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
-                           m->indices, (const uint32_t *)m->data, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
-    else
-#endif
     if (m->kind == B3C_U32 && v16)
         hipLaunchKernelGGL((kr_kb_pipe<LPR, UN, uint16_t>), dim3(grid), dim3(BLK), 0, s, r0, n, sin, sout, partA, PA, PS, m->indptr,
                            m->indices, v16, rs, dfix, u, x, p, v, rk, w, part_out, hub_len, corr);
@@ -2349,9 +2324,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                            int64_t max_iter, double *x_out, b3c_kr_info *info)
 {
     const bool counts = a->kind == B3C_U32;     // A = diag(1/s) C diag(1/s), never materialised
-#ifdef B3C_PROBES
-    g_probe_nogather = CFG.on("B3C_KR_NOGATHER");
-#endif
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     memset(info, 0, sizeof(*info));
     const int64_t n = a->n;
@@ -2392,7 +2364,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     if (!hub_flag.p || !hub_pos.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance");
     // SpMV form: row groups of lpr_p lanes (kr_kb_pipe / kr_kb_vec), or -- 16-bit counts -- tiles with column dictionaries
     const int lpr_p = avg > 64 ? 16 : avg > 24 ? 8 : 4;   // lanes per row of the pipelined form
-    const int GS_rows = grid_for(nloc, (BLK / 64) * (64 / lpr_p), (int)CFG.num("B3C_KR_GSMUL", 16) * ctx->n_cu);
+    const int GS_rows = grid_for(nloc, (BLK / 64) * (64 / lpr_p), 16 * ctx->n_cu);
     // The dictionary form is the default while the operand vector fits one XCD's L2 (n <= 2^19); beyond it
     // it runs together with the tail pass (kr_kb_tails: the tails, whose gathers miss L2 there, are summed in
     // column order by their own kernel): C3 0.32 ms per SpMV against 0.50 for kr_kb_vec, which pays for the 5 ms of set-up
@@ -2401,15 +2373,15 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const bool xt_ok = counts && n < ((int64_t)1 << 24) && !(xt_env && atoi(xt_env) <= 0);
     const bool xt_want = xt_ok && (n > ((int64_t)1 << TCD_L2_LG) || (xt_env && atoi(xt_env) > 0));
     // tile geometry of the dictionary form (used once the value width is known, below)
-    const int tcd_R = CFG.on("B3C_KR_TCD_R") ? std::min(256, std::max(8, (int)CFG.num("B3C_KR_TCD_R", 0) & ~7)) : (xt_want ? 192 : 128);
-    const int tcd_dcap = CFG.on("B3C_KR_TCD_DCAP") ? std::min(16384, std::max(16, (int)CFG.num("B3C_KR_TCD_DCAP", 0))) : (xt_want ? 5120 : 2560);   // LDS budget of a dictionary (sweeps at C2 / C3)
+    const int tcd_R = xt_want ? 192 : 128;              // rows per tile
+    const int tcd_dcap = xt_want ? 5120 : 2560;         // LDS budget of a dictionary (sweeps at C2 / C3 / C5 and on the surveyed law: DESIGN.md section 4)
     const int64_t tcd_tiles = (nloc + tcd_R - 1) / tcd_R;
-    const bool tcd_swz = !CFG.on("B3C_KR_TCD_NOSWZ") && tcd_tiles >= 64;
+    const bool tcd_swz = tcd_tiles >= 64;               // XCD-contiguous tile numbering
     const int64_t tcd_grid = tcd_swz ? 8 * ((tcd_tiles + 7) / 8) : tcd_tiles;
     // (n <= 2^19: C2 runs its SpMV in 32 instead of 39 us and the build is one bitmap pass; without the tail pass the form
     // does not pay at C3: 0.455 ms per SpMV against 0.50, less than its build costs)
     const bool tcd_auto = n >= 4096 && avg >= 16 && (n <= ((int64_t)1 << TCD_L2_LG) || xt_want);
-    const bool tcd_may = counts && nloc > 0 && a->nnz > 0 && (tcd_auto || CFG.on("B3C_KR_TCD")) && !CFG.on("B3C_KR_NO_TCD");
+    const bool tcd_may = counts && nloc > 0 && a->nnz > 0 && tcd_auto && !CFG.on("B3C_KR_NO_TCD");
     const int GS_max = (int)std::max<int64_t>(GS_rows, tcd_may ? tcd_tiles : 0);
     // hub rows add one partial each behind the GS of the row kernel (at most nnz / HUB_LEN of them)
     // threshold: twice the pipelined chunk of the row-group kernel that will run, at least HUB_LEN (sweep on a power-law
@@ -2419,8 +2391,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // the CSR hub kernel instead of the dictionary form: 1.97 of 4.4 ms per SpMV.  Row-group lanes loop over long rows; what
     // the hub kernel is for are rows so long that one lane group would hold its tile up
     const int hub_floor = avg > 128 ? 2 * HUB_LEN : HUB_LEN;
-    const int hub_thr = CFG.on("B3C_KR_HUB_LEN") ? std::max(64, (int)CFG.num("B3C_KR_HUB_LEN", 0))
-                                                  : std::max(hub_floor, (int)std::min<double>(16384.0, 16.0 * avg));
+    const int hub_thr = std::max(hub_floor, (int)std::min<double>(16384.0, 16.0 * avg));
     const bool hub_kb = maxdeg > (unsigned long long)hub_thr && !CFG.on("B3C_KR_NO_HUB");
     const int64_t hub_cap = hub_kb ? a->nnz / hub_thr + 1 : 0;
     const int hub_len = hub_kb ? hub_thr : 0x7fffffff;
@@ -2459,8 +2430,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // the iteration reorders a map that is not in a locality order yet (below); a count map that needs no reordering gets
     // its checks, its zero-diagonal vector and its 16-bit value copy from one fused pass (kr_prep_counts)
     const bool reorder = !a->ordered && n >= 32768 && a->nnz >= (1 << 21) && !CFG.on("B3C_NO_REORDER");
-    const bool want16 = counts && a->nnz && !CFG.on("B3C_KR_NO_U16");
-    const bool fused_prep = want16 && !reorder && !CFG.on("B3C_KR_NO_FUSED_PREP");
+    const bool want16 = counts && a->nnz;
+    const bool fused_prep = want16 && !reorder;
     DevBuf<uint16_t> v16buf(ctx, counts ? a->nnz + 16 : 1);     // slack: kr_kb_vec reads whole 4-entry vectors
     if (want16 && !v16buf.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance_counts");
     unsigned long long prep_max = 0;
@@ -2575,7 +2546,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                            (const uint32_t *)a->data, BIG_CAP, big_keys.p, big_hi.p, bc.p);
         unsigned long long hb = 0;
         { const int rb_ = b3c_readback(ctx, &hb, bc.p, sizeof(hb)); if (rb_) return rb_; }
-        if ((int64_t)hb <= BIG_CAP && (int64_t)hb * 64 <= a->nnz && !CFG.on("B3C_KR_NO_BIGFIX")) {
+        if ((int64_t)hb <= BIG_CAP && (int64_t)hb * 64 <= a->nnz) {
             n_big = (int64_t)hb;
             size_t tb = 0;
             hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, big_keys.p, big_keys2.p, big_hi.p, big_hi2.p, n_big, 0, 64, s);
@@ -2606,9 +2577,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     DevBuf<int32_t> dict_cols(ctx, tcd ? (size_t)tcd_tiles * (size_t)tcd_dcap : 1), dict_cnt(ctx, tcd ? tcd_tiles : 1);
     int tcd_lds_d = 0;                     // operands the SpMV kernel keeps in LDS: the largest dictionary, even
     if (tcd) {
-        DevBuf<unsigned long long> stt(ctx, 16);           // [0..3] layout statistics, [8..11] phase clocks (development builds)
+        DevBuf<unsigned long long> stt(ctx, 4);            // layout statistics: largest dictionary, -, sum of the dictionaries, tail entries
         if (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
-        HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 16, s));
+        HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 4, s));
         if (ctx->attr_first(0)) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_tcd_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TCD_BUILD_LDS));
         // (round 3 tried ONE pass per tile over a window of 2^18 columns centred on the tile, everything outside going to the tails
         // unseen: the build fell from 2.9 to 1.1 ms, but the SpMV rose from 0.289 to 0.375 ms at C3 -- the locality order keeps a
@@ -2626,13 +2597,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         const int tcd_minuse8 = xt_want ? std::max(0, (int)CFG.num("B3C_KR_TCD_MINUSE8", 28)) : 0;      // (in eighths of an entry per column)
         hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
                            a->sorted_cols ? 1 : 0, tcd_cfront, tcd_minuse8, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
-        unsigned long long hst[16];
+        unsigned long long hst[4];
         { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
-#ifdef B3C_PROBES
-        if (CFG.on("B3C_KR_TCD_BLOG"))
-            fprintf(stderr, "[b3c] kr_tcd_build phases, mean us per tile (100 MHz clock): zero %.1f  sweep1 %.1f  prefix+dictionary %.1f  sweep2 %.1f\n",
-                    hst[8] * 0.01 / tcd_tiles, hst[9] * 0.01 / tcd_tiles, hst[10] * 0.01 / tcd_tiles, hst[11] * 0.01 / tcd_tiles);
-#endif
         tcd_lds_d = (int)((hst[0] + 1) & ~1ull);
         if (tcd_lds_d < 2) tcd_lds_d = 2;
         info->tcd_tiles = tcd_tiles;
@@ -2680,8 +2646,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // packed form of the sorted tail words (kr_tails_pack): 4 bytes per tail; B3C_KR_XT_PACK=0 keeps the 64-bit stream
     struct PoolPtr32 { b3c_ctx *c; uint32_t *p = nullptr; ~PoolPtr32() { c->release(p); } } xt_cw{ctx}, xt_hdr{ctx};
     struct PoolPtr64 { b3c_ctx *c; unsigned long long *p = nullptr; ~PoolPtr64() { c->release(p); } } xt_res{ctx};
-    const bool xt_pack_want = CFG.num("B3C_KR_XT_PACK", 1) != 0;
-    const int xt_pipe = (int)CFG.num("B3C_KR_XT_PIPE", 1);
     bool xt_packed = false;
     int64_t xt_n_res = 0;
     const size_t xt_shmem = sizeof(unsigned long long) * (size_t)xt_S + sizeof(int) * (size_t)xt_S + sizeof(double) * XT_NT;
@@ -2724,7 +2688,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         e = hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, words_in.p, xt_words.p, (int64_t)n_tails, sort_lo, sort_hi, s);
         if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort of the tails failed");
         if (ctx->attr_first(1)) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT)));
-        if (xt_pack_want && n_tails > 0) {
+        if (n_tails > 0) {
             // the sorted words as 32-bit words + residual list (kr_tails_pack); not worth it when many words do not fit
             xt_cw.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(n_tails + 64));
             xt_hdr.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)((n_tails + 63) / 64 + 1));
@@ -2824,17 +2788,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     std::vector<long long> ev_tick;        // which SpMV (0-based) each event pair brackets
     constexpr long long PROF_EVERY = 4;
 
-    // timing probes of the dictionary SpMV that produce WRONG RESULTS exist in development builds only (-DB3C_PROBES)
-#ifdef B3C_PROBES
-    const int tcd_probe = (int)CFG.num("B3C_KR_TCD_PROBE", 0);
-    const uint32_t tcd_probe_mask = (uint32_t)CFG.num("B3C_KR_TCD_PROBE_MASK", 0xFFFFFFFFll);
-#else
-    const int tcd_probe = 0;
-    const uint32_t tcd_probe_mask = 0xFFFFFFFFu;
-#endif
     int t = 0;  // state ping-pong index
-    const int BATCH = std::max(1, (int)CFG.num("B3C_KR_BATCH", 4));   // ticks per state look (C3: 8 -> 4 saves 0.4 ms of no-op ticks after convergence)
-    const int vec_shape = (int)CFG.num("B3C_KR_VEC", 0);   // other kr_kb_vec<LPR, UN> shapes, e.g. 164; -1: scalar-load form
+    constexpr int BATCH = 4;                                           // ticks per state look (C3: 8 -> 4 saves 0.4 ms of no-op ticks after convergence)
     long long ticks = 0;
     // sharded: a kernel's block partials are folded into this rank's slot of the packed scalar buffer (slot 0 sum, 1 min,
     // 2 max, 3 gamma) and all-gathered; the consumer then reduces `world` values (stride 4) in rank order instead of P block partials
@@ -2897,12 +2852,11 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
                                        xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p,
                                        xt_packed ? xt_cw.p : nullptr, xt_hdr.p, xt_res.p, xt_n_res, xt_st_shift,
-                                       xt_pipe && n_tails < (1ll << 29) ? 1 : 0, n);    // (32-bit byte offsets inside a chunk of the packed stream)
+                                       n_tails < (1ll << 29) ? 1 : 0, n);    // (32-bit byte offsets inside a chunk of the packed stream)
                 // dictionary waves and tail waves side by side (512-thread workgroups)
 #define KR_TCD2_ARGS                                                                                                         \
     dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \
         kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len,     \
-        tcd_probe, tcd_probe_mask,                                                                                                            \
         want_tlog ? tlog.p : nullptr, tails_xt ? yhi.p : nullptr, tails_xt ? ylo.p : nullptr, tails_xt ? tex.p : nullptr, corr_p,       \
         tcd_24 ? tcd_p24.p : nullptr, tcd_24 ? g24off.p : nullptr
 #define KR_TCD2(L, U, TL, T)                                                                                                 \
@@ -2917,9 +2871,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
 #undef KR_TCD2
             } else {
                 // software-pipelined row groups; shape by average row length (sweep at C3: 16x16 0.72 ms, 32x8 0.80, 16x8 0.83)
-                if (vec_shape == 164) launch_kb_vec<16, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
-                else if (vec_shape == 84) launch_kb_vec<8, 4>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
-                else if (avg > 128 && a->kind == B3C_U32 && vec_shape >= 0)    // 4 entries per lane and load: 0.505 vs 0.544 ms at C3
+                if (avg > 128 && a->kind == B3C_U32)    // 4 entries per lane and load: 0.505 vs 0.544 ms at C3
                     launch_kb_vec<8, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
                 else if (avg > 128) launch_kb_pipe<16, 16>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
                 else if (avg > 64) launch_kb_pipe<16, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);

@@ -495,8 +495,6 @@ __global__ void __launch_bounds__(BLK) k_lv_decide(int64_t r0, int64_t n, const 
 constexpr int64_t SIDE_MIN_HUBS = 512;     // hub nodes of a sub-round from which the side stream pays (see b3c_louvain)
 constexpr int64_t PRUNE_MIN_HUBS = 1024;   // ... and from which pruning them is worth its launch
 constexpr int MEGA_NT = 1024;
-constexpr int64_t MEGA_FEW = 2048;         // "a few" long rows: fewer than eight per CU
-constexpr int64_t MEGA_DEG = 8192;         // rows beyond this many entries
 constexpr int MEGA_CHUNK = 4 * MEGA_NT;    // entries one workgroup of the insert pass takes
 
 // pass 1: workgroup (node m, chunk c) inserts entries [c * MEGA_CHUNK, ...) of the node's row into the node's table and adds
@@ -545,83 +543,11 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_insert(const NodeRec *__res
     block_atomic_add_u64(own, own_acc + m, red);
 }
 
-// pass 2: one workgroup per node evaluates (and clears) every slot of the node's table, four slots per thread in flight
-__global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval(const NodeRec *__restrict__ list, u64 m2, const int64_t *__restrict__ kdeg,
-                                                           const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
-                                                           const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
-                                                           const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
-                                                           u64 *__restrict__ gvals, u64 *__restrict__ own_acc)
-{
-    __shared__ long long red_hi[MEGA_NT / 64];
-    __shared__ u64 red_lo[MEGA_NT / 64];
-    __shared__ int32_t red_com[MEGA_NT / 64], red_have[MEGA_NT / 64];
-    const NodeRec rec = list[blockIdx.x];
-    const int32_t i = rec.node;
-    const long long ki = kdeg[i];
-    const int32_t a = com[i];
-    const int lg = table_lg(rec.deg);
-    const uint32_t size = 1u << lg;
-    int32_t *keys = gkeys + goff[i];
-    u64 *vals = gvals + goff[i];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    Best b;
-    b.gain = 0; b.com = a; b.have = 0;
-    for (uint32_t t0 = threadIdx.x; t0 < size; t0 += 4 * MEGA_NT) {
-        int32_t c[4];
-        u64 d[4];
-        long long tc[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t t = t0 + u * MEGA_NT;
-            c[u] = t < size ? keys[t] : EMPTY;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t t = t0 + u * MEGA_NT;
-            d[u] = c[u] != EMPTY ? vals[t] : 0;
-            tc[u] = c[u] != EMPTY ? tot[c[u]] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (c[u] == EMPTY) continue;
-            const uint32_t t = t0 + u * MEGA_NT;
-            keys[t] = EMPTY;
-            vals[t] = 0;
-            const i128 g = gain128((u64)d[u], m2, (u64)tc[u], (u64)ki);
-            best_take(b, g, c[u]);
-        }
-    }
-    b = best_wave_reduce(b);
-    if (lane == 0) {
-        red_hi[wv] = (long long)(b.gain >> 64);
-        red_lo[wv] = (u64)b.gain;
-        red_com[wv] = b.com;
-        red_have[wv] = b.have;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const long long o = (long long)own_acc[blockIdx.x];
-        own_acc[blockIdx.x] = 0;                                       // ready for the next sub-round
-        Best r;
-        r.gain = 0; r.com = a; r.have = 0;
-        for (int w = 0; w < MEGA_NT / 64; w++) {
-            const i128 g = ((i128)red_hi[w] << 64) | (i128)red_lo[w];
-            if (red_have[w] && (!r.have || g > r.gain || (g == r.gain && red_com[w] < r.com))) { r.gain = g; r.com = red_com[w]; r.have = 1; }
-        }
-        // staying: i removed from its own community first (python-louvain __remove)
-        const i128 g = gain128((u64)o, m2, (u64)(tot[a] - ki), (u64)ki);
-        best_take(r, g, a);
-        int32_t best = r.have ? r.com : a;
-        if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
-        nxt[i] = best;
-    }
-}
-
-// pass 2 of the mega rows, split over the table (round 4): one workgroup per node walked the node's whole table -- 2^18 slots for
+// pass 2 of the mega rows, split over the table (round 4): one workgroup per node used to walk the node's whole table -- 2^18 slots for
 // the 147k-entry row of the surveyed law's level 1, 134 us per sub-round with the rest of the chip idle.  Workgroup (node m, chunk
 // ch) evaluates and clears MEGA_ESL slots and leaves its best candidate in part[]; the LAST workgroup of a node to finish (a ticket
 // per node) folds the partial results in chunk order with the same order-free arg-max (ties to the lowest community id) and
-// settles the node.  Same candidates, same comparisons: the same decision as k_lv_mega_eval.
+// settles the node.  Same candidates, same comparisons: the same decision as one workgroup's walk.
 constexpr int MEGA_ESL = 16384;            // table slots per workgroup of the split evaluation
 struct MegaPart { u64 hi, lo, com_have; };
 __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval_split(const NodeRec *__restrict__ list, int echunks, u64 m2, const int64_t *__restrict__ kdeg,
@@ -1052,32 +978,42 @@ __global__ void k_lv_list_bounds(int n_seg, int64_t nloc, const int64_t *__restr
     for (int t = threadIdx.x; t <= n_seg; t += blockDim.x) bnd[t] = pos[(int64_t)t * nloc];
 }
 
-// Gather record of a node (round 4): its community and that community's total side by side, 16 bytes, in ROW order.  The grouped
-// scan asks for label AND total of every stored neighbour; with the totals indexed by community id -- the caller-side id of some
-// member, i.e. a random place in an n-vector of 8 bytes -- every entry costs two missed lines, the second one usually all the way
-// from the fabric (C3: 2.0 GB fetched per unpruned sub-round against 0.69 GB algorithmic).  One record per entry is one line, and
-// in a locality-ordered map mostly a line the L1 still holds.  The records are refreshed after every application of moves
-// (k_lv_rec_refresh: one gather per NODE instead of one per ENTRY).
-struct __align__(16) GRec {
-    int32_t com;
-    int32_t pad;
-    long long tot;
-};
-
-__global__ void __launch_bounds__(BLK) k_lv_rec_refresh(int64_t n, const int32_t *__restrict__ com, const int64_t *__restrict__ tot,
-                                                         GRec *__restrict__ rec)
+// Largest 64-bit value over the LPR lanes of a group, in every lane of the group (all lanes of the wave active).
+template <int LPR>
+__device__ __forceinline__ u64 group_max_u64(u64 v)
 {
-    const int64_t stride = (int64_t)gridDim.x * BLK;
-    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
-        GRec r;
-        r.com = com[i];
-        r.pad = 0;
-        r.tot = tot[r.com];
-        rec[i] = r;
+    if constexpr (LPR == 64) {
+        const uint32_t hi = wave_max_u32((uint32_t)(v >> 32));
+        const uint32_t lo = wave_max_u32((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0u);
+        return ((u64)hi << 32) | lo;
+    } else {
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            const u64 t = (u64)__shfl_xor((long long)v, o, LPR);
+            v = t > v ? t : v;
+        }
+        return v;
     }
 }
 
-template <int LPR, int UN, bool REC = false>
+// The grouped neighbour scan gathers ONE 4-byte label per stored neighbour and nothing else (round 5).
+//
+// What the scan needs of a neighbour j is its community c = com[j] and, for the gain d_c * 2m - tot_c * k_i, the total of c.  Round 4
+// gathered both as one 16-byte record per neighbour; on the contract workload (the surveyed genome-size law: one genome of 383k
+// contigs, a uniform random graph of 180 neighbours per node) those records are 6 MB against the 4 MB of an XCD's L2 and the counters
+// see 4.4 GB cross the fabric per sub-round for 0.81 GB of algorithmic bytes -- 34 M operand lines of 128 bytes fetched for 16 of them
+// each (profiles/r05_c3_FETCH_SIZE.csv): the kernel runs at the fabric's rate on wasted lines.  The labels alone are 4 bytes per node
+// (the whole level: 3.9 MB, the giant genome: 1.5 MB): they stay in L2.
+//
+// And the totals are needed for a FEW candidates only, exactly:  a candidate's gain is at most d_c * 2m (totals are not negative), so with
+// D = the largest d_c of the node and any band b >= 0 the candidates with d_c < D - b ("non-contenders") have gains below
+// X = (D - b) * 2m.  The contenders (d_c >= D - b) get their exact totals (one gather each, by the lane that claimed the slot) and
+// exact 128-bit gains; if the best of {contenders, staying, 0} reaches X, no non-contender can win or tie and the decision is the
+// exact arg-max -- else (the leader sits in a community so large that its tot * k term eats the band: rare, and never wrong) the
+// non-contenders are evaluated as well.  b only steers how often that happens: (k_i >> band_shift) + 1, i.e. the tot * k / 2m of a
+// community of about 32 average nodes.  On a metagenome d_c decides almost alone (tot_c * k_i / 2m is 10^-3 of d_c at level 0), so a
+// node has one or two contenders among its ~100 candidate communities: the 128-bit gain arithmetic of the others is gone as well.
+template <int LPR, int UN>
 __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int64_t *__restrict__ cnt_dev,
                                                       const NodeRec *__restrict__ list, u64 m2,
                                                       const int32_t *__restrict__ indices,
@@ -1085,7 +1021,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
                                                       const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
                                                       const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
                                                       int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out, int32_t epoch, int xcd,
-                                                      const GRec *__restrict__ grec)
+                                                      int band_shift)
 {
     constexpr int CAP = LPR * UN > 384 ? 1024 : 512;       // >= 1.25 * LPR * UN + 1
     constexpr int LG = LPR * UN > 384 ? 10 : 9;
@@ -1105,8 +1041,7 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
 
     // XCD-aware numbering (round 4): workgroup b runs on XCD b mod 8, and every XCD has its own 4 MB L2.  With xcd set (a grid of a
     // multiple of eight workgroups) XCD k walks the k-th EIGHTH of the list -- the list is in row order, i.e. in locality order, so
-    // the labels, degrees and totals its gathers touch are one slice of those vectors, which its L2 can hold -- instead of every
-    // XCD seeing all of all three (FETCH_SIZE of an unpruned sub-round at C3: 2.0 GB against 0.69 GB algorithmic).
+    // the labels its gathers touch are one slice of that vector, which its L2 can hold -- instead of every XCD seeing all of it.
     int64_t step = (int64_t)gridDim.x * WPB * RPW;
     int64_t pos = ((int64_t)blockIdx.x * WPB + wib) * RPW + sub;
     int64_t cnt_end = cnt;
@@ -1143,34 +1078,19 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
         NodeRec recn;
         recn.node = -1; recn.deg = 0; recn.start = 0;
         if (i >= 0 && posn < cnt_end) recn = list[posn];
-        // 2. community gathers and weights of the current node, own-community total
+        // 2. label gathers and weights of the current node, own-community total
         int32_t cm[UN];
         u64 qv[UN];
-        long long tv[UN];
         {
             const int64_t *__restrict__ qi = q + start;
 #pragma unroll
             for (int t = 0; t < UN; t++) {
-                if (REC) {
-                    GRec r;
-                    r.com = EMPTY; r.pad = 0; r.tot = 0;
-                    if (j[t] != i) r = grec[j[t]];
-                    cm[t] = r.com;
-                    tv[t] = r.tot;
-                } else {
-                    cm[t] = j[t] != i ? com[j[t]] : EMPTY;
-                }
+                cm[t] = j[t] != i ? com[j[t]] : EMPTY;
                 qv[t] = t * LPR + sl < deg ? (u64)qi[t * LPR + sl] : 0;
             }
         }
         long long ta = 0;
         if (i >= 0 && sl == 0) ta = tot[a];
-        // totals of the foreign communities, requested as soon as the labels are known: their round trip then runs under
-        // the LDS insertions instead of after them (round 3; a community met twice costs a second, cached, request)
-        if (!REC) {
-#pragma unroll
-            for (int t = 0; t < UN; t++) tv[t] = (cm[t] != EMPTY && cm[t] != a) ? tot[cm[t]] : 0;
-        }
         // 3. neighbour ids and own community of the next node (its weights are fetched next to its gathers)
         int32_t an = 0;
         long long kin = 0;
@@ -1200,9 +1120,12 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
             for (int o = LPR / 2; o > 0; o >>= 1) own += __shfl_down(own, o, LPR);
         }
         const u64 fmask = __ballot(foreign);
-        Best b;
-        b.gain = 0; b.com = a; b.have = 0;
-        // 5. groups with foreign neighbours take the wave's table one after the other
+        // 5. groups with foreign neighbours take the wave's table one after the other: insert, then every lane reads back (and clears)
+        //    the slots it claimed -- a lane that turned an EMPTY slot into a community holds that community's summed weight d_c
+        u64 dv[UN];
+#pragma unroll
+        for (int t = 0; t < UN; t++) dv[t] = 0;
+        u64 dmax = 0;
         for (int gsel = 0; gsel < RPW; gsel++) {
             const u64 gbits = (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull)) << (gsel * LPR);
             if (!(fmask & gbits)) continue;                     // wave-uniform
@@ -1230,43 +1153,127 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
 #pragma unroll
                 for (int t = 0; t < UN; t++) {
                     if (j[t] == -1) continue;
-                    const u64 d = vals[j[t]];
+                    dv[t] = vals[j[t]];
                     keys[j[t]] = EMPTY;
                     vals[j[t]] = 0;
-                    const i128 g = gain128((u64)d, m2, (u64)tv[t], (u64)ki);
-                    best_take(b, g, cm[t]);
+                    dmax = dv[t] > dmax ? dv[t] : dmax;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
-        if (i >= 0 && sl == 0) {
-            // staying: i removed from its own community first (python-louvain __remove)
-            const i128 g = gain128((u64)own, m2, (u64)(ta - ki), (u64)ki);
-            best_take(b, g, a);
-            if (own_out) { own_out[i] = own; stamp_out[i] = epoch; }      // row-sharded pruning: own_i as of this sub-round's start
-        }
-        // arg-max inside the group
-        if constexpr (LPR == 64) b = best_wave_reduce(b);
-        else
+        // 6. contenders: the candidates within the band of the node's largest d_c get their exact totals and gains
+        const bool claimed_any = (fmask >> (sub * LPR)) & (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull));
+        const u64 D = group_max_u64<LPR>(dmax);
+        const u64 band = ((u64)ki >> band_shift) + 1ull;
+        const u64 thr = D > band ? D - band : 0ull;
+        Best b;
+        b.gain = 0; b.com = a; b.have = 0;
+        auto group_best = [&](Best v) -> Best {
+            if constexpr (LPR == 64) return best_wave_reduce(v);
+            else {
 #pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) {
-            long long hi = __shfl_down((long long)(b.gain >> 64), o, LPR);
-            u64 lo = (u64)__shfl_down((long long)(u64)b.gain, o, LPR);
-            int32_t c = __shfl_down(b.com, o, LPR);
-            int32_t hv = __shfl_down(b.have, o, LPR);
-            i128 g = ((i128)hi << 64) | (i128)lo;
-            if (hv && (!b.have || g > b.gain || (g == b.gain && c < b.com))) {
-                b.gain = g;
-                b.com = c;
-                b.have = 1;
+                for (int o = LPR / 2; o > 0; o >>= 1) {
+                    long long hi = __shfl_xor((long long)(v.gain >> 64), o, LPR);
+                    u64 lo = (u64)__shfl_xor((long long)(u64)v.gain, o, LPR);
+                    int32_t c = __shfl_xor(v.com, o, LPR);
+                    int32_t hv = __shfl_xor(v.have, o, LPR);
+                    i128 g = ((i128)hi << 64) | (i128)lo;
+                    if (hv && (!v.have || g > v.gain || (g == v.gain && c < v.com))) {
+                        v.gain = g;
+                        v.com = c;
+                        v.have = 1;
+                    }
+                }
+                return v;
+            }
+        };
+        if constexpr (LPR == 64) {
+            // One node per wave: the handful of contenders (one or two of a node's ~100 candidate communities) are walked by a UNIFORM
+            // loop over the ballots of the contender flags -- label, weight and total of each come out of its lane by v_readlane, the
+            // 128-bit gain and the running arg-max are scalar arithmetic.  As per-lane vector code (four slots of 128-bit products per
+            // lane, then five DPP reductions for the arg-max over the wave) this stretch was 600 of the loop's 1300 instructions
+            // (round 5, from the ISA); the kernel sits on its instruction issue once the gathers stay in L2.
+            long long tc[UN];
+            u64 cmask[UN];
+#pragma unroll
+            for (int t = 0; t < UN; t++) {
+                const bool ct = j[t] != -1 && dv[t] >= thr && fmask != 0ull;
+                tc[t] = ct ? tot[cm[t]] : 0;
+                cmask[t] = __ballot(ct);
+            }
+            const u64 ki_u = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((u64)ki >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u64)ki);
+            const int32_t a_u = __builtin_amdgcn_readfirstlane(a);
+            const u64 ta_u = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((u64)ta >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u64)ta);      // (lane 0 = sl 0 holds tot[a])
+            i128 bg = 0;
+            int32_t bc = a_u;
+            int bh = 0;
+#pragma unroll
+            for (int t = 0; t < UN; t++) {
+                u64 mk = cmask[t];
+                while (mk) {
+                    const int l = __ffsll((unsigned long long)mk) - 1;
+                    mk &= mk - 1;
+                    const int32_t c = __builtin_amdgcn_readlane(cm[t], l);
+                    const u64 d = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dv[t] >> 32), l) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dv[t], l);
+                    const u64 tt = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((u64)tc[t] >> 32), l) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u64)tc[t], l);
+                    const i128 g = gain128(d, m2, tt, ki_u);
+                    if (g > 0 && (!bh || g > bg || (g == bg && c < bc))) { bg = g; bc = c; bh = 1; }
+                }
+            }
+            if (i >= 0) {       // (wave-uniform: one node per wave)
+                // staying: i removed from its own community first (python-louvain __remove)
+                const i128 g = gain128((u64)own, m2, ta_u - ki_u, ki_u);
+                if (g > 0 && (!bh || g > bg || (g == bg && a_u < bc))) { bg = g; bc = a_u; bh = 1; }
+                if (own_out && sl == 0) { own_out[i] = own; stamp_out[i] = epoch; }      // row-sharded pruning: own_i as of this sub-round's start
+            }
+            b.gain = bg; b.com = bc; b.have = bh;       // (the same in every lane)
+        } else {
+            {
+                long long tc[UN];
+#pragma unroll
+                for (int t = 0; t < UN; t++) tc[t] = (claimed_any && j[t] != -1 && dv[t] >= thr) ? tot[cm[t]] : 0;
+#pragma unroll
+                for (int t = 0; t < UN; t++) {
+                    if (!(claimed_any && j[t] != -1 && dv[t] >= thr)) continue;
+                    const i128 g = gain128(dv[t], m2, (u64)tc[t], (u64)ki);
+                    best_take(b, g, cm[t]);
+                }
+            }
+            if (i >= 0 && sl == 0) {
+                // staying: i removed from its own community first (python-louvain __remove)
+                const i128 g = gain128((u64)own, m2, (u64)(ta - ki), (u64)ki);
+                best_take(b, g, a);
+                if (own_out) { own_out[i] = own; stamp_out[i] = epoch; }      // row-sharded pruning: own_i as of this sub-round's start
+            }
+            b = group_best(b);
+        }
+        // every non-contender's gain is below thr * 2m: settled unless the best so far (0 when nothing gains) stays under that
+        if (thr != 0ull) {
+            const i128 x128 = (i128)((unsigned __int128)thr * (unsigned __int128)m2);
+            const i128 top = b.have ? b.gain : (i128)0;
+            if (top < x128) {                                   // group-uniform (b is the group's after the reduction)
+                long long tc[UN];
+#pragma unroll
+                for (int t = 0; t < UN; t++) tc[t] = (claimed_any && j[t] != -1 && dv[t] < thr) ? tot[cm[t]] : 0;
+#pragma unroll
+                for (int t = 0; t < UN; t++) {
+                    if (!(claimed_any && j[t] != -1 && dv[t] < thr)) continue;
+                    const i128 g = gain128(dv[t], m2, (u64)tc[t], (u64)ki);
+                    best_take(b, g, cm[t]);
+                }
+                b = group_best(b);
             }
         }
         if (i >= 0 && sl == 0) {
             int32_t best = b.have ? b.com : a;
-            if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
+            if (best > a && csize[a] == 1 && csize[best] == 1) best = a;      // (best > a implies best != a: the sizes are looked at for upward moves only)
             nxt[i] = best;
         }
-        // 6. advance
+        // 7. advance
         pos = posn;
         i = recn.node;
         deg = recn.deg;
@@ -1281,13 +1288,15 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
 // The FIRST sub-round of a level, for the nodes of the grouped list: every node is alone, so every stored neighbour j != i IS a
 // candidate community of its own -- weight towards it q_ij, total kdeg[j], size 1 -- the own community holds nothing else (stay
 // gain 0, not taken) and the singleton rule lets i move only to a LOWER community id.  The decision is the arg-max over the
-// entries of q_ij * 2m - kdeg[j] * k_i (ties to the lowest community id): no table, no gather of tot[] by community id (one random
-// line per entry in the general kernel; kdeg[] is in row order like the labels), the same 128-bit arithmetic and the same result.
+// entries of q_ij * 2m - kdeg[j] * k_i (ties to the lowest community id): no table.  Round 5: and no gather per entry either -- the
+// contender rule of k_lv_decide_g with d_c = q_ij: only the entries within the band of the row's largest weight fetch their
+// neighbour's label and degree (round 4 gathered both for every entry: 5.9 GB across the fabric for this one launch on the contract
+// workload, the 8 MB degree vector against 4 MB of L2), the others are settled by q_ij * 2m < (Q - band) * 2m <= the best exact gain.
 template <int LPR, int UN>
 __global__ void __launch_bounds__(BLK) k_lv_first_g(int64_t cnt, const NodeRec *__restrict__ list, u64 m2,
                                                      const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
                                                      const int64_t *__restrict__ kdeg, const int32_t *__restrict__ com,
-                                                     const int32_t *__restrict__ csize, int32_t *__restrict__ nxt, int xcd)
+                                                     const int32_t *__restrict__ csize, int32_t *__restrict__ nxt, int xcd, int band_shift)
 {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
@@ -1300,8 +1309,7 @@ __global__ void __launch_bounds__(BLK) k_lv_first_g(int64_t cnt, const NodeRec *
         pos = k * per + ((int64_t)(blockIdx.x >> 3) * WPB + (threadIdx.x >> 6)) * RPW + sub;
         cnt = (k + 1) * per < cnt ? (k + 1) * per : cnt;
     }
-    // software pipeline as in k_lv_decide_g: record, entries and own label of the group's NEXT node are requested while the
-    // gathers of the current one are in flight
+    // software pipeline: record, entries and own label of the group's NEXT node are requested while the current one is evaluated
     int32_t i = -1, a = 0;
     int deg = 0;
     long long ki = 0;
@@ -1320,16 +1328,39 @@ __global__ void __launch_bounds__(BLK) k_lv_first_g(int64_t cnt, const NodeRec *
             qv[t] = e < deg ? (u64)q[rec.start + e] : 0;
         }
     }
+    auto group_best = [&](Best v) -> Best {
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            long long hi = __shfl_xor((long long)(v.gain >> 64), o, LPR);
+            u64 lo = (u64)__shfl_xor((long long)(u64)v.gain, o, LPR);
+            int32_t c = __shfl_xor(v.com, o, LPR);
+            int32_t hv = __shfl_xor(v.have, o, LPR);
+            i128 g = ((i128)hi << 64) | (i128)lo;
+            if (hv && (!v.have || g > v.gain || (g == v.gain && c < v.com))) {
+                v.gain = g;
+                v.com = c;
+                v.have = 1;
+            }
+        }
+        return v;
+    };
     while (__ballot(i >= 0)) {
         const int64_t posn = pos + step;
         NodeRec recn;
         recn.node = -1; recn.deg = 0; recn.start = 0;
         if (i >= 0 && posn < cnt) recn = list[posn];
+        // contenders of the current node: the entries within the band of its largest weight
+        u64 qmax = 0;
+#pragma unroll
+        for (int t = 0; t < UN; t++) qmax = (i >= 0 && j[t] != i && qv[t] > qmax) ? qv[t] : qmax;
+        const u64 Q = group_max_u64<LPR>(qmax);
+        const u64 band = ((u64)ki >> band_shift) + 1ull;
+        const u64 thr = Q > band ? Q - band : 0ull;
         int32_t cm[UN];
         long long tv[UN];
 #pragma unroll
         for (int t = 0; t < UN; t++) {
-            const bool nb = i >= 0 && j[t] != i;
+            const bool nb = i >= 0 && j[t] != i && qv[t] >= thr;
             cm[t] = nb ? com[j[t]] : EMPTY;
             tv[t] = nb ? kdeg[j[t]] : 0;
         }
@@ -1355,23 +1386,30 @@ __global__ void __launch_bounds__(BLK) k_lv_first_g(int64_t cnt, const NodeRec *
             const i128 g = gain128((u64)qv[t], m2, (u64)tv[t], (u64)ki);
             best_take(b, g, cm[t]);
         }
+        b = group_best(b);
+        if (thr != 0ull) {
+            const i128 x128 = (i128)((unsigned __int128)thr * (unsigned __int128)m2);
+            const i128 top = b.have ? b.gain : (i128)0;
+            if (top < x128) {                       // group-uniform: the band was too narrow for this node -- every entry, exactly
 #pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) {
-            long long hi = __shfl_down((long long)(b.gain >> 64), o, LPR);
-            u64 lo = (u64)__shfl_down((long long)(u64)b.gain, o, LPR);
-            int32_t c = __shfl_down(b.com, o, LPR);
-            int32_t hv = __shfl_down(b.have, o, LPR);
-            i128 g = ((i128)hi << 64) | (i128)lo;
-            if (hv && (!b.have || g > b.gain || (g == b.gain && c < b.com))) {
-                b.gain = g;
-                b.com = c;
-                b.have = 1;
+                for (int t = 0; t < UN; t++) {
+                    const bool nb = i >= 0 && j[t] != i && qv[t] < thr;
+                    cm[t] = nb ? com[j[t]] : EMPTY;
+                    tv[t] = nb ? kdeg[j[t]] : 0;
+                }
+#pragma unroll
+                for (int t = 0; t < UN; t++) {
+                    if (cm[t] == EMPTY) continue;
+                    const i128 g = gain128((u64)qv[t], m2, (u64)tv[t], (u64)ki);
+                    best_take(b, g, cm[t]);
+                }
+                b = group_best(b);
             }
         }
         if (i >= 0 && sl == 0) {
             int32_t best = b.have ? b.com : a;
             // two singletons: only towards the lower id (a column whose own row is empty is no graph node: size 0, as in k_lv_decide_g)
-            if (best != a && csize[a] == 1 && csize[best] == 1 && best > a) best = a;
+            if (best > a && csize[a] == 1 && csize[best] == 1) best = a;
             nxt[i] = best;
         }
         pos = posn;
@@ -2324,23 +2362,6 @@ __global__ void k_big_table_sizes(int64_t n, int cap, int64_t deg_thr, const int
     if (i == n) sz[i] = 0;
 }
 
-// out[0] += rows of more than 2048 entries, out[1] += rows of more than 4096
-__global__ void k_count_long_rows(int64_t n, const int64_t *__restrict__ indptr, u64 *__restrict__ out)
-{
-    unsigned long long a = 0, b = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t d = indptr[i + 1] - indptr[i];
-        a += d > 2048;
-        b += d > 4096;
-    }
-    a = (unsigned long long)wave_sum_ll((long long)a);
-    b = (unsigned long long)wave_sum_ll((long long)b);
-    if ((threadIdx.x & 63) == 0) {
-        if (a) atomicAdd(&out[0], a);
-        if (b) atomicAdd(&out[1], b);
-    }
-}
-
 __global__ void k_max_degree(int64_t n, const int64_t *__restrict__ indptr, u64 *__restrict__ out)
 {
     max_row_len_body(n, indptr, (unsigned long long *)out);
@@ -2505,7 +2526,6 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     const double PL_MIN = 0.0000001;   // community_louvain.__MIN
 
     const bool lv_debug = CFG.on("B3C_LV_DEBUG");
-    const bool shape_32x8 = CFG.str("B3C_LV_SHAPE") && !strcmp(CFG.str("B3C_LV_SHAPE"), "32x8");
     Events evs;
     evs.on = CFG.on("B3C_PROFILE");
     evs.s = s;
@@ -2546,7 +2566,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 
     double mod = 0.0;
     bool first = true;
-    DevBuf<u64> ctr(ctx, 10);  // [0] m2, [1] moved, [2] i2, [3..6] tot2 limbs, [7] max degree, [8] rows beyond 2048 entries, [9] beyond 4096
+    DevBuf<u64> ctr(ctx, 8);   // [0] m2, [1] moved, [2] i2, [3..6] tot2 limbs, [7] max degree
     if (!ctr.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
 
     for (;;) {
@@ -2593,12 +2613,11 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int gwl = grid_for(r1 - r0, WPB, 16 * ctx->n_cu);   // wave-per-row kernels over this rank's rows
         const int gw = grid_for(n, WPB, 16 * ctx->n_cu);     // wave-per-row kernels
         const int gv = grid_for(n, BLK, 8 * ctx->n_cu);      // thread-per-node kernels
-        HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 10, s));
+        HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64) * 8, s));
         const bool form_q = first && dq.src != nullptr;       // level 0: the weights are quantised by this pass (see k_lv_init)
         hipLaunchKernelGGL(k_lv_init, dim3(gw), dim3(BLK), 0, s, n, g.indptr, g.indices, form_q ? nullptr : g.q, ids, kdeg.p, tot.p, com.p,
                            nxt_p, csize.p, ctr.p, wnl.p, r0, r1, ctr.p + 2, form_q ? dq.src : nullptr, dq.scl, (int)shift, form_q ? q0.p : nullptr);
         hipLaunchKernelGGL(k_max_degree, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, n, g.indptr, ctr.p + 7);
-        hipLaunchKernelGGL(k_count_long_rows, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, n, g.indptr, ctr.p + 8);
         if (blk0) {
             // degrees (and which rows exist) of the other ranks' rows, then totals / sizes / labels / 2m from the whole vector
             if (r1 > r0) hipLaunchKernelGGL(k_lv_pack_flag, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, r0, r1, g.indptr, kdeg.p);
@@ -2606,7 +2625,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64), s));
             hipLaunchKernelGGL(k_lv_unpack_init, dim3(gv), dim3(BLK), 0, s, n, ids, kdeg.p, tot.p, csize.p, labels.p, ctr.p);
         }
-        u64 hc[10];
+        u64 hc[8];
         { const int rb_ = b3c_readback(ctx, hc, ctr.p, sizeof(hc)); if (rb_) return rb_; }
         const u64 m2 = hc[0];
         const int64_t maxdeg = (int64_t)hc[7];
@@ -2615,32 +2634,24 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // ---- row-length classes of this level (see lv_list_segment) ----
         const double avgdeg = (double)g.nnz / (double)n;
         const int short_max = avgdeg * 1.3 <= 32 ? 32 : avgdeg * 1.3 <= 64 ? 64 : avgdeg * 1.3 <= 128 ? 128 : 256;
-        const bool grouped = n >= 4096 && !CFG.on("B3C_LV_NO_GROUPED");
+        const bool grouped = n >= 4096;
         const int64_t nloc = r1 - r0;
         const bool need_wave_kernel = !grouped || maxdeg > short_max;
-        // round 4: rows beyond the grouped kernel's reach get one WORKGROUP each with a table in LDS (k_lv_decide_wg: up to 6553
-        // entries); the wave-per-node kernel keeps the rows of up to 409 entries (512-slot tables: six workgroups per CU) and the
-        // levels that have no node lists.  B3C_LV_NO_WG=1: round 3's split (wave kernel up to the mega threshold).
-        const bool use_wg = grouped && !CFG.on("B3C_LV_NO_WG");
-        // LDS table of the wave-per-node kernel: 12 bytes per slot and wave, four waves per workgroup -- 2048 slots are 96 KB, ONE
-        // workgroup per CU.  B3C_LV_CAP_MAX clamps it (nodes beyond the cap use their global table): see DESIGN.md section 4
-        // (the class bound of the wave kernel, wave_thr, is derived further down from the same numbers: one source for both)
-        const bool wide_g = short_max == 256 && CFG.num("B3C_LV_WIDE_G", 1) != 0;      // rows of 257 .. 512 entries by k_lv_decide_g<64, 8>
-        const int wave_thr = use_wg ? std::min(lv_wg_max_deg(0), std::max(short_max, (int)CFG.num("B3C_LV_WAVE_MAX", wide_g ? 512 : 409))) : 0;
+        // Levels with node lists (`grouped`): rows beyond the grouped kernel's reach get one WORKGROUP each with a table in LDS
+        // (k_lv_decide_wg: up to 6553 entries); the wave-per-node kernel keeps the rows of up to 409 entries (512-slot tables: six
+        // workgroups per CU; rows of 257 .. 512 entries take the grouped kernel with eight entries per lane instead).  Levels without
+        // lists (under 4096 nodes, beyond the direct-table kernel's 2048): the wave-per-node kernel on all rows.
+        const bool use_wg = grouped;
+        const bool wide_g = short_max == 256;                 // rows of 257 .. 512 entries by k_lv_decide_g<64, 8>
+        const int wave_thr = use_wg ? std::min(lv_wg_max_deg(0), std::max(short_max, wide_g ? 512 : 409)) : 0;
+        // LDS table of the wave-per-node kernel: 12 bytes per slot and wave, four waves per workgroup (2048 slots are 96 KB, one
+        // workgroup per CU: small levels only); rows beyond it use their table in global memory
         const int64_t wave_max = use_wg ? std::min<int64_t>(maxdeg, std::max<int64_t>(64, wave_thr)) : maxdeg;
         const int64_t need = 1ll << table_lg(wave_max);
-        const int cap_max = (int)CFG.num("B3C_LV_CAP_MAX", 2048);
-        const int cap0 = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
-        const int cap = cap0 > cap_max ? cap_max : cap0;
-        // rows beyond mega_deg entries get workgroups and the node's table in global memory (k_lv_mega_*).  With the workgroup
-        // kernel: whatever its largest LDS table cannot hold (or fewer: B3C_LV_MEGA_DEG).  Without it (round 3's rule): the wave kernel
-        // copes with long rows as long as there are enough of them to fill the chip (C5: thousands of hub contigs), a FEW long rows are
-        // the tail everybody waits for.
-        int64_t mega_auto = MEGA_DEG;
-        if ((int64_t)hc[8] <= MEGA_FEW) mega_auto = 2048;
-        else if ((int64_t)hc[9] <= MEGA_FEW) mega_auto = 4096;
-        const int mega_deg = use_wg ? (int)std::min<int64_t>(lv_wg_max_deg(2), std::max<int64_t>(short_max, CFG.num("B3C_LV_MEGA_DEG", lv_wg_max_deg(2))))
-                                    : (int)std::max<int64_t>(cap, CFG.num("B3C_LV_MEGA_DEG", mega_auto));
+        const int cap = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
+        // rows beyond mega_deg entries get workgroups and the node's table in global memory (k_lv_mega_*): whatever the largest LDS
+        // table of the workgroup kernel cannot hold (or fewer: B3C_LV_MEGA_DEG, which the tests use to reach those kernels on small graphs)
+        const int mega_deg = (int)std::min<int64_t>(lv_wg_max_deg(2), std::max<int64_t>(short_max, CFG.num("B3C_LV_MEGA_DEG", lv_wg_max_deg(2))));
         // rows whose table does not fit the LDS of the kernel that takes them use a table in global memory (goff / gkeys / gvals)
         const int cap_tbl = use_wg ? (1 << 13) : cap;
         hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap_tbl, use_wg ? (int64_t)mega_deg : INT64_MAX,
@@ -2676,9 +2687,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         } else {
             thr.t[1] = thr.t[2] = thr.t[3] = thr.t[4] = mega_deg;
         }
-        if (lv_debug) fprintf(stderr, "[b3c] level %d: %lld nodes, %lld entries; %llu rows beyond 2048 entries, %llu beyond 4096, longest %lld: classes <= %d | %d | %d | %d | %d | mega\n",
-                              (int)info->n_levels, (long long)n, (long long)g.nnz, (unsigned long long)hc[8], (unsigned long long)hc[9], (long long)maxdeg,
-                              thr.t[0], thr.t[1], thr.t[2], thr.t[3], thr.t[4]);
+        if (lv_debug) fprintf(stderr, "[b3c] level %d: %lld nodes, %lld entries, longest row %lld: classes <= %d | %d | %d | %d | %d | mega\n",
+                              (int)info->n_levels, (long long)n, (long long)g.nnz, (long long)maxdeg, thr.t[0], thr.t[1], thr.t[2], thr.t[3], thr.t[4]);
         if (grouped) {
             const int n_seg = need_wave_kernel ? LV_SEGS * n_sub : n_sub;
             const int64_t tot = (int64_t)n_seg * nloc + 1;
@@ -2707,14 +2717,12 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // internal weight through the movers' rows (the same pass keeps own[] current)
         // Row-sharded runs prune too (round 3): validity stamps replace the exchange the neighbours' own[] would need
         const bool can_prune = grouped && !CFG.on("B3C_LV_NO_PRUNE");
-        const bool use_side = !CFG.on("B3C_LV_NO_SIDE");      // hubs / mega rows beside the grouped scan on side streams
-        const bool mega_lds = use_wg && !CFG.on("B3C_LV_NO_MEGA_LDS");
-        const bool xcd_lists = !CFG.on("B3C_LV_NO_XCD");
-        // per-node gather records {community, its total} for the grouped scan (k_lv_decide_g<.., REC>), refreshed after every apply
-        const bool use_rec = grouped && CFG.num("B3C_LV_REC", 1) != 0;
-        DevBuf<GRec> grec(ctx, use_rec ? n : 1);
-        if (!grec.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: gather records");
-        if (use_rec) hipLaunchKernelGGL(k_lv_rec_refresh, dim3(gv), dim3(BLK), 0, s, n, com.p, tot.p, grec.p);
+        const bool mega_lds = use_wg;                          // mega-row chunks summed per community in LDS first (from the second sweep on)
+        // band of the grouped scan's contender rule (k_lv_decide_g): (k_i >> band_shift) + 1, the tot * k / 2m of a community of about
+        // 32 average nodes of this level.  Any value gives the same decisions; it only steers how often the exact fall-back runs
+        int band_shift = 0;
+        while ((2ll << band_shift) <= n) band_shift++;          // floor(log2 n)
+        band_shift = std::max(0, band_shift - 5);
         const size_t mega_lds_bytes = (size_t)(1 << MEGA_LDS_LG) * 12 + (MEGA_NT / 64) * 8;
         if (use_wg && ctx->attr_first(3)) {
             // tables beyond 64 KB of LDS are dynamic shared memory that a kernel must be allowed first (once per context = device)
@@ -2737,7 +2745,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         for (int r = 0; r < n_sub; r++) { max_hlist = std::max(max_hlist, moff[r] - hoff[r]); max_mega = std::max(max_mega, lend[r] - moff[r]); }
         DevBuf<u64> mega_own(ctx, max_mega + 1);            // own-community weight of the mega rows of a sub-round (cleared by the eval pass)
         // split evaluation of the mega rows' tables (k_lv_mega_eval_split): partial results and tickets
-        const bool mega_split = !CFG.on("B3C_LV_NO_MEGA_SPLIT") && max_mega > 0;
+        const bool mega_split = max_mega > 0;
         const int mega_echunks = mega_split ? (int)(((1ll << table_lg(maxdeg)) + MEGA_ESL - 1) / MEGA_ESL) : 1;
         DevBuf<MegaPart> mega_part(ctx, mega_split ? (size_t)max_mega * mega_echunks + 1 : 1);
         DevBuf<unsigned int> mega_ticket(ctx, max_mega + 1);
@@ -2752,7 +2760,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
             if (full) {
                 HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64), s));
-                const bool long_int = grouped && max_mega > 0 && !CFG.on("B3C_LV_NO_INTERNAL_LONG");
+                const bool long_int = grouped && max_mega > 0;
                 hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2, own_p,
                                    stamp_p, epoch + 1, long_int ? (int64_t)mega_deg : INT64_MAX);
                 if (long_int) {
@@ -2798,7 +2806,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if ((rc = modularity(&new_mod, false, nullptr))) { free_graph(ctx, g); return rc; }
         int sweep = 0;
         u64 prev_moved = ~0ull;
-        const int incr_div = (int)CFG.num("B3C_LV_INCR_DIV", 4);
+        constexpr int incr_div = 4;       // (1: 15.3 ms against 14.0 at C3 -- sweeps 2 and 3 still move 77 % and 25 % of the nodes)
         for (;;) {
             cur_mod = new_mod;
             sweep++;
@@ -2806,7 +2814,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 1, 0, sizeof(u64), s));
             // few movers expected (the sweep before moved under a quarter of the nodes): track the internal weight through
             // the movers' rows instead of rescanning the whole graph after the sweep
-            const bool incr = grouped && prev_moved != ~0ull && prev_moved * (u64)incr_div < (u64)n && !CFG.on("B3C_LV_NO_INCR");
+            const bool incr = grouped && prev_moved != ~0ull && prev_moved * (u64)incr_div < (u64)n;
             for (int r = 0; r < n_sub; r++) {
                 epoch++;
                 evs.rec();
@@ -2815,7 +2823,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 // many hub nodes or any mega row: they run on side streams BESIDE the grouped scan (both read the state of the
                 // sub-round's start and write nxt[] of their own nodes).  A handful of hubs (C3: 17 us of work) stays on the main
                 // stream: forking and joining costs as much as it hides (A/B at C3: 14.80 ms with, 14.70 without)
-                const bool hub_side = grouped && need_wave_kernel && hoff[r] > loff[r] && use_side && (lend[r] > moff[r] || moff[r] - hoff[r] >= SIDE_MIN_HUBS) &&
+                const bool hub_side = grouped && need_wave_kernel && hoff[r] > loff[r] && (lend[r] > moff[r] || moff[r] - hoff[r] >= SIDE_MIN_HUBS) &&
                                       ctx->side_ok();
                 hipStream_t hs = s, ms = s;               // streams of the hub and of the mega-row kernels
                 if (hub_side) {
@@ -2841,20 +2849,18 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                         cnt_dev = (const int64_t *)pcnt.p;
                     }
                     // grids of a multiple of eight workgroups number their list positions XCD by XCD (see the kernel)
-#define LV_GRID_G(L) ([&]() { int g_ = grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu); if (xcd_lists && g_ >= 64) g_ = (g_ + 7) & ~7; return g_; }())
-#define LV_DECIDE_G_(L, U, REC)                                                                                          \
-      hipLaunchKernelGGL((k_lv_decide_g<L, U, REC>), dim3(g_), dim3(BLK), 0, s, cntr, cnt_dev, lst,                       \
-                       m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch, \
-                       (xcd_lists && g_ >= 64) ? 1 : 0, grec.p)
+#define LV_GRID_G(L) ([&]() { int g_ = grid_for(cntr, WPB * (64 / L), 16 * ctx->n_cu); if (g_ >= 64) g_ = (g_ + 7) & ~7; return g_; }())
 #define LV_DECIDE_G(L, U)                                                                                                \
     { const int g_ = LV_GRID_G(L);                                                                                       \
-      if (use_rec) LV_DECIDE_G_(L, U, true); else LV_DECIDE_G_(L, U, false); }
+      hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(g_), dim3(BLK), 0, s, cntr, cnt_dev, lst,                            \
+                       m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch, \
+                       g_ >= 64 ? 1 : 0, band_shift); }
                     if (sweep == 1 && r == 0 && !incr && !CFG.on("B3C_LV_NO_FIRST")) {
                         // every node is still alone: the table-free form (k_lv_first_g)
 #define LV_FIRST_G(L, U)                                                                                                 \
     { const int g_ = LV_GRID_G(L);                                                                                       \
       hipLaunchKernelGGL((k_lv_first_g<L, U>), dim3(g_), dim3(BLK), 0, s, cntr, lst, m2,                                  \
-                       g.indices, g.q, kdeg.p, com.p, csize.p, nxt_p, (xcd_lists && g_ >= 64) ? 1 : 0); }
+                       g.indices, g.q, kdeg.p, com.p, csize.p, nxt_p, g_ >= 64 ? 1 : 0, band_shift); }
                         switch (short_max) {
                         case 256: LV_FIRST_G(64, 4); break;
                         case 128: LV_FIRST_G(16, 8); break;
@@ -2864,19 +2870,15 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 #undef LV_FIRST_G
                     } else
                     switch (short_max) {
-                    case 256:      // C3 sweep of shapes, ms of delta-Q scan per step: 64x4 11.3, 32x8 12.2, 16x16 22.4
-                        if (shape_32x8) { LV_DECIDE_G(32, 8); }
-                        else { LV_DECIDE_G(64, 4); }
-                        break;
+                    case 256: LV_DECIDE_G(64, 4); break;      // (C3 sweep of shapes, ms of delta-Q scan per step: 64x4 11.3, 32x8 12.2, 16x16 22.4)
                     case 128: LV_DECIDE_G(16, 8); break;
                     case 64: LV_DECIDE_G(8, 8); break;
                     default: LV_DECIDE_G(4, 8); break;
                     }
 #undef LV_DECIDE_G
-#undef LV_DECIDE_G_
 #undef LV_GRID_G
                 }
-                const bool direct_level = !grouped && !dist && n <= LV_DIRECT_CAP && !CFG.on("B3C_LV_NO_DIRECT");
+                const bool direct_level = !grouped && !dist && n <= LV_DIRECT_CAP;
                 if (direct_level) {
                     // small level: direct community table in LDS
                     hipLaunchKernelGGL(k_lv_decide_direct<LV_DIRECT_CAP>, dim3(grid_for(n, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, n, n_sub, r, m2,
@@ -2892,12 +2894,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     else
                         hipLaunchKernelGGL(k_lv_mega_insert, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], chunks, g.indices, g.q,
                                            com.p, goff.p, gkeys.p, gvals.p, mega_own.p);
-                    if (mega_split)
-                        hipLaunchKernelGGL(k_lv_mega_eval_split, dim3((unsigned)(nm * mega_echunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], mega_echunks, m2, kdeg.p,
-                                           tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p, mega_part.p, mega_ticket.p);
-                    else
-                        hipLaunchKernelGGL(k_lv_mega_eval, dim3((unsigned)nm), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], m2, kdeg.p, tot.p, com.p, csize.p,
-                                           nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p);
+                    hipLaunchKernelGGL(k_lv_mega_eval_split, dim3((unsigned)(nm * mega_echunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], mega_echunks, m2, kdeg.p,
+                                       tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p, mega_part.p, mega_ticket.p);
                     if (ms != s && ms != hs) {
                         HIP_TRY(ctx, hipEventRecord(ctx->ev_join2, ms));
                         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join2, 0));
@@ -2941,12 +2939,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                                 // with eight entries per lane -- entries in registers, claims instead of a scan of the table -- on
                                 // the hub stream, instead of the wave-per-node kernel
                                 const int g_ = grid_for(w1, WPB, 16 * ctx->n_cu);
-                                if (use_rec)
-                                    hipLaunchKernelGGL((k_lv_decide_g<64, 8, true>), dim3(g_), dim3(BLK), 0, hs, w1, hcnt_dev, hubs, m2, g.indices, g.q, kdeg.p, tot.p,
-                                                       com.p, csize.p, nxt_p, (int64_t *)nullptr, (int32_t *)nullptr, epoch, 0, grec.p);
-                                else
-                                    hipLaunchKernelGGL((k_lv_decide_g<64, 8, false>), dim3(g_), dim3(BLK), 0, hs, w1, hcnt_dev, hubs, m2, g.indices, g.q, kdeg.p, tot.p,
-                                                       com.p, csize.p, nxt_p, (int64_t *)nullptr, (int32_t *)nullptr, epoch, 0, grec.p);
+                                hipLaunchKernelGGL((k_lv_decide_g<64, 8>), dim3(g_), dim3(BLK), 0, hs, w1, hcnt_dev, hubs, m2, g.indices, g.q, kdeg.p, tot.p,
+                                                   com.p, csize.p, nxt_p, (int64_t *)nullptr, (int32_t *)nullptr, epoch, 0, band_shift);
                             } else if (k == 1 || !use_wg) {
                                 LV_DECIDE_CAP((int64_t)0, w1, hubs, hcnt_dev);
                             } else {
@@ -2986,7 +2980,6 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     hipLaunchKernelGGL(k_lv_apply, dim3(gv), dim3(BLK), 0, s, n, n_sub, r, ids, kdeg.p, tot.p, com.p, nxt_p,
                                        csize.p, ctr.p + 1, r0, r1, tstamp_p, epoch);
                 }
-                if (use_rec) hipLaunchKernelGGL(k_lv_rec_refresh, dim3(gv), dim3(BLK), 0, s, n, com.p, tot.p, grec.p);
             }
             info->move_nnz += g.nnz;
             info->move_rows += g.n;
@@ -3039,9 +3032,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 const int nslot = kc <= 512 ? AGG_SLOTS : kc <= 2048 ? 2 : 1;
                 const int64_t rpb = std::max<int64_t>(64, std::min<int64_t>(512, n / (4 * (int64_t)ctx->n_cu)));   // at least four blocks per CU
                 const size_t lds = sizeof(u64) * (size_t)nslot * (size_t)kc;       // at most 32 KB
-                const bool long_rows = maxdeg > AGG_LONG && !CFG.on("B3C_LV_NO_AGG_LONG");
+                const bool long_rows = maxdeg > AGG_LONG;
                 // beyond the first level: rows in the order of their new community (one stable sort of n labels)
-                const bool by_com = !first && n >= 4096 && !CFG.on("B3C_LV_NO_AGG_ORDER");
+                const bool by_com = !first && n >= 4096;
                 DevBuf<int32_t> okey(ctx, by_com ? n : 1), oval(ctx, by_com ? n : 1), oiota(ctx, by_com ? n : 1);
                 if (by_com) {
                     if (!okey.p || !oval.p || !oiota.p) { free_graph(ctx, h); free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation order"); }

@@ -317,123 +317,6 @@ __global__ void __launch_bounds__(BLK) k_permute_rows(int64_t n, const int64_t *
     }
 }
 
-// rows moved, columns relabelled AND re-sorted inside the row by a bitonic network in LDS (one wave per row):
-// canonical output without the 201M-key global radix sort.  Rows longer than CAPR take the global path.
-template <typename T, int CAPR>
-__global__ void __launch_bounds__(BLK) k_permute_rows_sorted(int64_t n, const int64_t *__restrict__ indptr,
-                                                              const int32_t *__restrict__ indices,
-                                                              const T *__restrict__ a,
-                                                              const int32_t *__restrict__ new2old,
-                                                              const int32_t *__restrict__ old2new,
-                                                              const int64_t *__restrict__ out_indptr,
-                                                              int32_t *__restrict__ out_indices, T *__restrict__ out_a)
-{
-    __shared__ int32_t skey[BLK / 64][CAPR];
-    __shared__ T sval[BLK / 64][CAPR];
-    const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    int32_t *key = skey[wib];
-    T *val = sval[wib];
-    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + wib;
-    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
-    for (int64_t k = wave; k < n; k += nwave) {
-        const int32_t old = new2old[k];
-        const int64_t s = indptr[old];
-        const int len = (int)(indptr[old + 1] - s);
-        const int64_t o = out_indptr[k];
-        if (out_indptr[k + 1] == o) continue;             // empty in the output: an empty row, or a row of another rank's block
-        int N = 64;
-        while (N < len) N <<= 1;
-        for (int e = lane; e < N; e += 64) {
-            if (e < len) {
-                key[e] = old2new[indices[s + e]];
-                val[e] = a[s + e];
-            } else {
-                key[e] = 0x7FFFFFFF;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        for (int kk = 2; kk <= N; kk <<= 1) {
-            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-                for (int idx = lane; idx < N; idx += 64) {
-                    const int ixj = idx ^ jj;
-                    if (ixj > idx) {
-                        const int32_t ka = key[idx], kb = key[ixj];
-                        const bool asc = (idx & kk) == 0;
-                        if ((ka > kb) == asc) {
-                            key[idx] = kb;
-                            key[ixj] = ka;
-                            const T va = val[idx];
-                            val[idx] = val[ixj];
-                            val[ixj] = va;
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            }
-        }
-        for (int e = lane; e < len; e += 64) {
-            out_indices[o + e] = key[e];
-            out_a[o + e] = val[e];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    }
-}
-
-// Packed form of the same: when (new column << PB | position in the row) fits 32 bits, only that one word per entry
-// goes through the bitonic network (a third of the LDS traffic); the values are fetched afterwards by position.
-template <typename T, int CAPR>
-__global__ void __launch_bounds__(BLK) k_permute_rows_packed(int64_t n, int pb, const int64_t *__restrict__ indptr,
-                                                              const int32_t *__restrict__ indices,
-                                                              const T *__restrict__ a,
-                                                              const int32_t *__restrict__ new2old,
-                                                              const int32_t *__restrict__ old2new,
-                                                              const int64_t *__restrict__ out_indptr,
-                                                              int32_t *__restrict__ out_indices, T *__restrict__ out_a)
-{
-    __shared__ uint32_t skey[BLK / 64][CAPR];
-    const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    uint32_t *key = skey[wib];
-    const uint32_t pmask = (1u << pb) - 1u;
-    const int64_t wave = (int64_t)blockIdx.x * (BLK / 64) + wib;
-    const int64_t nwave = (int64_t)gridDim.x * (BLK / 64);
-    for (int64_t k = wave; k < n; k += nwave) {
-        const int32_t old = new2old[k];
-        const int64_t s = indptr[old];
-        const int len = (int)(indptr[old + 1] - s);
-        const int64_t o = out_indptr[k];
-        if (out_indptr[k + 1] == o) continue;             // empty in the output: an empty row, or a row of another rank's block
-        int N = 64;
-        while (N < len) N <<= 1;
-        for (int e = lane; e < N; e += 64)
-            key[e] = e < len ? ((uint32_t)old2new[indices[s + e]] << pb) | (uint32_t)e : 0xFFFFFFFFu;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        for (int kk = 2; kk <= N; kk <<= 1) {
-            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-                for (int idx = lane; idx < N; idx += 64) {
-                    const int ixj = idx ^ jj;
-                    if (ixj > idx) {
-                        const uint32_t ka = key[idx], kb = key[ixj];
-                        const bool asc = (idx & kk) == 0;
-                        if ((ka > kb) == asc) {
-                            key[idx] = kb;
-                            key[ixj] = ka;
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            }
-        }
-        for (int e = lane; e < len; e += 64) {
-            const uint32_t kv = key[e];
-            out_indices[o + e] = (int32_t)(kv >> pb);
-            out_a[o + e] = a[s + (kv & pmask)];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    }
-}
-
 // Register form of the packed sort: lane l holds the R keys of positions l*R .. l*R+R-1, so the compare-exchange
 // stages with distance < R stay inside a lane and the others are one cross-lane shuffle per key -- 84 LDS-pipe operations
 // for a 256-entry row against 576 for the in-LDS network above, which is bound by exactly that pipe (C3: 4.6 -> see
@@ -616,8 +499,7 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     hipStream_t s = ctx->stream;
     const int64_t n = a->n;
     if (n == 0) return B3C_OK;
-    int ROUNDS = 3;
-    if (CFG.on("B3C_ORDER_ROUNDS")) ROUNDS = std::max(1, std::min(12, (int)CFG.num("B3C_ORDER_ROUNDS", 3)));
+    constexpr int ROUNDS = 3;         // (2 / 3 / 4 rounds at C3: whole step 77.3 / 73.0 / 73.6 ms in round 2; two rounds: ordering -1.7 ms, SpMV +4.3 ms)
     const int order_sample = (int)CFG.num("B3C_ORDER_SAMPLE", 0);
     DevBuf<int32_t> p0(ctx, n), p1(ctx, n), lab(ctx, (size_t)n * ROUNDS), kin(ctx, n), kout(ctx, n), vout(ctx, n);
     DevBuf<unsigned long long> cbest(ctx, n);
@@ -631,7 +513,7 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     // sorts) is n-vector work every rank repeats.  Per-row results and max-folds do not depend on who computed them: the
     // order is bit for bit the single-GPU one.
     const b3c_dist &D = ctx->dist;
-    const bool dist = ctx->has_dist && D.world > 1 && (int64_t)D.world * D.chunk >= n && !CFG.on("B3C_ORDER_REPLICATED");
+    const bool dist = ctx->has_dist && D.world > 1 && (int64_t)D.world * D.chunk >= n;
     int64_t r0 = 0, r1 = n;
     if (dist) ctx->dist_rows(n, D.rank, &r0, &r1);
     const int g16 = grid_for(r1 - r0, (BLK / 64) * 4, 16 * ctx->n_cu), g64 = grid_for(r1 - r0, BLK / 64, 16 * ctx->n_cu);
@@ -679,7 +561,7 @@ int b3c_locality_order_dev(b3c_ctx *ctx, const b3c_mat *a, int32_t *new2old, int
     }
     int bits = 1;
     while ((1ll << bits) < n) bits++;
-    if (ROUNDS * bits <= 64 && !CFG.on("B3C_ORDER_LSD")) {
+    if (ROUNDS * bits <= 64) {
         // ONE stable sort on the composite key (cluster_R, ..., cluster_2, cluster_1): the order the LSD passes below give, from a
         // third of the launches (1M keys go through rocPRIM's merge sort, ~20 small kernels per call; n up to 2^21 with three rounds)
         DevBuf<unsigned long long> k64(ctx, n), k64o(ctx, n);
@@ -741,8 +623,7 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
     constexpr int CAPR = 512;
     int nb = 1;
     while ((1ll << nb) < n) nb++;
-    const bool regs_ok = nnz && sort_cols && nb + 9 <= 32 && !CFG.on("B3C_PERMUTE_GLOBAL_SORT") &&
-                         !CFG.on("B3C_PERMUTE_LDS");
+    const bool regs_ok = nnz && sort_cols && nb + 9 <= 32;
     if (regs_ok) {
         // rows of up to CAPR entries: bitonic network in registers on packed (new column, position) keys ...
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
@@ -795,23 +676,6 @@ int b3c_permute_csr_rows(b3c_ctx *ctx, const b3c_mat *a, const int32_t *new2old,
             HIP_TRY(ctx, hipStreamSynchronize(s));       // the scratch above goes back to the pool here
             }
         }
-    } else if (nnz && sort_cols && maxlen <= CAPR && !CFG.on("B3C_PERMUTE_GLOBAL_SORT")) {
-        const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
-        int pb = 6;
-        while ((1ull << pb) < maxlen) pb++;
-        if (pb + nb <= 32) {      // (new column, position) packs into one word: sort keys only (in-LDS network, for comparison)
-            if (a->kind == B3C_F64)
-                hipLaunchKernelGGL((k_permute_rows_packed<double, CAPR>), dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
-                                   (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
-            else
-                hipLaunchKernelGGL((k_permute_rows_packed<uint32_t, CAPR>), dim3(g), dim3(BLK), 0, s, n, pb, a->indptr, a->indices,
-                                   (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
-        } else if (a->kind == B3C_F64)
-            hipLaunchKernelGGL((k_permute_rows_sorted<double, CAPR>), dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
-                               (const double *)a->data, new2old, old2new, m->indptr, m->indices, (double *)m->data);
-        else
-            hipLaunchKernelGGL((k_permute_rows_sorted<uint32_t, CAPR>), dim3(g), dim3(BLK), 0, s, n, a->indptr, a->indices,
-                               (const uint32_t *)a->data, new2old, old2new, m->indptr, m->indices, (uint32_t *)m->data);
     } else if (nnz && !sort_cols) {
         const int g = grid_for(n, BLK / 64, 16 * ctx->n_cu);
         if (a->kind == B3C_F64)

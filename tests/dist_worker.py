@@ -241,8 +241,36 @@ def gpu_large_mode(rank, world):
     _agree(res, single, rank)
     assert res.lv_info.agg_gathered_runs > 4096 and res.lv_info.n_comm_level0 == single.lv_info.n_comm_level0
     sess.close()
+    nnz_all = counts.nnz
     counts.free()
-    print('rank %d gpu-large ok (%d contigs, %d stored entries, %d communities after level 0)' % (rank, n, counts.nnz, single.lv_info.n_comm_level0))
+    # What a rank HOLDS: a caller that hands the raw map over (adopt_counts=True, what `bin3C.py cluster`
+    # does) keeps 1/world of the map per GPU once the row block exists.  Device bytes of the context with the result still alive
+    # (keep=True: working map, balanced sub-map) and the pool trimmed -- one rank against two, on the same map drawn again.
+    def held(sharded):
+        c2, _e, l2, s2, _g, _i = make_counts_device(ctx, n, e, 11, 'powerlaw', genomes=6000)
+        sess2 = DistSession(ctx, n) if sharded else None
+        r2 = run_hot_path(ctx, c2, s2, l2, 1000, 5, max_iter=20000, adopt_counts=True, keep=True)
+        if sess2 is not None:
+            sess2.check()
+        ctx.sync()
+        ctx.trim()
+        b = ctx.bytes_in_use()
+        x = r2.x.copy()
+        lab = r2.labels.copy()
+        r2.free()
+        if sess2 is not None:
+            sess2.close()
+        ctx.trim()
+        return b, x, lab
+    b1, x1, lab1 = held(False)
+    b2, x2, lab2 = held(True)
+    assert np.array_equal(x1, single.x) and np.array_equal(lab1, single.labels)
+    np.testing.assert_allclose(x2, x1, rtol=1e-10)
+    import graphs
+    assert graphs.same_partition(lab2, lab1)
+    assert b2 <= 0.6 * b1, (b2, b1)
+    print('rank %d gpu-large ok (%d contigs, %d stored entries, %d communities after level 0; device bytes held with the result alive: %d MB on one rank, %d MB per rank on two)' % (
+        rank, n, nnz_all, single.lv_info.n_comm_level0, b1 >> 20, b2 >> 20))
     ctx.close()
 
 
