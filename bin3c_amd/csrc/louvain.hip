@@ -978,6 +978,10 @@ __global__ void k_lv_list_bounds(int n_seg, int64_t nloc, const int64_t *__restr
     for (int t = threadIdx.x; t <= n_seg; t += blockDim.x) bnd[t] = pos[(int64_t)t * nloc];
 }
 
+// 16-byte loads of entry streams that are only as aligned as their elements (a row starts anywhere)
+typedef int32_t i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef long long i64x2_u __attribute__((ext_vector_type(2), aligned(8)));
+
 // Largest 64-bit value over the LPR lanes of a group, in every lane of the group (all lanes of the wave active).
 template <int LPR>
 __device__ __forceinline__ u64 group_max_u64(u64 v)
@@ -1014,14 +1018,11 @@ __device__ __forceinline__ u64 group_max_u64(u64 v)
 // community of about 32 average nodes.  On a metagenome d_c decides almost alone (tot_c * k_i / 2m is 10^-3 of d_c at level 0), so a
 // node has one or two contenders among its ~100 candidate communities: the 128-bit gain arithmetic of the others is gone as well.
 template <int LPR, int UN>
-__global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int64_t *__restrict__ cnt_dev,
-                                                      const NodeRec *__restrict__ list, u64 m2,
-                                                      const int32_t *__restrict__ indices,
-                                                      const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg,
-                                                      const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
-                                                      const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
-                                                      int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out, int32_t epoch, int xcd,
-                                                      int band_shift)
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(LPR == 64 && UN <= 4 ? 5 : 2))) k_lv_decide_g(
+    int64_t cnt_max, const int64_t *__restrict__ cnt_dev, const NodeRec *__restrict__ list, u64 m2, const int32_t *__restrict__ indices,
+    const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg, const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
+    const int32_t *__restrict__ csize, int32_t *__restrict__ nxt, int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out,
+    int32_t epoch, int xcd, int band_shift)
 {
     constexpr int CAP = LPR * UN > 384 ? 1024 : 512;       // >= 1.25 * LPR * UN + 1
     constexpr int LG = LPR * UN > 384 ? 10 : 9;
@@ -1031,9 +1032,10 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
     __shared__ int32_t skeys[WPB][CAP];
     __shared__ u64 svals[WPB][CAP];
     constexpr int RPW = 64 / LPR;
+    constexpr u64 GMASK = LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull);
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const int sub = lane / LPR, sl = lane % LPR;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: list positions of a one-node-per-wave shape are scalars)
+    const int sub = LPR == 64 ? 0 : lane / LPR, sl = LPR == 64 ? lane : lane % LPR;
     int32_t *keys = skeys[wib];
     u64 *vals = svals[wib];
     for (int t = lane; t < CAP; t += 64) { keys[t] = EMPTY; vals[t] = 0; }
@@ -1051,161 +1053,204 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
         pos = k * per + ((int64_t)(blockIdx.x >> 3) * WPB + wib) * RPW + sub;
         cnt_end = (k + 1) * per < cnt ? (k + 1) * per : cnt;
     }
-    // current node
-    int32_t i = -1, a = 0;
-    int deg = 0;
-    long long ki = 0;
-    int64_t start = 0;
-    int32_t j[UN];
-    if (pos < cnt_end) {
-        const NodeRec rec = list[pos];
-        i = rec.node;
-        deg = rec.deg;
-        start = rec.start;
-        a = com[i];
-        ki = kdeg[i];
-        const int32_t *__restrict__ ci = indices + rec.start;
+    // What a CU's texture addresser charges is the INSTRUCTION: ~26 cycles per vector-memory instruction of a wave whatever it
+    // moves -- 4 bytes per lane or 16, one active lane or 64 (tools/probes/ta_probe.hip, round 5) -- and with its gathers in L2 this
+    // kernel sat exactly there: ~23 vector loads per node x 977 nodes per CU x 26 cycles = its 250 us.  Hence: a lane owns UN
+    // CONSECUTIVE entries of the row and fetches them as 16-byte vectors (ids: UN / 4 loads, weights: UN / 2, instead of UN each); with
+    // one node per wave everything that belongs to the NODE -- its list record, label, degree, its community's total and size -- has
+    // a wave-uniform address and comes through the scalar cache, which the addresser never sees.  Left per node: the UN label gathers,
+    // the contenders' totals, one store.
+    //
+    // Software pipeline.  Once its gathers stay in L2 the kernel waits on its dependent round trips -- node record -> entries ->
+    // labels of the neighbours -> totals of the contenders -- with a handful of waves per SIMD to hide them.  One node per wave
+    // (LPR == 64: DEEP): the first three belong to LATER nodes while the current one is worked on --
+    //   cur  node (i, a, ki, ta) with the labels cm[] and weights qv[] of its neighbours in registers,
+    //   nx1  record, own label / degree and neighbour ids j1[] of the node after it   (its labels are requested in this pass),
+    //   nx2  record of the one after that                                               (its entries are requested in this pass).
+    // Several nodes per wave (shorter rows, eight entries per lane): the groups of a wave are that many gather streams already and the
+    // registers are spoken for, so the node whose labels were just requested is the one worked on (nx1 IS the current node).
+    constexpr bool DEEP = LPR == 64 && UN <= 4;
+    auto load_rec = [&](int64_t p) -> NodeRec {
+        NodeRec r;
+        r.node = -1; r.deg = 0; r.start = 0;
+        if (p < cnt_end) r = list[p];
+        return r;
+    };
+    // entries UN * sl .. UN * sl + UN - 1 of a row as 16-byte vectors (a lane past the row's end re-reads its beginning and drops it;
+    // the streams carry 32 bytes of slack behind their last entry)
+    auto load_ids = [&](const NodeRec &r, int32_t (&jj)[UN]) {
+        const int eb = UN * sl < r.deg ? UN * sl : 0;
 #pragma unroll
-        for (int t = 0; t < UN; t++) {
-            const int e = t * LPR + sl;
-            j[t] = e < deg ? ci[e] : i;
+        for (int v = 0; v < UN / 4; v++) {
+            const i32x4_u x = *(const i32x4_u *)(indices + r.start + eb + 4 * v);
+#pragma unroll
+            for (int k = 0; k < 4; k++) jj[4 * v + k] = UN * sl + 4 * v + k < r.deg ? x[k] : r.node;
+        }
+    };
+    auto load_q = [&](const NodeRec &r, u64 (&qq)[UN]) {
+        const int eb = UN * sl < r.deg ? UN * sl : 0;
+#pragma unroll
+        for (int v = 0; v < UN / 2; v++) {
+            const i64x2_u y = *(const i64x2_u *)(q + r.start + eb + 2 * v);
+#pragma unroll
+            for (int k = 0; k < 2; k++) qq[2 * v + k] = UN * sl + 2 * v + k < r.deg ? (u64)y[k] : 0;
+        }
+    };
+    NodeRec rec1 = load_rec(pos + (DEEP ? step : 0)), rec2 = load_rec(pos + (DEEP ? 2 : 1) * step);
+    int32_t i = -1, a = 0;                    // DEEP: the node at `pos`, its labels and weights loaded
+    long long ki = 0, ta = 0;
+    int32_t cm[DEEP ? UN : 1];
+    u64 qv[DEEP ? UN : 1];
+    int32_t a1 = 0;
+    long long ki1 = 0;
+    int32_t j1[UN];
+    {
+        NodeRec rec0;
+        rec0.node = -1; rec0.deg = 0; rec0.start = 0;
+        if constexpr (DEEP) rec0 = load_rec(pos);
+        i = rec0.node;
+        if (i >= 0) { a = com[i]; ki = kdeg[i]; }
+        if (rec1.node >= 0) { a1 = com[rec1.node]; ki1 = kdeg[rec1.node]; }
+        load_ids(rec1, j1);
+        if constexpr (DEEP) {
+            int32_t j0[UN];
+            load_ids(rec0, j0);
+            load_q(rec0, qv);
+#pragma unroll
+            for (int t = 0; t < UN; t++) cm[t] = j0[t] != i && j0[t] >= 0 ? com[j0[t]] : EMPTY;
+            if (i >= 0) ta = tot[a];
         }
     }
-    // the loop runs while ANY group of the wave still has a node (groups take turns on the shared table)
-    while (__ballot(i >= 0)) {
-        // 1. record of the group's next node
-        const int64_t posn = pos + step;
-        NodeRec recn;
-        recn.node = -1; recn.deg = 0; recn.start = 0;
-        if (i >= 0 && posn < cnt_end) recn = list[posn];
-        // 2. label gathers and weights of the current node, own-community total
-        int32_t cm[UN];
-        u64 qv[UN];
-        {
-            const int64_t *__restrict__ qi = q + start;
+    auto group_best = [&](Best v) -> Best {
+        if constexpr (LPR == 64) return best_wave_reduce(v);
+        else {
 #pragma unroll
-            for (int t = 0; t < UN; t++) {
-                cm[t] = j[t] != i ? com[j[t]] : EMPTY;
-                qv[t] = t * LPR + sl < deg ? (u64)qi[t * LPR + sl] : 0;
+            for (int o = LPR / 2; o > 0; o >>= 1) {
+                long long hi = __shfl_xor((long long)(v.gain >> 64), o, LPR);
+                u64 lo = (u64)__shfl_xor((long long)(u64)v.gain, o, LPR);
+                int32_t c = __shfl_xor(v.com, o, LPR);
+                int32_t hv = __shfl_xor(v.have, o, LPR);
+                i128 g = ((i128)hi << 64) | (i128)lo;
+                if (hv && (!v.have || g > v.gain || (g == v.gain && c < v.com))) {
+                    v.gain = g;
+                    v.com = c;
+                    v.have = 1;
+                }
             }
+            return v;
         }
-        long long ta = 0;
-        if (i >= 0 && sl == 0) ta = tot[a];
-        // 3. neighbour ids and own community of the next node (its weights are fetched next to its gathers)
-        int32_t an = 0;
-        long long kin = 0;
-        int32_t j2[UN];
-        {
-            const int32_t inn = recn.node;
-            if (inn >= 0) { an = com[inn]; kin = kdeg[inn]; }
-            const int32_t *__restrict__ ci = indices + recn.start;
+    };
+    // the loop runs while ANY group of the wave still has a node (groups take turns on the shared table)
+    while (__ballot((DEEP ? i : rec1.node) >= 0)) {
+        // 1. record of the node furthest ahead
+        // (all loads of this stretch are UNCONDITIONAL -- a lane without an entry reads a harmless place and drops the value --
+        // so that they issue back to back instead of one exec-masked branch each)
+        const NodeRec rec3 = load_rec(pos + (DEEP ? 3 : 2) * step);
+        // 2. labels of nx1's neighbours, its weights and its community's total
+        int32_t cm1[UN];
+        u64 qv1[UN];
 #pragma unroll
-            for (int t = 0; t < UN; t++) {
-                const int e = t * LPR + sl;
-                j2[t] = e < recn.deg ? ci[e] : inn;
-            }
+        for (int t = 0; t < UN; t++) {
+            const int32_t jj = j1[t] >= 0 ? j1[t] : 0;
+            const int32_t cv = com[jj];
+            cm1[t] = j1[t] != rec1.node ? cv : EMPTY;
+        }
+        load_q(rec1, qv1);
+        const long long ta1 = tot[a1];                  // (a1 is a valid community id, 0 for a lane group without a node)
+        // 3. neighbour ids, own label and degree of nx2
+        int32_t j2[UN];
+        const int32_t n2 = rec2.node >= 0 ? rec2.node : 0;
+        const int32_t a2 = com[n2];
+        const long long ki2 = rec2.node >= 0 ? kdeg[n2] : 0;
+        load_ids(rec2, j2);
+        // the node worked on in this pass (register renames, no copies)
+        const int32_t wi = DEEP ? i : rec1.node, wa = DEEP ? a : a1;
+        const long long wki = DEEP ? ki : ki1, wta = DEEP ? ta : ta1;
+        int32_t wcm[UN];
+        u64 wqv[UN];
+#pragma unroll
+        for (int t = 0; t < UN; t++) {
+            if constexpr (DEEP) { wcm[t] = cm[t]; wqv[t] = qv[t]; }
+            else { wcm[t] = cm1[t]; wqv[t] = qv1[t]; }
         }
         // 4. own-community weight in registers; does the group see any foreign community?
         long long own = 0;
         bool foreign = false;
 #pragma unroll
         for (int t = 0; t < UN; t++) {
-            if (cm[t] == EMPTY) continue;
-            if (cm[t] == a) own += (long long)qv[t];
+            if (wcm[t] == EMPTY) continue;
+            if (wcm[t] == wa) own += (long long)wqv[t];
             else foreign = true;
         }
         if constexpr (LPR == 64) own = wave_sum_ll_all(own);
         else {
 #pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) own += __shfl_down(own, o, LPR);
+            for (int o = LPR / 2; o > 0; o >>= 1) own += __shfl_xor(own, o, LPR);
         }
         const u64 fmask = __ballot(foreign);
         // 5. groups with foreign neighbours take the wave's table one after the other: insert, then every lane reads back (and clears)
         //    the slots it claimed -- a lane that turned an EMPTY slot into a community holds that community's summed weight d_c
+        int32_t cs[UN];                        // slots this lane claimed (-1: none)
         u64 dv[UN];
 #pragma unroll
-        for (int t = 0; t < UN; t++) dv[t] = 0;
+        for (int t = 0; t < UN; t++) { cs[t] = -1; dv[t] = 0; }
         u64 dmax = 0;
         for (int gsel = 0; gsel < RPW; gsel++) {
-            const u64 gbits = (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull)) << (gsel * LPR);
-            if (!(fmask & gbits)) continue;                     // wave-uniform
+            if (!(fmask & (GMASK << (gsel * LPR)))) continue;                     // wave-uniform
             if (sub == gsel) {
 #pragma unroll
                 for (int t = 0; t < UN; t++) {
-                    uint32_t mine = 0xFFFFFFFFu;
-                    if (cm[t] != EMPTY && cm[t] != a) {
-                        uint32_t slot = hash_slot(cm[t], LG);
+                    if (wcm[t] != EMPTY && wcm[t] != wa) {
+                        uint32_t slot = hash_slot(wcm[t], LG);
                         for (;;) {
-                            const int32_t prev = atomicCAS(&keys[slot], EMPTY, cm[t]);
-                            if (prev == EMPTY || prev == cm[t]) {
-                                atomicAdd(&vals[slot], qv[t]);
-                                if (prev == EMPTY) mine = slot;
+                            const int32_t prev = atomicCAS(&keys[slot], EMPTY, wcm[t]);
+                            if (prev == EMPTY || prev == wcm[t]) {
+                                atomicAdd(&vals[slot], wqv[t]);
+                                if (prev == EMPTY) cs[t] = (int32_t)slot;
                                 break;
                             }
                             slot = (slot + 1) & (CAP - 1);
                         }
                     }
-                    j[t] = (int32_t)mine;                       // j is dead: reuse it for the claimed slot
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            // (the table is this WAVE's: its LDS operations complete in order, so a wavefront-scope fence -- compiler ordering only -- is all the
+            // read-back needs.  A workgroup-scope fence also waits for every global load in flight (s_waitcnt vmcnt(0)): the prefetched
+            // records, entries and labels of the NEXT nodes -- the whole software pipeline stalled on it once per node (round 5, from the ISA))
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             if (sub == gsel) {
 #pragma unroll
                 for (int t = 0; t < UN; t++) {
-                    if (j[t] == -1) continue;
-                    dv[t] = vals[j[t]];
-                    keys[j[t]] = EMPTY;
-                    vals[j[t]] = 0;
+                    if (cs[t] == -1) continue;
+                    dv[t] = vals[cs[t]];
+                    keys[cs[t]] = EMPTY;
+                    vals[cs[t]] = 0;
                     dmax = dv[t] > dmax ? dv[t] : dmax;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
         // 6. contenders: the candidates within the band of the node's largest d_c get their exact totals and gains
-        const bool claimed_any = (fmask >> (sub * LPR)) & (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull));
         const u64 D = group_max_u64<LPR>(dmax);
-        const u64 band = ((u64)ki >> band_shift) + 1ull;
+        const u64 band = ((u64)wki >> band_shift) + 1ull;
         const u64 thr = D > band ? D - band : 0ull;
         Best b;
-        b.gain = 0; b.com = a; b.have = 0;
-        auto group_best = [&](Best v) -> Best {
-            if constexpr (LPR == 64) return best_wave_reduce(v);
-            else {
-#pragma unroll
-                for (int o = LPR / 2; o > 0; o >>= 1) {
-                    long long hi = __shfl_xor((long long)(v.gain >> 64), o, LPR);
-                    u64 lo = (u64)__shfl_xor((long long)(u64)v.gain, o, LPR);
-                    int32_t c = __shfl_xor(v.com, o, LPR);
-                    int32_t hv = __shfl_xor(v.have, o, LPR);
-                    i128 g = ((i128)hi << 64) | (i128)lo;
-                    if (hv && (!v.have || g > v.gain || (g == v.gain && c < v.com))) {
-                        v.gain = g;
-                        v.com = c;
-                        v.have = 1;
-                    }
-                }
-                return v;
-            }
-        };
+        b.gain = 0; b.com = wa; b.have = 0;
         if constexpr (LPR == 64) {
             // One node per wave: the handful of contenders (one or two of a node's ~100 candidate communities) are walked by a UNIFORM
             // loop over the ballots of the contender flags -- label, weight and total of each come out of its lane by v_readlane, the
             // 128-bit gain and the running arg-max are scalar arithmetic.  As per-lane vector code (four slots of 128-bit products per
-            // lane, then five DPP reductions for the arg-max over the wave) this stretch was 600 of the loop's 1300 instructions
-            // (round 5, from the ISA); the kernel sits on its instruction issue once the gathers stay in L2.
-            long long tc[UN];
+            // lane, then five DPP reductions for the arg-max over the wave) this stretch was 600 of the loop's 1300 instructions.
+            // (a contender's total: its community id is uniform here, so the load is a SCALAR one -- the texture addresser, which
+            // bounds this kernel, never sees it)
             u64 cmask[UN];
 #pragma unroll
-            for (int t = 0; t < UN; t++) {
-                const bool ct = j[t] != -1 && dv[t] >= thr && fmask != 0ull;
-                tc[t] = ct ? tot[cm[t]] : 0;
-                cmask[t] = __ballot(ct);
-            }
-            const u64 ki_u = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((u64)ki >> 32)) << 32) |
-                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u64)ki);
-            const int32_t a_u = __builtin_amdgcn_readfirstlane(a);
-            const u64 ta_u = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((u64)ta >> 32)) << 32) |
-                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u64)ta);      // (lane 0 = sl 0 holds tot[a])
+            for (int t = 0; t < UN; t++) cmask[t] = __ballot(cs[t] != -1 && dv[t] >= thr);
+            const u64 ki_u = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((u64)wki >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u64)wki);
+            const int32_t a_u = __builtin_amdgcn_readfirstlane(wa);
+            const u64 ta_u = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((u64)wta >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u64)wta);      // (lane 0 = sl 0 holds tot[a])
             i128 bg = 0;
             int32_t bc = a_u;
             int bh = 0;
@@ -1215,39 +1260,38 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
                 while (mk) {
                     const int l = __ffsll((unsigned long long)mk) - 1;
                     mk &= mk - 1;
-                    const int32_t c = __builtin_amdgcn_readlane(cm[t], l);
+                    const int32_t c = __builtin_amdgcn_readlane(wcm[t], l);
                     const u64 d = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dv[t] >> 32), l) << 32) |
                                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dv[t], l);
-                    const u64 tt = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((u64)tc[t] >> 32), l) << 32) |
-                                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u64)tc[t], l);
+                    const u64 tt = (u64)tot[c];
                     const i128 g = gain128(d, m2, tt, ki_u);
                     if (g > 0 && (!bh || g > bg || (g == bg && c < bc))) { bg = g; bc = c; bh = 1; }
                 }
             }
-            if (i >= 0) {       // (wave-uniform: one node per wave)
+            if (wi >= 0) {       // (wave-uniform: one node per wave)
                 // staying: i removed from its own community first (python-louvain __remove)
                 const i128 g = gain128((u64)own, m2, ta_u - ki_u, ki_u);
                 if (g > 0 && (!bh || g > bg || (g == bg && a_u < bc))) { bg = g; bc = a_u; bh = 1; }
-                if (own_out && sl == 0) { own_out[i] = own; stamp_out[i] = epoch; }      // row-sharded pruning: own_i as of this sub-round's start
+                if (own_out && sl == 0) { own_out[wi] = own; stamp_out[wi] = epoch; }      // row-sharded pruning: own_i as of this sub-round's start
             }
             b.gain = bg; b.com = bc; b.have = bh;       // (the same in every lane)
         } else {
             {
                 long long tc[UN];
 #pragma unroll
-                for (int t = 0; t < UN; t++) tc[t] = (claimed_any && j[t] != -1 && dv[t] >= thr) ? tot[cm[t]] : 0;
+                for (int t = 0; t < UN; t++) tc[t] = (cs[t] != -1 && dv[t] >= thr) ? tot[wcm[t]] : 0;
 #pragma unroll
                 for (int t = 0; t < UN; t++) {
-                    if (!(claimed_any && j[t] != -1 && dv[t] >= thr)) continue;
-                    const i128 g = gain128(dv[t], m2, (u64)tc[t], (u64)ki);
-                    best_take(b, g, cm[t]);
+                    if (!(cs[t] != -1 && dv[t] >= thr)) continue;
+                    const i128 g = gain128(dv[t], m2, (u64)tc[t], (u64)wki);
+                    best_take(b, g, wcm[t]);
                 }
             }
-            if (i >= 0 && sl == 0) {
+            if (wi >= 0 && sl == 0) {
                 // staying: i removed from its own community first (python-louvain __remove)
-                const i128 g = gain128((u64)own, m2, (u64)(ta - ki), (u64)ki);
-                best_take(b, g, a);
-                if (own_out) { own_out[i] = own; stamp_out[i] = epoch; }      // row-sharded pruning: own_i as of this sub-round's start
+                const i128 g = gain128((u64)own, m2, (u64)(wta - wki), (u64)wki);
+                best_take(b, g, wa);
+                if (own_out) { own_out[wi] = own; stamp_out[wi] = epoch; }      // row-sharded pruning: own_i as of this sub-round's start
             }
             b = group_best(b);
         }
@@ -1258,30 +1302,37 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_g(int64_t cnt_max, const int6
             if (top < x128) {                                   // group-uniform (b is the group's after the reduction)
                 long long tc[UN];
 #pragma unroll
-                for (int t = 0; t < UN; t++) tc[t] = (claimed_any && j[t] != -1 && dv[t] < thr) ? tot[cm[t]] : 0;
+                for (int t = 0; t < UN; t++) tc[t] = (cs[t] != -1 && dv[t] < thr) ? tot[wcm[t]] : 0;
 #pragma unroll
                 for (int t = 0; t < UN; t++) {
-                    if (!(claimed_any && j[t] != -1 && dv[t] < thr)) continue;
-                    const i128 g = gain128(dv[t], m2, (u64)tc[t], (u64)ki);
-                    best_take(b, g, cm[t]);
+                    if (!(cs[t] != -1 && dv[t] < thr)) continue;
+                    const i128 g = gain128(dv[t], m2, (u64)tc[t], (u64)wki);
+                    best_take(b, g, wcm[t]);
                 }
                 b = group_best(b);
             }
         }
-        if (i >= 0 && sl == 0) {
-            int32_t best = b.have ? b.com : a;
-            if (best > a && csize[a] == 1 && csize[best] == 1) best = a;      // (best > a implies best != a: the sizes are looked at for upward moves only)
-            nxt[i] = best;
+        if (wi >= 0 && sl == 0) {
+            int32_t best = b.have ? b.com : wa;
+            if (best > wa && csize[wa] == 1 && csize[best] == 1) best = wa;      // (best > a implies best != a: the sizes are looked at for upward moves only)
+            nxt[wi] = best;
         }
-        // 7. advance
-        pos = posn;
-        i = recn.node;
-        deg = recn.deg;
-        start = recn.start;
-        a = an;
-        ki = kin;
+        // 7. advance the pipeline
+        pos += step;
+        if constexpr (DEEP) {
+            i = rec1.node;
+            a = a1;
+            ki = ki1;
+            ta = ta1;
 #pragma unroll
-        for (int t = 0; t < UN; t++) j[t] = j2[t];
+            for (int t = 0; t < UN; t++) { cm[t] = cm1[t]; qv[t] = qv1[t]; }
+        }
+#pragma unroll
+        for (int t = 0; t < UN; t++) j1[t] = j2[t];
+        rec1 = rec2;
+        a1 = a2;
+        ki1 = ki2;
+        rec2 = rec3;
     }
 }
 
@@ -1476,29 +1527,72 @@ __global__ void __launch_bounds__(BLK) k_lv_prune(int64_t cnt, const NodeRec *__
                                                    NodeRec *__restrict__ out, unsigned long long *__restrict__ out_cnt,
                                                    const int32_t *__restrict__ stamp, const int32_t *__restrict__ tstamp)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * BLK;
-    for (int64_t base = (int64_t)blockIdx.x * BLK; base < cnt; base += stride) {
-        const int64_t t = base + threadIdx.x;
-        bool keep = false;
-        NodeRec rec;
-        rec.node = 0; rec.deg = 0; rec.start = 0;
-        if (t < cnt) {
-            rec = list[t];
-            const int32_t i = rec.node;
-            const int32_t a = com[i];
-            const long long ki = kdeg[i], o = own[i], f = wnl[i] - o;
-            const i128 stay = gain128((u64)o, m2, (u64)(tot[a] - ki), (u64)ki);
-            bool stays = f <= 0 || (stay > 0 && (i128)f * (i128)m2 < stay);
-            if (stamp && !(tstamp[a] < stamp[i])) stays = false;      // own_i may miss a foreign mover: rescan
-            if (stays) nxt[i] = a;
-            keep = !stays;
+    // A workgroup settles PRUNE_PER * BLK consecutive list positions and reserves the places of its survivors with ONE atomic: the
+    // per-wave reservation of rounds 2-4 queued 3,900 atomics of a 250k-node list on one address at ~11 ns each -- 43 of the
+    // kernel's 51 us (round 5, from the kernel trace).  Inside a workgroup the survivors keep their list order.
+    constexpr int PER = 4;
+    __shared__ unsigned int wcnt[PER][WPB];
+    __shared__ unsigned long long wbase;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t chunk = blockIdx.x; chunk * (PER * BLK) < cnt; chunk += gridDim.x) {
+        NodeRec rec[PER];
+        bool keep[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int64_t t = chunk * (PER * BLK) + u * BLK + threadIdx.x;
+            keep[u] = false;
+            rec[u].node = 0; rec[u].deg = 0; rec[u].start = 0;
+            if (t < cnt) rec[u] = list[t];
         }
-        const unsigned long long m = __ballot(keep);
-        unsigned long long at = 0;
-        if (lane == 0 && m) at = atomicAdd(out_cnt, (unsigned long long)__popcll(m));
-        at = __shfl((long long)at, 0, 64);
-        if (keep) out[at + __popcll(m & ((1ull << lane) - 1ull))] = rec;
+        int32_t a[PER];
+        long long ki[PER], o[PER], f[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int64_t t = chunk * (PER * BLK) + u * BLK + threadIdx.x;
+            const int32_t i = rec[u].node;
+            a[u] = t < cnt ? com[i] : 0;
+            ki[u] = t < cnt ? kdeg[i] : 0;
+            o[u] = t < cnt ? own[i] : 0;
+            f[u] = t < cnt ? wnl[i] - o[u] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int64_t t = chunk * (PER * BLK) + u * BLK + threadIdx.x;
+            if (t < cnt) {
+                const int32_t i = rec[u].node;
+                const i128 stay = gain128((u64)o[u], m2, (u64)(tot[a[u]] - ki[u]), (u64)ki[u]);
+                bool stays = f[u] <= 0 || (stay > 0 && (i128)f[u] * (i128)m2 < stay);
+                if (stamp && !(tstamp[a[u]] < stamp[i])) stays = false;      // own_i may miss a foreign mover: rescan
+                if (stays) nxt[i] = a[u];
+                keep[u] = !stays;
+            }
+        }
+        unsigned long long m[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            m[u] = __ballot(keep[u]);
+            if (lane == 0) wcnt[u][wv] = (unsigned int)__popcll(m[u]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int total = 0;
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+#pragma unroll
+                for (int w = 0; w < WPB; w++) total += wcnt[u][w];
+            wbase = total ? atomicAdd(out_cnt, (unsigned long long)total) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long at = wbase;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+#pragma unroll
+            for (int w = 0; w < WPB; w++) {
+                if (w == wv && keep[u]) out[at + __popcll(m[u] & ((1ull << lane) - 1ull))] = rec[u];
+                at += wcnt[u][w];
+            }
+        }
+        __syncthreads();            // wcnt / wbase are reused by the next chunk
     }
 }
 
@@ -1534,6 +1628,35 @@ __global__ void __launch_bounds__(BLK) k_lv_apply(int64_t n, int n_sub, int roun
     if (threadIdx.x == 0 && bcnt) atomicAdd(moved, (u64)bcnt);
 }
 
+// tot[key] += val, csize[key] += dsz for the lanes with `active`, where MANY lanes may name the same community (level 1 and up: the
+// community of an abundant genome absorbs tens of thousands of nodes in one sub-round, and their atomics queue up on ONE address
+// at ~11 ns each -- 333 us for an apply launch of the surveyed law's level 1).  Up to two rounds: the lanes that share the first
+// active lane's community are summed over the wave and added by one atomic; whoever is left adds for itself.  All 64 lanes call it.
+__device__ __forceinline__ void wave_agg_add(bool active, int32_t key, long long val, int dsz, int64_t *__restrict__ tot, int32_t *__restrict__ csize)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int r = 0; r < 2; r++) {
+        const u64 act = __ballot(active);
+        if (__popcll(act) < 8) break;                      // wave-uniform
+        const int l = __ffsll((unsigned long long)act) - 1;
+        const int32_t k0 = __builtin_amdgcn_readlane(key, l);
+        const bool same = active && key == k0;
+        const u64 sm = __ballot(same);
+        if (__popcll(sm) < 4) break;
+        const long long sum = wave_sum_ll_all(same ? val : 0);
+        if (lane == l) {
+            atomicAdd((u64 *)&tot[k0], (u64)sum);
+            atomicAdd(&csize[k0], dsz * (int)__popcll(sm));
+        }
+        active = active && !same;
+    }
+    if (active) {
+        atomicAdd((u64 *)&tot[key], (u64)val);
+        atomicAdd(&csize[key], dsz);
+    }
+}
+
 // the same over a prepared node list (single-GPU: only the nodes of the sub-round are visited)
 __global__ void __launch_bounds__(BLK) k_lv_apply_list(int64_t cnt, const NodeRec *__restrict__ list,
                                                         const int64_t *__restrict__ kdeg, int64_t *__restrict__ tot,
@@ -1542,17 +1665,20 @@ __global__ void __launch_bounds__(BLK) k_lv_apply_list(int64_t cnt, const NodeRe
 {
     const int64_t stride = (int64_t)gridDim.x * BLK;
     int c = 0;
-    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < cnt; t += stride) {
-        const int32_t i = list[t].node;
-        const int32_t a = com[i], b = nxt[i];
-        if (a == b) continue;
-        const long long ki = kdeg[i];
-        atomicAdd((u64 *)&tot[a], (u64)(-ki));
-        atomicAdd((u64 *)&tot[b], (u64)ki);
-        atomicSub(&csize[a], 1);
-        atomicAdd(&csize[b], 1);
-        com[i] = b;
-        c++;
+    for (int64_t base = (int64_t)blockIdx.x * BLK; base < cnt; base += stride) {        // (whole waves stay in the loop: see wave_agg_add)
+        const int64_t t = base + threadIdx.x;
+        int32_t i = 0, a = 0, b = 0;
+        if (t < cnt) {
+            i = list[t].node;
+            a = com[i];
+            b = nxt[i];
+        }
+        const bool mv = t < cnt && a != b;
+        if (!__ballot(mv)) continue;
+        const long long ki = mv ? kdeg[i] : 0;
+        wave_agg_add(mv, b, ki, 1, tot, csize);
+        wave_agg_add(mv, a, -ki, -1, tot, csize);
+        if (mv) { com[i] = b; c++; }
     }
     __shared__ int bcnt;
     if (threadIdx.x == 0) bcnt = 0;
@@ -1568,9 +1694,17 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
                                                       const int32_t *__restrict__ indices,
                                                       const int64_t *__restrict__ q, const int32_t *__restrict__ com,
                                                       u64 *__restrict__ i2, int64_t *__restrict__ own,
-                                                      int32_t *__restrict__ stamp, int32_t epoch, int64_t long_deg)
+                                                      int32_t *__restrict__ stamp, int32_t epoch, int64_t long_deg,
+                                                      const u64 *__restrict__ moved_dev, int64_t n_level)
 {
     // rows of more than long_deg entries are left to k_lv_internal_long (workgroups per row): this pass only clears their own[]
+    // HALF mode (round 5).  The graph is symmetric (q_ij == q_ji, both stored), so I2 is twice the sum over the entries above the
+    // diagonal plus the loops: the entries below it are skipped without gathering their labels.  own[] -- the per-node by-product the
+    // exact pruning starts from -- needs whole rows, but is only read if the NEXT sweep tracks the internal weight through the movers'
+    // rows, i.e. if the sweep just finished moved under a quarter of the nodes: the host applies that rule when the count comes back
+    // (b3c_louvain: `incr`), this kernel reads the same count from device memory.  Both rules are one expression: keep them one.
+    const bool half = moved_dev != nullptr && *moved_dev * 4ull >= (u64)n_level;
+    if (half) own = nullptr;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * WPB;
@@ -1608,14 +1742,17 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
 #pragma unroll
             for (int h = 0; h < 2; h++)
 #pragma unroll
-                for (int t = 0; t < 4; t++) c[h][t] = j[h][t] >= 0 ? com[j[h][t]] : -2;
+                for (int t = 0; t < 4; t++) {
+                    if (half && j[h][t] < (int32_t)rw[h]) j[h][t] = -1;        // below the diagonal: its mirror entry counts for both
+                    c[h][t] = j[h][t] >= 0 ? com[j[h][t]] : -2;
+                }
 #pragma unroll
             for (int h = 0; h < 2; h++)
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     if (j[h][t] < 0) continue;
                     if (j[h][t] == (int32_t)rw[h]) acc += 2 * w[h][t];
-                    else if (c[h][t] == a[h]) { acc += w[h][t]; mine[h] += w[h][t]; }
+                    else if (c[h][t] == a[h]) { acc += half ? 2 * w[h][t] : w[h][t]; mine[h] += w[h][t]; }
                 }
         }
         if (own) {                                            // by-product for k_lv_prune (wave-uniform branch)
@@ -1638,8 +1775,11 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
 // of node list[m]; integer sums, own[] was cleared by k_lv_internal.
 __global__ void __launch_bounds__(1024) k_lv_internal_long(const NodeRec *__restrict__ list, int chunks, const int32_t *__restrict__ indices,
                                                             const int64_t *__restrict__ q, const int32_t *__restrict__ com,
-                                                            u64 *__restrict__ i2, int64_t *__restrict__ own)
+                                                            u64 *__restrict__ i2, int64_t *__restrict__ own,
+                                                            const u64 *__restrict__ moved_dev, int64_t n_level)
 {
+    const bool half = moved_dev != nullptr && *moved_dev * 4ull >= (u64)n_level;        // see k_lv_internal
+    if (half) own = nullptr;
     const NodeRec rec = list[blockIdx.x / chunks];
     const int64_t c0 = (int64_t)(blockIdx.x % chunks) * 4096;
     if (c0 >= rec.deg) return;
@@ -1657,12 +1797,15 @@ __global__ void __launch_bounds__(1024) k_lv_internal_long(const NodeRec *__rest
     }
     int32_t c[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) c[t] = j[t] >= 0 ? com[j[t]] : -2;
+    for (int t = 0; t < 4; t++) {
+        if (half && j[t] < row) j[t] = -1;
+        c[t] = j[t] >= 0 ? com[j[t]] : -2;
+    }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         if (j[t] < 0) continue;
         if (j[t] == row) acc += 2 * w[t];
-        else if (c[t] == a) { acc += w[t]; mine += w[t]; }
+        else if (c[t] == a) { acc += half ? 2 * w[t] : w[t]; mine += w[t]; }
     }
     acc = wave_sum_ll(acc);
     mine = wave_sum_ll(mine);
@@ -1676,39 +1819,60 @@ __global__ void __launch_bounds__(1024) k_lv_internal_long(const NodeRec *__rest
 // for every node that does not move).  An off-diagonal entry (v, u) changes its indicator only if v or u moves; scanning
 // the rows of the MOVERS covers the entries (v, *) directly and, by symmetry of the graph, the mirror entries (u, v) of
 // the neighbours that stay -- hence the factor two for those.  Exact integer arithmetic, any order.
+constexpr int LV_DELTA_NPW = 8;          // list positions a wave of k_lv_delta_internal looks at per pass
 __global__ void __launch_bounds__(BLK) k_lv_delta_internal(int64_t cnt, const NodeRec *__restrict__ list,
                                                             const int32_t *__restrict__ indices, const int64_t *__restrict__ q,
                                                             const int32_t *__restrict__ com, const int32_t *__restrict__ nxt,
                                                             u64 *__restrict__ i2, int64_t *__restrict__ own, int64_t r0, int64_t r1,
                                                             int32_t *__restrict__ stamp, int32_t epoch)
 {
+    // Round 5: the list holds every node of the sub-round, the movers are a few per cent of it.  A wave looks at LV_DELTA_NPW nodes per
+    // pass (one per lane: their records and labels in flight together), then walks the rows of the movers among them one after the
+    // other.  One wave per NODE -- a dependent record -> labels round trip for each of 250,000 nodes to find 10,000 movers -- was
+    // 60-115 us per sub-round on the contract workload (from the kernel trace); 64 nodes per pass left too few waves for the rows
+    // (193 us: a wave then walks several movers' rows one after the other).
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * WPB;
     long long acc = 0;
-    for (int64_t t = wave; t < cnt; t += nwave) {
-        const NodeRec rec = list[t];
-        const int32_t a = com[rec.node], b = nxt[rec.node];
-        if (a == b) continue;
-        long long mine = 0;                                   // the mover's weight towards its NEW community, after all moves
-        for (int64_t k = rec.start + lane; k < rec.start + rec.deg; k += 64) {
-            const int32_t j = indices[k];
-            if (j == rec.node) continue;
-            const int32_t cj = com[j], nj = nxt[j];
-            const int d = (int)(nj == b) - (int)(cj == a);
-            if (d) acc += (long long)d * q[k] * (cj == nj ? 2 : 1);
-            if (own) {
-                if (nj == b) mine += q[k];
-                // a neighbour that stays: this mover leaves or joins its community (movers recompute theirs from scratch)
-                // (row-sharded: own[] of another rank's nodes is that rank's business -- see k_lv_prune)
-                if (cj == nj && (cj == a || cj == b) && j >= r0 && j < r1) atomicAdd((u64 *)&own[j], (u64)(cj == a ? -q[k] : q[k]));
-            }
+    for (int64_t base = wave * LV_DELTA_NPW; base < cnt; base += nwave * LV_DELTA_NPW) {
+        const int64_t t = lane < LV_DELTA_NPW ? base + lane : cnt;
+        NodeRec rec;
+        rec.node = 0; rec.deg = 0; rec.start = 0;
+        int32_t la = 0, lb = 0;
+        if (t < cnt) {
+            rec = list[t];
+            la = com[rec.node];
+            lb = nxt[rec.node];
         }
-        if (own) {
-            mine = wave_sum_ll(mine);
-            if (lane == 0) {
-                own[rec.node] = mine;
-                if (stamp) stamp[rec.node] = epoch;                 // formed from the labels AFTER this sub-round's moves
+        u64 mk = __ballot(t < cnt && la != lb);
+        while (mk) {
+            const int l = __ffsll((unsigned long long)mk) - 1;
+            mk &= mk - 1;
+            const int32_t node = __builtin_amdgcn_readlane(rec.node, l), deg = __builtin_amdgcn_readlane(rec.deg, l);
+            const int64_t start = (int64_t)(((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((u64)rec.start >> 32), l) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u64)rec.start, l));
+            const int32_t a = __builtin_amdgcn_readlane(la, l), b = __builtin_amdgcn_readlane(lb, l);
+            long long mine = 0;                                   // the mover's weight towards its NEW community, after all moves
+            for (int64_t k = start + lane; k < start + deg; k += 64) {
+                const int32_t j = indices[k];
+                if (j == node) continue;
+                const int32_t cj = com[j], nj = nxt[j];
+                const int d = (int)(nj == b) - (int)(cj == a);
+                if (d) acc += (long long)d * q[k] * (cj == nj ? 2 : 1);
+                if (own) {
+                    if (nj == b) mine += q[k];
+                    // a neighbour that stays: this mover leaves or joins its community (movers recompute theirs from scratch)
+                    // (row-sharded: own[] of another rank's nodes is that rank's business -- see k_lv_prune)
+                    if (cj == nj && (cj == a || cj == b) && j >= r0 && j < r1) atomicAdd((u64 *)&own[j], (u64)(cj == a ? -q[k] : q[k]));
+                }
+            }
+            if (own) {
+                mine = wave_sum_ll(mine);
+                if (lane == 0) {
+                    own[node] = mine;
+                    if (stamp) stamp[node] = epoch;                     // formed from the labels AFTER this sub-round's moves
+                }
             }
         }
     }
@@ -2547,7 +2711,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     const int32_t *ids0 = reorder ? new2old.p : a->ids;
 
     DevBuf<int32_t> labels(ctx, n0);
-    DevBuf<int64_t> q0(ctx, a->nnz);
+    DevBuf<int64_t> q0(ctx, a->nnz + 8);           // (+ 8: the scans read the entry streams as 16-byte vectors, up to 7 entries past a row)
     if (!labels.p || !q0.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain");
     int32_t shift = 0;
     // sharded level 0 on a row block (b3c_mat_permute_rows + compress): this rank holds the entries of its rows only
@@ -2761,14 +2925,16 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             if (full) {
                 HIP_TRY(ctx, hipMemsetAsync(ctr.p + 2, 0, sizeof(u64), s));
                 const bool long_int = grouped && max_mega > 0;
+                // (moved != nullptr: the recount after a sweep -- ctr[1] holds that sweep's move count, see the kernel's HALF mode)
+                const u64 *mv_dev = moved ? ctr.p + 1 : nullptr;
                 hipLaunchKernelGGL(k_lv_internal, dim3(gwl), dim3(BLK), 0, s, r0, r1, g.indptr, g.indices, g.q, com.p, ctr.p + 2, own_p,
-                                   stamp_p, epoch + 1, long_int ? (int64_t)mega_deg : INT64_MAX);
+                                   stamp_p, epoch + 1, long_int ? (int64_t)mega_deg : INT64_MAX, mv_dev, n);
                 if (long_int) {
                     const int chunks = (int)((maxdeg + 4095) / 4096);
                     for (int r = 0; r < n_sub; r++)
                         if (lend[r] > moff[r])
                             hipLaunchKernelGGL(k_lv_internal_long, dim3((unsigned)((lend[r] - moff[r]) * chunks)), dim3(1024), 0, s, nlist_p + moff[r], chunks,
-                                               g.indices, g.q, com.p, ctr.p + 2, own_p);
+                                               g.indices, g.q, com.p, ctr.p + 2, own_p, mv_dev, n);
                 }
             }
             hipLaunchKernelGGL(k_lv_tot2, dim3(gv), dim3(BLK), 0, s, n, tot.p, ctr.p + 3);
@@ -2843,7 +3009,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                     const int64_t *cnt_dev = nullptr;
                     if (incr && can_prune) {
                         // nodes that provably stay are settled from four numbers each; the rest go through the scan
-                        hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(cntr, BLK, 8 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, m2, kdeg.p,
+                        hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(cntr, 4 * BLK, 8 * ctx->n_cu)), dim3(BLK), 0, s, cntr, lst, m2, kdeg.p,
                                            wnl.p, own.p, tot.p, com.p, nxt_p, plist.p, pcnt.p, stamp_p, tstamp_p);
                         lst = plist.p;
                         cnt_dev = (const int64_t *)pcnt.p;
@@ -2929,7 +3095,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                                 // them in every late sweep was 85 % of the stage).  Row-sharded runs keep scanning them: these kernels
                                 // do not refresh own[] / stamp[] (see k_lv_prune)
                                 NodeRec *pl = plist_h.p + (off[r][k] - off[r][1]);
-                                hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(w1, BLK, 8 * ctx->n_cu)), dim3(BLK), 0, hs, w1, hubs, m2, kdeg.p,
+                                hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(w1, 4 * BLK, 8 * ctx->n_cu)), dim3(BLK), 0, hs, w1, hubs, m2, kdeg.p,
                                                    wnl.p, own.p, tot.p, com.p, nxt_p, pl, pcnt.p + k, stamp_p, tstamp_p);
                                 hubs = pl;
                                 hcnt_dev = (const int64_t *)(pcnt.p + k);
@@ -2968,7 +3134,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (incr) {
                     // grouped nodes and hubs of the sub-round are adjacent in the list: one launch
                     const int64_t c1 = lend[r] - loff[r];
-                    if (c1) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c1, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, c1,
+                    if (c1) hipLaunchKernelGGL(k_lv_delta_internal, dim3(grid_for(c1, WPB * LV_DELTA_NPW, 32 * ctx->n_cu)), dim3(BLK), 0, s, c1,
                                                nlist_p + loff[r], g.indices, g.q, com.p, nxt_p, ctr.p + 2, own_p, r0, r1, stamp_p, epoch + 1);
                 }
                 if (grouped && !dist) {
@@ -3074,8 +3240,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             int64_t nu = 0;
             { const int rb_ = b3c_readback(ctx, &nu, h.indptr + kc, sizeof(int64_t)); if (rb_) { free_graph(ctx, h); free_graph(ctx, g); return rb_; } }
             h.nnz = nu;
-            h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu > 0 ? nu : 1));
-            h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu > 0 ? nu : 1));
+            h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu + 8));      // (+ 8: vector loads past the last row)
+            h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu + 8));
             if (!h.indices || !h.q) {
                 free_graph(ctx, h);
                 free_graph(ctx, g);
@@ -3158,8 +3324,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             int64_t nu = 0;
             { const int rb_ = b3c_readback(ctx, &nu, h.indptr + kc, sizeof(int64_t)); if (rb_) { free_graph(ctx, h); return rb_; } }
             h.nnz = nu;
-            h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu > 0 ? nu : 1));
-            h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu > 0 ? nu : 1));
+            h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu + 8));      // (+ 8: vector loads past the last row)
+            h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu + 8));
             if (!h.indices || !h.q) { free_graph(ctx, h); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: next level"); }
             hipLaunchKernelGGL(k_aggh_compact, dim3(grid_for(kc, WPB, 16 * ctx->n_cu)), dim3(BLK), 0, s, kc, ubpos.p, h.indptr, tix.p, tq.p, h.indices, h.q);
             {
@@ -3223,8 +3389,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
 
         h.n = kc; h.nnz = nu; h.owned = true;
         h.indptr = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(kc + 1));
-        h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu > 0 ? nu : 1));
-        h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu > 0 ? nu : 1));
+        h.indices = (int32_t *)ctx->alloc(sizeof(int32_t) * (size_t)(nu + 8));      // (+ 8: vector loads past the last row)
+        h.q = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)(nu + 8));
         if (!h.indptr || !h.indices || !h.q) {
             free_graph(ctx, h);
             return ctx->fail(B3C_E_NOMEM, "b3c_louvain: next level");
