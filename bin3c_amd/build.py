@@ -30,8 +30,6 @@ def build_lib(force=False, verbose=False):
         obj = os.path.join(HERE, 'build', src.replace('.hip', '.o'))
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC,
                '-Wno-unused-result', '-c', os.path.join(CSRC, src), '-o', obj]
-        if os.environ.get('B3C_BUILD_PROBES'):         # development: the timing probes that give wrong results (tools/tcd_probe.py)
-            cmd.insert(-4, '-DB3C_PROBES')
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

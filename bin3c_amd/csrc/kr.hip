@@ -1185,22 +1185,15 @@ __global__ void __launch_bounds__(256) kr_tails_emit(int64_t r0, int64_t r1, int
 // than 8 bits stays a 64-bit word in a short residual list (its slot in the stream becomes a zero: no contribution), which the
 // kernel adds straight into the global row sums.  All sums are integer sums: x stays bit for bit what the 64-bit stream gives.
 constexpr int XT_PACK_CB = 8;           // count bits of a packed word
-// Round 5: and one header per BLOCK of 256 consecutive words (four groups): its smallest column, with the top bit set when the
-// block's columns span at most XT_SPAN of them (`dense`: a block inside an abundant genome -- 256 column-sorted words of a super-tile
-// there cover ~65 columns).  kr_kb_tails_blk fetches the operands of a dense block with ONE 16-byte load per lane instead of one
-// gather per word (see there).
-constexpr int XT_SPAN = 128;            // columns a dense block may span (two per lane of the wave that fetches them)
 __global__ void __launch_bounds__(256) kr_tails_pack(int64_t n_tails, int rbits, int cshift, uint32_t cmask,
                                                       const unsigned long long *__restrict__ words, uint32_t *__restrict__ cw,
-                                                      uint32_t *__restrict__ hdr, uint32_t *__restrict__ bhdr, unsigned long long *__restrict__ rwords,
-                                                      unsigned long long *__restrict__ n_res, unsigned long long *__restrict__ n_dense)
+                                                      uint32_t *__restrict__ hdr, unsigned long long *__restrict__ rwords,
+                                                      unsigned long long *__restrict__ n_res)
 {
-    __shared__ uint32_t gmin[4], gmax[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t nblocks = (n_tails + 255) >> 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t groups = (n_tails + 63) >> 6;
     const int db = 32 - rbits - XT_PACK_CB;
-    for (int64_t bk = blockIdx.x; bk < nblocks; bk += gridDim.x) {           // the four waves of a workgroup take the four groups of a block
-        const int64_t g = bk * 4 + wv;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += (int64_t)gridDim.x * 4) {
         const int64_t k = g * 64 + lane;
         const bool valid = k < n_tails;
         const unsigned long long w = valid ? words[k] : 0ull;
@@ -1215,25 +1208,7 @@ __global__ void __launch_bounds__(256) kr_tails_pack(int64_t n_tails, int rbits,
         const bool fits = valid && c != 0 && d < (1u << db) && c < (1u << XT_PACK_CB);
         const bool res = valid && c != 0 && !fits;
         if (valid) cw[k] = fits ? (d << (rbits + XT_PACK_CB)) | (r << XT_PACK_CB) | c : 0u;
-        hdr[g] = base == 0xFFFFFFFFu ? 0u : base;          // (every lane the same value; a group past the stream: column 0)
-        // span of the block over the words that stay in the packed stream
-        uint32_t lo = fits ? col : 0xFFFFFFFFu, hi = fits ? col : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t t = (uint32_t)__shfl_xor((int)lo, o, 64), v = (uint32_t)__shfl_xor((int)hi, o, 64);
-            lo = t < lo ? t : lo;
-            hi = v > hi ? v : hi;
-        }
-        if (lane == 0) { gmin[wv] = lo; gmax[wv] = hi; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-#pragma unroll
-            for (int q = 0; q < 4; q++) { mn = gmin[q] < mn ? gmin[q] : mn; mx = gmax[q] > mx ? gmax[q] : mx; }
-            const bool any = mn != 0xFFFFFFFFu, dense = any && mx - mn < (uint32_t)XT_SPAN;
-            bhdr[bk] = (any ? mn : 0u) | (dense ? 0x80000000u : 0u);
-            if (dense) atomicAdd(n_dense, 1ull);
-        }
+        if (lane == 0) hdr[g] = base;
         const unsigned long long m = __ballot(res);
         if (m) {
             unsigned long long at = 0;
@@ -1241,7 +1216,6 @@ __global__ void __launch_bounds__(256) kr_tails_pack(int64_t n_tails, int rbits,
             at = (unsigned long long)__shfl((long long)at, 0, 64);
             if (res) rwords[at + __popcll(m & ((1ull << lane) - 1ull))] = w;
         }
-        __syncthreads();            // gmin / gmax are reused by the next block
     }
 }
 
@@ -1436,137 +1410,6 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
                 atomicAdd(&acc[r], (unsigned long long)f);
                 if (l) atomicAdd(&lo[r], l);
             }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < S && ra + i < n; i += XT_NT) {
-        if (acc[i]) atomicAdd(&yhi[ra - r0 + i], acc[i]);
-        if (lo[i]) atomicAdd(&ylo[ra - r0 + i], lo[i]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The tail pass by BLOCKS of 256 words (round 5).  What bounds kr_kb_tails on a map whose tails are most of the matrix (the
-// contract workload: 175 M words per SpMV) is neither HBM nor the L1 but the NUMBER of vector-memory instructions: a CU's texture
-// addresser spends ~26 cycles on every one of them whatever it moves (tools/probes/ta_probe.hip: 4 or 16 bytes per lane, 16 lanes
-// or 64, one line or two -- all 26 cycles; counters of the pass: addresser busy 94 % of the launch, 3 % of it stalled by the cache),
-// and the pass issues two per 64 words -- the words and their gathers.  Here a wave takes 256 CONSECUTIVE words per step:
-//   * the words are one 16-byte load per lane (four consecutive words);
-//   * in a DENSE block (kr_tails_pack: its columns span at most 128 -- inside an abundant genome 256 column-sorted words cover ~65)
-//     the operands of all its columns are one more 16-byte load per lane (columns base + 2 lane, + 1), parked in 1 KB of LDS of the
-//     wave, from where every word reads its own; a block that spans more (the inter-genome noise between the genomes' column
-//     ranges) gathers per word as before;
-//   * block base and the four group bases are scalar loads.
-// Two vector loads per 256 words instead of eight.  Same products, same fixed-point sums (integers: any order): x is bit for bit
-// the older pass's.  The LDS atomics are next in line (52 % of the launch with 69 % of their cycles in bank conflicts).
-// ---------------------------------------------------------------------------------------------
-typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
-__global__ void __launch_bounds__(XT_NT) kr_kb_tails_blk(const KRState *__restrict__ sin, const double *__restrict__ pumax, int PU,
-                                                          int lg_bound, int lo_bits, int chunks, int64_t n_tails, const int64_t *__restrict__ toff, int64_t r0, int64_t n,
-                                                          int S, int rbits, uint32_t cmask, const double *__restrict__ u,
-                                                          unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex,
-                                                          const uint32_t *__restrict__ cw, const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ bhdr,
-                                                          const unsigned long long *__restrict__ rwords, int64_t n_res, int st_shift, int64_t ncols)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned long long xt_lds[];
-    unsigned long long *acc = xt_lds;                 // S 64-bit sums
-    int *lo = (int *)(acc + S);                       // S 32-bit sums of the remainders
-    double *red = (double *)(lo + S);                 // XT_NT doubles (S is a multiple of 2)
-    double *span = red + XT_NT;                       // XT_SPAN operands per wave
-    const int32_t phase = sin->phase;
-    if (phase != A_INNER && phase != A_OUTER) return;           // no SpMV in this tick (the row kernel decides the same way)
-    const double umax = reduce_max_n<XT_NT>(pumax, PU, red);
-    int E = 0;
-    const bool live = umax > 0.0 && umax < INFINITY;
-    if (live) E = 61 - lg_bound - (ilogb(umax) + 1);            // count * |operand| * 2^E < 2^(61 - lg(longest tail))
-    if (E > 900) E = 900;                                       // (operands below 2^-860: keep 2^E finite)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { tex[0] = E; tex[1] = lo_bits; }
-    if (!live) return;
-    const double scale = ldexp(1.0, E), lo_scale = ldexp(1.0, lo_bits);
-    const int stile = blockIdx.x / chunks, ch = blockIdx.x % chunks;
-    for (int i = threadIdx.x; i < S; i += XT_NT) { acc[i] = 0; lo[i] = 0; }
-    __syncthreads();
-    const int64_t ra = r0 + (int64_t)stile * S, rb = ra + S < n ? ra + S : n;
-    const int cshift = 16 + rbits;
-    const uint32_t rmask = (1u << rbits) - 1u;
-    const int64_t a = toff[ra - r0], b = rb >= n ? n_tails : toff[rb - r0];
-    const int64_t len = (b - a + chunks - 1) / chunks;
-    const int64_t s0 = a + ch * len, e0 = s0 + len < b ? s0 + len : b;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    constexpr int NW = XT_NT / 64;
-    double *sp = span + wave * XT_SPAN;
-    const int csh = rbits + XT_PACK_CB;
-    const int64_t bend = e0 > s0 ? (e0 + 255) >> 8 : 0;                       // blocks [s0 >> 8, bend) touch this chunk
-    // the words of a block (zeroed outside [s0, e0): a block at a chunk boundary is shared with the neighbour) and its headers
-    auto fetch = [&](int64_t bi, u32x4_a4 &w, uint32_t &bh, u32x4_a4 &hd) {
-        w = (u32x4_a4){0u, 0u, 0u, 0u};
-        hd = w;
-        bh = 0u;
-        if (bi < bend) {                                                        // (wave-uniform)
-            w = *(const u32x4_a4 *)(cw + bi * 256 + 4 * lane);
-            bh = bhdr[bi];
-            hd = *(const u32x4_a4 *)(hdr + 4 * bi);
-            const int64_t k0 = bi * 256 + 4 * lane;
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                if (k0 + t < s0 || k0 + t >= e0) w[t] = 0u;
-        }
-    };
-    int64_t bi = (s0 >> 8) + wave;
-    u32x4_a4 wn, hn;
-    uint32_t bn;
-    fetch(bi, wn, bn, hn);
-    for (; bi < bend; bi += NW) {
-        const u32x4_a4 w = wn, hd = hn;
-        const uint32_t bh = bn;
-        const uint32_t B = bh & 0x7FFFFFFFu;
-        const bool dense = (bh >> 31) != 0u;                                    // (wave-uniform: one scalar per block)
-        const uint32_t gb = lane < 16 ? hd[0] : lane < 32 ? hd[1] : lane < 48 ? hd[2] : hd[3];      // base column of this lane's group
-        double g[4];
-        if (dense) {
-            // (u carries XT_SPAN doubles of zeros behind its last column)
-            const f64x2_a8 ov = *(const f64x2_a8 *)(u + B + 2 * lane);
-            fetch(bi + NW, wn, bn, hn);
-            *(f64x2_a8 *)(sp + 2 * lane) = ov;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");              // (the wave's own LDS operations complete in order)
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                uint32_t d = (w[t] >> csh) + gb - B;                            // (a zero word may point anywhere: clamped, and its count is 0)
-                d = d < (uint32_t)(XT_SPAN - 1) ? d : (uint32_t)(XT_SPAN - 1);
-                g[t] = sp[d];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                uint32_t c = (w[t] >> csh) + gb;
-                c = c < (uint32_t)ncols ? c : 0u;
-                g[t] = u[c];
-            }
-            fetch(bi + NW, wn, bn, hn);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const double ps = (g[t] * (double)(w[t] & ((1u << XT_PACK_CB) - 1u))) * scale;
-            long long f;
-            int l;
-            xt_split(ps, lo_scale, f, l);
-            const uint32_t r = (w[t] >> XT_PACK_CB) & rmask;
-            atomicAdd(&acc[r], (unsigned long long)f);
-            atomicAdd(&lo[r], l);
-        }
-    }
-    // the few words that did not fit: straight into the global row sums (integer atomics: order-free)
-    for (int64_t j = (int64_t)blockIdx.x * XT_NT + threadIdx.x; j < n_res; j += (int64_t)gridDim.x * XT_NT) {
-        const unsigned long long w = rwords[j];
-        const double ps = (u[(uint32_t)(w >> cshift) & cmask] * (double)(uint32_t)(w & 0xFFFFu)) * scale;
-        long long f;
-        int l;
-        xt_split(ps, lo_scale, f, l);
-        const int64_t row = (int64_t)(w >> st_shift) * S + ((uint32_t)(w >> 16) & rmask);
-        atomicAdd(&yhi[row], (unsigned long long)f);
-        if (l) atomicAdd(&ylo[row], l);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < S && ra + i < n; i += XT_NT) {
@@ -2554,8 +2397,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     const int hub_len = hub_kb ? hub_thr : 0x7fffffff;
     const int P = (int)std::max<int64_t>(GA, (int64_t)GS_max + hub_cap);
 
-    // (u: XT_SPAN zeros behind the last column -- kr_kb_tails_blk fetches the operands of a block as 128 consecutive columns)
-    DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z_own(ctx, n), rk(ctx, n), v(ctx, n), w(ctx, n), u(ctx, n + XT_SPAN), dfix(ctx, n);
+    DevBuf<double> x(ctx, n), y(ctx, n), p(ctx, n), Z_own(ctx, n), rk(ctx, n), v(ctx, n), w(ctx, n), u(ctx, n), dfix(ctx, n);
     struct { double *p; } Z{Z_own.p};
     DevBuf<double> pmin(ctx, P), pmax(ctx, P), psum(ctx, P), pgam(ctx, P), pk1(ctx, P), pkb(ctx, P);   // block partials, see the kernels
     DevBuf<KRState> states(ctx, 2);
@@ -2566,7 +2408,6 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     int *flags = (int *)(counters.p + 2);
 
     HIP_TRY(ctx, hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * 4, s));
-    HIP_TRY(ctx, hipMemsetAsync(u.p + n, 0, sizeof(double) * XT_SPAN, s));
     // count form: sanitised sites and their reciprocals on the device
     DevBuf<double> sd(ctx, counts ? n : 1), rsd(ctx, counts ? n : 1);
     const double *rs = nullptr;
@@ -2803,8 +2644,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     DevBuf<int64_t> xt_off(ctx, tails_xt ? nloc + 2 : 1);
     int xt_lg_bound = 0, xt_lo_bits = 20;
     // packed form of the sorted tail words (kr_tails_pack): 4 bytes per tail; B3C_KR_XT_PACK=0 keeps the 64-bit stream
-    struct PoolPtr32 { b3c_ctx *c; uint32_t *p = nullptr; ~PoolPtr32() { c->release(p); } } xt_cw{ctx}, xt_hdr{ctx}, xt_bhdr{ctx};
-    bool xt_blk = false;
+    struct PoolPtr32 { b3c_ctx *c; uint32_t *p = nullptr; ~PoolPtr32() { c->release(p); } } xt_cw{ctx}, xt_hdr{ctx};
     struct PoolPtr64 { b3c_ctx *c; unsigned long long *p = nullptr; ~PoolPtr64() { c->release(p); } } xt_res{ctx};
     bool xt_packed = false;
     int64_t xt_n_res = 0;
@@ -2847,37 +2687,23 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (!tmp.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: tail sort workspace");
         e = hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, words_in.p, xt_words.p, (int64_t)n_tails, sort_lo, sort_hi, s);
         if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort of the tails failed");
-        if (ctx->attr_first(1)) {
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT)));
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails_blk, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)(12 * XT_S + sizeof(double) * XT_NT + sizeof(double) * XT_SPAN * (XT_NT / 64))));
-        }
+        if (ctx->attr_first(1)) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT)));
         if (n_tails > 0) {
             // the sorted words as 32-bit words + residual list (kr_tails_pack); not worth it when many words do not fit
-            // (whole blocks of 256 words: kr_kb_tails_blk reads the last block of the stream to its end)
-            const int64_t xt_nblk = (n_tails + 255) / 256;
-            xt_cw.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(xt_nblk * 256 + 64));
-            xt_hdr.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(xt_nblk * 4 + 4));
-            xt_bhdr.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(xt_nblk + 1));
+            xt_cw.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(n_tails + 64));
+            xt_hdr.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)((n_tails + 63) / 64 + 1));
             xt_res.p = (unsigned long long *)ctx->alloc(sizeof(unsigned long long) * (size_t)(n_tails + 4));
-            if (!xt_cw.p || !xt_hdr.p || !xt_bhdr.p || !xt_res.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: packed tails");
-            HIP_TRY(ctx, hipMemsetAsync(xst.p, 0, sizeof(unsigned long long) * 2, s));
-            // (the words behind the stream's end inside its last block, and the sentinel group base hdr[groups] that lanes past the end
-            // of the stream clamp their group index to -- kr_kb_tails -- are zeros / column 0, not what the pooled block held before)
-            HIP_TRY(ctx, hipMemsetAsync(xt_cw.p + n_tails, 0, sizeof(uint32_t) * (size_t)(xt_nblk * 256 + 64 - n_tails), s));
-            HIP_TRY(ctx, hipMemsetAsync(xt_hdr.p + xt_nblk * 4, 0, sizeof(uint32_t) * 4, s));
-            hipLaunchKernelGGL(kr_tails_pack, dim3((unsigned)std::min<int64_t>(xt_nblk, 16 * (int64_t)ctx->n_cu)), dim3(256), 0, s, n_tails, xt_rbits,
-                               16 + xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, xt_cw.p, xt_hdr.p, xt_bhdr.p, xt_res.p, xst.p, xst.p + 1);
-            unsigned long long nr[2] = {0, 0};
-            { const int rb_ = b3c_readback(ctx, nr, xst.p, sizeof(nr)); if (rb_) return rb_; }
-            xt_n_res = (int64_t)nr[0];
+            if (!xt_cw.p || !xt_hdr.p || !xt_res.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: packed tails");
+            HIP_TRY(ctx, hipMemsetAsync(xst.p, 0, sizeof(unsigned long long), s));
+            // the sentinel hdr[groups]: lanes past the end of the stream clamp their group index to it (kr_kb_tails) -- it must be a
+            // column, not whatever the pooled block held before
+            HIP_TRY(ctx, hipMemsetAsync(xt_hdr.p + (n_tails + 63) / 64, 0, sizeof(uint32_t), s));
+            hipLaunchKernelGGL(kr_tails_pack, dim3((unsigned)std::min<int64_t>(((n_tails + 63) / 64 + 3) / 4, 16 * (int64_t)ctx->n_cu)), dim3(256), 0, s, n_tails, xt_rbits,
+                               16 + xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, xt_cw.p, xt_hdr.p, xt_res.p, xst.p);
+            unsigned long long nr = 0;
+            { const int rb_ = b3c_readback(ctx, &nr, xst.p, sizeof(nr)); if (rb_) return rb_; }
+            xt_n_res = (int64_t)nr;
             xt_packed = xt_n_res * 8 <= n_tails;
-            // by blocks of 256 words (kr_kb_tails_blk) when at least a quarter of them are dense; the row sums of a super-tile and the
-            // waves' operand spans must fit the LDS together (8192-row super-tiles)
-            xt_blk = xt_packed && xt_S == XT_S && (int64_t)nr[1] * 4 >= xt_nblk && CFG.num("B3C_KR_XT_BLK", 1) != 0;
-            if (CFG.on("B3C_KR_DEBUG"))
-                fprintf(stderr, "[b3c] tail pass: %llu of %lld blocks of 256 words span at most %d columns (%s)\n", nr[1], (long long)xt_nblk, XT_SPAN,
-                        xt_blk ? "block form in use" : "word form");
             if (CFG.on("B3C_KR_DEBUG"))
                 fprintf(stderr, "[b3c] tail pass: %lld of %lld words stay 64-bit (%s)\n", (long long)xt_n_res, (long long)n_tails, xt_packed ? "packed stream in use" : "too many: 64-bit stream kept");
         }
@@ -3022,11 +2848,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             const int kbP = dist ? GK : G, kbS = 1;
             double *const w_kb = dist ? D.vec : w.p;             // sharded: KB writes its slice of w straight into the exchange buffer
             if (tcd) {
-                if (tails_xt && xt_blk)
-                    hipLaunchKernelGGL(kr_kb_tails_blk, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem + sizeof(double) * XT_SPAN * (XT_NT / 64), s, s0, pumax.p, GA,
-                                       xt_lg_bound, xt_lo_bits, xt_chunks, n_tails, xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), u.p, yhi.p,
-                                       ylo.p, tex.p, xt_cw.p, xt_hdr.p, xt_bhdr.p, xt_res.p, xt_n_res, xt_st_shift, n);
-                else if (tails_xt)
+                if (tails_xt)
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
                                        xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p,
                                        xt_packed ? xt_cw.p : nullptr, xt_hdr.p, xt_res.p, xt_n_res, xt_st_shift,

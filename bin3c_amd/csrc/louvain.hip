@@ -37,6 +37,12 @@ constexpr int BLK = 256;
 constexpr int WPB = BLK / 64;
 typedef __int128 i128;
 typedef unsigned long long u64;
+// 16-byte loads of entry streams that are only as aligned as their elements (a row starts anywhere).  A CU's texture addresser spends
+// ~26 cycles on every vector-memory instruction of a wave whatever it moves (tools/probes/ta_probe.hip): four consecutive entries
+// per lane and load instead of one.  The streams carry 32 bytes of slack behind their last entry.
+typedef int32_t i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef long long i64x2_u __attribute__((ext_vector_type(2), aligned(8)));
+typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));
 
 __host__ __device__ __forceinline__ uint32_t bucket_of(int64_t i, int n_sub)
 {
@@ -210,35 +216,43 @@ __global__ void __launch_bounds__(BLK) k_lv_init(int64_t n, const int64_t *__res
         for (int64_t off = 0; off < span; off += 256) {
             int32_t j[2][4];
             long long w[2][4];
+            // (four consecutive entries per lane as 16-byte vectors; a lane past the row's end re-reads its beginning and drops it)
             if (wq) {
                 double a[2][4];
 #pragma unroll
-                for (int h = 0; h < 2; h++)
+                for (int h = 0; h < 2; h++) {
+                    const int64_t k0 = rs_[h] + off + 4 * lane, kb = k0 < re_[h] ? k0 : rs_[h];
+                    const i32x4_u jv = *(const i32x4_u *)(indices + kb);
+                    const f64x2_u a0 = *(const f64x2_u *)(wq + kb), a1 = *(const f64x2_u *)(wq + kb + 2);
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
-                        const int64_t k = rs_[h] + off + t * 64 + lane;
-                        const bool ok = k < re_[h];
-                        j[h][t] = ok ? indices[k] : -1;
-                        a[h][t] = ok ? wq[k] : 0.0;
+                        const bool ok = k0 + t < re_[h];
+                        j[h][t] = ok ? jv[t] : -1;
+                        a[h][t] = ok ? (t < 2 ? a0[t] : a1[t - 2]) : 0.0;
                     }
+                }
 #pragma unroll
-                for (int h = 0; h < 2; h++)
+                for (int h = 0; h < 2; h++) {
+                    const int64_t k0 = rs_[h] + off + 4 * lane;
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
-                        const int64_t k = rs_[h] + off + t * 64 + lane;
                         w[h][t] = j[h][t] >= 0 ? __double2ll_rn(ldexp(a[h][t] * wscl, shift)) : 0;
-                        if (j[h][t] >= 0) q_out[k] = w[h][t];
+                        if (j[h][t] >= 0) q_out[k0 + t] = w[h][t];
                     }
+                }
             } else {
 #pragma unroll
-                for (int h = 0; h < 2; h++)
+                for (int h = 0; h < 2; h++) {
+                    const int64_t k0 = rs_[h] + off + 4 * lane, kb = k0 < re_[h] ? k0 : rs_[h];
+                    const i32x4_u jv = *(const i32x4_u *)(indices + kb);
+                    const i64x2_u w0 = *(const i64x2_u *)(q + kb), w1 = *(const i64x2_u *)(q + kb + 2);
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
-                        const int64_t k = rs_[h] + off + t * 64 + lane;
-                        const bool ok = k < re_[h];
-                        j[h][t] = ok ? indices[k] : -1;
-                        w[h][t] = ok ? q[k] : 0;
+                        const bool ok = k0 + t < re_[h];
+                        j[h][t] = ok ? jv[t] : -1;
+                        w[h][t] = ok ? (t < 2 ? w0[t] : w1[t - 2]) : 0;
                     }
+                }
             }
 #pragma unroll
             for (int h = 0; h < 2; h++)
@@ -324,6 +338,24 @@ __device__ __forceinline__ Best best_wave_reduce(Best b)
     r.gain = (i128)(((unsigned __int128)(((u64)m[0] << 32) | m[1]) << 64) | (unsigned __int128)(((u64)m[2] << 32) | m[3]));
     r.com = r.have ? (int32_t)~mc : b.com;
     return r;
+}
+
+// Largest 64-bit value over the LPR lanes of a group, in every lane of the group (all lanes of the wave active).
+template <int LPR>
+__device__ __forceinline__ u64 group_max_u64(u64 v)
+{
+    if constexpr (LPR == 64) {
+        const uint32_t hi = wave_max_u32((uint32_t)(v >> 32));
+        const uint32_t lo = wave_max_u32((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0u);
+        return ((u64)hi << 32) | lo;
+    } else {
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            const u64 t = (u64)__shfl_xor((long long)v, o, LPR);
+            v = t > v ? t : v;
+        }
+        return v;
+    }
 }
 
 struct NodeRec {
@@ -690,16 +722,20 @@ __global__ void __launch_bounds__(NT) k_lv_decide_wg(int64_t cnt_max, const int6
         const int32_t *__restrict__ ci = indices + rec.start;
         const int64_t *__restrict__ qi = q + rec.start;
         long long own = 0;
-        for (int base = tid; base < rec.deg; base += 4 * NT) {
+        // (four CONSECUTIVE entries per thread as 16-byte vectors: one load of ids and two of weights instead of four each -- the
+        // texture addresser charges per instruction; the contender rule of k_lv_decide_g was tried here too: a second pass over the
+        // table and two more barriers per node cost what the saved gathers of tot[] gained -- 172 -> 180 us per launch, not kept)
+        for (int base = 4 * tid; base < rec.deg; base += 4 * NT) {
+            const i32x4_u jv = *(const i32x4_u *)(ci + base);
+            const i64x2_u w0 = *(const i64x2_u *)(qi + base), w1 = *(const i64x2_u *)(qi + base + 2);
             int32_t j[4];
             u64 qv[4];
             int32_t c[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int k = base + u * NT;
-                const bool ok = k < rec.deg;
-                j[u] = ok ? ci[k] : i;
-                qv[u] = ok ? (u64)qi[k] : 0;
+                const bool ok = base + u < rec.deg;
+                j[u] = ok ? jv[u] : i;
+                qv[u] = ok ? (u64)(u < 2 ? w0[u] : w1[u - 2]) : 0;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) c[u] = j[u] != i ? com[j[u]] : EMPTY;
@@ -976,28 +1012,6 @@ __global__ void k_lv_list_fill(int64_t r0, int64_t r1, int n_sub, LvThr thr, int
 __global__ void k_lv_list_bounds(int n_seg, int64_t nloc, const int64_t *__restrict__ pos, int64_t *__restrict__ bnd)
 {
     for (int t = threadIdx.x; t <= n_seg; t += blockDim.x) bnd[t] = pos[(int64_t)t * nloc];
-}
-
-// 16-byte loads of entry streams that are only as aligned as their elements (a row starts anywhere)
-typedef int32_t i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef long long i64x2_u __attribute__((ext_vector_type(2), aligned(8)));
-
-// Largest 64-bit value over the LPR lanes of a group, in every lane of the group (all lanes of the wave active).
-template <int LPR>
-__device__ __forceinline__ u64 group_max_u64(u64 v)
-{
-    if constexpr (LPR == 64) {
-        const uint32_t hi = wave_max_u32((uint32_t)(v >> 32));
-        const uint32_t lo = wave_max_u32((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0u);
-        return ((u64)hi << 32) | lo;
-    } else {
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) {
-            const u64 t = (u64)__shfl_xor((long long)v, o, LPR);
-            v = t > v ? t : v;
-        }
-        return v;
-    }
 }
 
 // The grouped neighbour scan gathers ONE 4-byte label per stored neighbour and nothing else (round 5).
@@ -1725,19 +1739,25 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
         }
         long long mine[2] = {0, 0};                           // weight towards the other members of the own community
         const int64_t span = (re_[0] - rs_[0]) > (re_[1] - rs_[1]) ? (re_[0] - rs_[0]) : (re_[1] - rs_[1]);
-        // four 64-entry slices per row in flight: index and weight loads first, then the label gathers (integer sums: any order)
+        // 256 entries per row in flight, four CONSECUTIVE ones per lane as 16-byte vectors (the texture addresser charges per
+        // instruction, not per byte: one load of ids and two of weights instead of four each; a lane past the row's end re-reads its
+        // beginning and drops it): index and weight loads first, then the label gathers (integer sums: any order)
         for (int64_t off = 0; off < span; off += 256) {
             int32_t j[2][4];
             long long w[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; h++)
+            for (int h = 0; h < 2; h++) {
+                const int64_t k0 = rs_[h] + off + 4 * lane;
+                const int64_t kb = k0 < re_[h] ? k0 : rs_[h];
+                const i32x4_u jv = *(const i32x4_u *)(indices + kb);
+                const i64x2_u w0 = *(const i64x2_u *)(q + kb), w1 = *(const i64x2_u *)(q + kb + 2);
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    const int64_t k = rs_[h] + off + t * 64 + lane;
-                    const bool ok = k < re_[h];
-                    j[h][t] = ok ? indices[k] : -1;
-                    w[h][t] = ok ? q[k] : 0;
+                    const bool ok = k0 + t < re_[h];
+                    j[h][t] = ok ? jv[t] : -1;
+                    w[h][t] = ok ? (t < 2 ? w0[t] : w1[t - 2]) : 0;
                 }
+            }
             int32_t c[2][4];
 #pragma unroll
             for (int h = 0; h < 2; h++)

@@ -279,31 +279,6 @@ def test_tail_pass_layouts_of_far_maps(ctx, oracle_lib, monkeypatch, env):
     cm.free()
 
 
-@pytest.mark.parametrize('genome_law', ['sqrt', 'survey'])
-def test_tail_pass_by_blocks_of_256_words(ctx, oracle_lib, monkeypatch, genome_law):
-    """kr_kb_tails_blk (round 5): a wave takes 256 consecutive words and fetches the operands of a DENSE block (columns spanning at
-    most 128) with one 16-byte load per lane instead of one gather per word; sparse blocks gather per word.  Same fixed-point
-    sums: x is bit for bit the word form's (B3C_KR_XT_BLK=0), the iteration count the oracle's, x within 1e-9 of it.  Two maps:
-    many small genomes (blocks of inter-genome noise: mostly sparse) and the surveyed genome-size law (one genome with a third of
-    the contigs: its tiles keep no dictionary and their tails are dense blocks)."""
-    from bin3c_amd.synth import make_synth
-    sm = make_synth(40000, 1300000, 41, genome_law=genome_law)
-    nd = oracle_lib.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
-    rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
-    assert rc == oracle_lib.OK
-    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
-    monkeypatch.setenv('B3C_KR_TCD_XT', '1')
-    monkeypatch.setenv('B3C_KR_XT_BLK', '0')
-    _, x0, i0 = ctx.kr_balance_counts(cm, sm.sites)
-    monkeypatch.delenv('B3C_KR_XT_BLK')
-    _, x, info = ctx.kr_balance_counts(cm, sm.sites)
-    assert info.tcd_xt_tails > 0 and info.tcd_xt_tails == i0.tcd_xt_tails
-    assert info.n_iter == st.n_iter == i0.n_iter
-    np.testing.assert_allclose(x, xo, rtol=1e-9)
-    assert np.array_equal(x, x0)
-    cm.free()
-
-
 def test_symmetry_guard_fast_and_exact_paths(ctx):
     """Checksum path (bitwise symmetric), exact path (asymmetric beyond tol, and within tol but not bitwise)."""
     g = np.load(os.path.join(GOLDEN, 'kr_random1000.npz'))

@@ -8,11 +8,11 @@ import torch
 from bin3c_amd.pipeline import make_context
 from bin3c_amd.synth import CONFIGS, make_edges
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'C3'
-variants = sys.argv[2:] or ['B3C_KR_NO_TCD=1', '', 'B3C_KR_TCD_XT=0', 'B3C_KR_TCD_R=128,B3C_KR_TCD_DCAP=4096', 'B3C_KR_TCD_NOSWZ=1']
-os.environ['B3C_KR_TCD'] = '1'
+variants = sys.argv[2:] or ['B3C_KR_NO_TCD=1', '', 'B3C_KR_TCD_XT=0', 'B3C_KR_TCD_P24=0', 'B3C_KR_TCD_MINUSE8=0']
+genome_law = os.environ.get('TCD_PROBE_LAW', 'survey')      # the contract workload unless told otherwise
 n, E, seed, law = CONFIGS[cfg]
 ctx = make_context(0)
-lo, hi, cnt, diag, lengths_h, sites_h, _g = make_edges(n, E, seed, law)
+lo, hi, cnt, diag, lengths_h, sites_h, _g = make_edges(n, E, seed, law, genome_law=genome_law)
 counts, e_true = ctx.coo_symmetrise(n, lo, hi, cnt, diag)
 del lo, hi, cnt
 n2o, o2n = ctx.locality_order(counts)
@@ -28,7 +28,7 @@ for var in variants:
             keys.append(k)
     ctx.reload_env()          # libb3c reads its switches once per context
     for rep in range(2):
-        t = time.time(); rc, x, info = ctx.kr_balance_counts(work, sites, max_iter=30 if "PROBE" in var else 1000, check=False); dt = time.time() - t
+        t = time.time(); rc, x, info = ctx.kr_balance_counts(work, sites, max_iter=1000, check=False); dt = time.time() - t
     print('%-40s KR %.2f ms, spmv avg %.1f us over %d, n_iter %d; tiles %d dmax %d dmean %.0f tails %.1f%%' % (
         var or '(default)', dt * 1e3, info.spmv_ms / max(info.n_spmv, 1) * 1e3, info.n_spmv, info.n_iter, info.tcd_tiles,
         info.tcd_dict_max, info.tcd_dict_total / max(1, info.tcd_tiles), 100.0 * info.tcd_tail_entries / work.nnz), flush=True)
