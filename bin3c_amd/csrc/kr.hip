@@ -1513,7 +1513,8 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
                                                    double *__restrict__ part_out, int hub_len,
                                                    unsigned long long *__restrict__ tlog,
                                                    unsigned long long *__restrict__ yhi, int *__restrict__ ylo, const int *__restrict__ tex,
-                                                   const double *__restrict__ corr, const uint32_t *__restrict__ p24, const int64_t *__restrict__ g24)
+                                                   const double *__restrict__ corr, const uint32_t *__restrict__ p24, const int64_t *__restrict__ g24,
+                                                   const int32_t *__restrict__ tile_list)
 {
     // XT: the tails are summed by kr_kb_tails beforehand (fixed point in yhi / ylo, exponent tex[0]); all eight waves run
     // dictionary rows here and the epilogue converts the row's tail sum and clears it for the next SpMV
@@ -1524,12 +1525,14 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
     double *lds = (double *)(ipl + R + 1);    // TBK doubles for the reductions
     int32_t *n1l = (int32_t *)(lds + TBK);    // R dictionary-entry counts
     int32_t *g24l = n1l + R;                  // P24: R + 1 group offsets of the rows in the 24-bit stream, relative to the tile's first
+    // tile_list (round 5): the launch covers the listed tiles only -- those WITH a dictionary; the others are kr_kb_epi's
     int64_t tile = blockIdx.x;
     if (swz) {
         const int per = (ntiles + 7) / 8;
         tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
     }
     const bool live = tile < ntiles;          // padding blocks of the swizzled grid carry no tile
+    if (tile_list && live) tile = tile_list[tile];
     const int tid = threadIdx.x;
     const long long tl0 = tlog ? wall_clock64() : 0;      // B3C_KR_TCD_TLOG: phase timeline of every tile (100 MHz ticks)
     const int64_t ra = r0 + (live ? tile : 0) * R;
@@ -1805,6 +1808,84 @@ __global__ void __launch_bounds__(TBK) kr_kb_tcd2(int64_t r0, int64_t r1, int64_
             tlog[tile * 8 + 6] = (unsigned long long)wall_clock64();
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tiles WITHOUT a dictionary get their epilogue from a kernel of their own (round 5).  On the contract workload (the surveyed
+// genome-size law at C3) four tiles in five keep no dictionary -- every entry of theirs is summed by the tail pass -- and
+// kr_kb_tcd2 was, for them, a 512-thread workgroup holding 50 KB of LDS (three per CU) to run a 192-row epilogue behind two
+// dependent round trips.  Here such a tile is 256 threads and a few bytes of LDS, eight workgroups per CU; kr_kb_tcd2 runs over
+// the list of the tiles that do have a dictionary.  Both write the partials of THEIR tiles (part_out is indexed by tile) and both
+// carry the control state forward identically.  kr_tile_lists sorts the tiles once per balance call.
+// ---------------------------------------------------------------------------------------------
+__global__ void kr_tile_lists(int ntiles, const int32_t *__restrict__ dict_cnt, int32_t *__restrict__ with_dict, int32_t *__restrict__ without,
+                              unsigned int *__restrict__ counts)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    // (any order inside a list: a tile's result does not depend on which workgroup computes it)
+    if (dict_cnt[t] > 0) with_dict[atomicAdd(&counts[0], 1u)] = t;
+    else without[atomicAdd(&counts[1], 1u)] = t;
+}
+
+__global__ void __launch_bounds__(BLK) kr_kb_epi(int64_t r0, int64_t r1, int R, int ntl, const int32_t *__restrict__ tile_list,
+                                                  const KRState *__restrict__ sin, KRState *__restrict__ sout,
+                                                  const double *__restrict__ partA, int PA, int PS, const int64_t *__restrict__ indptr,
+                                                  const double *__restrict__ rs, const double *__restrict__ dfix,
+                                                  const double *__restrict__ x, const double *__restrict__ p, double *__restrict__ v,
+                                                  double *__restrict__ rk, double *__restrict__ w, double *__restrict__ part_out, int hub_len,
+                                                  unsigned long long *__restrict__ yhi, int *__restrict__ ylo, const int *__restrict__ tex,
+                                                  const double *__restrict__ corr)
+{
+    __shared__ double lds[BLK];
+    const int tid = threadIdx.x;
+    const int64_t tile = tile_list[blockIdx.x < ntl ? blockIdx.x : 0];
+    const int64_t ra = r0 + tile * R;
+    const int nrows = (int)((ra + R < r1 ? ra + R : r1) - ra);
+    // everything that does not depend on the control state is requested first
+    double ex = 0.0, ed = 0.0, er = 1.0, ep = 0.0, ev = 0.0, ec = 0.0;
+    long long xt_h = 0;
+    int xt_l = 0, xt_e = 0, xt_lb = 20;
+    bool hub = false;
+    if (tid < nrows) {
+        const int64_t row = ra + tid;
+        ex = x[row];
+        ed = dfix[row];
+        er = rs ? rs[row] : 1.0;
+        ep = p[row];
+        ev = v[row];
+        if (corr) ec = corr[row];
+        hub = indptr[row + 1] - indptr[row] > hub_len;      // hub rows are written by kr_kb_hub
+        xt_h = (long long)yhi[row - r0];
+        xt_l = ylo[row - r0];
+        xt_e = tex[0];
+        xt_lb = tex[1];
+    }
+    const KBMode md = kb_enter(sin, sout, partA, PA, PS, lds,
+                               [](const double *pp, int P, int S, double *l) { return reduce_partials<0>(pp, P, S, l); });
+    if (!md.run) return;                        // no SpMV in this tick
+    double contrib = 0.0;
+    if (tid < nrows && !hub) {
+        const int64_t row = ra + tid;
+        const double pi = md.inner ? ep : 0.0;
+        double tails = ldexp((double)xt_h, -xt_e) + ldexp((double)xt_l, -(xt_e + xt_lb));
+        if (xt_h) yhi[row - r0] = 0ull;
+        if (xt_l) ylo[row - r0] = 0;
+        tails += ec;                                        // the part of counts beyond 65535 the packed words leave out
+        const double t = (0.0 + tails) * er + ed * (md.inner ? ex * pi : ex);
+        if (md.inner) {
+            const double wi = ex * t + ev * pi;
+            w[row] = wi;
+            contrib = pi * wi;
+        } else {
+            const double vn = ex * t;
+            const double r = 1.0 - vn;
+            v[row] = vn;
+            rk[row] = r;
+            contrib = r * r;
+        }
+    }
+    block_partial_at<0>(contrib, part_out, tile, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2609,6 +2690,22 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             fprintf(stderr, "[b3c] dictionary layout: %lld tiles of %d rows, largest dictionary %llu (cap %d), mean %.0f, %.1f %% of the entries in tails\n",
                     (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles, 100.0 * (double)hst[3] / (double)a->nnz);
     }
+    // tiles with / without a dictionary, listed once: with the tail pass on, the latter get their epilogue from kr_kb_epi when they
+    // are at least a quarter of the tiles (the contract workload: four in five)
+    DevBuf<int32_t> tl_with(ctx, tcd ? tcd_tiles : 1), tl_without(ctx, tcd ? tcd_tiles : 1);
+    int64_t n_tl_with = 0, n_tl_without = 0;
+    bool tile_split = false;
+    if (tcd && xt_want && tcd_tiles < (1ll << 31)) {
+        DevBuf<unsigned int> tlc(ctx, 2);
+        if (!tl_with.p || !tl_without.p || !tlc.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: tile lists");
+        HIP_TRY(ctx, hipMemsetAsync(tlc.p, 0, sizeof(unsigned int) * 2, s));
+        hipLaunchKernelGGL(kr_tile_lists, dim3((unsigned)((tcd_tiles + 255) / 256)), dim3(256), 0, s, (int)tcd_tiles, dict_cnt.p, tl_with.p, tl_without.p, tlc.p);
+        unsigned int hcnt[2] = {0, 0};
+        { const int rb_ = b3c_readback(ctx, hcnt, tlc.p, sizeof(hcnt)); if (rb_) return rb_; }
+        n_tl_with = hcnt[0];
+        n_tl_without = hcnt[1];
+        tile_split = n_tl_without * 4 >= tcd_tiles;
+    }
     // ---- tails as their own pass (kr_kb_tails): column-ordered tail words per super-tile, fixed-point row sums ----
     // n < 2^24 (24-bit columns in a tail word), 512-thread dictionary kernel; automatic for n > 2^19.  Sharded path: every
     // rank has the tails of ITS rows (the operand vector and its maximum are complete on every rank after KA)
@@ -2854,11 +2951,16 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                                        xt_packed ? xt_cw.p : nullptr, xt_hdr.p, xt_res.p, xt_n_res, xt_st_shift,
                                        n_tails < (1ll << 29) ? 1 : 0, n);    // (32-bit byte offsets inside a chunk of the packed stream)
                 // dictionary waves and tail waves side by side (512-thread workgroups)
+                const bool split = tile_split && tails_xt;      // dictionary tiles by list, the others by kr_kb_epi
+                if (split && n_tl_without)
+                    hipLaunchKernelGGL(kr_kb_epi, dim3((unsigned)n_tl_without), dim3(BLK), 0, s, r0, r1, tcd_R, (int)n_tl_without, tl_without.p, s0, s1, kbp, kbP, kbS,
+                                       a->indptr, rs, dfix.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, yhi.p, ylo.p, tex.p, corr_p);
 #define KR_TCD2_ARGS                                                                                                         \
-    dim3((unsigned)tcd_grid), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap, (int)tcd_tiles, tcd_swz ? 1 : 0, s0, s1, kbp, \
+    dim3((unsigned)(split ? std::max<int64_t>(n_tl_with, 1) : tcd_grid)), dim3(TBK), tcd_shmem2, s, r0, r1, n, tcd_R, tcd_lds_d, tcd_dcap,     \
+        (int)(split ? n_tl_with : tcd_tiles), (!split && tcd_swz) ? 1 : 0, s0, s1, kbp,                                                        \
         kbP, kbS, a->indptr, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len,     \
         want_tlog ? tlog.p : nullptr, tails_xt ? yhi.p : nullptr, tails_xt ? ylo.p : nullptr, tails_xt ? tex.p : nullptr, corr_p,       \
-        tcd_24 ? tcd_p24.p : nullptr, tcd_24 ? g24off.p : nullptr
+        tcd_24 ? tcd_p24.p : nullptr, tcd_24 ? g24off.p : nullptr, split ? tl_with.p : (const int32_t *)nullptr
 #define KR_TCD2(L, U, TL, T)                                                                                                 \
     do {                                                                                                                     \
         if (tails_xt && tcd_24) hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, true, true>), KR_TCD2_ARGS);                     \

@@ -1,6 +1,6 @@
 """Resource usage (VGPRs, scratch, LDS, occupancy) of every kernel of libb3c: hipcc -Rpass-analysis=kernel-resource-usage.
 
-    python tools/resource_usage.py [file.hip ...] [--scratch-only]
+    python tools/resource_usage.py [file.hip ...] [--scratch-only] [--all]
 
 tools/profile_round.sh writes its output to profiles/<round>_resource_usage.txt, so that a stack object that lands in
 scratch (round 2: a 128-byte KRState copy in every lane of kr_kb_tcd2) is seen in the round it appears.
@@ -60,15 +60,21 @@ def main():
     files = args or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
     print('{:<78} {:>5} {:>5} {:>7} {:>7} {:>4}'.format('kernel', 'VGPR', 'AGPR', 'scratch', 'LDS', 'occ'))
     bad = 0
+    lib_only = '--all' not in sys.argv      # libb3c's own kernels; --all adds the rocPRIM / hipCUB template instantiations (sorts, scans)
+    skipped = 0
     for f in files:
         for r in usage(f):
             sc = int(r.get('ScratchSize [bytes/lane]', '0'))
+            third_party = r['name'].startswith(('rocprim::', 'hipcub::', 'thrust::')) or '::detail::' in r['name']
+            if lib_only and third_party:
+                skipped += 1
+                continue
             bad += sc > 0
             if scratch_only and sc == 0:
                 continue
             print('{:<78} {:>5} {:>5} {:>7} {:>7} {:>4}'.format(r['name'][:78], r.get('VGPRs', '?'), r.get('AGPRs', '?'), sc,
                                                               r.get('LDS Size [bytes/block]', '?'), r.get('Occupancy [waves/SIMD]', '?')))
-    print('# kernels with scratch: {}'.format(bad))
+    print('# kernels with scratch: {}{}'.format(bad, ' ({} rocPRIM / hipCUB instantiations not listed: --all)'.format(skipped) if lib_only else ''))
 
 
 if __name__ == '__main__':
