@@ -1185,37 +1185,49 @@ __global__ void __launch_bounds__(256) kr_tails_emit(int64_t r0, int64_t r1, int
 // than 8 bits stays a 64-bit word in a short residual list (its slot in the stream becomes a zero: no contribution), which the
 // kernel adds straight into the global row sums.  All sums are integer sums: x stays bit for bit what the 64-bit stream gives.
 constexpr int XT_PACK_CB = 8;           // count bits of a packed word
+// Where the sorted word k sits in the packed stream (round 5): blocks of 256 words, word 64 c + l of a block at 4 l + c -- ONE
+// 16-byte load hands lane l the l-th word of each of the block's four groups of 64, so the four gathers of a wave still walk 64
+// neighbouring columns each while the words cost one vector-memory instruction instead of four (the addresser charges per
+// instruction, tools/probes/ta_probe.hip).  hdr[] stays indexed by sorted group (k >> 6).
+__device__ __forceinline__ int64_t xt_pos(int64_t k) { return (k & ~255ll) + ((k & 63) << 2) + ((k >> 6) & 3); }
+
 __global__ void __launch_bounds__(256) kr_tails_pack(int64_t n_tails, int rbits, int cshift, uint32_t cmask,
                                                       const unsigned long long *__restrict__ words, uint32_t *__restrict__ cw,
                                                       uint32_t *__restrict__ hdr, unsigned long long *__restrict__ rwords,
                                                       unsigned long long *__restrict__ n_res)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t groups = (n_tails + 63) >> 6;
+    const int64_t blocks = (n_tails + 255) >> 8;
     const int db = 32 - rbits - XT_PACK_CB;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += (int64_t)gridDim.x * 4) {
-        const int64_t k = g * 64 + lane;
-        const bool valid = k < n_tails;
-        const unsigned long long w = valid ? words[k] : 0ull;
-        const uint32_t col = (uint32_t)(w >> cshift) & cmask;
-        uint32_t base = valid ? col : 0xFFFFFFFFu;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < blocks; b += (int64_t)gridDim.x * 4) {
+        u32x4 out;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t t = (uint32_t)__shfl_xor((int)base, o, 64);
-            base = t < base ? t : base;
+        for (int c4 = 0; c4 < 4; c4++) {
+            const int64_t k = b * 256 + c4 * 64 + lane;
+            const bool valid = k < n_tails;
+            const unsigned long long w = valid ? words[k] : 0ull;
+            const uint32_t col = (uint32_t)(w >> cshift) & cmask;
+            uint32_t base = valid ? col : 0xFFFFFFFFu;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t = (uint32_t)__shfl_xor((int)base, o, 64);
+                base = t < base ? t : base;
+            }
+            if (base == 0xFFFFFFFFu) base = 0u;                       // a group past the end of the stream: zero words, column 0
+            const uint32_t c = (uint32_t)(w & 0xFFFFu), r = (uint32_t)(w >> 16) & ((1u << rbits) - 1u), d = col - base;
+            const bool fits = valid && c != 0 && d < (1u << db) && c < (1u << XT_PACK_CB);
+            const bool res = valid && c != 0 && !fits;
+            out[c4] = fits ? (d << (rbits + XT_PACK_CB)) | (r << XT_PACK_CB) | c : 0u;
+            if (lane == 0) hdr[b * 4 + c4] = base;
+            const unsigned long long m = __ballot(res);
+            if (m) {
+                unsigned long long at = 0;
+                if (lane == 0) at = atomicAdd(n_res, (unsigned long long)__popcll(m));
+                at = (unsigned long long)__shfl((long long)at, 0, 64);
+                if (res) rwords[at + __popcll(m & ((1ull << lane) - 1ull))] = w;
+            }
         }
-        const uint32_t c = (uint32_t)(w & 0xFFFFu), r = (uint32_t)(w >> 16) & ((1u << rbits) - 1u), d = col - base;
-        const bool fits = valid && c != 0 && d < (1u << db) && c < (1u << XT_PACK_CB);
-        const bool res = valid && c != 0 && !fits;
-        if (valid) cw[k] = fits ? (d << (rbits + XT_PACK_CB)) | (r << XT_PACK_CB) | c : 0u;
-        if (lane == 0) hdr[g] = base;
-        const unsigned long long m = __ballot(res);
-        if (m) {
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(n_res, (unsigned long long)__popcll(m));
-            at = (unsigned long long)__shfl((long long)at, 0, 64);
-            if (res) rwords[at + __popcll(m & ((1ull << lane) - 1ull))] = w;
-        }
+        *(u32x4 *)(cw + b * 256 + 4 * lane) = out;
     }
 }
 
@@ -1302,38 +1314,40 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
         //    round trip instead of two dependent ones (four waves per SIMD: 0.407 -> 0.368 ms per SpMV on the surveyed law by itself).
         if (pipe) {
             const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            const int B = (int)(s0 & 63);
-            const int64_t nw = e0 > s0 ? e0 - s0 : 0;                       // (< 2^29 words: the host checks the longest chunk)
-            const int64_t hlast = (n_tails + 63) >> 6;                     // hdr[] has hlast + 1 entries
-            const int64_t g0 = ((s0 - B) >> 6) + wave;
-            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(cw + s0), 0, (int)(nw * 4), 0x00020000);
+            const int lane = (int)(threadIdx.x & 63);
+            const int64_t nblk_all = (n_tails + 255) >> 8;                 // hdr[] has 4 * nblk_all + 4 entries, the last four zero
+            const int64_t bs = s0 >> 8, be = e0 > s0 ? (e0 + 255) >> 8 : bs; // the 256-word blocks the chunk touches (< 2^21: the host checks the longest chunk)
+            const int nb = (int)(be - bs);
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(cw + bs * 256), 0, nb * 1024, 0x00020000);
             // (the operand vector holds ncols doubles -- not 2^cbits: a gather beyond it reads zero instead of the next pooled block)
             const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, (int)(ncols * 8), 0x00020000);
-            const int steps = (int)((B + nw + 4 * XT_NT - 1) / (4 * XT_NT));
+            const int steps = (nb + 15) >> 4;
             const int csh = rbits + XT_PACK_CB;
-            uint32_t voff = (uint32_t)((int)threadIdx.x - B) * 4u;
-            uint32_t wn[4], hn[4];
+            // one block of 256 words per wave and step: lane l holds word 64 c + l of it in component c (xt_pos)
+            u32x4 wn, hn;
             auto fetch = [&](int st) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    uint32_t off = voff + (uint32_t)q * (XT_NT * 4u);
-                    if (st == 0 && (int32_t)off < 0) off = 0x80000000u;      // lanes before the chunk (first step only): beyond any descriptor, no wrap-around in its range test
-                    wn[q] = __builtin_amdgcn_raw_buffer_load_b32(rw, off, 0, 0);
-                    int64_t gi = g0 + 16 * q + 64 * (int64_t)st;
-                    gi = gi < hlast ? gi : hlast;
-                    hn[q] = hdr[gi];
-                }
-                voff += 4u * XT_NT * 4u;
+                const int blk = __builtin_amdgcn_readfirstlane(16 * st + wave);
+                wn = __builtin_amdgcn_raw_buffer_load_b128(rw, (uint32_t)(blk * 1024 + lane * 16), 0, 0);   // beyond the chunk's blocks: zeros
+                int64_t gi = bs + blk;
+                gi = gi < nblk_all ? gi : nblk_all;
+                hn = *(const u32x4 *)(hdr + 4 * gi);                          // uniform: one scalar load of the four base columns
             };
             fetch(0);
             for (int st = 0; st < steps; st++) {
-                uint32_t w[4];
+                u32x4 w = wn;
+                const u32x4 hb = hn;
                 u32x2 gw[4];
+                const int64_t i0 = (bs + 16 * st + wave) * 256;
+                if (i0 < s0 || i0 + 256 > e0) {
+                    // first / last block of the chunk: the words outside [s0, e0) belong to a neighbour
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    w[q] = wn[q];
-                    gw[q] = __builtin_amdgcn_raw_buffer_load_b64(ru, ((w[q] >> csh) + hn[q]) << 3, 0, 0);
+                    for (int q = 0; q < 4; q++) {
+                        const int64_t i = i0 + 64 * q + lane;
+                        if (i < s0 || i >= e0) w[q] = 0u;
+                    }
                 }
+#pragma unroll
+                for (int q = 0; q < 4; q++) gw[q] = __builtin_amdgcn_raw_buffer_load_b64(ru, ((w[q] >> csh) + hb[q]) << 3, 0, 0);
                 fetch(st + 1);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -1353,7 +1367,7 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int64_t k = kb + q * XT_NT;
-                wn[q] = k < e0 ? cw[k] : 0u;
+                wn[q] = k < e0 ? cw[xt_pos(k)] : 0u;
                 hn[q] = k < e0 ? hdr[k >> 6] : 0u;
             }
         };
@@ -2787,15 +2801,16 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (ctx->attr_first(1)) HIP_TRY(ctx, hipFuncSetAttribute((const void *)kr_kb_tails, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * XT_S_BIG + sizeof(double) * XT_NT)));
         if (n_tails > 0) {
             // the sorted words as 32-bit words + residual list (kr_tails_pack); not worth it when many words do not fit
-            xt_cw.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(n_tails + 64));
-            xt_hdr.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)((n_tails + 63) / 64 + 1));
+            const int64_t xt_blocks = (n_tails + 255) / 256;            // the stream is laid out in blocks of 256 words (xt_pos)
+            xt_cw.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(xt_blocks * 256 + 256));
+            xt_hdr.p = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)(xt_blocks * 4 + 4));
             xt_res.p = (unsigned long long *)ctx->alloc(sizeof(unsigned long long) * (size_t)(n_tails + 4));
             if (!xt_cw.p || !xt_hdr.p || !xt_res.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: packed tails");
             HIP_TRY(ctx, hipMemsetAsync(xst.p, 0, sizeof(unsigned long long), s));
-            // the sentinel hdr[groups]: lanes past the end of the stream clamp their group index to it (kr_kb_tails) -- it must be a
-            // column, not whatever the pooled block held before
-            HIP_TRY(ctx, hipMemsetAsync(xt_hdr.p + (n_tails + 63) / 64, 0, sizeof(uint32_t), s));
-            hipLaunchKernelGGL(kr_tails_pack, dim3((unsigned)std::min<int64_t>(((n_tails + 63) / 64 + 3) / 4, 16 * (int64_t)ctx->n_cu)), dim3(256), 0, s, n_tails, xt_rbits,
+            // the sentinel block hdr[4 * blocks ..]: waves past the end of the stream clamp their block index to it (kr_kb_tails) -- it
+            // must hold columns, not whatever the pooled block held before
+            HIP_TRY(ctx, hipMemsetAsync(xt_hdr.p + xt_blocks * 4, 0, 4 * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(kr_tails_pack, dim3((unsigned)std::min<int64_t>((xt_blocks + 3) / 4, 16 * (int64_t)ctx->n_cu)), dim3(256), 0, s, n_tails, xt_rbits,
                                16 + xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, xt_cw.p, xt_hdr.p, xt_res.p, xst.p);
             unsigned long long nr = 0;
             { const int rb_ = b3c_readback(ctx, &nr, xst.p, sizeof(nr)); if (rb_) return rb_; }

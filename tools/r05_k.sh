@@ -1,5 +1,5 @@
 #!/bin/bash
-out=gpurun_out/r05j
+out=gpurun_out/r05k
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 1200 python -m pytest tests/test_gpu_kr.py tests/test_gpu_fuzz.py tests/test_gpu_louvain.py "tests/test_gpu_fullsize.py::test_full_size_matches_the_oracle" tests/test_gpu_big.py -m gpu -x -q --durations=5 > $out/tests.log 2>&1

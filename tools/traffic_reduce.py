@@ -62,9 +62,10 @@ if fp:
 source = ('profiles/%s_%s_FETCH_SIZE.csv, profiles/%s_%s_WRITE_SIZE.csv (rocprofv3 --pmc, one counter per pass, bench.py --steps 1 --warmup 0 on: %s)'
           % (rnd, tag, rnd, tag, wl))
 
-# one SpMV = all launches of one product: kr_kb_tails + kr_kb_tcd2 (+ kr_kb_hub), or the CSR row kernel
+# one SpMV = all launches of one product: kr_kb_tails + kr_kb_tcd2 (+ kr_kb_epi for the tiles without a dictionary, + kr_kb_hub),
+# or the CSR row kernel
 det, tot, na, nt = {}, 0.0, 0, 0
-parts = [k for k in ('kr_kb_tails', 'kr_kb_tcd2', 'kr_kb_hub', 'kr_kb_vec', 'kr_kb_pipe') if k in kernels]
+parts = [k for k in ('kr_kb_tails', 'kr_kb_tcd2', 'kr_kb_epi', 'kr_kb_hub', 'kr_kb_vec', 'kr_kb_pipe') if k in kernels]
 for k in parts:
     f_, a_, t_ = active('FETCH_SIZE', k)
     w_, _, _ = active('WRITE_SIZE', k)
