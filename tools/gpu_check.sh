@@ -1,5 +1,8 @@
 #!/bin/bash
-out=gpurun_out/r05k
+# GPU box: the quick check after a kernel change -- the KR / fuzz / Louvain / full-size-oracle / big-map tests, one default bench line
+# (contract workload + variant leg, no CPU baseline) and a kernel trace of three C3 steps.
+# usage (from the build container): tools/gpu_retry.sh 2400 'bash tools/gpu_check.sh <tag>'   (outputs under gpurun_out/<tag>/)
+out=gpurun_out/${1:-check}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 1200 python -m pytest tests/test_gpu_kr.py tests/test_gpu_fuzz.py tests/test_gpu_louvain.py "tests/test_gpu_fullsize.py::test_full_size_matches_the_oracle" tests/test_gpu_big.py -m gpu -x -q --durations=5 > $out/tests.log 2>&1

@@ -9,9 +9,11 @@ tag=$1
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-REGEX="kr_kb_vec|kr_kb_tails|kr_kb_tcd2|kr_prep_counts|k_lv_decide_g|k_lv_first_g"
+REGEX="kr_kb_vec|kr_kb_tails|kr_kb_tcd2|kr_kb_epi|kr_prep_counts|k_lv_decide_g|k_lv_first_g"
 timeout 900 python bench.py --config C3 --steps 5 --warmup 2 > $out/bench_c3.json 2> $out/bench_c3.err
 timeout 300 python bench.py --config C2 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_c2.json 2> $out/bench_c2.err
+# the line in the form the driver runs it
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_c3_driver_form.json 2> $out/bench_c3_driver_form.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c3 -- python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --no-variant-leg > $out/trace_c3.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c3_variant -- python bench.py --config C3 --synth sqrt --steps 3 --warmup 1 --no-cpu-baseline > $out/trace_c3_variant.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2 -- python bench.py --config C2 --steps 10 --warmup 3 --no-cpu-baseline --no-variant-leg > $out/trace_c2.log 2>&1
@@ -29,6 +31,9 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c
 # SQ / TA / TCP counter groups of the Louvain neighbour scan
 B3C_PMC_KERNEL="k_lv_decide_g" bash tools/pmc_kr.sh $tag/lv > $out/pmc_lv.log 2>&1
 python tools/pmc_reduce.py $out/lv > $out/k_lv_decide_g_counters.txt 2>&1
+# ... and of the tail pass of the SpMV
+B3C_PMC_KERNEL="kr_kb_tails" bash tools/pmc_kr.sh $tag/tails > $out/pmc_tails.log 2>&1
+python tools/pmc_reduce.py $out/tails > $out/kr_kb_tails_counters.txt 2>&1
 # VGPRs / scratch / LDS / occupancy of every kernel as compiled (a stack object in scratch shows up here, not in a timing)
 timeout 900 python tools/resource_usage.py > $out/resource_usage.txt 2>&1
 for f in bench_c3 bench_c2 bench_c3_variant bench_c2_hard bench_c2_variant bench_c5 bench_c5_unique; do tail -1 $out/$f.json | python tools/bsum.py; done
