@@ -129,15 +129,17 @@ def main():
                     help="'same': the oracle on the very map the GPU ran (about two minutes at C3); 'sample': on a bounded "
                          "sample of the same generator (n = 200k, E = 10M)")
     ap.add_argument('--mode', default='auto', choices=['auto', 'sharded', 'replicas'], help='N > 1 only')
-    ap.add_argument('--synth', default='survey', choices=['survey', 'sqrt'],
+    ap.add_argument('--synth', default=None, choices=['survey', 'sqrt'],
                     help="genome layout of the synthetic map: 'survey' (default, the contract workload) = SURVEY.md 8(d) to the letter, "
                          "G = n/200 genomes ~ Zipf(1.5); 'sqrt' = the variant rounds 1-4 were tuned on, G = n/500 genomes ~ rank^-0.5 "
-                         "(runs as a labelled extra leg, \"variant_workload\", after the headline)")
+                         "(runs as a labelled extra leg, \"variant_workload\", after the headline).  '--config C5 --c5-counts unique' "
+                         "defaults to 'sqrt' (the map of rounds 3-4): on the survey's law the device draw stream ran out of GPU memory before it "
+                         "reached 1e9 UNIQUE edges (round 5; most genomes there hold under 10 contigs and saturate)")
     ap.add_argument('--c5-counts', default='summed-draws', choices=['unique', 'summed-draws'],
                     help="power-law maps: 'summed-draws' (default; SURVEY 8(d): duplicates summed) = the stated number of DRAWS with "
                          "duplicates summed, the host generator's rule (C5: 4.6e8 edges whose hub pairs carry counts of 10^5..10^6 -- about "
                          "2,450 KR iterations); 'unique' = the stated number of UNIQUE edges, one count per pair (an easier map for KR: "
-                         "report it as an additional, labelled line only)")
+                         "report it as an additional, labelled line only; on the VARIANT genome-size law unless --synth says otherwise)")
     ap.add_argument('--no-variant-leg', action='store_true',
                     help='skip the second leg on the rank^-0.5 genome-size variant (printed under "variant_workload")')
     ap.add_argument('--n-sub', type=int, default=0, help='sub-rounds per Louvain sweep (0: the library default, 4)')
@@ -218,6 +220,8 @@ def main():
         w.nnz = w.counts.nnz
         return w
 
+    if args.synth is None:
+        args.synth = 'sqrt' if (args.config == 'C5' and args.c5_counts == 'unique') else 'survey'
     W = build_workload(args.config, args.synth, args.hard)
 
     def barrier():

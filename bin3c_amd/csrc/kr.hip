@@ -2754,7 +2754,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     DevBuf<int> ylo(ctx, tails_xt ? nloc : 1), tex(ctx, 2);
     DevBuf<int64_t> xt_off(ctx, tails_xt ? nloc + 2 : 1);
     int xt_lg_bound = 0, xt_lo_bits = 20;
-    // packed form of the sorted tail words (kr_tails_pack): 4 bytes per tail; B3C_KR_XT_PACK=0 keeps the 64-bit stream
+    // packed form of the sorted tail words (kr_tails_pack): 4 bytes per tail (the 64-bit stream stays when too many words do not fit)
     struct PoolPtr32 { b3c_ctx *c; uint32_t *p = nullptr; ~PoolPtr32() { c->release(p); } } xt_cw{ctx}, xt_hdr{ctx};
     struct PoolPtr64 { b3c_ctx *c; unsigned long long *p = nullptr; ~PoolPtr64() { c->release(p); } } xt_res{ctx};
     bool xt_packed = false;

@@ -206,14 +206,5 @@ def test_locality_order_shortcut_equals_the_full_gather(ctx):
             os.environ.pop('B3C_ORDER_SAMPLE', None)
             ctx.reload_env()
         assert np.array_equal(fast[0], full[0]) and np.array_equal(fast[1], full[1])
-        # ... and ONE stable sort on the composite key (cluster_3, cluster_2, cluster_1) gives the order of the three LSD passes
-        os.environ['B3C_ORDER_LSD'] = '1'
-        ctx.reload_env()
-        try:
-            lsd = ctx.locality_order(m)
-        finally:
-            os.environ.pop('B3C_ORDER_LSD', None)
-            ctx.reload_env()
-        assert np.array_equal(fast[0], lsd[0]) and np.array_equal(fast[1], lsd[1])
         assert np.array_equal(np.sort(fast[0]), np.arange(ip.shape[0] - 1))
         m.free()

@@ -15,7 +15,9 @@ import re
 import sys
 
 src, rnd, KEY = sys.argv[1], sys.argv[2], sys.argv[3]
-bench = sorted(glob.glob('%s/bench*.json' % src) + glob.glob('%s/diag.json' % src))
+cfg = KEY.split('_')[0].lower()            # the bench line of the SAME config carries the sizes (a directory holds several)
+bench = (sorted(glob.glob('%s/bench_%s.json' % (src, cfg))) or sorted(glob.glob('%s/bench_%s*.json' % (src, cfg)))
+         or sorted(glob.glob('%s/bench*.json' % src) + glob.glob('%s/diag.json' % src)))
 line = [l for l in open(bench[0]) if l.startswith('{')][-1]
 wl = json.loads(line)['config']['workload']
 NNZ, N = int(re.search(r'nnz=(\d+)', wl).group(1)), int(re.search(r'n=(\d+)', wl).group(1))
