@@ -1318,7 +1318,7 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
             const int64_t nblk_all = (n_tails + 255) >> 8;                 // hdr[] has 4 * nblk_all + 4 entries, the last four zero
             const int64_t bs = s0 >> 8, be = e0 > s0 ? (e0 + 255) >> 8 : bs; // the 256-word blocks the chunk touches (< 2^21: the host checks the longest chunk)
             const int nb = (int)(be - bs);
-            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(cw + bs * 256), 0, nb * 1024, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(cw + bs * 256), 0, (int)((uint32_t)nb * 1024u), 0x00020000);
             // (the operand vector holds ncols doubles -- not 2^cbits: a gather beyond it reads zero instead of the next pooled block)
             const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, (int)(ncols * 8), 0x00020000);
             const int steps = (nb + 15) >> 4;
