@@ -284,8 +284,11 @@ def main():
         streamed = float(ki.spmv_stream_bytes)             # this rank's rows, as the library laid them out
         tcd = getattr(ki, 'tcd_tiles', 0) > 0              # tile-dictionary layout (automatic from 4096 contigs on)
         xt = getattr(ki, 'tcd_xt_tails', 0) > 0            # ... with the tails summed by their own pass (beyond 2^19 contigs)
-        kname = ('kr_kb_tails + kr_kb_tcd2 (ONE SpMV as two launches: tails summed in column order in fixed point, then dictionary '
-                 'rows + fused KR epilogue; times and bytes are those of the pair)' if xt
+        nodict = xt and getattr(ki, 'tcd_dict_total', 0) == 0     # every entry a tail word (the library's rule for thin dictionary shares)
+        kname = ('kr_kb_tails + kr_kb_epi (ONE SpMV: every stored entry a tail word, summed in column order in fixed point, then the fused '
+                 'KR epilogue per row; times and bytes are those of all its launches)' if nodict
+                 else 'kr_kb_tails + kr_kb_tcd2 + kr_kb_epi (ONE SpMV: tails summed in column order in fixed point, then dictionary '
+                 'rows + fused KR epilogue; times and bytes are those of all its launches)' if xt
                  else 'kr_kb_tcd2 (tile-dictionary SpMV on raw counts + fused KR epilogue)' if tcd
                  else 'kr_kb_vec (CSR SpMV on raw counts + fused KR epilogue)')
         avg_ms = acc['spmv_ms'] / max(acc['spmv_n'], 1)

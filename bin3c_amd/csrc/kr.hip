@@ -1133,7 +1133,7 @@ __global__ void __launch_bounds__(256) kr_tails_count(int64_t r0, int64_t r1, in
     int64_t c = 0;
     if (row < r1) {
         const int64_t len = indptr[row + 1] - indptr[row];
-        c = len > hub_len ? 0 : len - n1v[row - r0];
+        c = len > hub_len ? 0 : len - (n1v ? n1v[row - r0] : 0);          // (n1v == nullptr: every entry of the row is a tail)
     }
     tcnt[row - r0] = c;
 }
@@ -1165,7 +1165,7 @@ __global__ void __launch_bounds__(256) kr_tails_emit(int64_t r0, int64_t r1, int
             const int64_t base = indptr[rw[h]], len = indptr[rw[h] + 1] - base;
             if (len > hub_len) continue;
             const int64_t rr = rw[h] - r0;             // super-tiles count from the first row of this rank
-            ts[h] = base + n1v[rr];
+            ts[h] = base + (n1v ? n1v[rr] : 0);      // (n1v == nullptr: every entry -- `packed` / `pcol` are the CSR count and column arrays then)
             te[h] = base + len;
             o[h] = toff[rr] - ts[h];                   // word slot of entry k: o + k
             hi[h] = ((unsigned long long)(rr / S) << st_shift) | ((unsigned long long)(rr % S) << 16);
@@ -2707,6 +2707,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     DevBuf<int32_t> pcol(ctx, tcd ? a->nnz + 8 : 1), n1v(ctx, tcd ? nloc : 1);
     DevBuf<int32_t> dict_cols(ctx, tcd ? (size_t)tcd_tiles * (size_t)tcd_dcap : 1), dict_cnt(ctx, tcd ? tcd_tiles : 1);
     int tcd_lds_d = 0;                     // operands the SpMV kernel keeps in LDS: the largest dictionary, even
+    bool xt_all = false;                   // no dictionary anywhere: every entry is a tail word (decided below)
     if (tcd) {
         DevBuf<unsigned long long> stt(ctx, 4);            // layout statistics: largest dictionary, -, sum of the dictionaries, tail entries
         if (!packed.p || !pcol.p || !n1v.p || !dict_cols.p || !dict_cnt.p || !stt.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: dictionary layout");
@@ -2739,6 +2740,19 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (CFG.on("B3C_KR_DEBUG"))
             fprintf(stderr, "[b3c] dictionary layout: %lld tiles of %d rows, largest dictionary %llu (cap %d), mean %.0f, %.1f %% of the entries in tails\n",
                     (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles, 100.0 * (double)hst[3] / (double)a->nnz);
+        // What the dictionaries that survived the rule above hold may not be worth a dictionary KERNEL: on the contract workload they
+        // are 13 % of the entries, kr_kb_tcd2 spends 44 us per SpMV on them (staging and per-tile latency: 0.6 G entries per ms) where
+        // the tail pass -- which gets denser, i.e. cheaper per word, with every entry it is given -- takes 0.95 G per ms.  Under a
+        // fifth of the entries: every entry goes to the tail pass (its words are then cut straight from the CSR arrays), all tiles get
+        // their epilogue from kr_kb_epi.  Measured on that map: SpMV 278 -> 259 us (round 5).  Integer row sums: same x to 1e-14.
+        if (xt_want && (a->nnz - (int64_t)hst[3]) * 5 < a->nnz && hst[3] > 0 && CFG.num("B3C_KR_TCD_ALLTAILS", 1) != 0) {
+            xt_all = true;
+            HIP_TRY(ctx, hipMemsetAsync(dict_cnt.p, 0, sizeof(int32_t) * (size_t)tcd_tiles, s));
+            info->tcd_dict_max = 0;
+            info->tcd_dict_total = 0;
+            info->tcd_tail_entries = a->nnz;           // (upper bound until the words are counted: rows beyond hub_len stay with kr_kb_hub)
+            tcd_lds_d = 2;
+        }
     }
     // tiles with / without a dictionary, listed once: with the tail pass on, the latter get their epilogue from kr_kb_epi when they
     // are at least a quarter of the tiles (the contract workload: four in five)
@@ -2805,11 +2819,12 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         HIP_TRY(ctx, hipMemsetAsync(ylo.p, 0, sizeof(int) * (size_t)nloc, s));
         HIP_TRY(ctx, hipMemsetAsync(xst.p, 0, sizeof(unsigned long long) * 2, s));
         HIP_TRY(ctx, hipMemsetAsync(tex.p, 0, sizeof(int) * 2, s));
-        hipLaunchKernelGGL(kr_tails_count, dim3((unsigned)((nloc + 256) / 256)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, n1v.p, tcnt.p);
+        hipLaunchKernelGGL(kr_tails_count, dim3((unsigned)((nloc + 256) / 256)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, xt_all ? (const int32_t *)nullptr : n1v.p, tcnt.p);
         int rct;
         if ((rct = b3c_exclusive_scan_i64(ctx, tcnt.p, xt_off.p, nloc + 1))) return rct;
-        hipLaunchKernelGGL(kr_tails_emit, dim3((unsigned)grid_for(nloc, 4, 16 * ctx->n_cu)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, packed.p, pcol.p,
-                           n1v.p, xt_off.p, xt_S, 16 + xt_rbits, xt_st_shift, words_in.p, xst.p);
+        hipLaunchKernelGGL(kr_tails_emit, dim3((unsigned)grid_for(nloc, 4, 16 * ctx->n_cu)), dim3(256), 0, s, r0, r1, hub_len, a->indptr,
+                           xt_all ? (const uint32_t *)a->data : packed.p, xt_all ? a->indices : pcol.p, xt_all ? (const int32_t *)nullptr : n1v.p,
+                           xt_off.p, xt_S, 16 + xt_rbits, xt_st_shift, words_in.p, xst.p);
         { const int rb_ = b3c_readback(ctx, &n_tails, xt_off.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
         if (n_tails < 0 || n_tails > info->tcd_tail_entries)
             return ctx->fail(B3C_E_HIP, "b3c_kr_balance: tail count out of bounds (%lld of %lld)", (long long)n_tails, (long long)info->tcd_tail_entries);
@@ -2857,6 +2872,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         }
         HIP_TRY(ctx, hipStreamSynchronize(s));        // the scratch above goes back to the pool here
         info->tcd_xt_tails = n_tails;
+        if (xt_all) info->tcd_tail_entries = n_tails;             // (the entries of hub rows are kr_kb_hub's)
         if (CFG.on("B3C_KR_DEBUG"))
             fprintf(stderr, "[b3c] tail pass: %lld tails in %lld super-tiles of %d rows, largest count %llu, longest tail %llu\n",
                     (long long)n_tails, (long long)xt_super, xt_S, hx[0], hx[1]);
@@ -2865,7 +2881,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     struct PoolPtr24 { b3c_ctx *c; uint32_t *p = nullptr; ~PoolPtr24() { c->release(p); } } tcd_p24{ctx};
     DevBuf<int64_t> g24cnt(ctx, tails_xt ? nloc + 2 : 1), g24off(ctx, tails_xt ? nloc + 2 : 1);
     bool tcd_24 = false;
-    if (tails_xt && tcd_dcap <= (1 << (24 - TCD24_CB)) && vmax_counts < (1ull << 16) && CFG.num("B3C_KR_TCD_P24", 1) != 0) {
+    if (tails_xt && !xt_all && tcd_dcap <= (1 << (24 - TCD24_CB)) && vmax_counts < (1ull << 16) && CFG.num("B3C_KR_TCD_P24", 1) != 0) {
         if (!g24cnt.p || !g24off.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: 24-bit dictionary words");
         hipLaunchKernelGGL(kr_tcd24_groups, dim3((unsigned)((nloc + 256) / 256)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, n1v.p, g24cnt.p);
         int rcg;

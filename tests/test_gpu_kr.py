@@ -195,6 +195,30 @@ def test_dictionaries_not_worth_their_staging_are_dropped(ctx, monkeypatch):
     cm.free()
 
 
+def test_thin_dictionary_share_goes_to_the_tail_pass_altogether(ctx, monkeypatch):
+    """When the dictionaries that survive the build-time rule hold under a fifth of the entries, every entry becomes a tail word (cut
+    straight from the CSR arrays) and all tiles get their epilogue from kr_kb_epi (round 5; B3C_KR_TCD_ALLTAILS=0 keeps the mixed
+    layout).  Same iteration count, x to 1e-11 (the tail sums are exact integers, the dictionary sums fp64), bit-identical repeats."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(40000, 1300000, 47, genome_law='survey')
+    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    monkeypatch.setenv('B3C_KR_TCD_XT', '1')
+    monkeypatch.setenv('B3C_KR_TCD_MINUSE8', '96')          # 12 uses per column: only the densest tiles keep a dictionary
+    res = {}
+    for sw in ('0', '1'):
+        monkeypatch.setenv('B3C_KR_TCD_ALLTAILS', sw)
+        _, x, info = ctx.kr_balance_counts(cm, sm.sites)
+        _, x2, _ = ctx.kr_balance_counts(cm, sm.sites)
+        assert np.array_equal(x, x2)
+        res[sw] = (x, info)
+    (x0, i0), (x1, i1) = res['0'], res['1']
+    assert 0 < i0.tcd_dict_total and (cm.nnz - i0.tcd_tail_entries) * 5 < cm.nnz, (i0.tcd_dict_total, i0.tcd_tail_entries, cm.nnz)   # the rule's case
+    assert i1.tcd_dict_total == 0 and i1.tcd_xt_tails > i0.tcd_xt_tails and i1.tcd_xt_tails == i1.tcd_tail_entries
+    assert i1.n_iter == i0.n_iter
+    np.testing.assert_allclose(x1, x0, rtol=1e-11)
+    cm.free()
+
+
 def test_tail_pass_with_long_tails(ctx, monkeypatch):
     """Tail pass of the dictionary SpMV on a power-law map whose hub rows stay in the tiles (B3C_KR_NO_HUB): tails of
     thousands of entries narrow the 32-bit remainder sums of the fixed-point accumulation; x must agree with the CSR
