@@ -73,8 +73,8 @@ for k in parts:
     w_, _, _ = active('WRITE_SIZE', k)
     det[k] = {'FETCH_SIZE_raw_bytes_per_launch': f_, 'WRITE_SIZE_raw_bytes_per_launch': w_}
     tot += 2.0 * f_ + w_
-    if k in ('kr_kb_tcd2', 'kr_kb_vec', 'kr_kb_pipe'):
-        na, nt = a_, t_
+    if k in ('kr_kb_tails', 'kr_kb_vec', 'kr_kb_pipe') or (k == 'kr_kb_tcd2' and not na):
+        na, nt = a_, t_          # (launches that did work: the tail pass where it runs -- kr_kb_tcd2 may be a no-op list of tiles)
 if parts:
     name = ' + '.join(parts)
     out[KEY] = dict(det, kernel=name + (' (one SpMV: tails in column order in fixed point, dictionary rows + fused KR epilogue)'
