@@ -794,7 +794,7 @@ constexpr size_t TCD_BUILD_LDS = sizeof(uint32_t) * 2 * TCD_WORDS + sizeof(uint1
 // pass starts where the one before stopped (rdone) and stops at the first slice that leaves its column range -- each entry
 // is read once per sweep, whatever the number of passes.  The row pointers of the tile sit in LDS, and a wave has the first
 // slice of its NEXT row in flight while it works on the current one.
-__global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap, int sorted, uint32_t cfront, int minuse8,
+__global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, int R, int64_t ncols, int hub_len, int d1cap, int sorted, uint32_t cfront, int minuse8, int tile_step,
                                                         const int64_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices,
                                                         const uint32_t *__restrict__ counts, uint32_t *__restrict__ packed,
@@ -813,7 +813,7 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
     uint32_t *rcnt = rdone + TCD_RMAX;                // per row: entries of this pass
     int64_t *ipl = (int64_t *)(rcnt + TCD_RMAX);      // row pointers of the tile
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t tile = blockIdx.x;
+    const int64_t tile = (int64_t)blockIdx.x * tile_step;       // (tile_step > 1: a SAMPLE of the tiles -- statistics for the all-tails rule)
     const int64_t ra = r0 + tile * R;
     const int nrows = (int)((ra + R < r1 ? ra + R : r1) - ra);
     uint4 *b14 = (uint4 *)bm1, *b24 = (uint4 *)bm2;
@@ -1028,8 +1028,14 @@ __global__ void __launch_bounds__(TCD_TB) kr_tcd_build(int64_t r0, int64_t r1, i
         atomicMax(&stats[0], (unsigned long long)d1);
         atomicAdd(&stats[2], (unsigned long long)d1);
     }
-    // entries left in the tails (statistics only)
-    if (tid < nrows && nback[tid]) atomicAdd(&stats[3], (unsigned long long)nback[tid]);
+    // entries left in the tails, entries of the tile's rows below the hub length (statistics; one pair of atomics per wave -- a
+    // million same-address atomics, one per row, queue up in the L2)
+    {
+        long long tb = tid < nrows ? (long long)nback[tid] : 0, te = tid < nrows ? (long long)nfront[tid] + (long long)nback[tid] : 0;
+        tb = wave_sum_ll(tb);
+        te = wave_sum_ll(te);
+        if ((tid & 63) == 0 && te) { atomicAdd(&stats[3], (unsigned long long)tb); atomicAdd(&stats[1], (unsigned long long)te); }
+    }
 }
 
 template <int OP>
@@ -1210,6 +1216,89 @@ __global__ void __launch_bounds__(256) kr_tails_emit(int64_t r0, int64_t r1, int
         if (cmax > __atomic_load_n(&stats[0], __ATOMIC_RELAXED)) atomicMax(&stats[0], cmax);
         if (tmax > __atomic_load_n(&stats[1], __ATOMIC_RELAXED)) atomicMax(&stats[1], tmax);
     }
+}
+
+// All-tails layouts of a (bitwise) symmetric map: the column-ordered words of a super-tile without sorting them by column (round 5).
+// The words of super-tile s are the entries (i, j) of its rows i, wanted in column order j.  By symmetry they are the entries (j, i)
+// of ALL rows j whose column i falls into the super-tile -- and the CSR stream lists exactly those in (j, i) order.  So the words
+// are written in CSR order with the super-tile of their COLUMN as the key, and ONE stable radix pass on those few bits (instead of
+// three over super-tile and column) leaves every super-tile's words ordered by (column j, row i).  The segment of super-tile s in
+// the sorted stream starts at indptr[first row of s]: no counting pass, no scan.  Entries whose column is a hub row (its sum is
+// kr_kb_hub's) become zero words.  Same multiset of words per super-tile as the row-wise emission: the integer sums are identical.
+__global__ void __launch_bounds__(256) kr_tails_emit_tr(int64_t n, int hub_len, const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                         const uint32_t *__restrict__ counts, const uint8_t *__restrict__ is_hub, int S, int cshift, int st_shift,
+                                                         unsigned long long *__restrict__ words, unsigned long long *__restrict__ stats)
+{
+    typedef int32_t pi4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef uint32_t pu4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef unsigned long long pq2 __attribute__((ext_vector_type(2), aligned(8)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    const bool s13 = S == 8192;                       // (S is 8192 or 12288 = 3 * 4096)
+    unsigned long long cmax = 0, tmax = 0;
+    for (int64_t row0 = wave; row0 < n; row0 += 2 * nwave) {
+        int64_t rw[2], ts[2], te[2];
+        rw[0] = row0;
+        rw[1] = row0 + nwave < n ? row0 + nwave : -1;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            ts[h] = te[h] = 0;
+            if (rw[h] < 0) continue;
+            ts[h] = indptr[rw[h]];
+            te[h] = indptr[rw[h] + 1];
+            const unsigned long long tl = (unsigned long long)(te[h] - ts[h]);
+            if (tl <= (unsigned long long)hub_len) tmax = tl > tmax ? tl : tmax;      // the longest tail: the longest row below the hub length
+        }
+        const int64_t span = (te[0] - ts[0]) > (te[1] - ts[1]) ? (te[0] - ts[0]) : (te[1] - ts[1]);
+        for (int64_t off = 0; off < span; off += 256) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int64_t k0 = ts[h] + off + 4 * lane;
+                if (k0 >= te[h]) continue;
+                const pi4 iv = *(const pi4 *)(indices + k0);          // (32 bytes of slack behind both streams)
+                const pu4 cv = *(const pu4 *)(counts + k0);
+                const unsigned long long colbits = (unsigned long long)(uint32_t)rw[h] << cshift;
+                unsigned long long w[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const bool ok = k0 + t < te[h];
+                    const uint32_t i = ok ? (uint32_t)iv[t] : 0u;
+                    unsigned long long c = ok ? (cv[t] & 0xFFFFu) : 0u;
+                    if (is_hub && ok && is_hub[i]) c = 0;
+                    const uint32_t st = s13 ? i >> 13 : (i >> 12) / 3u;
+                    w[t] = ((unsigned long long)st << st_shift) | colbits | ((unsigned long long)(i - st * (uint32_t)S) << 16) | c;
+                    cmax = c > cmax ? c : cmax;
+                }
+                if (k0 + 3 < te[h]) {
+                    pq2 a, b;
+                    a[0] = w[0]; a[1] = w[1]; b[0] = w[2]; b[1] = w[3];
+                    *(pq2 *)(words + k0) = a;
+                    *(pq2 *)(words + k0 + 2) = b;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if (k0 + t < te[h]) words[k0 + t] = w[t];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = (unsigned long long)__shfl_down((long long)cmax, o, 64), b = (unsigned long long)__shfl_down((long long)tmax, o, 64);
+        cmax = a > cmax ? a : cmax;
+        tmax = b > tmax ? b : tmax;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cmax > __atomic_load_n(&stats[0], __ATOMIC_RELAXED)) atomicMax(&stats[0], cmax);
+        if (tmax > __atomic_load_n(&stats[1], __ATOMIC_RELAXED)) atomicMax(&stats[1], tmax);
+    }
+}
+
+__global__ void kr_hub_bytes(int64_t n, int hub_len, const int64_t *__restrict__ indptr, uint8_t *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = indptr[i + 1] - indptr[i] > hub_len ? 1 : 0;
 }
 
 // The sorted tail words once more, as 32-bit words (round 4).  kr_kb_tails streams 8 bytes per tail, and on a map where the
@@ -2727,10 +2816,23 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         // 8 (and 0.318 with NO dictionary at all: on that map the dictionary is worth nothing), the headline map unchanged up to 5 and
         // slower from 8 on (0.241 -> 0.253 ms).
         const int tcd_minuse8 = xt_want ? std::max(0, (int)CFG.num("B3C_KR_TCD_MINUSE8", 28)) : 0;      // (in eighths of an entry per column)
-        hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
-                           a->sorted_cols ? 1 : 0, tcd_cfront, tcd_minuse8, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
-        unsigned long long hst[4];
-        { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
+        // The all-tails rule (below) first on a SAMPLE of the tiles, every 16th: where the dictionaries are plainly not worth a kernel
+        // (the contract workload) the full layout pass -- 2.3 ms at C3 -- is not run at all.
+        const bool alltails_on = xt_want && CFG.num("B3C_KR_TCD_ALLTAILS", 1) != 0;
+        unsigned long long hst[4] = {0, 0, 0, 0};
+        if (alltails_on && tcd_tiles >= 256) {
+            const int step = 16;
+            hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)((tcd_tiles + step - 1) / step)), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
+                               a->sorted_cols ? 1 : 0, tcd_cfront, tcd_minuse8, step, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
+            { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
+            xt_all = hst[1] > 0 && hst[3] > 0 && (hst[1] - hst[3]) * 6 < hst[1];      // (a sixth on the sample, a fifth on the whole map below)
+            if (!xt_all) HIP_TRY(ctx, hipMemsetAsync(stt.p, 0, sizeof(unsigned long long) * 4, s));
+        }
+        if (!xt_all) {
+            hipLaunchKernelGGL(kr_tcd_build, dim3((unsigned)tcd_tiles), dim3(TCD_TB), TCD_BUILD_LDS, s, r0, r1, tcd_R, n, hub_len, tcd_dcap,
+                               a->sorted_cols ? 1 : 0, tcd_cfront, tcd_minuse8, 1, a->indptr, a->indices, (const uint32_t *)a->data, packed.p, pcol.p, n1v.p, dict_cols.p, dict_cnt.p, stt.p);
+            { const int rb_ = b3c_readback(ctx, hst, stt.p, sizeof(hst)); if (rb_) return rb_; }
+        }
         tcd_lds_d = (int)((hst[0] + 1) & ~1ull);
         if (tcd_lds_d < 2) tcd_lds_d = 2;
         info->tcd_tiles = tcd_tiles;
@@ -2738,15 +2840,16 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         info->tcd_dict_total = (int64_t)hst[2];
         info->tcd_tail_entries = (int64_t)hst[3];
         if (CFG.on("B3C_KR_DEBUG"))
-            fprintf(stderr, "[b3c] dictionary layout: %lld tiles of %d rows, largest dictionary %llu (cap %d), mean %.0f, %.1f %% of the entries in tails\n",
-                    (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles, 100.0 * (double)hst[3] / (double)a->nnz);
+            fprintf(stderr, "[b3c] dictionary layout%s: %lld tiles of %d rows, largest dictionary %llu (cap %d), mean %.0f, %.1f %% of the entries in tails\n",
+                    xt_all ? " (a sample of the tiles)" : "", (long long)tcd_tiles, tcd_R, hst[0], tcd_dcap, (double)hst[2] / (double)tcd_tiles,
+                    100.0 * (double)hst[3] / (double)(hst[1] ? hst[1] : 1));
         // What the dictionaries that survived the rule above hold may not be worth a dictionary KERNEL: on the contract workload they
         // are 13 % of the entries, kr_kb_tcd2 spends 44 us per SpMV on them (staging and per-tile latency: 0.6 G entries per ms) where
         // the tail pass -- which gets denser, i.e. cheaper per word, with every entry it is given -- takes 0.95 G per ms.  Under a
         // fifth of the entries: every entry goes to the tail pass (its words are then cut straight from the CSR arrays), all tiles get
         // their epilogue from kr_kb_epi.  Measured on that map: SpMV 278 -> 259 us (round 5).  Integer row sums: same x to 1e-14.
-        if (xt_want && (a->nnz - (int64_t)hst[3]) * 5 < a->nnz && hst[3] > 0 && CFG.num("B3C_KR_TCD_ALLTAILS", 1) != 0) {
-            xt_all = true;
+        if (!xt_all && alltails_on && hst[1] > 0 && hst[3] > 0 && (hst[1] - hst[3]) * 5 < hst[1]) xt_all = true;
+        if (xt_all) {
             HIP_TRY(ctx, hipMemsetAsync(dict_cnt.p, 0, sizeof(int32_t) * (size_t)tcd_tiles, s));
             info->tcd_dict_max = 0;
             info->tcd_dict_total = 0;
@@ -2808,6 +2911,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     struct PoolPtr32 { b3c_ctx *c; uint32_t *p = nullptr; ~PoolPtr32() { c->release(p); } } xt_cw{ctx}, xt_hdr{ctx};
     struct PoolPtr64 { b3c_ctx *c; unsigned long long *p = nullptr; ~PoolPtr64() { c->release(p); } } xt_res{ctx};
     bool xt_packed = false;
+    bool xt_tr = false;                    // all-tails layout emitted through the symmetry (kr_tails_emit_tr): the super-tile offsets are indptr
     int64_t xt_n_res = 0;
     const size_t xt_shmem = sizeof(unsigned long long) * (size_t)xt_S + sizeof(int) * (size_t)xt_S + sizeof(double) * XT_NT;
     if (tails_xt) {
@@ -2819,6 +2923,18 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         HIP_TRY(ctx, hipMemsetAsync(ylo.p, 0, sizeof(int) * (size_t)nloc, s));
         HIP_TRY(ctx, hipMemsetAsync(xst.p, 0, sizeof(unsigned long long) * 2, s));
         HIP_TRY(ctx, hipMemsetAsync(tex.p, 0, sizeof(int) * 2, s));
+        // all-tails layout of a bitwise symmetric whole map: the words in CSR order keyed by the super-tile of their column, one radix
+        // pass on the super-tile bits (kr_tails_emit_tr); else row-wise emission and the sort on (super-tile, column)
+        xt_tr = xt_all && info->bitwise_symmetric && !a->row_block && r0 == 0 && r1 == n;
+        DevBuf<uint8_t> hubflag(ctx, xt_tr && n_hub > 0 ? n : 1);
+        if (!hubflag.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: tail pass");
+        if (xt_tr) {
+            const bool hubs = n_hub > 0;
+            if (hubs) hipLaunchKernelGGL(kr_hub_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, hub_len, a->indptr, hubflag.p);
+            hipLaunchKernelGGL(kr_tails_emit_tr, dim3((unsigned)grid_for(n, 4, 16 * ctx->n_cu)), dim3(256), 0, s, n, hub_len, a->indptr, a->indices,
+                               (const uint32_t *)a->data, hubs ? hubflag.p : (const uint8_t *)nullptr, xt_S, 16 + xt_rbits, xt_st_shift, words_in.p, xst.p);
+            n_tails = a->nnz;            // (the entries of hub rows ride along as zero words)
+        } else {
         hipLaunchKernelGGL(kr_tails_count, dim3((unsigned)((nloc + 256) / 256)), dim3(256), 0, s, r0, r1, hub_len, a->indptr, xt_all ? (const int32_t *)nullptr : n1v.p, tcnt.p);
         int rct;
         if ((rct = b3c_exclusive_scan_i64(ctx, tcnt.p, xt_off.p, nloc + 1))) return rct;
@@ -2826,6 +2942,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                            xt_all ? (const uint32_t *)a->data : packed.p, xt_all ? a->indices : pcol.p, xt_all ? (const int32_t *)nullptr : n1v.p,
                            xt_off.p, xt_S, 16 + xt_rbits, xt_st_shift, words_in.p, xst.p);
         { const int rb_ = b3c_readback(ctx, &n_tails, xt_off.p + nloc, sizeof(int64_t)); if (rb_) return rb_; }
+        }
         if (n_tails < 0 || n_tails > info->tcd_tail_entries)
             return ctx->fail(B3C_E_HIP, "b3c_kr_balance: tail count out of bounds (%lld of %lld)", (long long)n_tails, (long long)info->tcd_tail_entries);
         unsigned long long hx[2];
@@ -2841,7 +2958,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         // emission order (the sort is stable), which costs the gather nothing and saves three key bits
         int st_bits = 1;
         while ((1ll << st_bits) < xt_super) st_bits++;
-        const int sort_lo = 16 + xt_rbits + (xt_cbits > 3 ? 3 : 0), sort_hi = xt_st_shift + st_bits;
+        const int sort_lo = xt_tr ? xt_st_shift : 16 + xt_rbits + (xt_cbits > 3 ? 3 : 0), sort_hi = xt_st_shift + st_bits;
         size_t tb = 0;
         hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tb, words_in.p, xt_words.p, (int64_t)n_tails, sort_lo, sort_hi, s);
         if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "radix sort sizing failed");
@@ -3014,7 +3131,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             if (tcd) {
                 if (tails_xt)
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
-                                       xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p,
+                                       xt_tr ? (const int64_t *)a->indptr : (const int64_t *)xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p,
                                        xt_packed ? xt_cw.p : nullptr, xt_hdr.p, xt_res.p, xt_n_res, xt_st_shift,
                                        n_tails < (1ll << 29) ? 1 : 0, n);    // (32-bit byte offsets inside a chunk of the packed stream)
                 // dictionary waves and tail waves side by side (512-thread workgroups)
