@@ -3151,7 +3151,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         else if (tails_xt) hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, true>), KR_TCD2_ARGS);                               \
         else hipLaunchKernelGGL((kr_kb_tcd2<L, U, TL, T, false>), KR_TCD2_ARGS);                                            \
     } while (0)
-                if (avg > 128) KR_TCD2(16, 4, 8, 2);       // (tail shapes 8x1, 4x2, 4x4 within 5 % of this one at C3, 2x4 17 % slower)
+                if (split && n_tl_with == 0 && n_tl_without > 0) {}     // no dictionary tile at all: kr_kb_epi carried the state forward as well
+                else if (avg > 128) KR_TCD2(16, 4, 8, 2);       // (tail shapes 8x1, 4x2, 4x4 within 5 % of this one at C3, 2x4 17 % slower)
                 else if (avg > 48) KR_TCD2(8, 4, 4, 2);
                 else KR_TCD2(4, 4, 4, 1);
 #undef KR_TCD2
