@@ -19,7 +19,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2 -- python bench.py --config C2 --steps 10 --warmup 3 --no-cpu-baseline --no-variant-leg > $out/trace_c2.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$REGEX" --output-format csv -d $out/pmc_fetch -- python bench.py --config C3 --steps 1 --warmup 0 --no-cpu-baseline --no-variant-leg > $out/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$REGEX" --output-format csv -d $out/pmc_write -- python bench.py --config C3 --steps 1 --warmup 0 --no-cpu-baseline --no-variant-leg > $out/pmc_write.log 2>&1
-B3C_KR_TCD_TLOG=1 timeout 300 python tools/tcd_probe.py C3 "" "B3C_KR_TCD_P24=0" "B3C_KR_NO_TCD=1" > $out/tcd_timeline.txt 2>&1
+B3C_KR_TCD_TLOG=1 timeout 300 python tools/tcd_probe.py C3 "" "B3C_KR_TCD_ALLTAILS=0" "B3C_KR_NO_TCD=1" > $out/tcd_timeline.txt 2>&1
 # the rank^-0.5 genome-size variant (the headline of rounds 1-4) and a hard clustering problem as their own lines
 timeout 400 python bench.py --config C3 --synth sqrt --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_c3_variant.json 2> $out/bench_c3_variant.err
 timeout 300 python bench.py --config C2 --hard --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_c2_hard.json 2> $out/bench_c2_hard.err
