@@ -62,7 +62,9 @@ typedef struct {
     /* tile-local column dictionaries (16-bit counts): tiles of the SpMV, the largest dictionary, the sum of all
      * dictionary sizes and the entries outside the dictionaries (tails); all 0 for the other forms */
     int64_t tcd_tiles, tcd_dict_max, tcd_dict_total, tcd_tail_entries;
-    /* tails summed by their own pass (kr_kb_tails, maps beyond 2^19 contigs on one GPU); 0: by the row kernel */
+    /* tails summed by their own pass (kr_kb_tails, maps beyond 2^19 contigs on one GPU); 0: by the row kernel.  With
+     * tcd_dict_total == 0 every stored entry below the hub length is such a tail word (the library's choice when the
+     * dictionaries would hold under a fifth of the entries) */
     int64_t tcd_xt_tails;
     /* counts beyond 65535 handled by the correction list beside the 16-bit forms (0: none, or too many: 32-bit values) */
     int64_t big_counts;
