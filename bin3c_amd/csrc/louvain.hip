@@ -688,6 +688,9 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval_split(const NodeRec *_
 // clear every slot of the node's table size, exact 128-bit gains, order-free arg-max (ties to the lowest community id) -- hence
 // the same result.
 constexpr int LV_WG_CLASSES = 3;
+// the scan's workgroup classes (round 5: a 2048-slot class between the first two -- rows of 820 .. 1638 entries, the bulk of level 1 on
+// the contract workload, get six workgroups per CU instead of three)
+__host__ __device__ __forceinline__ int lv_dwg_max_deg(int cls) { return cls == 0 ? 819 : cls == 1 ? 1638 : cls == 2 ? 3276 : 6553; }   // table_lg() <= 10 / 11 / 12 / 13
 __host__ __device__ __forceinline__ int lv_wg_max_deg(int cls) { return cls == 0 ? 819 : cls == 1 ? 3276 : 6553; }   // table_lg() <= 10 / 12 / 13
 
 template <int LGS, int NT>
@@ -962,12 +965,12 @@ __global__ void __launch_bounds__(BLK) k_lv_decide_direct(int64_t n, int n_sub, 
 // ---------------------------------------------------------------------------------------------
 // Node lists of one level, all at once.  Without hubs: segment r = the nodes of sub-round r.  With hubs every sub-round has
 // LV_SEGS adjacent segments by row length: [0] at most thr[0] entries (grouped kernel), [1] at most thr[1] (wave-per-node kernel),
-// [2 .. 4] at most thr[2 .. 4] (workgroup-per-node kernel with a table of 1024 / 4096 / 8192 slots), [5] the MEGA rows beyond
+// [2 .. 5] at most thr[2 .. 5] (workgroup-per-node kernel with a table of 1024 / 2048 / 4096 / 8192 slots), [6] the MEGA rows beyond
 // (workgroups per node, table in global memory) -- adjacent, so that the passes that treat them alike (apply, internal-weight
 // delta) cover a sub-round in ONE launch.  A node sets the flag of its segment; ONE exclusive scan over the n_seg * nloc flags
 // gives every listed node its position in the common list and, at the segment starts, the list boundaries.  Inside a segment
 // the nodes ascend, as they did when every segment had its own scan.
-constexpr int LV_SEGS = 6;
+constexpr int LV_SEGS = 7;
 struct LvThr { int t[LV_SEGS - 1]; };
 __device__ __forceinline__ int lv_list_segment(int64_t i, int n_sub, LvThr thr, int with_hubs, const int64_t *__restrict__ indptr,
                                                const int32_t *__restrict__ ids, const int64_t *__restrict__ kdeg)
@@ -2837,7 +2840,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // lists (under 4096 nodes, beyond the direct-table kernel's 2048): the wave-per-node kernel on all rows.
         const bool use_wg = grouped;
         const bool wide_g = short_max == 256;                 // rows of 257 .. 512 entries by k_lv_decide_g<64, 8>
-        const int wave_thr = use_wg ? std::min(lv_wg_max_deg(0), std::max(short_max, wide_g ? 512 : 409)) : 0;
+        const int wave_thr = use_wg ? std::min(lv_dwg_max_deg(0), std::max(short_max, wide_g ? 512 : 409)) : 0;
         // LDS table of the wave-per-node kernel: 12 bytes per slot and wave, four waves per workgroup (2048 slots are 96 KB, one
         // workgroup per CU: small levels only); rows beyond it use their table in global memory
         const int64_t wave_max = use_wg ? std::min<int64_t>(maxdeg, std::max<int64_t>(64, wave_thr)) : maxdeg;
@@ -2845,7 +2848,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const int cap = need <= 128 ? 128 : need <= 256 ? 256 : need <= 512 ? 512 : need <= 1024 ? 1024 : 2048;
         // rows beyond mega_deg entries get workgroups and the node's table in global memory (k_lv_mega_*): whatever the largest LDS
         // table of the workgroup kernel cannot hold (or fewer: B3C_LV_MEGA_DEG, which the tests use to reach those kernels on small graphs)
-        const int mega_deg = (int)std::min<int64_t>(lv_wg_max_deg(2), std::max<int64_t>(short_max, CFG.num("B3C_LV_MEGA_DEG", lv_wg_max_deg(2))));
+        const int mega_deg = (int)std::min<int64_t>(lv_dwg_max_deg(3), std::max<int64_t>(short_max, CFG.num("B3C_LV_MEGA_DEG", lv_dwg_max_deg(3))));
         // rows whose table does not fit the LDS of the kernel that takes them use a table in global memory (goff / gkeys / gvals)
         const int cap_tbl = use_wg ? (1 << 13) : cap;
         hipLaunchKernelGGL(k_big_table_sizes, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, n, cap_tbl, use_wg ? (int64_t)mega_deg : INT64_MAX,
@@ -2865,8 +2868,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // of the boundaries for all sub-rounds
         DevBuf<NodeRec> lists(ctx, grouped ? nloc + 1 : 1);
         const NodeRec *nlist_p = lists.p;
-        // off[r][k] .. off[r][k + 1]: segment k of sub-round r in the common list (k = 0 grouped, 1 wave kernel, 2 .. 4 workgroup
-        // kernel, 5 mega rows)
+        // off[r][k] .. off[r][k + 1]: segment k of sub-round r in the common list (k = 0 grouped, 1 wave kernel, 2 .. 5 workgroup
+        // kernel, 6 mega rows)
         std::vector<std::array<int64_t, LV_SEGS + 1>> off(n_sub);
         for (auto &o : off) o.fill(0);
         LvThr thr;
@@ -2874,15 +2877,16 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if (use_wg) {
             // ascending by construction (lv_list_segment counts the bounds a row exceeds): the wave kernel's bound never passes the
             // first workgroup class -- a row of the 1024-slot class with a longer table would write past its LDS
-            thr.t[2] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(0)));
-            thr.t[3] = std::min(mega_deg, std::max(short_max, lv_wg_max_deg(1)));
-            thr.t[4] = mega_deg;
+            thr.t[2] = std::min(mega_deg, std::max(short_max, lv_dwg_max_deg(0)));
+            thr.t[3] = std::min(mega_deg, std::max(short_max, lv_dwg_max_deg(1)));
+            thr.t[4] = std::min(mega_deg, std::max(short_max, lv_dwg_max_deg(2)));
+            thr.t[5] = mega_deg;
             thr.t[1] = std::min(thr.t[2], std::max(short_max, wave_thr));
         } else {
-            thr.t[1] = thr.t[2] = thr.t[3] = thr.t[4] = mega_deg;
+            thr.t[1] = thr.t[2] = thr.t[3] = thr.t[4] = thr.t[5] = mega_deg;
         }
-        if (lv_debug) fprintf(stderr, "[b3c] level %d: %lld nodes, %lld entries, longest row %lld: classes <= %d | %d | %d | %d | %d | mega\n",
-                              (int)info->n_levels, (long long)n, (long long)g.nnz, (long long)maxdeg, thr.t[0], thr.t[1], thr.t[2], thr.t[3], thr.t[4]);
+        if (lv_debug) fprintf(stderr, "[b3c] level %d: %lld nodes, %lld entries, longest row %lld: classes <= %d | %d | %d | %d | %d | %d | mega\n",
+                              (int)info->n_levels, (long long)n, (long long)g.nnz, (long long)maxdeg, thr.t[0], thr.t[1], thr.t[2], thr.t[3], thr.t[4], thr.t[5]);
         if (grouped) {
             const int n_seg = need_wave_kernel ? LV_SEGS * n_sub : n_sub;
             const int64_t tot = (int64_t)n_seg * nloc + 1;
@@ -2948,7 +2952,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if (!mega_own.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: mega rows");
         HIP_TRY(ctx, hipMemsetAsync(mega_own.p, 0, sizeof(u64) * (size_t)(max_mega + 1), s));
         DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1), plist_h(ctx, can_prune ? max_hlist + 1 : 1);
-        DevBuf<unsigned long long> pcnt(ctx, LV_SEGS);    // [0] grouped nodes left after pruning, [1 .. 4] hubs left, by class
+        DevBuf<unsigned long long> pcnt(ctx, LV_SEGS);    // [0] grouped nodes left after pruning, [1 .. 5] hubs left, by class
         if (!plist.p || !plist_h.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
         auto modularity = [&](double *out, bool full, u64 *moved) -> int {
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
@@ -3113,7 +3117,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                         // all rows of this rank (small levels)
                         LV_DECIDE_CAP(r0, r1, (const NodeRec *)nullptr, (const int64_t *)nullptr);
                     } else {
-                        // the hubs the grouped kernel left out, class by class: [1] one wave per node, [2 .. 4] one workgroup per node
+                        // the hubs the grouped kernel left out, class by class: [1] one wave per node, [2 .. 5] one workgroup per node
                         for (int k = 1; k < LV_SEGS - 1; k++) {
                             const int64_t w1 = off[r][k + 1] - off[r][k];
                             if (w1 <= 0) continue;
@@ -3144,7 +3148,8 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     hipLaunchKernelGGL((k_lv_decide_wg<LGS, NT>), dim3((unsigned)std::min<int64_t>(w1, MAXG)), dim3(NT), (lv_wg_lds<LGS, NT>()), hs, w1, hcnt_dev,  \
                        hubs, m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p)
                                 if (k == 2) LV_DECIDE_WG(10, 256, 16 * (int64_t)ctx->n_cu);
-                                else if (k == 3) LV_DECIDE_WG(12, 256, 6 * (int64_t)ctx->n_cu);
+                                else if (k == 3) LV_DECIDE_WG(11, 256, 12 * (int64_t)ctx->n_cu);
+                                else if (k == 4) LV_DECIDE_WG(12, 256, 6 * (int64_t)ctx->n_cu);
                                 else LV_DECIDE_WG(13, 1024, 2 * (int64_t)ctx->n_cu);
 #undef LV_DECIDE_WG
                             }
