@@ -7,8 +7,9 @@ reference's ingest produces (sparse_utils.py:246-266, ``Sparse2DAccumulator.get_
 symmetric uint32 matrix without duplicate coordinates whose diagonal holds self-contacts, plus
 per-contig ``length`` and ``sites`` (contact_map.py:19 ``SeqInfo``).
 
-Model (SURVEY.md section 8(d), with the deviations listed in DESIGN.md): ``G = max(4, n // 500)`` genomes
-whose contig counts follow rank**-0.5, contig ids randomly permuted (no id locality), contig length
+Model (SURVEY.md section 8(d) -- the CONTRACT law, the default since round 6): ``G = max(2, n // 200)`` genomes whose contig
+counts follow Zipf(1.5) (one genome holds 38 % of the contigs, most hold a handful); ``genome_law='sqrt'`` gives the variant
+rounds 1-4 were tuned on (``G = max(4, n // 500)``, sizes ~ rank**-0.5).  Contig ids randomly permuted (no id locality), contig length
 ~ lognormal(ln 8000, 1) clipped >= 500 (about 2 % fall under the default min_len of 1000), sites = max(1, Poisson(length / 256)); ~90 % of edges join
 two contigs of one genome, ~10 % are uniform noise; pair counts Geometric(0.2) x 5 (intra) or x 1
 (noise), duplicates summed; diagonal Geometric(0.02) with 5 % forced zeros (exercises the
@@ -16,7 +17,10 @@ zero-diagonal substitution of sparse_utils.py:110-115).
 """
 import numpy as np
 
-__all__ = ['SynthMap', 'make_edges', 'make_synth', 'CONFIGS']
+__all__ = ['SynthMap', 'make_edges', 'make_synth', 'CONFIGS', 'DEFAULT_GENOME_LAW']
+
+# genome-size law of every generator call that does not name one: SURVEY.md 8(d)'s (the contract workload)
+DEFAULT_GENOME_LAW = 'survey'
 
 # BASELINE.json configs -> (n contigs, E undirected edges, seed, degree law)
 CONFIGS = {
@@ -78,10 +82,12 @@ def _solve_draws(target_unique, pair_cap, share):
     return hi
 
 
-def genome_layout(n, genomes=None, genome_law='sqrt'):
-    """Genome sizes of a map.  'sqrt' (hic-synth-v1 as benchmarked): G = max(4, n // 500) genomes, sizes ~ rank**-0.5.
-    'survey' (SURVEY.md 8(d) to the letter): G = max(2, n // 200), sizes ~ Zipf(1.5) -- 38 % of the contigs in the largest
-    genome, most genomes of a handful.  `genomes` overrides G (tests: thousands of small genomes)."""
+def genome_layout(n, genomes=None, genome_law=None):
+    """Genome sizes of a map.  'survey' (SURVEY.md 8(d) to the letter; the default, DEFAULT_GENOME_LAW): G = max(2, n // 200),
+    sizes ~ Zipf(1.5) -- 38 % of the contigs in the largest genome, most genomes of a handful.  'sqrt' (the variant rounds 1-4
+    benchmarked): G = max(4, n // 500) genomes, sizes ~ rank**-0.5.  `genomes` overrides G (tests: thousands of small genomes)."""
+    if genome_law is None:
+        genome_law = DEFAULT_GENOME_LAW
     if genome_law == 'survey':
         g = max(2, n // 200) if genomes is None else int(genomes)
         return _genome_sizes(n, min(g, n // 2), 1.5)
@@ -91,7 +97,7 @@ def genome_layout(n, genomes=None, genome_law='sqrt'):
     return _genome_sizes(n, min(g, n // 2), 0.5)
 
 
-def make_edges(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5, genomes=None, genome_law='sqrt'):
+def make_edges(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5, genomes=None, genome_law=None):
     """
     Draw the contact pair stream.  `noise`: share of the edges that join two random contigs (inter-genome); `intra_boost`:
     multiplier of the intra-genome counts.  The defaults are hic-synth-v1; larger noise / boost 1 give a HARD clustering
@@ -185,7 +191,7 @@ def symmetrise_to_csr(n, lo, hi, c, diag):
     return indptr, indices, counts
 
 
-def make_synth(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5, genomes=None, genome_law='sqrt'):
+def make_synth(n, n_edges, seed, degree_law='flat', noise=0.1, intra_boost=5, genomes=None, genome_law=None):
     """Full host-side generation -> :class:`SynthMap`."""
     lo, hi, c, diag, lengths, sites, genome = make_edges(n, n_edges, seed, degree_law, noise, intra_boost, genomes, genome_law)
     indptr, indices, counts = symmetrise_to_csr(n, lo, hi, c, diag)

@@ -54,7 +54,7 @@ def _reduce_batch(key, c):
 
 
 def make_counts_device(ctx, n, n_edges, seed, degree_law='powerlaw', noise=0.1, intra_boost=5, genomes=None,
-                       genome_law='sqrt', batch=1 << 28, tol=0.005, max_batches=200, verbose=False, extra=None, dup='first', draws_only=False):
+                       genome_law=None, batch=1 << 28, tol=0.005, max_batches=200, verbose=False, extra=None, dup='first', draws_only=False):
     """
     :param dup: what a pair drawn more than once keeps.  'sum': the sum of its draws' counts, as the host generator does -- under
                 the power law a hub pair is then drawn thousands of times and carries a count of 10^5..10^6 beside tail pairs of 5,

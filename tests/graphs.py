@@ -1,4 +1,6 @@
 """Small hand-checkable graphs and pipeline helpers shared by the Louvain tests (CSR, symmetric, fp64)."""
+# genome-size laws of the synthetic generator: the contract workload (the default) and the variant of rounds 1-4
+LAWS = ('survey', 'sqrt')
 import numpy as np
 import scipy.sparse as sp
 
@@ -60,10 +62,10 @@ def same_partition(a, b):
     return len(pairs) == len(set(p[0] for p in pairs)) == len(set(p[1] for p in pairs))
 
 
-def synth_graph(oracle, n, n_edges, seed, min_len=1000, min_sig=5, degree_law='flat', noise=0.1, intra_boost=5):
+def synth_graph(oracle, n, n_edges, seed, min_len=1000, min_sig=5, degree_law='flat', noise=0.1, intra_boost=5, genome_law=None):
     """Synthetic contact map pushed through the oracle's normalise/KR/compress steps -> graph CSR + weights."""
     from bin3c_amd.synth import make_synth
-    sm = make_synth(n, n_edges, seed, degree_law, noise, intra_boost)
+    sm = make_synth(n, n_edges, seed, degree_law, noise, intra_boost, genome_law=genome_law)
     sig = oracle.max_offdiag_u32(sm.indptr, sm.indices, sm.counts)
     mask = (sm.lengths >= min_len) & (sig >= min_sig)
     nd = oracle.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)

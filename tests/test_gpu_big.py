@@ -5,6 +5,8 @@ drawn on the device, bin3c_amd/synth_device.py, so the test no longer needs 25 G
 * a power-law contact map whose stored entries exceed 2^31 BYTES (every 32-bit byte or item count on the path would wrap)
   with planted hub contigs of 10^5 - 10^6 contacts (rows that go through kr_kb_hub, the radix-sorted long rows of the
   permutation and Louvain's global hash tables);
+* BASELINE.json's C5 as SURVEY 8(d)'s generator writes it (Zipf genome sizes, power-law endpoints, duplicate draws summed): the reference
+  at its default max_iter raises there, and so must the device (test_c5_contract_generator_...);
 * a C5-shaped map (power law, thousands of genomes) whose Louvain level 0 ends with MORE communities than the kc x kc bin
   table of the aggregation holds, i.e. the sort path -- single GPU here, row-sharded in tests/test_dist.py.
 
@@ -50,7 +52,7 @@ def test_power_law_map_beyond_2_31_bytes(ctx):
         extra_hi.append(np.maximum(others, h))
         extra_c.append(rs.geometric(0.3, others.shape[0]).astype(np.int64))
     extra = (np.concatenate(extra_lo), np.concatenate(extra_hi), np.concatenate(extra_c))
-    counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, 5, 'powerlaw', extra=extra)
+    counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, 5, 'powerlaw', extra=extra, genome_law='sqrt')
     assert abs(n_edges - e) < 0.01 * e + 1.5e6, (n_edges, info)
     assert counts.nnz * 8 > 2 ** 31, counts.nnz
     # (heavy-tailed degrees: more balancing iterations than the flat maps need; with duplicate draws SUMMED instead -- dup='sum',
@@ -72,7 +74,7 @@ def test_c5_shaped_map_leaves_more_communities_than_the_bin_table(ctx):
     from bin3c_amd.pipeline import run_hot_path
     from bin3c_amd.synth_device import make_counts_device
     n, e = 1500000, 60000000
-    counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, 11, 'powerlaw', genomes=6000)
+    counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, 11, 'powerlaw', genomes=6000, genome_law='sqrt')
     assert abs(n_edges - e) < 0.01 * e
     res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=20000)
     # level 0 ends with more communities than the bin table holds (later levels merge some of the smallest genomes)
@@ -107,7 +109,9 @@ def test_c5_at_its_stated_size(ctx):
     # the suite's shared context and torch's allocator still hold the blocks of the maps before this one: give them back first
     ctx.trim()
     torch.cuda.empty_cache()
-    counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, seed, law)
+    # (one count per UNIQUE pair on the rank^-0.5 genome sizes: on SURVEY 8(d)'s genome sizes the draw stream cannot reach 1e9 unique edges
+    # -- most genomes there hold under ten contigs and saturate; the contract generator's literal C5 is the test below)
+    counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, seed, law, genome_law='sqrt')
     torch.cuda.empty_cache()                      # (the draws were torch tensors)
     assert abs(n_edges - e) < 0.01 * e, (n_edges, info)
     assert counts.nnz > 2 ** 30 and counts.nnz * 8 > 2 ** 33
@@ -126,6 +130,49 @@ def test_c5_at_its_stated_size(ctx):
     assert longest > 10000          # (one count per unique pair: the hub contigs of this law have 10^4 .. 10^5 partners)
     # a repeat of the balance (the ~3000 dependent ticks are the bulk of the step): bit-identical x
     again = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=5000, cluster=False)
+    assert again.kr_info.n_iter == res.kr_info.n_iter and np.array_equal(again.x, res.x)
+    counts.free()
+    ctx.trim()
+
+
+def test_c5_contract_generator_raises_at_the_reference_default_and_balances_beyond(ctx):
+    """BASELINE.json configs[4] to the letter of SURVEY 8(d)'s generator on one GPU: 5,000,000 contigs in n/200 genomes ~ Zipf(1.5),
+    1e9 power-law DRAWS with duplicates summed (7.1e8 undirected edges whose hub pairs carry counts of 10^5 .. 10^6 beside tail pairs
+    of 5).  The reference at its default max_iter=1000 RAISES on this map (sparse_utils.py:213-214: the outer loop stops at the
+    first n_iter >= max_iter, and n_iter > max_iter then raises with the count it reached), so the device must too: B3C_E_NOCONV,
+    the reference's message, n_iter > 1000.  With the limit the map needs, the size-independent properties: sampled rows of the
+    balanced map (the longest hubs included) sum to one, every accepted contig labelled, a bit-identical repeat balance."""
+    import re
+    import torch
+    from bin3c_amd import _native
+    from bin3c_amd.pipeline import run_hot_path
+    from bin3c_amd.synth import CONFIGS
+    from bin3c_amd.synth_device import make_counts_device
+    n, e, seed, law = CONFIGS['C5']
+    ctx.trim()
+    torch.cuda.empty_cache()
+    counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, seed, law, genome_law='survey', dup='sum', draws_only=True)
+    torch.cuda.empty_cache()
+    assert 5e8 < n_edges < e and counts.nnz > 2 ** 30, (n_edges, info)
+    # (1) the reference's default limit: raises, with the reference's words and the iteration count it stopped at
+    with pytest.raises(_native.B3CError) as ei:
+        run_hot_path(ctx, counts, sites, lengths, 1000, 5)                 # max_iter=1000, sparse_utils.py:90
+    assert ei.value.code == _native.E_NOCONV
+    m = re.match(r'matrix balancing failed to converge in (\d+) iterations$', str(ei.value))
+    assert m and 1000 < int(m.group(1)) < 1000 + 200, str(ei.value)     # (one outer step past the limit: its inner iterations)
+    # (2) the limit this map needs
+    res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=20000)
+    assert 1000 < res.kr_info.n_iter < 20000, res.kr_info.n_iter
+    assert res.kr_info.bitwise_symmetric == 1 and np.isfinite(res.x).all() and (res.x > 0).all()
+    assert res.labels.shape[0] == int(res.mask.sum()) and res.labels.min() >= 0
+    assert res.lv_info.n_levels >= 2 and res.lv_info.modularity > 0.5, (res.lv_info.n_levels, res.lv_info.modularity)
+    ip, ix, data = counts.download()
+    hubs = np.argsort(np.diff(ip))[-5:].tolist()
+    rs = np.random.RandomState(5)
+    longest = _row_sums_are_one((ip, ix, data), sites, res.x, hubs + rs.randint(0, n, 500).tolist(), tol=2e-5)
+    del ip, ix, data
+    assert longest > 100000         # (hub contigs of 10^5 .. 10^6 partners)
+    again = run_hot_path(ctx, counts, sites, lengths, 1000, 5, max_iter=20000, cluster=False)
     assert again.kr_info.n_iter == res.kr_info.n_iter and np.array_equal(again.x, res.x)
     counts.free()
     ctx.trim()

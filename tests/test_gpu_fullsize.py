@@ -20,12 +20,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(ctx, cfg, reorder=True, keep=False):
-    """cfg: a BASELINE.json config on the rank^-0.5 genome-size variant ('C2', 'C3'), or -- '-survey' appended -- on the contract
-    generator as SURVEY 8(d) writes it (G = n/200 genomes ~ Zipf(1.5)), the map bench.py's headline runs"""
+    """cfg: a BASELINE.json config on the contract generator as SURVEY 8(d) writes it ('C2', 'C3': G = n/200 genomes ~ Zipf(1.5), the
+    map bench.py's headline runs), or -- '-variant' appended -- on the rank^-0.5 genome-size variant rounds 1-4 were tuned on"""
     from bin3c_amd.pipeline import run_hot_path
     from bin3c_amd.synth import CONFIGS, make_edges
     n, e, seed, law = CONFIGS[cfg.split('-')[0]]
-    lo, hi, c, diag, lengths, sites, genome = make_edges(n, e, seed, law, genome_law='survey' if cfg.endswith('-survey') else 'sqrt')
+    lo, hi, c, diag, lengths, sites, genome = make_edges(n, e, seed, law, genome_law='sqrt' if cfg.endswith('-variant') else 'survey')
     counts, n_edges = ctx.coo_symmetrise(n, lo, hi, c, diag)
     res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, reorder=reorder, keep=keep)
     return counts, n_edges, sites, lengths, genome, res
@@ -100,16 +100,18 @@ def compare_with_oracle(ctx, orc, counts, sites, lengths, res, max_iter=1000, se
         orc.set_threads(1)
 
 
-@pytest.mark.parametrize('cfg', ['C2', 'C3', 'C3-survey'])
+@pytest.mark.parametrize('cfg', ['C2', 'C3', 'C2-variant', 'C3-variant'])
 def test_full_size_matches_the_oracle(ctx, oracle_lib, cfg):
-    """'C3-survey' is the map bench.py's headline runs (the contract generator at 1M contigs / 100M edges: 162 SpMVs of which 87 % of
-    the entries take the tail pass, three Louvain levels, 26 sweeps, mega rows, hash aggregation): every stage against the oracle
-    at ITS size.  Its sequential-Louvain comparison is made at C2's size below (the python-louvain-style oracle needs minutes on the
-    185k-node induced graph)."""
+    """'C3' is the map bench.py's headline runs (the contract generator at 1M contigs / 100M edges: 162 SpMVs whose every entry takes
+    the tail pass, three Louvain levels, 26 sweeps, mega rows, hash aggregation): every stage against the oracle at ITS size.  Its
+    sequential-Louvain comparison is made at C2's size (the python-louvain-style oracle needs minutes on the 185k-node induced
+    graph): there the two schedules end in different optima of a flat landscape and how far apart is asserted (seq='quality');
+    on the variant law both find the same partition."""
     counts, n_edges, sites, lengths, genome, res = _run(ctx, cfg, keep=True)
     try:
-        st, ref = compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res, seq=not cfg.endswith('-survey'))
-        if cfg == 'C3-survey':
+        seq = True if cfg.endswith('-variant') else ('quality' if cfg == 'C2' else False)
+        st, ref = compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res, seq=seq)
+        if cfg == 'C3':
             assert st.n_iter > 100 and ref['n_levels'] >= 3 and ref['n_sweeps'] >= 20, (st.n_iter, ref['n_levels'], ref['n_sweeps'])
             assert res.kr_info.tcd_xt_tails > 0.5 * counts.nnz          # the tail pass carries most of this map
     finally:
@@ -117,62 +119,63 @@ def test_full_size_matches_the_oracle(ctx, oracle_lib, cfg):
         counts.free()
 
 
-@pytest.mark.parametrize('variant', ['survey', 'hard'])
-def test_c2_on_other_workload_definitions_matches_the_oracle(ctx, oracle_lib, variant):
-    """C2's size on the workload as SURVEY 8(d) writes it (G = n/200 genomes ~ Zipf(1.5): one genome holds 38 % of the contigs, its
-    community is a MEGA row of the level-1 graph -- k_lv_mega_insert / k_lv_mega_eval -- and the Louvain needs three levels and
-    twenty sweeps) and on a hard clustering problem (45 % inter-genome noise, no intra-genome boost: modularity 0.62): every stage
-    against the oracle, as at C2 / C3."""
+@pytest.mark.parametrize('variant', ['hard', 'hard-variant'])
+def test_c2_on_a_hard_clustering_problem_matches_the_oracle(ctx, oracle_lib, variant):
+    """C2's size on a hard clustering problem (45 % inter-genome noise, no intra-genome boost: modularity ~0.6), on the contract
+    genome sizes and on the rank^-0.5 variant: every stage against the oracle, as at C2 / C3.  (C2 on the plain contract workload --
+    one genome with 38 % of the contigs, a MEGA row at level 1, three levels, twenty sweeps -- is test_full_size_matches_the_oracle[C2].)"""
     from bin3c_amd.pipeline import run_hot_path
     from bin3c_amd.synth import make_edges
-    kw = dict(genome_law='survey') if variant == 'survey' else dict(noise=0.45, intra_boost=1)
-    lo, hi, c, diag, lengths, sites, genome = make_edges(100000, 5000000, 2, 'flat', **kw)
+    lo, hi, c, diag, lengths, sites, genome = make_edges(100000, 5000000, 2, 'flat', noise=0.45, intra_boost=1,
+                                                         genome_law='sqrt' if variant.endswith('-variant') else 'survey')
     counts, n_edges = ctx.coo_symmetrise(100000, lo, hi, c, diag)
     res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, keep=True)
     try:
         # the device's schedule against the sequential python-louvain-style sweep: not the same partition on these maps (by design,
         # DESIGN.md section 2) -- the modularity within 0.01 and the agreement of the two partitions are asserted and printed
         st, ref = compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res, seq='quality')
-        assert ref['n_sweeps'] >= 15 and (ref['n_levels'] >= 2 or variant == 'hard')
+        assert ref['n_sweeps'] >= 10
     finally:
         res.free()
         counts.free()
 
 
-@pytest.mark.parametrize('dup', ['first', 'sum'])
-def test_power_law_map_matches_the_oracle(ctx, oracle_lib, dup):
+@pytest.mark.parametrize('dup,glaw', [('first', 'sqrt'), ('sum', 'sqrt'), ('sum', 'survey')])
+def test_power_law_map_matches_the_oracle(ctx, oracle_lib, dup, glaw):
     """C5's SHAPE at sizes the oracle finishes in a minute (rank^-0.8 endpoint preference, drawn on the device,
     bin3c_amd/synth_device.py).  'first': 400k contigs, 1.6e7 UNIQUE edges -- the draws go on until the stated count is reached,
     every pair keeps one count: hub contigs with 10^4 partners, well conditioned.  'sum': 300k contigs, 1.08e7 draws whose
     duplicates are SUMMED (the host generator's rule: the draws collapse onto hub pairs, counts of 10^4..10^5 beside 5s):
-    a hundred KR iterations with bound cuts, hub rows through kr_kb_hub, counts beyond 65535 through the correction list."""
+    a hundred KR iterations with bound cuts, hub rows through kr_kb_hub, counts beyond 65535 through the correction list.
+    ('sum', 'survey') is the contract generator's literal rule for C5: Zipf genome sizes, duplicate draws summed."""
     from bin3c_amd.pipeline import run_hot_path
     from bin3c_amd.synth_device import make_counts_device
     if dup == 'first':
         n, e = 400000, 16000000
-        counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, 5, 'powerlaw')
+        counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, 5, 'powerlaw', genome_law=glaw)
         assert abs(n_edges - e) < 0.01 * e, (n_edges, info)
         assert info['intra_draws'] > 1.5 * info['intra_unique']        # the draws collapse onto hub pairs: that is the point
     else:
         n, e = 300000, 12000000
-        counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, 5, 'powerlaw', dup='sum', draws_only=True)
+        counts, n_edges, lengths, sites, genome, info = make_counts_device(ctx, n, e, 5, 'powerlaw', dup='sum', draws_only=True, genome_law=glaw)
         assert n_edges < 0.8 * e                                        # one batch of draws: under the power law most are repeats
     res = run_hot_path(ctx, counts, sites, lengths, 1000, 5, keep=True, max_iter=5000)
     try:
         st, ref = compare_with_oracle(ctx, oracle_lib, counts, sites, lengths, res, max_iter=5000, seq=False)
         assert st.n_iter > (50 if dup == 'first' else 80), st.n_iter
         # the planted genomes are found on this law too (the sequential oracle is left out: minutes on hub-heavy graphs)
-        assert res.lv_info.modularity > 0.8
+        assert res.lv_info.modularity > (0.8 if glaw == 'sqrt' else 0.5)
     finally:
         res.free()
         counts.free()
 
 
-@pytest.mark.parametrize('cfg', ['C2', 'C3'])
+@pytest.mark.parametrize('cfg', ['C2', 'C3', 'C2-variant', 'C3-variant'])
 def test_full_size_properties(ctx, cfg):
     counts, n_edges, sites, lengths, genome, res = _run(ctx, cfg)
     n = counts.n
-    assert abs(n_edges - {'C2': 5000000, 'C3': 100000000}[cfg]) < 0.002 * n_edges
+    contract = not cfg.endswith('-variant')
+    assert abs(n_edges - {'C2': 5000000, 'C3': 100000000}[cfg.split('-')[0]]) < 0.002 * n_edges
     # (1) KR: diag(x) A' diag(x) is doubly stochastic, A' = A with a unit diagonal where A's is zero
     ip, ix, data = counts.download()
     s = np.where(sites == 0, 1.0, sites)
@@ -191,27 +194,38 @@ def test_full_size_properties(ctx, cfg):
     assert np.array_equal(res.mask, (lengths >= 1000) & (sig >= 5))
     # (3) Louvain: every accepted contig labelled, planted genomes recovered, modularity high
     assert res.labels.min() >= 0 and res.labels.shape[0] == int(res.mask.sum())
-    assert graphs.same_partition(res.labels, genome[res.mask])
-    assert res.lv_info.modularity > 0.9
+    if contract:
+        # the giant genome of the contract law is a uniform random graph of ~180 neighbours per contig: modularity optimisation
+        # may split it, and merges some two-contig genomes -- agreement with the planted genomes is asserted, not identity
+        assert graphs.adjusted_rand(res.labels, genome[res.mask]) > 0.9
+        assert res.lv_info.modularity > 0.7
+    else:
+        assert graphs.same_partition(res.labels, genome[res.mask])
+        assert res.lv_info.modularity > 0.9
     # (4) determinism and layout independence
     from bin3c_amd.pipeline import run_hot_path
     again = run_hot_path(ctx, counts, sites, lengths, 1000, 5, keep=True)
     assert np.array_equal(again.x, res.x) and np.array_equal(again.labels, res.labels)
     # (5) heat-map block reduction of the balanced map: mass is conserved, the maximum survives
-    b = 250 if cfg == 'C3' else 25
+    b = 250 if cfg.startswith('C3') else 25
     ds_max = ctx.downsample(again.processed, b, 'max')
     assert ctx.max_value(ds_max) == ctx.max_value(again.processed)
     ds_max.free()
     ds = ctx.downsample(again.processed, b, 'mean')
     assert ds.n == -(-n // b)
-    if cfg == 'C2':
+    if cfg.startswith('C2'):
         total = again.processed.download(structure=False)[2].sum()
         np.testing.assert_allclose(ds.download(structure=False)[2].sum() * b * b, total, rtol=1e-11)
     ds.free()
     again.free()
-    if cfg == 'C2':
+    if cfg.startswith('C2'):
         plain = run_hot_path(ctx, counts, sites, lengths, 1000, 5, reorder=False)
         assert plain.kr_info.n_iter == res.kr_info.n_iter
         np.testing.assert_allclose(plain.x, res.x, rtol=1e-10)
-        assert graphs.same_partition(plain.labels, res.labels)
+        # (x differs in its last bits with the summation order; on the flat landscape of the contract law's giant genome that may
+        # tip single contigs, so the partitions are compared by agreement there)
+        if contract:
+            assert graphs.adjusted_rand(plain.labels, res.labels) > 0.95
+        else:
+            assert graphs.same_partition(plain.labels, res.labels)
     counts.free()

@@ -97,12 +97,18 @@ def test_pipeline_golden_graph(ctx, oracle_lib, n_sub):
     _assert_same(ref, labels, info)
 
 
+@pytest.mark.parametrize('law', graphs.LAWS)
 @pytest.mark.parametrize('n,e,seed', [(1000, 50000, 1), (5000, 100000, 2), (30000, 900000, 3)])
-def test_synthetic_maps(ctx, oracle_lib, n, e, seed):
-    gr = graphs.synth_graph(oracle_lib, n, e, seed)
+def test_synthetic_maps(ctx, oracle_lib, n, e, seed, law):
+    gr = graphs.synth_graph(oracle_lib, n, e, seed, genome_law=law)
     ref, labels, info = _run_both(ctx, oracle_lib, gr['indptr'], gr['indices'], gr['data'], gr['scl'])
     _assert_same(ref, labels, info)
-    assert graphs.same_partition(labels, gr['sm'].genome[gr['mask']])
+    # the planted genomes: found exactly on the variant law; on the contract law (two-contig genomes, a giant one) the optimum may
+    # merge a few of the smallest, so agreement is asserted (recorded: ARI 1.0 / 1.0 / 0.99996)
+    if law == 'sqrt':
+        assert graphs.same_partition(labels, gr['sm'].genome[gr['mask']])
+    else:
+        assert graphs.adjusted_rand(labels, gr['sm'].genome[gr['mask']]) > 0.99
 
 
 def test_hub_rows_use_global_table(ctx, oracle_lib):

@@ -35,12 +35,13 @@ def test_pipeline_matches_reference_fixture(ctx, oracle_lib):
     res.free()
 
 
+@pytest.mark.parametrize('law', graphs.LAWS)
 @pytest.mark.parametrize('n,e,seed', [(3000, 90000, 5), (40000, 1300000, 21)])
-def test_pipeline_ordered_equals_unordered(ctx, oracle_lib, n, e, seed):
+def test_pipeline_ordered_equals_unordered(ctx, oracle_lib, n, e, seed, law):
     """The locality-ordered layout is a pure performance device: every output is unchanged."""
     from bin3c_amd.pipeline import run_hot_path
     from bin3c_amd.synth import make_synth
-    sm = make_synth(n, e, seed)
+    sm = make_synth(n, e, seed, genome_law=law)
     counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
     r1 = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5, reorder=True)
     r2 = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5, reorder=False)
@@ -48,8 +49,13 @@ def test_pipeline_ordered_equals_unordered(ctx, oracle_lib, n, e, seed):
     assert r1.kr_info.n_iter == r2.kr_info.n_iter
     np.testing.assert_allclose(r1.x, r2.x, rtol=1e-10)
     # x differs in the last bits (summation order), so compare partitions, not raw labels
-    assert graphs.same_partition(r1.labels, r2.labels)
-    assert graphs.same_partition(r1.labels, sm.genome[r1.mask])
+    if law == 'sqrt':
+        assert graphs.same_partition(r1.labels, r2.labels)
+        assert graphs.same_partition(r1.labels, sm.genome[r1.mask])
+    else:
+        # (the contract law's giant genome is a flat landscape: last-bit differences of x may tip single contigs)
+        assert graphs.adjusted_rand(r1.labels, r2.labels) > 0.98
+        assert graphs.adjusted_rand(r1.labels, sm.genome[r1.mask]) > 0.98
     # against the oracle end to end
     sig = oracle_lib.max_offdiag_u32(sm.indptr, sm.indices, sm.counts)
     assert np.array_equal(r1.signal, sig)

@@ -1,6 +1,7 @@
 """
 Development tool (GPU box): randomised differential testing of libb3c against the CPU oracle -- random symmetric maps of
-random size, density, weight law, hub rows, empty rows, zero diagonals and masks through KR (count and fp64 forms),
+random size, density, weight law, hub rows, empty rows, zero diagonals and masks -- and, a third of the cases, planted-genome maps of
+the synthetic generator on the contract genome-size law or its variant -- through KR (count and fp64 forms),
 compress, the fused sub-map, the permutation, downsample and Louvain.  usage: tools/fuzz_parity.py [n_cases] [seed]
 Prints one line per failing case and a summary; exit code 1 if anything differed.
 """
@@ -17,9 +18,27 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = make_context(0)
 fails = 0
 n_unstable = [0]         # maps on which x is not determined to 1e-6 (see the probe below)
+# share of the cases drawn from the synthetic generator's genome-structured maps (two thirds of them on the contract law) instead
+# of the unstructured random maps below
+GENOME_SHARE = float(os.environ.get('B3C_FUZZ_GENOME_SHARE', '0.35'))
+
+
+def genome_map(rs):
+    """a contact map of the synthetic generator (bin3c_amd/synth.py): planted genomes on the CONTRACT genome-size law (SURVEY 8(d):
+    n/200 genomes ~ Zipf(1.5), one of them with 38 % of the contigs) or, one time in three, on the rank^-0.5 variant; flat or
+    power-law endpoints, easy or noisy"""
+    from bin3c_amd.synth import make_synth
+    n = int(rs.choice([400, 1000, 2500, 6000, 12000]))
+    e = int(n * float(rs.choice([4, 15, 40])))
+    law = 'survey' if rs.rand() < 0.67 else 'sqrt'
+    noise, boost = (0.1, 5) if rs.rand() < 0.6 else (float(rs.choice([0.3, 0.45])), 1)
+    sm = make_synth(n, e, int(rs.randint(1, 1 << 30)), 'powerlaw' if rs.rand() < 0.3 else 'flat', noise, boost, genome_law=law)
+    return n, sm.indptr, sm.indices, sm.counts, sm.sites
 
 
 def random_map(rs):
+    if GENOME_SHARE > 0 and rs.rand() < GENOME_SHARE:
+        return genome_map(rs)
     n = int(rs.choice([3, 17, 64, 65, 200, 513, 1500, 4000, 6000, 9000]))    # from 4096 rows on (and 16 entries per row) KR takes the dictionary form
     deg = float(rs.choice([1.5, 6, 30, 150, 400]))
     deg = min(deg, n - 1)

@@ -189,7 +189,7 @@ def kr_cases():
     cases['maxiter_warn'] = (sym_random(600, 0.05, 81), {'max_iter': None})
     cases['tol1e-10'] = (sym_random(1000, 0.05, 42), {'tol': 1e-10})
     # power-law degrees
-    sm = make_synth(6000, 100000, 5, 'powerlaw')
+    sm = make_synth(6000, 100000, 5, 'powerlaw', genome_law='sqrt')
     cases['powerlaw6000'] = (sm.to_scipy(np.float64), {})
     # COO input (the CLI path hands COO: contact_map.py:929)
     cases['coo_input'] = (sym_random(300, 0.05, 91).tocoo(), {})
@@ -254,7 +254,7 @@ def main():
              tol=kwargs.get('tol', 1e-6), max_iter=kwargs.get('max_iter', 1000), **res)
 
     # ---------------- max_offdiag / compress ----------------
-    sm = make_synth(1500, 30000, 17)
+    sm = make_synth(1500, 30000, 17, genome_law='sqrt')
     a = sm.to_scipy(np.uint32)
     mo = ns['max_offdiag'](a.tocoo())
     # rows whose only entry is the diagonal
@@ -286,7 +286,7 @@ def main():
 
     # ---------------- cluster pipeline: mask -> site norm -> KR -> compress -> scl ----------------
     # follows cluster.py:301-316 / contact_map.py:888-945,966-981 call by call with the sliced functions
-    sm = make_synth(1500, 40000, 23)
+    sm = make_synth(1500, 40000, 23, genome_law='sqrt')
     seq_map = sm.to_scipy(np.uint32).tocoo()
     min_len, min_sig = 2500, 40
     signal = ns['max_offdiag'](seq_map)

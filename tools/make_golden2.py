@@ -75,7 +75,7 @@ def main():
     class _Self(object):
         pass
 
-    sm = make_synth(300, 4000, 41)
+    sm = make_synth(300, 4000, 41, genome_law='sqrt')
     amat = sm.to_scipy(np.float64)
     order = np.random.RandomState(42).permutation(300)
     me = _Self()

@@ -216,7 +216,7 @@ def old_scipy(m):
 
 def main():
     from bin3c_amd.synth import make_synth
-    sm = make_synth(60, 500, 77)
+    sm = make_synth(60, 500, 77, genome_law='sqrt')
     n = sm.n
     seq_map = sm.to_scipy(np.uint32).tocoo()
     seqinfo_cls = Global('mzd.contact_map', 'SeqInfo')
