@@ -230,19 +230,35 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    def timed_leg(w, steps, warmup):
-        """W warm-up steps, then exactly K timed steps between barriers; time = max over ranks."""
+    def timed_leg(w, steps, warmup, hand_over=False):
+        """W warm-up steps, then exactly K timed steps between barriers; time = max over ranks.
+        hand_over (the sharded leg): every step gets its OWN resident copy of the raw map and hands it over
+        (run_hot_path(adopt_counts=True), what `bin3C.py cluster` does): the copy is freed as soon as the rank's row block of
+        the ordered map exists, so from there on a rank holds 1/world of the map, as a production run does.  The copies are
+        made before the timed region (inputs resident in HBM); when they would not fit beside the map, the leg keeps one."""
         acc = {'stage': {}, 'spmv_ms': 0.0, 'spmv_n': 0, 'move_ms': 0.0, 'move_n': 0, 'move_nnz': 0, 'move_rows': 0,
                'first_ms': 0.0, 'first_n': 0}
         last = None
+        copies = []
+        if hand_over:
+            free_b, _tot = torch.cuda.mem_get_info()
+            per = w.nnz * 8 + (w.n + 1) * 8
+            if (steps + warmup) * per < 0.5 * free_b:
+                copies = [ctx.clone(w.counts) for _ in range(steps + warmup)]
+        acc['raw_map_handed_over'] = bool(copies)
+
+        def step():
+            if copies:
+                return run_hot_path(ctx, copies.pop(), w.sites, w.lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub, adopt_counts=True)
+            return run_hot_path(ctx, w.counts, w.sites, w.lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub)
         for _ in range(warmup):
-            last = run_hot_path(ctx, w.counts, w.sites, w.lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub)
+            last = step()
         gc.collect()
         gc.disable()            # a generation-2 collection in the middle of a step shows up as a 20 ms hole in the GPU timeline
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            last = run_hot_path(ctx, w.counts, w.sites, w.lengths, min_len, min_sig, max_iter=max_iter, n_sub=args.n_sub)
+            last = step()
             for k, v in last.timings.items():
                 acc['stage'][k] = acc['stage'].get(k, 0.0) + v
             acc['spmv_ms'] += last.kr_info.spmv_ms
@@ -484,7 +500,7 @@ def main():
             sess = DistSession(ctx, W.n)
             if os.environ.get('B3C_BENCH_FAIL_SHARDED'):          # test hook (tests/test_dist.py)
                 raise RuntimeError('sharded leg disabled by B3C_BENCH_FAIL_SHARDED')
-            dt, last, acc = timed_leg(W, args.steps, args.warmup)
+            dt, last, acc = timed_leg(W, args.steps, args.warmup, hand_over=True)
             sess.check()
             n_exchanges = sess.n_exchanges
             sess.close()
@@ -492,7 +508,9 @@ def main():
             watchdog.cancel()
             give_up(repr(ex))
         watchdog.cancel()
-        extra = {'exchanges_per_step': n_exchanges // (args.steps + args.warmup)}
+        extra = {'exchanges_per_step': n_exchanges // (args.steps + args.warmup),
+                 'raw_map_handed_over': acc.get('raw_map_handed_over', False),
+                 'louvain_levels_sharded': int(getattr(last.lv_info, 'levels_sharded', 0))}
         if rep is not None:
             extra['replicas'] = {'value': rep['value'], 'unit': 'edges/s', 'ms_per_step': rep['ms_per_step'],
                                  'scaling': 'weak', 'parallelism': rep['config']['parallelism']}

@@ -35,7 +35,7 @@ class KRInfo(C.Structure):
 
 class LouvainInfo(C.Structure):
     _fields_ = [('n_comm', C.c_int32), ('n_levels', C.c_int32), ('n_sweeps', C.c_int64), ('n_moves', C.c_int64),
-                ('quant_shift', C.c_int32), ('reserved', C.c_int32), ('modularity', C.c_double),
+                ('quant_shift', C.c_int32), ('levels_sharded', C.c_int32), ('modularity', C.c_double),
                 ('move_ms', C.c_double), ('n_move_launch', C.c_int64), ('move_nnz', C.c_int64),
                 ('move_rows', C.c_int64), ('n_comm_level0', C.c_int64), ('agg_gathered_runs', C.c_int64),
                 ('first_sweep_ms', C.c_double), ('first_sweep_launches', C.c_int64), ('agg_nnz', C.c_int64)]
@@ -289,6 +289,13 @@ class Context(object):
             kind = U32 if getattr(data, 'element_size', lambda: 8)() == 4 else F64
         h = _VP()
         self._check(self.lib.b3c_mat_upload(self.h, n, nnz, _ptr(indptr), _ptr(indices), _ptr(data), kind, C.byref(h)))
+        return Mat(self, h)
+
+    def clone(self, mat):
+        """a second device copy of a matrix (device-to-device; a plain CSR copy: ordering ids and cached maxima are not carried)"""
+        a, b, c = mat.device_ptrs()
+        h = _VP()
+        self._check(self.lib.b3c_mat_upload(self.h, mat.n, mat.nnz, C.c_void_p(a), C.c_void_p(b), C.c_void_p(c), mat.kind, C.byref(h)))
         return Mat(self, h)
 
     # ---- ingest tail ----

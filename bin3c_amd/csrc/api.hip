@@ -20,7 +20,7 @@ extern "C" int b3c_abi_layout(int which, int32_t *out, int cap)
                                  F(b3c_kr_info, xt_word_bytes), F(b3c_kr_info, xt_residual_words), F(b3c_kr_info, spmv_stream_bytes)};
     static const int32_t lv[] = {(int32_t)sizeof(b3c_louvain_info), 0,
                                  F(b3c_louvain_info, n_comm), F(b3c_louvain_info, n_levels), F(b3c_louvain_info, n_sweeps),
-                                 F(b3c_louvain_info, n_moves), F(b3c_louvain_info, quant_shift), F(b3c_louvain_info, reserved),
+                                 F(b3c_louvain_info, n_moves), F(b3c_louvain_info, quant_shift), F(b3c_louvain_info, levels_sharded),
                                  F(b3c_louvain_info, modularity), F(b3c_louvain_info, move_ms), F(b3c_louvain_info, n_move_launch),
                                  F(b3c_louvain_info, move_nnz), F(b3c_louvain_info, move_rows), F(b3c_louvain_info, n_comm_level0),
                                  F(b3c_louvain_info, agg_gathered_runs), F(b3c_louvain_info, first_sweep_ms),

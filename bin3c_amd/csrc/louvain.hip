@@ -2775,8 +2775,16 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             free_graph(ctx, g);
             return ctx->fail(B3C_E_NOMEM, "b3c_louvain: level buffers");
         }
-        // multi-GPU: level 0 is row-sharded (decide + internal-weight scan); induced graphs are tiny and replicated
-        const bool dist = ctx->has_dist && first && (int64_t)ctx->dist.world * ctx->dist.chunk >= n;
+        // multi-GPU: level 0 is row-sharded (decide + internal-weight scan).  An induced graph is REPLICATED (every rank builds the
+        // same one from the reduced aggregation), but when it is still large -- the contract workload at C3: level 1 has 185,559
+        // nodes and 1.4e8 entries, as many as level 0 -- its sweeps are sharded too (round 6): every rank scans and recounts a row
+        // range of its copy, the decisions of a sub-round are gathered like level 0's, moves are applied by every rank.  Small
+        // levels stay whole on every rank: four label gathers and one partial sum per sweep would cost more than their scan
+        // (B3C_LV_DIST_MIN_NNZ: the tests shard every level)
+        const int64_t lv_dist_min_nnz = CFG.num("B3C_LV_DIST_MIN_NNZ", 1 << 24);
+        const bool dist = ctx->has_dist && (first || (g.nnz >= lv_dist_min_nnz && n >= 2 * (int64_t)ctx->dist.world)) &&
+                          (int64_t)ctx->dist.world * ctx->dist.chunk >= n;
+        if (dist && !first) info->levels_sharded++;
         const b3c_dist &D = ctx->dist;
         if (first && blockm && !dist) { free_graph(ctx, g); return ctx->fail(B3C_E_ARG, "b3c_louvain: row block larger than the exchange buffers"); }
         const bool blk0 = dist && blockm;             // level 0 on a row block
@@ -2797,8 +2805,29 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 }
                 starts[D.world] = all[2 * (size_t)D.world - 1];
                 if (starts[0] != 0 || starts[D.world] != n) { free_graph(ctx, g); return ctx->fail(B3C_E_ARG, "b3c_louvain: the ranks' row blocks do not tile the matrix"); }
-            } else {
+            } else if (first) {
                 for (int r = 0; r < D.world; r++) { int64_t e_; ctx->dist_rows(n, r, &starts[r], &e_); }
+                starts[D.world] = n;
+            } else {
+                // a later level: row ranges of the replicated induced graph balanced by STORED ENTRIES (its rows run from a handful
+                // of entries to a mega row of 10^5); every rank holds the same graph, so the ranges need no exchange
+                // (a transport without ragged slices stages a rank's labels through its equal slice of the exchange buffer: equal
+                // row counts then, which always fit)
+                const bool ragged_ok = D.starts && (D.comm || D.allgatherv);
+                if (ragged_ok) {
+                    std::vector<int64_t> hip_(n + 1);
+                    { const int rb_ = b3c_readback(ctx, hip_.data(), g.indptr, sizeof(int64_t) * (size_t)(n + 1)); if (rb_) return rb_; }
+                    const int64_t tot_e = hip_[n];
+                    for (int r = 1; r < D.world; r++) {
+                        const int64_t target = (int64_t)((unsigned __int128)tot_e * (unsigned)r / (unsigned)D.world);
+                        int64_t cut = std::lower_bound(hip_.begin(), hip_.end(), target) - hip_.begin();
+                        cut = std::min<int64_t>(n, (cut + 15) / 16 * 16);
+                        starts[r] = std::max(cut, starts[r - 1]);
+                    }
+                } else {
+                    const int64_t per = ((n + D.world - 1) / D.world + 15) / 16 * 16;
+                    for (int r = 1; r < D.world; r++) starts[r] = std::min<int64_t>(n, (int64_t)r * per);
+                }
                 starts[D.world] = n;
             }
             HIP_TRY(ctx, hipMemcpyAsync(starts_dev.p, starts.data(), sizeof(int64_t) * starts.size(), hipMemcpyHostToDevice, s));

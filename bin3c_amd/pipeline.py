@@ -208,6 +208,8 @@ def run_hot_path(ctx, counts, sites, lengths, min_len, min_sig, tol=1e-6, n_sub=
                 if adopt_counts:
                     counts.free()              # the result never took it over
                 raise
+            if adopt_counts:
+                counts.free()                  # handed over: from here on the ordered copy (a rank's row block when sharded) is the map
             # the per-contig tables in the working order (libb3c gathers: torch is plumbing here, not arithmetic)
             sites_t = ctx.vec_permute(sites_t, n2o, torch.empty_like(sites_t))
             lengths_t = ctx.vec_permute(lengths_t, n2o, torch.empty_like(lengths_t))

@@ -82,7 +82,8 @@ typedef struct {
     int64_t n_sweeps;
     int64_t n_moves;
     int32_t quant_shift;  /* fixed-point scale 2^shift applied to the edge weights */
-    int32_t reserved;
+    int32_t levels_sharded; /* row-sharded runs: levels BEYOND the first whose sweeps were sharded over the ranks too (their induced graph
+                             * is replicated; every rank scans a row range of it balanced by stored entries); 0 on one GPU */
     double modularity;    /* exact-integer modularity of the returned partition, as double */
     double move_ms;       /* device time in the delta-Q neighbour-scan kernel */
     int64_t n_move_launch;

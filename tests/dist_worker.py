@@ -194,7 +194,9 @@ def gpu_many_mode(rank, world):
     sm2 = make_synth(40000, 1300000, 21, noise=0.4, intra_boost=1)
     c2 = ctx.upload(sm2.indptr, sm2.indices, sm2.counts)
     single2 = run_hot_path(ctx, c2, sm2.sites, sm2.lengths, 1000, 5)
-    for env in ({'B3C_LV_AGG_SORT': '1'}, {'B3C_LV_NO_PRUNE': '1'}, {}):
+    # ... and with the sweeps of EVERY level sharded over the ranks (round 6: automatic for induced graphs of 2^24 entries and more --
+    # the contract workload's level 1 at C3 -- forced here on the small levels of a hard map)
+    for env in ({'B3C_LV_AGG_SORT': '1'}, {'B3C_LV_NO_PRUNE': '1'}, {'B3C_LV_DIST_MIN_NNZ': '1'}, {'B3C_LV_DIST_MIN_NNZ': '1', 'B3C_LV_NO_PRUNE': '1'}, {}):
         os.environ.update(env)
         ctx.reload_env()
         sess = DistSession(ctx, sm2.n)
@@ -203,6 +205,8 @@ def gpu_many_mode(rank, world):
         _agree(res2, single2, rank)
         if 'B3C_LV_AGG_SORT' in env:
             assert res2.lv_info.agg_gathered_runs > 0
+        assert res2.lv_info.levels_sharded == (res2.lv_info.n_levels if 'B3C_LV_DIST_MIN_NNZ' in env else 0), (res2.lv_info.levels_sharded, res2.lv_info.n_levels)
+        assert single2.lv_info.n_levels >= 2
         sess.close()
         for k in env:
             os.environ.pop(k)
@@ -304,6 +308,8 @@ def gpu_c4_mode(rank, world):
     assert int(most.item()) <= 1.10 * counts.nnz / world, (int(most.item()), counts.nnz)
     _agree(res, single, rank)
     assert res.lv_info.n_comm_level0 == single.lv_info.n_comm_level0 and res.lv_info.n_comm == single.lv_info.n_comm
+    # level 1 of this map (185,559 nodes, 1.4e8 entries: as large as level 0) is sharded too; the small levels after it are not
+    assert res.lv_info.levels_sharded == 1 and single.lv_info.levels_sharded == 0, res.lv_info.levels_sharded
     n_spmv = res.kr_info.n_iter + 1
     cuts = res.kr_info.hit_delta + res.kr_info.hit_Delta
     assert n_spmv <= sess.n_exchanges <= (n_spmv + cuts + 12) + 5 * (res.lv_info.n_sweeps + 1) + 14 + 8 * res.lv_info.n_levels, (sess.n_exchanges, n_spmv)

@@ -128,6 +128,7 @@ def test_bench_two_ranks_one_gpu(mode):
         assert d['scaling'] == 'weak' and 'replicas x2' in d['config']['parallelism']
         return
     assert d['scaling'] == 'strong' and d['exchanges_per_step'] > 100
+    assert d['raw_map_handed_over'] is True          # every step adopted its own resident copy of the raw map (a rank keeps its row block)
     assert 'one map over 2 GPUs by contig-row blocks' in d['config']['parallelism']
     if mode == 'auto':
         assert d['replicas']['value'] > 0 and d['replicas']['scaling'] == 'weak' and d['agrees_with_single_gpu'] is True

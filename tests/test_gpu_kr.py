@@ -141,7 +141,7 @@ def test_dictionary_words_of_24_bits(ctx, oracle_lib, monkeypatch, scale):
     24-bit words stay in use; without that rule (B3C_KR_TCD_DEMOTE=0) the pack kernel reports the overflow and the 32-bit words stay
     -- same x up to the order of the sums."""
     from bin3c_amd.synth import make_synth
-    sm = make_synth(40000, 1300000, 41)
+    sm = make_synth(40000, 1300000, 41, genome_law='sqrt')      # (the variant law: its dictionaries hold most entries and its counts stay below 656)
     cnt = (sm.counts.astype(np.uint64) * scale).astype(np.uint32)
     assert cnt.max() < 65536 and (cnt.max() > 2047) == (scale > 1)
     nd = oracle_lib.site_norm(sm.indptr, sm.indices, cnt.astype(np.float64), sm.sites)
