@@ -2787,7 +2787,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if (dist && !first) info->levels_sharded++;
         const b3c_dist &D = ctx->dist;
         if (first && blockm && !dist) { free_graph(ctx, g); return ctx->fail(B3C_E_ARG, "b3c_louvain: row block larger than the exchange buffers"); }
-        const bool blk0 = dist && blockm;             // level 0 on a row block
+        const bool blk0 = dist && blockm && first;    // level 0 on a row block (later levels are whole on every rank, sharded or not)
         // rows of every rank: equal chunks of a whole matrix, or the row blocks the ranks hold (their bounds are exchanged)
         std::vector<int64_t> starts(dist ? (size_t)D.world + 1 : 2, 0);
         DevBuf<int64_t> starts_dev(ctx, dist ? D.world + 1 : 1);
