@@ -702,34 +702,38 @@ __global__ void kr_hub_fill(int64_t r0, int64_t n, const int64_t *__restrict__ f
     if (i < n && flag[i - r0]) rows[pos[i - r0]] = i;
 }
 
+// Hub rows (round 6).  (a) A lane takes CONSECUTIVE entries per gather: the longest rows of a power-law map hold a fifth of all
+// columns, so 64 neighbouring entries sit on ~20 operand lines; with four consecutive entries per lane (the 16-byte loads of
+// rounds 2-5) a gather's 64 lanes were 4 entries apart and touched 64 lines.  (b) A row beyond HUB_SPLIT entries is cut into pieces
+// of HUB_SPLIT entries, one workgroup each (C5 on the contract generator: rows of 10^6 entries, each of which used to be ONE
+// workgroup's 2.5 ms of gathers while the kernel's other workgroups had long finished); kr_kb_hub_fin adds a row's pieces in piece
+// order and runs the epilogue.  Maps whose longest row fits one piece keep the single launch (pieces == nullptr).
+constexpr int HUB_SPLIT = 16384;        // (B3C_KR_HUB_SPLIT: the tests cut shorter rows)
+
+struct HubPiece { int32_t row_idx, piece; };        // index into hub_rows, piece number inside the row
+
 template <typename VT>
-__global__ void __launch_bounds__(BLK) kr_kb_hub(const int64_t *__restrict__ hub_rows, const KRState *__restrict__ sin,
-                                                  const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                  const VT *__restrict__ a, const double *__restrict__ rs,
-                                                  const double *__restrict__ dfix, const double *__restrict__ u,
-                                                  const double *__restrict__ x, const double *__restrict__ p,
-                                                  double *__restrict__ v, double *__restrict__ rk, double *__restrict__ w,
-                                                  double *__restrict__ part_out)
+__device__ __forceinline__ double hub_dot(const int32_t *__restrict__ indices, const VT *__restrict__ a, const double *__restrict__ u,
+                                           int64_t s, int64_t len, double *lds)
 {
-    __shared__ double lds[BLK];
-    const int32_t phase = sin->phase;
-    if (phase != A_INNER && phase != A_OUTER) {          // P_DONE (or anything that runs no SpMV): contribute nothing
-        if (threadIdx.x == 0) part_out[blockIdx.x] = 0.0;
-        return;
-    }
-    const bool inner = phase == A_INNER;
-    const int64_t row = hub_rows[blockIdx.x];
-    const int64_t s = indptr[row];
-    const int64_t len = indptr[row + 1] - s;
+    // four spans of 64 consecutive entries per wave and pass: index and value loads of all four in flight, then the four gathers
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc = 0.0;
-    for (int64_t base = (int64_t)threadIdx.x * 4; base < len; base += BLK * 4) {
-        const Vec4<int32_t> c = *(const Vec4<int32_t> *)(indices + s + base);
-        const Vec4<VT> m = *(const Vec4<VT> *)(a + s + base);
+    for (int64_t base = (int64_t)wv * 256; base < len; base += (BLK / 64) * 256) {
+        int32_t c[4];
+        VT m[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t k = base + q * 64 + lane;
+            const int64_t kk = k < len ? k : 0;
+            c[q] = indices[s + kk];
+            m[q] = a[s + kk];
+        }
         double g[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) g[j] = u[base + j < len ? (uint32_t)c.v[j] : 0u];
+        for (int q = 0; q < 4; q++) g[q] = u[(uint32_t)c[q]];
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc += (base + j < len ? (double)m.v[j] : 0.0) * g[j];
+        for (int q = 0; q < 4; q++) acc += (base + q * 64 + lane < len ? (double)m[q] : 0.0) * g[q];
     }
     lds[threadIdx.x] = acc;
     __syncthreads();
@@ -738,26 +742,90 @@ __global__ void __launch_bounds__(BLK) kr_kb_hub(const int64_t *__restrict__ hub
         if ((int)threadIdx.x < st) lds[threadIdx.x] += lds[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const double xi = x[row];
-        const double ri = rs ? rs[row] : 1.0;
-        double contrib;
-        if (inner) {
-            const double pi = p[row];
-            const double t = lds[0] * ri + dfix[row] * (xi * pi);
-            const double wi = xi * t + v[row] * pi;
-            w[row] = wi;
-            contrib = pi * wi;
-        } else {
-            const double t = lds[0] * ri + dfix[row] * xi;
-            const double vn = xi * t;
-            const double r = 1.0 - vn;
-            v[row] = vn;
-            rk[row] = r;
-            contrib = r * r;
-        }
-        part_out[blockIdx.x] = contrib;
+    return lds[0];
+}
+
+__device__ __forceinline__ double hub_epilogue(bool inner, int64_t row, double dot, const double *__restrict__ rs, const double *__restrict__ dfix,
+                                               const double *__restrict__ x, const double *__restrict__ p, double *__restrict__ v,
+                                               double *__restrict__ rk, double *__restrict__ w)
+{
+    const double xi = x[row];
+    const double ri = rs ? rs[row] : 1.0;
+    if (inner) {
+        const double pi = p[row];
+        const double t = dot * ri + dfix[row] * (xi * pi);
+        const double wi = xi * t + v[row] * pi;
+        w[row] = wi;
+        return pi * wi;
     }
+    const double t = dot * ri + dfix[row] * xi;
+    const double vn = xi * t;
+    const double r = 1.0 - vn;
+    v[row] = vn;
+    rk[row] = r;
+    return r * r;
+}
+
+template <typename VT>
+__global__ void __launch_bounds__(BLK) kr_kb_hub(const int64_t *__restrict__ hub_rows, const KRState *__restrict__ sin,
+                                                  const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                  const VT *__restrict__ a, const double *__restrict__ rs,
+                                                  const double *__restrict__ dfix, const double *__restrict__ u,
+                                                  const double *__restrict__ x, const double *__restrict__ p,
+                                                  double *__restrict__ v, double *__restrict__ rk, double *__restrict__ w,
+                                                  double *__restrict__ part_out, const HubPiece *__restrict__ pieces,
+                                                  double *__restrict__ piece_sum, int hub_split)
+{
+    __shared__ double lds[BLK];
+    const int32_t phase = sin->phase;
+    if (phase != A_INNER && phase != A_OUTER) {          // P_DONE (or anything that runs no SpMV): contribute nothing
+        if (threadIdx.x == 0 && !pieces) part_out[blockIdx.x] = 0.0;
+        return;
+    }
+    if (pieces) {
+        // one piece of a (long) row: its dot product only; kr_kb_hub_fin adds the pieces and runs the row's epilogue
+        const HubPiece pc = pieces[blockIdx.x];
+        const int64_t row = hub_rows[pc.row_idx];
+        const int64_t s = indptr[row] + (int64_t)pc.piece * hub_split;
+        const int64_t left = indptr[row + 1] - s;
+        const double d = hub_dot<VT>(indices, a, u, s, left < hub_split ? left : hub_split, lds);
+        if (threadIdx.x == 0) piece_sum[blockIdx.x] = d;
+        return;
+    }
+    const int64_t row = hub_rows[blockIdx.x];
+    const int64_t s = indptr[row];
+    const double d = hub_dot<VT>(indices, a, u, s, indptr[row + 1] - s, lds);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = hub_epilogue(phase == A_INNER, row, d, rs, dfix, x, p, v, rk, w);
+}
+
+// one thread per hub row: its pieces' sums in piece order (fixed: deterministic), then the epilogue
+__global__ void __launch_bounds__(BLK) kr_kb_hub_fin(int64_t n_hub, const int64_t *__restrict__ hub_rows, const KRState *__restrict__ sin,
+                                                      const int64_t *__restrict__ piece_first, const double *__restrict__ piece_sum,
+                                                      const double *__restrict__ rs, const double *__restrict__ dfix,
+                                                      const double *__restrict__ x, const double *__restrict__ p, double *__restrict__ v,
+                                                      double *__restrict__ rk, double *__restrict__ w, double *__restrict__ part_out)
+{
+    const int64_t r = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (r >= n_hub) return;
+    const int32_t phase = sin->phase;
+    if (phase != A_INNER && phase != A_OUTER) { part_out[r] = 0.0; return; }
+    double d = 0.0;
+    for (int64_t k = piece_first[r]; k < piece_first[r + 1]; k++) d += piece_sum[k];
+    part_out[r] = hub_epilogue(phase == A_INNER, hub_rows[r], d, rs, dfix, x, p, v, rk, w);
+}
+
+__global__ void kr_hub_piece_count(int64_t n_hub, int hub_split, const int64_t *__restrict__ hub_rows, const int64_t *__restrict__ indptr, int64_t *__restrict__ cnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_hub) return;
+    cnt[r] = r < n_hub ? (indptr[hub_rows[r] + 1] - indptr[hub_rows[r]] + hub_split - 1) / hub_split : 0;
+}
+
+__global__ void kr_hub_piece_fill(int64_t n_hub, const int64_t *__restrict__ first, HubPiece *__restrict__ pieces)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_hub) return;
+    for (int64_t k = first[r]; k < first[r + 1]; k++) { HubPiece pc; pc.row_idx = (int32_t)r; pc.piece = (int32_t)(k - first[r]); pieces[k] = pc; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2731,6 +2799,24 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         if (n_hub > hub_cap) return ctx->fail(B3C_E_HIP, "b3c_kr_balance: hub row count out of bounds");
         if (n_hub) hipLaunchKernelGGL(kr_hub_fill, dim3(gh), dim3(256), 0, s, r0, r1, hub_flag.p, hub_pos.p, hub_rows.p);
     }
+    // rows beyond HUB_SPLIT entries run as pieces of HUB_SPLIT entries (kr_kb_hub with `pieces`, then kr_kb_hub_fin)
+    struct PoolPtrHub { b3c_ctx *c; void *p = nullptr; ~PoolPtrHub() { c->release(p); } } hub_pieces{ctx}, hub_piece_sum{ctx}, hub_piece_first{ctx};
+    int64_t n_hub_pieces = 0;
+    const int hub_split = (int)std::max<int64_t>(BLK, CFG.num("B3C_KR_HUB_SPLIT", HUB_SPLIT));
+    if (n_hub > 0 && maxdeg > (unsigned long long)hub_split && n_hub < (1ll << 31)) {
+        DevBuf<int64_t> pcnt_(ctx, n_hub + 1);
+        hub_piece_first.p = ctx->alloc(sizeof(int64_t) * (size_t)(n_hub + 1));
+        if (!pcnt_.p || !hub_piece_first.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: hub pieces");
+        hipLaunchKernelGGL(kr_hub_piece_count, dim3((unsigned)((n_hub + 256) / 256)), dim3(256), 0, s, n_hub, hub_split, hub_rows.p, a->indptr, pcnt_.p);
+        int rcp;
+        if ((rcp = b3c_exclusive_scan_i64(ctx, pcnt_.p, (int64_t *)hub_piece_first.p, n_hub + 1))) return rcp;
+        { const int rb_ = b3c_readback(ctx, &n_hub_pieces, (int64_t *)hub_piece_first.p + n_hub, sizeof(int64_t)); if (rb_) return rb_; }
+        hub_pieces.p = ctx->alloc(sizeof(HubPiece) * (size_t)(n_hub_pieces + 1));
+        hub_piece_sum.p = ctx->alloc(sizeof(double) * (size_t)(n_hub_pieces + 1));
+        if (!hub_pieces.p || !hub_piece_sum.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: hub pieces");
+        hipLaunchKernelGGL(kr_hub_piece_fill, dim3((unsigned)((n_hub + 255) / 256)), dim3(256), 0, s, n_hub, (const int64_t *)hub_piece_first.p, (HubPiece *)hub_pieces.p);
+        HIP_TRY(ctx, hipStreamSynchronize(s));           // (pcnt_ goes back to the pool)
+    }
     // count form: 16-bit copy of the values when they all fit (built on the matrix the iteration runs on)
     const uint16_t *v16 = nullptr;
     unsigned long long vmax_counts = 0;
@@ -3166,15 +3252,21 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                 else launch_kb_pipe<4, 8>(s, GS, r0, r1, s0, s1, kbp, kbP, kbS, a, v16, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, pkb.p, hub_len, corr_p);
             }
             if (n_hub) {       // the rows the row-group kernel left out; same state slot, partials behind its GS
+                const unsigned hub_grid = (unsigned)(n_hub_pieces ? n_hub_pieces : n_hub);
+                const HubPiece *hp = n_hub_pieces ? (const HubPiece *)hub_pieces.p : nullptr;
+                double *hps = (double *)hub_piece_sum.p;
                 if (a->kind == B3C_U32 && v16 && !n_big)           // (hub rows read the full 32-bit counts when some are large)
-                    hipLaunchKernelGGL(kr_kb_hub<uint16_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices, v16,
-                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out);
+                    hipLaunchKernelGGL(kr_kb_hub<uint16_t>, dim3(hub_grid), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices, v16,
+                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out, hp, hps, hub_split);
                 else if (a->kind == B3C_U32)
-                    hipLaunchKernelGGL(kr_kb_hub<uint32_t>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out);
+                    hipLaunchKernelGGL(kr_kb_hub<uint32_t>, dim3(hub_grid), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
+                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out, hp, hps, hub_split);
                 else
-                    hipLaunchKernelGGL(kr_kb_hub<double>, dim3((unsigned)n_hub), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out);
+                    hipLaunchKernelGGL(kr_kb_hub<double>, dim3(hub_grid), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
+                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out, hp, hps, hub_split);
+                if (n_hub_pieces)
+                    hipLaunchKernelGGL(kr_kb_hub_fin, dim3((unsigned)((n_hub + BLK - 1) / BLK)), dim3(BLK), 0, s, n_hub, hub_rows.p, s0, (const int64_t *)hub_piece_first.p,
+                                       (const double *)hub_piece_sum.p, rs, dfix.p, x.p, p.p, v.p, rk.p, w_kb, hub_out);
                 if (hub_fold) hipLaunchKernelGGL(kr_fold_chunks, dim3((unsigned)hub_parts), dim3(BLK), 0, s, hubraw.p, n_hub, HUB_CHUNK, pkb.p + GS);
             }
             if (timed) HIP_TRY(ctx, hipEventRecord(evs.back(), s));

@@ -219,6 +219,44 @@ def test_thin_dictionary_share_goes_to_the_tail_pass_altogether(ctx, monkeypatch
     cm.free()
 
 
+def test_long_hub_rows_run_as_pieces(ctx, oracle_lib, monkeypatch):
+    """Round 6: a hub row beyond HUB_SPLIT entries (16384; BASELINE's C5 has rows of 10^6) is cut into pieces, one workgroup each, whose
+    sums kr_kb_hub_fin adds in piece order before the row's epilogue.  Forced here on a power-law map of 30,000 contigs (longest row
+    ~6,000 entries) with pieces of 1024 and 256 entries, on the CSR row kernels and beside the dictionary / tail-pass forms: same
+    iteration count, x to 1e-11 of the one-workgroup-per-row form and to 1e-9 of the oracle, bit-identical repeats."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(30000, 900000, 9, 'powerlaw')
+    assert int(np.diff(sm.indptr).max()) > 2048
+    nd = oracle_lib.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
+    rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
+    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    fm = ctx.upload(sm.indptr, sm.indices, nd)
+    for env in ({}, {'B3C_KR_NO_TCD': '1'}, {'B3C_KR_TCD_XT': '1'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _, x0, i0 = ctx.kr_balance_counts(cm, sm.sites)
+        assert i0.n_iter == st.n_iter
+        np.testing.assert_allclose(x0, xo, rtol=1e-9)
+        for split in ('1024', '256'):
+            monkeypatch.setenv('B3C_KR_HUB_SPLIT', split)
+            _, x1, i1 = ctx.kr_balance_counts(cm, sm.sites)
+            _, x2, _ = ctx.kr_balance_counts(cm, sm.sites)
+            assert i1.n_iter == st.n_iter and np.array_equal(x1, x2)
+            np.testing.assert_allclose(x1, x0, rtol=1e-11)
+            monkeypatch.delenv('B3C_KR_HUB_SPLIT')
+        for k in env:
+            monkeypatch.delenv(k)
+    # the fp64 matrix form (kr_kb_hub<double>)
+    _, xf0, if0 = ctx.kr_balance(fm)
+    monkeypatch.setenv('B3C_KR_HUB_SPLIT', '512')
+    _, xf1, if1 = ctx.kr_balance(fm)
+    assert if0.n_iter == if1.n_iter == st.n_iter
+    np.testing.assert_allclose(xf1, xf0, rtol=1e-11)
+    np.testing.assert_allclose(xf1, xo, rtol=1e-9)
+    cm.free()
+    fm.free()
+
+
 def test_tail_pass_with_long_tails(ctx, monkeypatch):
     """Tail pass of the dictionary SpMV on a power-law map whose hub rows stay in the tiles (B3C_KR_NO_HUB): tails of
     thousands of entries narrow the 32-bit remainder sums of the fixed-point accumulation; x must agree with the CSR
