@@ -63,3 +63,30 @@ def test_pipeline_ordered_equals_unordered(ctx, oracle_lib, n, e, seed, law):
     rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
     assert st.n_iter == r1.kr_info.n_iter
     np.testing.assert_allclose(r1.x, xo, rtol=1e-9)
+
+
+@pytest.mark.parametrize('drop', [0.0, 0.03, 0.2, 0.6])
+def test_fused_sub_map_in_graph_form_counts_from_the_dropped_rows(ctx, oracle_lib, drop):
+    """b3c_normalise_scale_compress in graph form (the call of the cluster step).  With few rows dropped its first pass finds the kept
+    entries of every row from the DROPPED rows' side (round 6: row j dropped and (j, i) stored <=> (i, j) stored -- the map is
+    structurally symmetric); with many, by the mask gather.  Either way: structure == compress of the oracle, the lower triangle bit
+    for bit, the upper one mirroring it."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(20000, 600000, 13)
+    nd = oracle_lib.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
+    rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
+    rs = np.random.RandomState(int(drop * 100) + 1)
+    mask = rs.rand(sm.n) >= drop
+    proc = oracle_lib.scale_sym(sm.indptr, sm.indices, nd, xo)
+    m, sip, six, sa = oracle_lib.compress(sm.indptr, sm.indices, proc, mask)
+    counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    sub = ctx.normalise_scale_compress(counts, sm.sites, xo, mask, graph_form=True)
+    dip, dix, da = sub.download()
+    assert sub.n == m and np.array_equal(dip, sip) and np.array_equal(dix, six)
+    lower = np.repeat(np.arange(m), np.diff(sip)) >= six
+    assert np.array_equal(da[lower], sa[lower])
+    import scipy.sparse as sp
+    g = sp.csr_matrix((da, dix, dip), shape=(m, m))
+    assert (g != g.T).nnz == 0                       # both triangles carry the lower one's value
+    sub.free()
+    counts.free()
