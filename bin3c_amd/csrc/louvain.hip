@@ -50,6 +50,10 @@ __host__ __device__ __forceinline__ uint32_t bucket_of(int64_t i, int n_sub)
     return (h >> 16) % (uint32_t)n_sub;
 }
 
+// ONE rule, used by the host (b3c_louvain: `incr`) and by the recount kernels (HALF mode): the sweep that follows one which moved
+// under 35 % of the level's nodes tracks the internal weight through the movers' rows (and prunes), the others recount it in full
+__host__ __device__ __forceinline__ bool lv_track_next(unsigned long long moved, unsigned long long n_level) { return moved * 20ull < n_level * 7ull; }
+
 struct LvGraph {
     int64_t n = 0, nnz = 0;
     int64_t *indptr = nullptr;
@@ -1718,9 +1722,9 @@ __global__ void __launch_bounds__(BLK) k_lv_internal(int64_t r0, int64_t n, cons
     // HALF mode (round 5).  The graph is symmetric (q_ij == q_ji, both stored), so I2 is twice the sum over the entries above the
     // diagonal plus the loops: the entries below it are skipped without gathering their labels.  own[] -- the per-node by-product the
     // exact pruning starts from -- needs whole rows, but is only read if the NEXT sweep tracks the internal weight through the movers'
-    // rows, i.e. if the sweep just finished moved under a quarter of the nodes: the host applies that rule when the count comes back
+    // rows, i.e. if the sweep just finished moved under 35 % of the nodes (lv_track_next): the host applies that rule when the count comes back
     // (b3c_louvain: `incr`), this kernel reads the same count from device memory.  Both rules are one expression: keep them one.
-    const bool half = moved_dev != nullptr && *moved_dev * 4ull >= (u64)n_level;
+    const bool half = moved_dev != nullptr && !lv_track_next(*moved_dev, (u64)n_level);
     if (half) own = nullptr;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -1801,7 +1805,7 @@ __global__ void __launch_bounds__(1024) k_lv_internal_long(const NodeRec *__rest
                                                             u64 *__restrict__ i2, int64_t *__restrict__ own,
                                                             const u64 *__restrict__ moved_dev, int64_t n_level)
 {
-    const bool half = moved_dev != nullptr && *moved_dev * 4ull >= (u64)n_level;        // see k_lv_internal
+    const bool half = moved_dev != nullptr && !lv_track_next(*moved_dev, (u64)n_level);        // see k_lv_internal
     if (half) own = nullptr;
     const NodeRec rec = list[blockIdx.x / chunks];
     const int64_t c0 = (int64_t)(blockIdx.x % chunks) * 4096;
@@ -3035,7 +3039,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         if ((rc = modularity(&new_mod, false, nullptr))) { free_graph(ctx, g); return rc; }
         int sweep = 0;
         u64 prev_moved = ~0ull;
-        constexpr int incr_div = 4;       // (1: 15.3 ms against 14.0 at C3 -- sweeps 2 and 3 still move 77 % and 25 % of the nodes)
+        // (tracking from the first sweep on: 15.3 ms against 14.0 at C3 on the variant law -- its sweeps 2 and 3 still move 77 % and 25 %
+        // of the nodes.  Round 6, contract law: the bar is 35 % instead of 25 % -- level 0's third sweep follows one that moved 32 %,
+        // moves 13 % itself and was recounted in full for 1.3 ms; level 1's fifth follows 33.6 % and moves 1 %)
         for (;;) {
             cur_mod = new_mod;
             sweep++;
@@ -3043,7 +3049,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 1, 0, sizeof(u64), s));
             // few movers expected (the sweep before moved under a quarter of the nodes): track the internal weight through
             // the movers' rows instead of rescanning the whole graph after the sweep
-            const bool incr = grouped && prev_moved != ~0ull && prev_moved * (u64)incr_div < (u64)n;
+            const bool incr = grouped && prev_moved != ~0ull && lv_track_next(prev_moved, (u64)n);
             for (int r = 0; r < n_sub; r++) {
                 epoch++;
                 evs.rec();
