@@ -347,7 +347,7 @@ int b3c_dist_allgather_rows(b3c_ctx *ctx, void *full, int esz, const int64_t *st
 int b3c_dist_allgatherv(b3c_ctx *ctx, void *base, int esz, const int64_t *starts_host);   // ragged, in place
 // ragged gather of (key, value) pairs of 64-bit words; *out: pooled block of 2 * *total words (keys of all ranks in rank
 // order, then the values), released by the caller with ctx->release
-int b3c_dist_gather_pairs(b3c_ctx *ctx, const int64_t *keys, const int64_t *vals, int64_t cnt, int64_t **out, int64_t *total);
+int b3c_dist_alltoallv_u64(b3c_ctx *ctx, const int64_t *send, int64_t *recv, const int64_t *cmat);   // cmat[s * world + d]: words s -> d
 int b3c_mat_alloc(b3c_ctx *ctx, int64_t n, int64_t nnz, int kind, b3c_mat **out);
 int b3c_copy_in(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);
 int b3c_copy_out(b3c_ctx *ctx, void *dst, const void *src, size_t bytes);

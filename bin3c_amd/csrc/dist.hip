@@ -21,6 +21,8 @@ typedef int (*fn_comm_destroy)(void *);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_send)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_recv)(void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_group)(void);
 typedef const char *(*fn_err)(int);
 
@@ -35,6 +37,8 @@ struct Rccl {
     fn_all_gather all_gather = nullptr;
     fn_all_reduce all_reduce = nullptr;
     fn_broadcast broadcast = nullptr;
+    fn_send send = nullptr;
+    fn_recv recv = nullptr;
     fn_group group_start = nullptr, group_end = nullptr;
     fn_err err = nullptr;
     bool ok = false;
@@ -59,6 +63,8 @@ Rccl *rccl()
     r.all_gather = (fn_all_gather)dlsym(r.h, "ncclAllGather");
     r.all_reduce = (fn_all_reduce)dlsym(r.h, "ncclAllReduce");
     r.broadcast = (fn_broadcast)dlsym(r.h, "ncclBroadcast");
+    r.send = (fn_send)dlsym(r.h, "ncclSend");
+    r.recv = (fn_recv)dlsym(r.h, "ncclRecv");
     r.group_start = (fn_group)dlsym(r.h, "ncclGroupStart");
     r.group_end = (fn_group)dlsym(r.h, "ncclGroupEnd");
     r.err = (fn_err)dlsym(r.h, "ncclGetErrorString");
@@ -264,43 +270,52 @@ int b3c_dist_allgather_rows(b3c_ctx *ctx, void *full, int esz, const int64_t *st
     return B3C_OK;
 }
 
-// Ragged gather of (key, value) pairs: rank r contributes cnt_r pairs of 64-bit words; afterwards every rank holds the
-// keys of all ranks in rank order followed by the values (2 * total words in one pooled block, *out).  The counts travel
-// through the integer exchange buffer; the payload is summed into a zeroed buffer of the final layout (every word has
-// exactly one non-zero contributor, so the integer all-reduce IS the gather, bit for bit, on both transports).  A ring
-// all-reduce moves twice what a ragged all-gather would; these runs are the already reduced community pairs of a level,
-// a few percent of the entries a rank streamed to form them.
-int b3c_dist_gather_pairs(b3c_ctx *ctx, const int64_t *keys, const int64_t *vals, int64_t cnt, int64_t **out, int64_t *total)
+// All-to-all of 64-bit words with per-pair counts (round 6: the aggregation by OWNER).  cmat[s * world + d] = words rank s sends to
+// rank d -- the whole matrix, known to every rank (the caller all-reduces it first).  `send` holds this rank's words ordered by
+// destination, `recv` receives the words for this rank ordered by source.  RCCL: one grouped launch of ncclSend / ncclRecv pairs
+// (point to point over xGMI: every word crosses one link once).  Callback transport (the gloo tests): a sum into a zeroed buffer of
+// the global layout -- every word has one non-zero contributor, so the integer all-reduce IS the exchange, bit for bit.
+int b3c_dist_alltoallv_u64(b3c_ctx *ctx, const int64_t *send, int64_t *recv, const int64_t *cmat)
 {
     const b3c_dist &D = ctx->dist;
-    *out = nullptr;
-    *total = 0;
-    const int64_t mine[2] = {cnt, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
-    int rc = b3c_dist_exchange(ctx, B3C_BUF_ISUM);
-    if (rc) return rc;
-    std::vector<int64_t> all(2 * (size_t)D.world);
-    if ((rc = b3c_readback(ctx, all.data(), D.isum, sizeof(int64_t) * all.size()))) return rc;
-    int64_t off = 0, tot = 0;
-    for (int r = 0; r < D.world; r++) {
-        if (all[2 * (size_t)r] < 0) return ctx->fail(B3C_E_ARG, "b3c_dist_gather_pairs: negative count from rank %d", r);
-        if (r < D.rank) off += all[2 * (size_t)r];
-        tot += all[2 * (size_t)r];
-    }
-    int64_t *buf = (int64_t *)ctx->alloc(sizeof(int64_t) * 2 * (size_t)(tot > 0 ? tot : 1));
-    if (!buf) return ctx->fail(B3C_E_NOMEM, "b3c_dist_gather_pairs: %lld pairs", (long long)tot);
-    struct Hold { b3c_ctx *c; int64_t *p; ~Hold() { c->release(p); } } hold{ctx, buf};
-    if (tot) {
-        HIP_TRY(ctx, hipMemsetAsync(buf, 0, sizeof(int64_t) * 2 * (size_t)tot, ctx->stream));
-        if (cnt) {
-            HIP_TRY(ctx, hipMemcpyAsync(buf + off, keys, sizeof(int64_t) * (size_t)cnt, hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(buf + tot + off, vals, sizeof(int64_t) * (size_t)cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    const int W = D.world, me = D.rank;
+    ctx->n_exchanges++;
+    std::vector<int64_t> soff(W + 1, 0), roff(W + 1, 0);
+    for (int d = 0; d < W; d++) soff[d + 1] = soff[d] + cmat[(size_t)me * W + d];
+    for (int sr = 0; sr < W; sr++) roff[sr + 1] = roff[sr] + cmat[(size_t)sr * W + me];
+    if (D.comm) {
+        Rccl *r = rccl();
+        if (!r->ok || !r->send || !r->recv) return ctx->fail(B3C_E_RCCL, "librccl.so.1 lacks ncclSend / ncclRecv");
+        int rc = 0;
+        if ((rc = r->group_start()) != 0) return rccl_fail(ctx, "ncclGroupStart", rc);
+        for (int pr = 0; pr < W; pr++) {
+            const int64_t ns = soff[pr + 1] - soff[pr], nr = roff[pr + 1] - roff[pr];
+            if (ns > 0 && (rc = r->send(send + soff[pr], (size_t)ns, NCCL_INT64, pr, D.comm, ctx->stream)) != 0) { (void)r->group_end(); return rccl_fail(ctx, "ncclSend", rc); }
+            if (nr > 0 && (rc = r->recv(recv + roff[pr], (size_t)nr, NCCL_INT64, pr, D.comm, ctx->stream)) != 0) { (void)r->group_end(); return rccl_fail(ctx, "ncclRecv", rc); }
         }
-        if ((rc = b3c_dist_allreduce_u64(ctx, buf, 2 * tot))) return rc;
+        if ((rc = r->group_end()) != 0) return rccl_fail(ctx, "ncclGroupEnd", rc);
+        return B3C_OK;
     }
-    hold.p = nullptr;
-    *out = buf;
-    *total = tot;
+    // global layout: destination-major, then source
+    std::vector<int64_t> goff((size_t)W * W + 1, 0);
+    for (int d = 0; d < W; d++)
+        for (int sr = 0; sr < W; sr++) goff[(size_t)d * W + sr + 1] = goff[(size_t)d * W + sr] + cmat[(size_t)sr * W + d];
+    const int64_t total = goff[(size_t)W * W];
+    if (total == 0) return B3C_OK;
+    int64_t *g = (int64_t *)ctx->alloc(sizeof(int64_t) * (size_t)total);
+    if (!g) return ctx->fail(B3C_E_NOMEM, "b3c_dist_alltoallv_u64: %lld words", (long long)total);
+    struct Hold { b3c_ctx *c; int64_t *p; ~Hold() { c->release(p); } } hold{ctx, g};
+    HIP_TRY(ctx, hipMemsetAsync(g, 0, sizeof(int64_t) * (size_t)total, ctx->stream));
+    for (int d = 0; d < W; d++) {
+        const int64_t ns = soff[d + 1] - soff[d];
+        if (ns > 0) HIP_TRY(ctx, hipMemcpyAsync(g + goff[(size_t)d * W + me], send + soff[d], sizeof(int64_t) * (size_t)ns, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ctx->n_exchanges--;                      // (the all-reduce below counts itself: ONE exchange)
+    int rc = b3c_dist_allreduce_u64(ctx, g, total);
+    if (rc) return rc;
+    const int64_t nr = roff[W];
+    if (nr > 0) HIP_TRY(ctx, hipMemcpyAsync(recv, g + goff[(size_t)me * W], sizeof(int64_t) * (size_t)nr, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // (g goes back to the pool)
     return B3C_OK;
 }
 

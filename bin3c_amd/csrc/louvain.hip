@@ -60,6 +60,10 @@ struct LvGraph {
     int32_t *indices = nullptr;
     int64_t *q = nullptr;
     bool owned = false;
+    // row-sharded runs: this rank holds the rows [starts[rank], starts[rank + 1]) only (the others are empty); starts: world + 1
+    // offsets, the same on every rank.  Level 0 on a row block of the map, and every induced graph built by OWNER (round 6)
+    bool block = false;
+    std::vector<int64_t> starts;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1497,6 +1501,20 @@ __global__ void __launch_bounds__(BLK) k_lv_first_g(int64_t cnt, const NodeRec *
 // Sharded level 0 on a ROW BLOCK (this rank's rows hold entries, the others are empty here): the weighted degrees are
 // gathered over the ranks with a "row is not empty" flag riding in bit 62 (degrees stay below 2^61), then totals, community
 // sizes, the initial labels and 2m are formed from the gathered vector by every rank.
+// offsets of `nb` ascending bounds in a sorted key array (first key >= bound): the segments of a run list by owner
+__global__ void k_key_bounds(int64_t nu, const int64_t *__restrict__ keys, int nb, const int64_t *__restrict__ bounds, int64_t *__restrict__ off)
+{
+    const int t = threadIdx.x;
+    if (t >= nb) return;
+    const int64_t b = bounds[t];
+    int64_t lo = 0, hi = nu;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    off[t] = lo;
+}
+
 __global__ void k_lv_pack_flag(int64_t r0, int64_t r1, const int64_t *__restrict__ indptr, int64_t *__restrict__ kdeg)
 {
     const int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1517,7 +1535,7 @@ __global__ void __launch_bounds__(BLK) k_lv_unpack_init(int64_t n, const int32_t
         kdeg[i] = d;
         tot[id] = d;
         csize[id] = flag;
-        labels[i] = flag ? (int32_t)i : -1;
+        if (labels) labels[i] = flag ? (int32_t)i : -1;       // (level 0 only: later levels relabel through cn)
         sum += d;
     }
     sum = wave_sum_ll(sum);
@@ -2786,18 +2804,23 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         // levels stay whole on every rank: four label gathers and one partial sum per sweep would cost more than their scan
         // (B3C_LV_DIST_MIN_NNZ: the tests shard every level)
         const int64_t lv_dist_min_nnz = CFG.num("B3C_LV_DIST_MIN_NNZ", 1 << 24);
-        const bool dist = ctx->has_dist && (first || (g.nnz >= lv_dist_min_nnz && n >= 2 * (int64_t)ctx->dist.world)) &&
+        const bool dist = ctx->has_dist && (first || g.block || (g.nnz >= lv_dist_min_nnz && n >= 2 * (int64_t)ctx->dist.world)) &&
                           (int64_t)ctx->dist.world * ctx->dist.chunk >= n;
+        if (g.block && !dist) { free_graph(ctx, g); return ctx->fail(B3C_E_ARG, "b3c_louvain: a row-block level without its sharding"); }
         if (dist && !first) info->levels_sharded++;
         const b3c_dist &D = ctx->dist;
         if (first && blockm && !dist) { free_graph(ctx, g); return ctx->fail(B3C_E_ARG, "b3c_louvain: row block larger than the exchange buffers"); }
-        const bool blk0 = dist && blockm && first;    // level 0 on a row block (later levels are whole on every rank, sharded or not)
+        // this level's graph is a ROW BLOCK: level 0 on a row block of the map, or an induced graph the owners built (round 6);
+        // otherwise every rank holds it whole (sharded or not)
+        const bool blk0 = dist && (first ? blockm : g.block);
         // rows of every rank: equal chunks of a whole matrix, or the row blocks the ranks hold (their bounds are exchanged)
         std::vector<int64_t> starts(dist ? (size_t)D.world + 1 : 2, 0);
         DevBuf<int64_t> starts_dev(ctx, dist ? D.world + 1 : 1);
         if (dist) {
             if (!starts_dev.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain"); }
-            if (blk0) {
+            if (blk0 && !first) {
+                starts = g.starts;                  // the owners' ranges: the same on every rank, nothing to exchange
+            } else if (blk0) {
                 const int64_t mine[2] = {a->row0, a->row1};
                 HIP_TRY(ctx, hipMemcpyAsync(D.isum + 2 * D.rank, mine, sizeof(mine), hipMemcpyHostToDevice, s));
                 { const int rx_ = b3c_dist_exchange(ctx, B3C_BUF_ISUM); if (rx_) return rx_; }
@@ -2853,7 +2876,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             if (r1 > r0) hipLaunchKernelGGL(k_lv_pack_flag, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, r0, r1, g.indptr, kdeg.p);
             if ((rc = b3c_dist_allgather_rows(ctx, kdeg.p, 8, starts.data(), starts_dev.p))) { free_graph(ctx, g); return rc; }
             HIP_TRY(ctx, hipMemsetAsync(ctr.p, 0, sizeof(u64), s));
-            hipLaunchKernelGGL(k_lv_unpack_init, dim3(gv), dim3(BLK), 0, s, n, ids, kdeg.p, tot.p, csize.p, labels.p, ctr.p);
+            hipLaunchKernelGGL(k_lv_unpack_init, dim3(gv), dim3(BLK), 0, s, n, ids, kdeg.p, tot.p, csize.p, first ? labels.p : (int32_t *)nullptr, ctr.p);
         }
         u64 hc[8];
         { const int rb_ = b3c_readback(ctx, hc, ctr.p, sizeof(hc)); if (rb_) return rb_; }
@@ -3322,7 +3345,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
             HIP_TRY(ctx, hipStreamSynchronize(s));
         } else {
         // many communities: sort (community pair) keys, sum weights.  On a row block every rank reduces the pairs of ITS rows,
-        // the reduced runs of all ranks are gathered (b3c_dist_gather_pairs) and reduced once more: integer sums, so the
+        // the reduced runs travel to the OWNER of their row community (below) and are reduced there once more: integer sums, so the
         // induced graph is bit for bit the single-GPU one whatever the split ("tuples keyed by community pair,
         // then local sort-reduce"; the graph of the next level is small against level 0 and stays replicated).
         const bool agg_hash = !blk0 && !CFG.on("B3C_LV_NO_AGG_HASH");
@@ -3446,15 +3469,45 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         ukeys = k_in.p;
         uvals = v_in.p;
         if (blk0) {
+            // ---- aggregation by OWNER (round 6) ----
+            // The new communities are dealt to the ranks in equal id ranges; every rank sends each owner the reduced runs whose
+            // row community the owner holds (the runs are sorted by key = row community * kc + column community: one contiguous
+            // segment per owner), the owner reduces what it received -- a community whose members sit in several ranks' blocks has
+            // runs from each -- and keeps the rows it owns: the next level is a ROW BLOCK again, nobody ever holds or reduces the
+            // whole induced graph (rounds 3-5 gathered all runs to every rank and reduced them there a second time: at C3 on the
+            // contract law 1.4e8 pairs on every rank).  Integer sums: the graph is bit for bit the single-GPU one.
+            const int W = D.world;
+            std::vector<int64_t> cb(W + 1, 0);
+            const int64_t per = ((kc + W - 1) / W + 15) / 16 * 16;
+            for (int o = 1; o < W; o++) cb[o] = std::min<int64_t>(kc, (int64_t)o * per);
+            cb[W] = kc;
+            std::vector<int64_t> bnd(W + 1), soff(W + 1, 0);
+            for (int o = 0; o <= W; o++) bnd[o] = cb[o] * kc;
+            DevBuf<int64_t> bnd_dev(ctx, W + 1), soff_dev(ctx, W + 1);
+            DevBuf<u64> cmat_dev(ctx, (size_t)W * W);
+            if (!bnd_dev.p || !soff_dev.p || !cmat_dev.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation by owner");
+            HIP_TRY(ctx, hipMemcpyAsync(bnd_dev.p, bnd.data(), sizeof(int64_t) * (size_t)(W + 1), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_key_bounds, dim3(1), dim3(((W + 1 + 63) / 64) * 64), 0, s, nu, k_in.p, W + 1, bnd_dev.p, soff_dev.p);
+            { const int rb_ = b3c_readback(ctx, soff.data(), soff_dev.p, sizeof(int64_t) * (size_t)(W + 1)); if (rb_) return rb_; }
+            // who sends how much to whom: every rank fills its row of the matrix, an integer all-reduce completes it
+            std::vector<int64_t> cmat((size_t)W * W, 0);
+            for (int o = 0; o < W; o++) cmat[(size_t)D.rank * W + o] = soff[o + 1] - soff[o];
+            HIP_TRY(ctx, hipMemcpyAsync(cmat_dev.p, cmat.data(), sizeof(int64_t) * cmat.size(), hipMemcpyHostToDevice, s));
+            if ((rc = b3c_dist_allreduce_u64(ctx, cmat_dev.p, (int64_t)W * W))) return rc;
+            { const int rb_ = b3c_readback(ctx, cmat.data(), cmat_dev.p, sizeof(int64_t) * cmat.size()); if (rb_) return rb_; }
             int64_t total = 0;
-            if ((rc = b3c_dist_gather_pairs(ctx, k_in.p, v_in.p, nu, &merged.p, &total))) return rc;
+            for (int sr = 0; sr < W; sr++) total += cmat[(size_t)sr * W + D.rank];
+            merged.p = (int64_t *)ctx->alloc(sizeof(int64_t) * 2 * (size_t)(total > 0 ? total : 1));
             DevBuf<int64_t> k2(ctx, total), v2(ctx, total);
-            if (!k2.p || !v2.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation buffers");
-            // a community whose members sit in two ranks' blocks has runs on both: second reduction over the gathered runs
+            if (!merged.p || !k2.p || !v2.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: aggregation buffers");
+            if ((rc = b3c_dist_alltoallv_u64(ctx, k_in.p, merged.p, cmat.data()))) return rc;
+            if ((rc = b3c_dist_alltoallv_u64(ctx, v_in.p, merged.p + total, cmat.data()))) return rc;
             if ((rc = sort_reduce(merged.p, merged.p + total, k2.p, v2.p, total, nruns.p, &nu))) return rc;
             ukeys = merged.p;
             uvals = merged.p + total;
             info->agg_gathered_runs += total;
+            h.block = true;
+            h.starts = cb;
         }
 
         h.n = kc; h.nnz = nu; h.owned = true;

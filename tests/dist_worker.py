@@ -187,8 +187,10 @@ def gpu_many_mode(rank, world):
     sess.check()
     assert res.row_block == (sess.r0, sess.r1) and res.work_nnz < 0.8 * counts.nnz
     _agree(res, single, rank)
-    # the sort path ran on the row blocks: runs were gathered, and level 0 left more communities than the bins hold
-    assert res.lv_info.agg_gathered_runs > 4096, res.lv_info.agg_gathered_runs
+    # the pair path ran on the row blocks: this rank received the runs of the communities it owns, level 0 left more communities than
+    # the bins hold, and level 1 is a row block again (built by owner: round 6)
+    assert res.lv_info.agg_gathered_runs > 2048, res.lv_info.agg_gathered_runs
+    assert res.lv_info.levels_sharded >= 1
     sess.close()
     # the same path forced on a map with few communities (every level through sort + gather), pruning on and off
     sm2 = make_synth(40000, 1300000, 21, noise=0.4, intra_boost=1)
@@ -205,7 +207,11 @@ def gpu_many_mode(rank, world):
         _agree(res2, single2, rank)
         if 'B3C_LV_AGG_SORT' in env:
             assert res2.lv_info.agg_gathered_runs > 0
-        assert res2.lv_info.levels_sharded == (res2.lv_info.n_levels if 'B3C_LV_DIST_MIN_NNZ' in env else 0), (res2.lv_info.levels_sharded, res2.lv_info.n_levels)
+        # (the pair path builds the next level BY OWNER: a row block again, sharded whatever its size; the bins leave it whole on
+        # every rank, and a whole level is sharded from 2^24 entries on)
+        sharded_all = 'B3C_LV_DIST_MIN_NNZ' in env or 'B3C_LV_AGG_SORT' in env
+        want = res2.lv_info.n_levels if sharded_all else (1 if single2.lv_info.n_comm_level0 > 4096 else 0)
+        assert res2.lv_info.levels_sharded == want, (env, res2.lv_info.levels_sharded, res2.lv_info.n_levels, single2.lv_info.n_comm_level0)
         assert single2.lv_info.n_levels >= 2
         sess.close()
         for k in env:

@@ -79,6 +79,14 @@ def test_sharded_aggregation_beyond_the_bin_table_two_ranks_one_gpu():
 
 
 @pytest.mark.gpu
+def test_aggregation_by_owner_three_ranks_one_gpu():
+    """the same maps with three ranks: unequal owner ranges of the new communities, three-way all-to-all of the reduced runs, row-block
+    levels after the first (round 6)"""
+    text = _launch('gpu-many', 1200, world=3)
+    assert all('rank %d gpu-many ok' % r in text for r in range(3))
+
+
+@pytest.mark.gpu
 def test_sharded_hot_path_beyond_a_million_contigs_two_ranks_one_gpu():
     """the sharded path on a C5-shaped map of 1.2M contigs / 4.8e7 edges: balanced row blocks, level 0 beyond the bin table"""
     text = _launch('gpu-large', 900)
