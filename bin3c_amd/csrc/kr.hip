@@ -3011,6 +3011,10 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
         HIP_TRY(ctx, hipMemsetAsync(tex.p, 0, sizeof(int) * 2, s));
         // all-tails layout of a bitwise symmetric whole map: the words in CSR order keyed by the super-tile of their column, one radix
         // pass on the super-tile bits (kr_tails_emit_tr); else row-wise emission and the sort on (super-tile, column)
+        // (`bitwise_symmetric` comes from two order-free 64-bit checksum pairs over (i, j, bits) of the upper and the mirrored lower
+        // triangle, kr_prep_counts: the transposed emission takes count(j, i) for count(i, j) and row offsets for column-segment
+        // offsets, so here the checksum is a correctness precondition, not a report -- an asymmetric map passes it with probability
+        // 2^-128; B3C_KR_EXACT_SYMCHECK=1 runs the exact per-entry comparison as well and reports it in is_symmetric)
         xt_tr = xt_all && info->bitwise_symmetric && !a->row_block && r0 == 0 && r1 == n;
         DevBuf<uint8_t> hubflag(ctx, xt_tr && n_hub > 0 ? n : 1);
         if (!hubflag.p) return ctx->fail(B3C_E_NOMEM, "b3c_kr_balance: tail pass");
@@ -3128,6 +3132,9 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             info->spmv_stream_bytes = ent * (4 + vbytes) + nloc * 56 + n * 8;             // CSR: column + value per entry; per row indptr, x / p / v / 1/s / dfix, out; the operand vector once
         }
     }
+    // an all-tails layout never built (or only sampled) the dictionary arrays: the dictionary kernel must not run on it
+    if (xt_all && !(tile_split && tails_xt && n_tl_with == 0))
+        return ctx->fail(B3C_E_HIP, "b3c_kr_balance: all-tails layout with dictionary tiles listed (%lld)", (long long)n_tl_with);
     const int GS = tcd ? (int)tcd_tiles : GS_rows;
     // partials the SpMV step leaves behind: row groups / tiles + hub rows.  EVERY block of KCD reduces all of them, so many
     // hub rows (a power-law map: 10^5) are first summed in chunks by their own launch (fixed order: deterministic)

@@ -326,7 +326,13 @@ int b3c_normalise_scale_compress(b3c_ctx *ctx, const b3c_mat *counts, const doub
 /* to_graph's weight scaling (cluster.py:316-321) + louvain.cluster / community.best_partition
  * (louvain.py:70) on a structurally symmetric B3C_F64 matrix: labels[i] in [0, n_comm) or -1 for a
  * node whose row is empty (never added to the graph by cluster.py:321).  scl multiplies every
- * weight (pass 1/max for scale=True).  n_sub = sub-rounds per sweep (0 -> default 4). */
+ * weight (pass 1/max for scale=True).  n_sub = sub-rounds per sweep (0 -> default 4).
+ * The graph is UNDIRECTED: the weight of (i, j) as the library forms it (the lower-triangle value on both sides, cluster.py:319-321)
+ * is symmetric by construction, and the internal-weight recount relies on it (it counts the entries above the diagonal twice after
+ * a sweep that moved many nodes); the structure must hold both (i, j) and (j, i).
+ * Row-sharded runs: a row block (b3c_mat_permute_rows) must come ordered by the caller; maps of more than 2^23 contigs whose rows
+ * all stay within 512 entries cannot be cut into row blocks by b3c_mat_permute_rows (B3C_E_ARG) -- sharding is supported up to
+ * 2^23 contigs, the single-GPU path up to 2^24 (the tail pass of the balancing) and 2^31 - 1 (everything else). */
 int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub, int max_sweeps,
                 int32_t *labels /*host|dev*/, b3c_louvain_info *info);
 

@@ -257,6 +257,31 @@ def test_long_hub_rows_run_as_pieces(ctx, oracle_lib, monkeypatch):
     fm.free()
 
 
+def test_all_tails_rule_decided_on_a_sample_of_the_tiles(ctx, oracle_lib, monkeypatch):
+    """From 256 tiles on, the all-tails rule is first applied to every 16th tile and the full dictionary pass is skipped when the
+    sample already says "no dictionary kernel" (round 5; the dictionary arrays of the other tiles are then never written).  A
+    contract-law map of 60,000 contigs (312 tiles) with the tail pass forced: every entry a tail word, the transposed emission of a
+    bitwise symmetric map, x equal to the mixed layout's to 1e-11 and to the oracle's to 1e-9, same iteration count."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(60000, 2500000, 7)
+    nd = oracle_lib.site_norm(sm.indptr, sm.indices, sm.counts.astype(np.float64), sm.sites)
+    rc, xo, st = oracle_lib.kr_balance(sm.indptr, sm.indices, nd)
+    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    monkeypatch.setenv('B3C_KR_TCD_XT', '1')
+    monkeypatch.setenv('B3C_KR_TCD_MINUSE8', '96')           # 12 uses per column: only the densest tiles would keep a dictionary
+    monkeypatch.setenv('B3C_KR_TCD_ALLTAILS', '0')
+    _, x0, i0 = ctx.kr_balance_counts(cm, sm.sites)
+    monkeypatch.setenv('B3C_KR_TCD_ALLTAILS', '1')
+    _, x1, i1 = ctx.kr_balance_counts(cm, sm.sites)
+    _, x2, _ = ctx.kr_balance_counts(cm, sm.sites)
+    assert i1.tcd_tiles >= 256 and i1.tcd_dict_total == 0 and i1.tcd_xt_tails == i1.tcd_tail_entries
+    assert 0 < i0.tcd_dict_total and (cm.nnz - i0.tcd_tail_entries) * 5 < cm.nnz, (i0.tcd_dict_total, i0.tcd_tail_entries, cm.nnz)
+    assert i0.n_iter == i1.n_iter == st.n_iter and np.array_equal(x1, x2)
+    np.testing.assert_allclose(x1, x0, rtol=1e-11)
+    np.testing.assert_allclose(x1, xo, rtol=1e-9)
+    cm.free()
+
+
 def test_tail_pass_with_long_tails(ctx, monkeypatch):
     """Tail pass of the dictionary SpMV on a power-law map whose hub rows stay in the tiles (B3C_KR_NO_HUB): tails of
     thousands of entries narrow the 32-bit remainder sums of the fixed-point accumulation; x must agree with the CSR
