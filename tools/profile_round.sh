@@ -31,6 +31,8 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c
 # SQ / TA / TCP counter groups of the Louvain neighbour scan
 B3C_PMC_KERNEL="k_lv_decide_g" bash tools/pmc_kr.sh $tag/lv > $out/pmc_lv.log 2>&1
 python tools/pmc_reduce.py $out/lv > $out/k_lv_decide_g_counters.txt 2>&1
+# ... the same per LAUNCH, in launch order (first sweep against the pruned late sweeps)
+python tools/pmc_by_launch.py $out/lv 'k_lv_decide_g<64, 4>' 64 > $out/k_lv_decide_g_by_launch.txt 2>&1
 # ... and of the tail pass of the SpMV
 B3C_PMC_KERNEL="kr_kb_tails" bash tools/pmc_kr.sh $tag/tails > $out/pmc_tails.log 2>&1
 python tools/pmc_reduce.py $out/tails > $out/kr_kb_tails_counters.txt 2>&1
