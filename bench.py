@@ -503,12 +503,18 @@ def main():
             dt, last, acc = timed_leg(W, args.steps, args.warmup, hand_over=True)
             sess.check()
             n_exchanges = sess.n_exchanges
+            n_direct = sess.n_exchanges_direct
+            transport = sess.transport
             sess.close()
         except Exception as ex:
             watchdog.cancel()
             give_up(repr(ex))
         watchdog.cancel()
-        extra = {'exchanges_per_step': n_exchanges // (args.steps + args.warmup),
+        per = args.steps + args.warmup
+        extra = {'exchanges_per_step': n_exchanges // per,
+                 # by kind: collectives (RCCL in libb3c, or the callback transport) / peer writes into IPC windows (B3C_DIST_TRANSPORT=direct)
+                 'exchanges_per_step_by_kind': {'collective': (n_exchanges - n_direct) // per, 'direct': n_direct // per},
+                 'transport': transport,
                  'raw_map_handed_over': acc.get('raw_map_handed_over', False),
                  'louvain_levels_sharded': int(getattr(last.lv_info, 'levels_sharded', 0))}
         if rep is not None:

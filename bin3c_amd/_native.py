@@ -84,6 +84,10 @@ SYMBOLS = [
     ('b3c_dist_comm_create', C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
     ('b3c_dist_comm_destroy', C.c_int, [_VP, _VP]),
     ('b3c_ctx_exchanges', C.c_int64, [_VP]),
+    ('b3c_ctx_exchanges_direct', C.c_int64, [_VP]),
+    ('b3c_dist_window_create', C.c_int, [_VP, C.c_int64, _VP]),
+    ('b3c_dist_window_open', C.c_int, [_VP, _VP]),
+    ('b3c_dist_window_close', C.c_int, [_VP]),
     ('b3c_dist_max_f64', C.c_int, [_VP, C.POINTER(C.c_double)]),
     ('b3c_dist_allgather_i32', C.c_int, [_VP, _VP, C.c_int64]),
     ('b3c_mat_permute_rows', C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int64, C.c_int64, C.POINTER(_VP)]),

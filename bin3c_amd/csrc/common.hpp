@@ -97,6 +97,19 @@ struct b3c_ctx {
     }
     bool has_dist = false;
     int64_t n_exchanges = 0;  // collectives issued (b3c_dist_exchange)
+    // direct transport (dist.hip, b3c_dist_window_*): a window in this rank's HBM that the peers write into (IPC-mapped), two
+    // slots of [staging bytes | one sequence flag per source rank]; peer[r] = rank r's window as mapped here (peer[rank] = local)
+    struct Window {
+        char *local = nullptr;
+        std::vector<char *> peer;
+        std::vector<char> opened;       // peer[r] came from hipIpcOpenMemHandle
+        int64_t slot_bytes = 0;         // staging bytes of one slot (flags follow)
+        unsigned long long seq = 0;     // exchanges done through the window
+        char **peer_dev = nullptr;      // the peer pointers in device memory
+        unsigned int *ticket = nullptr; // last-block ticket of the push kernel
+        bool open = false;
+    } win;
+    int64_t n_exchanges_direct = 0;
 
     int fail(int code, const char *fmt, ...)
     {

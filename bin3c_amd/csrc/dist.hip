@@ -145,10 +145,13 @@ int ragged_calls(b3c_ctx *ctx, Rccl *r, void *base, int esz, const int64_t *star
 }
 }  // namespace
 
+namespace { int win_allgather(b3c_ctx *ctx, int nitems, void *a_base, int a_esz, const int64_t *a_starts, void *b_base, int b_esz, const int64_t *b_starts); }
+
 // Ragged in-place all-gather of a row-indexed vector: rank r owns elements [starts[r], starts[r + 1]) of `base` (esz 4 or 8).
 int b3c_dist_allgatherv(b3c_ctx *ctx, void *base, int esz, const int64_t *starts)
 {
     const b3c_dist &D = ctx->dist;
+    if (ctx->win.open) return win_allgather(ctx, 1, base, esz, starts, nullptr, 0, nullptr);
     ctx->n_exchanges++;
     if (!D.comm) {
         if (!D.allgatherv) return ctx->fail(B3C_E_ARG, "ragged multi-GPU exchange without communicator or callback");
@@ -164,6 +167,202 @@ int b3c_dist_allgatherv(b3c_ctx *ctx, void *base, int esz, const int64_t *starts
     return B3C_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct transport (round 6): the in-place all-gathers as PEER WRITES instead of collectives.
+//
+// Every rank owns a window in its HBM -- two slots of staging bytes, each followed by one 64-bit sequence flag per source rank --
+// and maps the windows of all peers (hipIpcGetMemHandle / hipIpcOpenMemHandle: between GPUs of a node the stores travel over xGMI,
+// between two processes on ONE GPU, the tests, they stay in its HBM).  An exchange k (slot k & 1) is two small launches on the
+// context's stream:
+//   push  this rank's range of every item (up to two: the scalar and the vector buffer of a KR tick) is stored into EVERY peer's
+//         slot at the offset it has in the full vector; every workgroup waits for its stores (vmcnt), one thread of it releases at
+//         system scope, the LAST workgroup to finish (a ticket) stores k into its flag of every peer's slot;
+//   pull  every workgroup polls this rank's slot until all `world` flags show k (one lane per source rank, bounded: a trap after
+//         five seconds instead of a hang), acquires, and copies the OTHER ranks' ranges from the slot into the full vector.
+// No collective, no rendezvous: ~2 launches and one fabric round trip per exchange against 20-30 us of an RCCL all-gather.  Two
+// slots suffice: a rank can run at most one exchange ahead of a peer -- it completes exchange k + 1 only with that peer's push of
+// k + 1, which the peer issues after its own pull of k.  The pull grid is a few dozen workgroups, so ranks sharing a GPU cannot
+// starve each other of compute units.  All-reduces and the all-to-all of the aggregation stay on the RCCL / callback transport.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct WinItem { char *base; int64_t off, bytes; };     // this rank's range of a full vector: bytes [off, off + bytes) of base
+
+constexpr unsigned long long WIN_TIMEOUT = 500000000ull;      // wall_clock64 ticks (100 MHz): five seconds
+
+__global__ void __launch_bounds__(256) k_win_push(int world, int me, char *const *__restrict__ peer, int64_t slot_off, int64_t flag_off,
+                                                  WinItem a, WinItem b, int64_t b_stage, unsigned long long seq, unsigned int *__restrict__ ticket)
+{
+    // 16-byte granules where the range allows (offsets of the row-indexed buffers are multiples of 64 rows), 4-byte ones else
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int it = 0; it < 2; it++) {
+        const WinItem w = it == 0 ? a : b;
+        if (!w.base || w.bytes <= 0) continue;
+        const int64_t stage = it == 0 ? 0 : b_stage;
+        const bool wide = ((w.off | w.bytes | stage) & 15) == 0 && (((uintptr_t)w.base) & 15) == 0;
+        for (int pr = 0; pr < world; pr++) {
+            if (pr == me) continue;
+            char *dst = peer[pr] + slot_off + stage + w.off;
+            const char *src = w.base + w.off;
+            if (wide) for (int64_t i = t0 * 16; i < w.bytes; i += stride * 16) *(uint4 *)(dst + i) = *(const uint4 *)(src + i);
+            else for (int64_t i = t0 * 4; i < w.bytes; i += stride * 4) *(uint32_t *)(dst + i) = *(const uint32_t *)(src + i);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // this wave's stores have been acknowledged
+    __syncthreads();
+    __shared__ int last_s;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");               // ... and are visible system-wide before the ticket
+        const unsigned int t = atomicAdd(ticket, 1u);
+        last_s = t == gridDim.x - 1;
+        if (last_s) *ticket = 0u;
+    }
+    __syncthreads();
+    if (last_s && (int)threadIdx.x < world && (int)threadIdx.x != me)
+        __hip_atomic_store((unsigned long long *)(peer[threadIdx.x] + flag_off) + me, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(256) k_win_pull(int world, int me, char *__restrict__ local, int64_t slot_off, int64_t flag_off, int nitems,
+                                                  char *a_base, int a_esz, const int64_t *__restrict__ a_starts,
+                                                  char *b_base, int b_esz, const int64_t *__restrict__ b_starts, int64_t b_stage,
+                                                  unsigned long long seq)
+{
+    if ((int)threadIdx.x < world && (int)threadIdx.x != me) {
+        const unsigned long long *f = (const unsigned long long *)(local + flag_off) + threadIdx.x;
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0 && wall_clock64() - t0 > WIN_TIMEOUT) __builtin_trap();      // a peer never arrived: fail, do not hang
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                   // nothing of the slot cached from an earlier exchange
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int it = 0; it < nitems; it++) {
+        char *base = it == 0 ? a_base : b_base;
+        const int esz = it == 0 ? a_esz : b_esz;
+        const int64_t *st = it == 0 ? a_starts : b_starts;
+        const int64_t stage = it == 0 ? 0 : b_stage;
+        for (int r = 0; r < world; r++) {
+            if (r == me) continue;
+            const int64_t off = st[r] * esz, bytes = (st[r + 1] - st[r]) * esz;
+            const char *src = local + slot_off + stage + off;
+            char *dst = base + off;
+            const bool wide = ((off | bytes | stage) & 15) == 0 && (((uintptr_t)base) & 15) == 0;
+            if (wide) for (int64_t i = t0 * 16; i < bytes; i += stride * 16) *(uint4 *)(dst + i) = *(const uint4 *)(src + i);
+            else for (int64_t i = t0 * 4; i < bytes; i += stride * 4) *(uint32_t *)(dst + i) = *(const uint32_t *)(src + i);
+        }
+    }
+}
+
+// one exchange through the window: up to two full vectors (esz 4 | 8), rank r owning elements [starts[r], starts[r + 1]) of each
+int win_allgather(b3c_ctx *ctx, int nitems, void *a_base, int a_esz, const int64_t *a_starts, void *b_base, int b_esz, const int64_t *b_starts)
+{
+    b3c_ctx::Window &Wn = ctx->win;
+    const b3c_dist &D = ctx->dist;
+    const int W = D.world, me = D.rank;
+    const int64_t a_total = a_starts[W] * a_esz;
+    const int64_t b_stage = (a_total + 255) & ~(int64_t)255;
+    const int64_t need = b_stage + (nitems > 1 ? b_starts[W] * b_esz : 0);
+    if (need > Wn.slot_bytes) return ctx->fail(B3C_E_ARG, "direct exchange of %lld bytes beyond the window's %lld", (long long)need, (long long)Wn.slot_bytes);
+    Wn.seq++;
+    ctx->n_exchanges++;
+    ctx->n_exchanges_direct++;
+    const int64_t slot = (int64_t)(Wn.seq & 1ull);
+    const int64_t slot_stride = Wn.slot_bytes + 8 * (int64_t)((W + 31) & ~31);
+    const int64_t slot_off = slot * slot_stride, flag_off = slot_off + Wn.slot_bytes;
+    // the ranges in device memory for the pull kernel: a small pooled block per call (W + 1 offsets per item)
+    int64_t *st_dev = (int64_t *)ctx->alloc(sizeof(int64_t) * 2 * (size_t)(W + 1));
+    if (!st_dev) return ctx->fail(B3C_E_NOMEM, "direct exchange");
+    struct Hold { b3c_ctx *c; void *p; ~Hold() { c->release(p); } } hold{ctx, st_dev};
+    HIP_TRY(ctx, hipMemcpyAsync(st_dev, a_starts, sizeof(int64_t) * (size_t)(W + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (nitems > 1) HIP_TRY(ctx, hipMemcpyAsync(st_dev + W + 1, b_starts, sizeof(int64_t) * (size_t)(W + 1), hipMemcpyHostToDevice, ctx->stream));
+    WinItem ia{(char *)a_base, a_starts[me] * a_esz, (a_starts[me + 1] - a_starts[me]) * a_esz};
+    WinItem ib{nitems > 1 ? (char *)b_base : nullptr, nitems > 1 ? b_starts[me] * b_esz : 0, nitems > 1 ? (b_starts[me + 1] - b_starts[me]) * b_esz : 0};
+    const int64_t most = std::max(ia.bytes, ib.bytes);
+    const int gp = (int)std::max<int64_t>(1, std::min<int64_t>(64, (most * (W - 1) / 16 + 255) / 256));
+    hipLaunchKernelGGL(k_win_push, dim3(gp), dim3(256), 0, ctx->stream, W, me, (char *const *)Wn.peer_dev, slot_off, flag_off, ia, ib, b_stage, Wn.seq, Wn.ticket);
+    const int64_t all = a_total + (nitems > 1 ? b_starts[W] * b_esz : 0);
+    const int gq = (int)std::max<int64_t>(1, std::min<int64_t>(64, (all / 16 + 255) / 256));
+    hipLaunchKernelGGL(k_win_pull, dim3(gq), dim3(256), 0, ctx->stream, W, me, Wn.local, slot_off, flag_off, nitems, (char *)a_base, a_esz, st_dev,
+                       (char *)b_base, b_esz, st_dev + W + 1, b_stage, Wn.seq);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (the pooled offsets; a per-context ring of them would drop this wait)
+    return B3C_OK;
+}
+}  // namespace
+
+extern "C" int b3c_dist_window_create(b3c_ctx *ctx, int64_t slot_bytes, void *handle64)
+{
+    if (!ctx) return B3C_E_ARG;
+    if (!handle64 || slot_bytes < 256 || !ctx->has_dist && ctx->dist.world < 1) return ctx->fail(B3C_E_ARG, "b3c_dist_window_create: bad argument (install the sharding first)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    b3c_ctx::Window &Wn = ctx->win;
+    if (Wn.local) return ctx->fail(B3C_E_ARG, "b3c_dist_window_create: a window exists already");
+    const int W = ctx->dist.world;
+    Wn.slot_bytes = (slot_bytes + 255) & ~(int64_t)255;
+    const int64_t slot_stride = Wn.slot_bytes + 8 * (int64_t)((W + 31) & ~31);
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, (size_t)(2 * slot_stride)));            // (its own allocation: an IPC handle exports a whole one)
+    HIP_TRY(ctx, hipMemset(p, 0, (size_t)(2 * slot_stride)));
+    Wn.local = (char *)p;
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is exchanged as 64 bytes");
+    HIP_TRY(ctx, hipIpcGetMemHandle(&h, p));
+    memcpy(handle64, &h, 64);
+    return B3C_OK;
+}
+
+extern "C" int b3c_dist_window_open(b3c_ctx *ctx, const void *handles)
+{
+    if (!ctx) return B3C_E_ARG;
+    b3c_ctx::Window &Wn = ctx->win;
+    if (!handles || !Wn.local || Wn.open) return ctx->fail(B3C_E_ARG, "b3c_dist_window_open: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->dist.world, me = ctx->dist.rank;
+    Wn.peer.assign(W, nullptr);
+    Wn.opened.assign(W, 0);
+    for (int r = 0; r < W; r++) {
+        if (r == me) { Wn.peer[r] = Wn.local; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + 64 * (size_t)r, 64);
+        void *p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return ctx->fail(B3C_E_HIP, "b3c_dist_window_open: hipIpcOpenMemHandle of rank %d: %s", r, hipGetErrorString(e));
+        Wn.peer[r] = (char *)p;
+        Wn.opened[r] = 1;
+    }
+    void *pd = nullptr, *tk = nullptr;
+    HIP_TRY(ctx, hipMalloc(&pd, sizeof(char *) * (size_t)W));
+    HIP_TRY(ctx, hipMemcpy(pd, Wn.peer.data(), sizeof(char *) * (size_t)W, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc(&tk, 256));
+    HIP_TRY(ctx, hipMemset(tk, 0, 256));
+    Wn.peer_dev = (char **)pd;
+    Wn.ticket = (unsigned int *)tk;
+    Wn.seq = 0;
+    Wn.open = true;
+    return B3C_OK;
+}
+
+extern "C" int b3c_dist_window_close(b3c_ctx *ctx)
+{
+    if (!ctx) return B3C_E_ARG;
+    b3c_ctx::Window &Wn = ctx->win;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (size_t r = 0; r < Wn.peer.size(); r++)
+        if (Wn.opened[r] && Wn.peer[r]) (void)hipIpcCloseMemHandle(Wn.peer[r]);
+    if (Wn.peer_dev) (void)hipFree(Wn.peer_dev);
+    if (Wn.ticket) (void)hipFree(Wn.ticket);
+    if (Wn.local) (void)hipFree(Wn.local);
+    Wn = b3c_ctx::Window();
+    return B3C_OK;
+}
+
+extern "C" int64_t b3c_ctx_exchanges_direct(const b3c_ctx *ctx) { return ctx ? ctx->n_exchanges_direct : 0; }
+
 // All-gather exchange buffer `buf` in place (B3C_BUF_SCAL_VEC: the scalar and the vector buffer, one grouped launch).  The scalar
 // and integer buffers are `world` equal slices; the vector and label buffers are indexed by contig row, every rank's slice being
 // its row range: equal slices of `chunk`, or -- with b3c_dist.starts -- the ragged ranges the caller balanced by stored entries.
@@ -171,6 +370,36 @@ int b3c_dist_exchange(b3c_ctx *ctx, int buf)
 {
     const b3c_dist &D = ctx->dist;
     const bool ragged = D.starts != nullptr;
+    if (ctx->win.open) {
+        // through the window: the scalar / integer buffers as `world` equal slices, the row-indexed ones by the installed row ranges
+        const int W = D.world;
+        std::vector<int64_t> eq(W + 1), rows(W + 1);
+        auto ranges = [&](int id, void **base, int *esz, const int64_t **st) -> bool {
+            BufDesc d;
+            if (!describe(D, id, &d)) return false;
+            *base = d.p;
+            *esz = d.type == NCCL_INT32 ? 4 : 8;
+            if (id == B3C_BUF_SCAL || id == B3C_BUF_ISUM) {
+                for (int r = 0; r <= W; r++) eq[r] = (int64_t)r * (int64_t)d.count;
+                *st = eq.data();
+            } else if (ragged) {
+                *st = D.starts;
+            } else {
+                for (int r = 0; r <= W; r++) rows[r] = (int64_t)r * D.chunk;
+                *st = rows.data();
+            }
+            return true;
+        };
+        void *ba = nullptr, *bb = nullptr;
+        int ea = 0, eb = 0;
+        const int64_t *sa = nullptr, *sb = nullptr;
+        if (buf == B3C_BUF_SCAL_VEC) {
+            if (!ranges(B3C_BUF_SCAL, &ba, &ea, &sa) || !ranges(B3C_BUF_VEC, &bb, &eb, &sb)) return ctx->fail(B3C_E_ARG, "unknown exchange buffer %d", buf);
+            return win_allgather(ctx, 2, ba, ea, sa, bb, eb, sb);
+        }
+        if (!ranges(buf, &ba, &ea, &sa)) return ctx->fail(B3C_E_ARG, "unknown exchange buffer %d", buf);
+        return win_allgather(ctx, 1, ba, ea, sa, nullptr, 0, nullptr);
+    }
     if (!D.comm) {
         if (ragged && buf != B3C_BUF_SCAL && buf != B3C_BUF_ISUM) {
             // callback transport with ragged ranges: the scalars by the slice callback, the row-indexed buffer by the ragged one
@@ -255,7 +484,7 @@ int b3c_dist_allgather_rows(b3c_ctx *ctx, void *full, int esz, const int64_t *st
     // a transport that moves ragged slices gathers the vector where it stands.  Only a session that INSTALLED ragged ranges has
     // shown that its stack can (DistSession's self-test gates set_starts: ADVICE round 4); one that fell back to equal ranges keeps
     // the staged equal-slice path below for Louvain's row-block gathers too
-    if (D.starts && (D.comm || D.allgatherv)) return b3c_dist_allgatherv(ctx, full, esz, starts_host);
+    if (ctx->win.open || (D.starts && (D.comm || D.allgatherv))) return b3c_dist_allgatherv(ctx, full, esz, starts_host);
     const int64_t slot_bytes = D.chunk * 8;
     const int64_t mine = (starts_host[D.rank + 1] - starts_host[D.rank]) * esz;
     for (int r = 0; r < D.world; r++)

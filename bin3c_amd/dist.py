@@ -139,7 +139,7 @@ class DistSession(object):
         lib = ctx.lib
         # RCCL inside libb3c when the job runs on the nccl backend (or on request); the callback transport otherwise
         want = os.environ.get('B3C_DIST_TRANSPORT', 'auto')
-        use_rccl = want == 'rccl' or (want == 'auto' and dist.get_backend(group) == 'nccl')
+        use_rccl = 'rccl' in want or (want in ('auto', 'direct') and dist.get_backend(group) == 'nccl')
         self.comm = None
         if use_rccl:
             ident = np.zeros(128, dtype=np.uint8)
@@ -156,6 +156,7 @@ class DistSession(object):
             ctx._check(lib.b3c_dist_comm_create(ctx.h, self.world, self.rank, ident.ctypes.data_as(C.c_void_p), C.byref(comm)))
             self.comm = comm
         self.transport = 'rccl (in libb3c)' if self.comm else 'callback ({})'.format(dist.get_backend(group))
+        self.direct = False
         self._x0 = int(lib.b3c_ctx_exchanges(ctx.h))
         torch.cuda.synchronize(dev)                       # the buffers were zero-filled on torch's stream, libb3c writes them on its own
         self._install(None)
@@ -165,6 +166,10 @@ class DistSession(object):
         self.ragged_ok = self.world == 1 or self._selftest_ragged(dev)
         torch.cuda.synchronize(dev)
         self._x0 = int(lib.b3c_ctx_exchanges(ctx.h))       # (the self-test's exchange is not the caller's)
+        # Direct transport (B3C_DIST_TRANSPORT=direct[+rccl]): the all-gathers as peer writes into IPC-mapped windows (dist.hip);
+        # all-reduces and the aggregation's all-to-all stay on the transport chosen above
+        if 'direct' in want and self.world > 1:
+            self._open_window(dev)
         ctx.dist_session = self                           # pipeline.run_hot_path shards the map over the ranks when set
 
     def _install(self, starts):
@@ -206,6 +211,29 @@ class DistSession(object):
         t = torch.tensor([ok], dtype=torch.int32, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return bool(int(t.item()))
+
+    def _open_window(self, dev):
+        """every rank creates its window, the 64-byte IPC handles travel over torch.distributed, every rank maps its peers'"""
+        import torch
+        import torch.distributed as dist
+        lib = self.ctx.lib
+        slot = 8 * self.world * self.chunk + 64 * self.world + 4096
+        mine = np.zeros(64, dtype=np.uint8)
+        self.ctx._check(lib.b3c_dist_window_create(self.ctx.h, slot, mine.ctypes.data_as(C.c_void_p)))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine.tobytes(), group=self.group)
+        buf = np.frombuffer(b''.join(handles), dtype=np.uint8).copy()
+        assert buf.shape[0] == 64 * self.world
+        self.ctx._check(lib.b3c_dist_window_open(self.ctx.h, buf.ctypes.data_as(C.c_void_p)))
+        dist.barrier(group=self.group)                   # every window is mapped everywhere before the first push
+        self.direct = True
+        self.transport += ' + direct peer writes for the all-gathers'
+        self._xd0 = int(lib.b3c_ctx_exchanges_direct(self.ctx.h))
+
+    @property
+    def n_exchanges_direct(self):
+        """exchanges of this session that went through the window (peer writes) instead of a collective"""
+        return int(self.ctx.lib.b3c_ctx_exchanges_direct(self.ctx.h)) - getattr(self, '_xd0', 0) if self.direct else 0
 
     def set_starts(self, starts):
         """Row ranges of the ranks from here on (all ranks must pass the same array), or None for equal chunks again.  The
@@ -276,6 +304,13 @@ class DistSession(object):
             self.ctx.dist_session = None
         if self.ctx.h is not None:
             self._final = self.n_exchanges
+            self._final_direct = self.n_exchanges_direct
+            if self.direct:
+                import torch.distributed as dist
+                self.ctx.sync()
+                dist.barrier(group=self.group)           # nobody unmaps a window a peer may still write into
+                self.ctx.lib.b3c_dist_window_close(self.ctx.h)
+                self.direct = False
             self.ctx.lib.b3c_ctx_set_dist(self.ctx.h, None)
             if self.comm:
                 self.ctx._check(self.ctx.lib.b3c_dist_comm_destroy(self.ctx.h, self.comm))

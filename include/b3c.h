@@ -184,8 +184,21 @@ int b3c_dist_comm_destroy(b3c_ctx *ctx, void *comm);
  * the rows [rank*chunk, (rank+1)*chunk) (the off-diagonal signal of the acceptance mask, contact_map.py:899). */
 int b3c_dist_max_f64(b3c_ctx *ctx, double *value);
 int b3c_dist_allgather_i32(b3c_ctx *ctx, int32_t *vec /*host|dev*/, int64_t n);
-/* Exchanges issued through this context since it was created (both transports). */
+/* Exchanges issued through this context since it was created (every transport). */
 int64_t b3c_ctx_exchanges(const b3c_ctx *ctx);
+/* Direct transport (optional, after b3c_ctx_set_dist): the in-place all-gathers of the exchange buffers and of the ragged row
+ * vectors as PEER WRITES into a window instead of collectives.  Every rank creates a window of two slots of `slot_bytes` staging
+ * bytes (at least 8 * world * chunk + 64 * world + 256: the vector and the scalar buffer of a KR tick travel together) in its
+ * HBM and obtains its 64-byte IPC handle (hipIpcGetMemHandle); the caller hands all ranks' handles to every rank (any side
+ * channel), b3c_dist_window_open maps them (hipIpcOpenMemHandle: xGMI between the GPUs of a node; the same GPU between two
+ * processes sharing one).  From then on an exchange is two small launches on the context's stream -- push this rank's range into
+ * every peer's slot and raise a sequence flag there, wait for all flags of the own slot and copy the others' ranges out -- with
+ * no collective and no rendezvous; all-reduces and the aggregation's all-to-all keep using `comm` / the callbacks.
+ * b3c_ctx_exchanges_direct counts the exchanges that went through the window.  Collective over the ranks, like the exchanges. */
+int b3c_dist_window_create(b3c_ctx *ctx, int64_t slot_bytes, void *handle64 /*host, 64 bytes out*/);
+int b3c_dist_window_open(b3c_ctx *ctx, const void *handles /*host, world * 64 bytes*/);
+int b3c_dist_window_close(b3c_ctx *ctx);
+int64_t b3c_ctx_exchanges_direct(const b3c_ctx *ctx);
 
 /* ---- matrices ------------------------------------------------------------------------------ */
 

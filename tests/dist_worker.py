@@ -326,6 +326,67 @@ def gpu_c4_mode(rank, world):
     ctx.close()
 
 
+def gpu_direct_mode(rank, world):
+    """The direct transport (round 6): the all-gathers of a sharded run as peer writes into IPC-mapped windows (here: between processes
+    sharing ONE GPU) instead of collectives.  The same bytes arrive in the same places, so every result must be BITWISE that of the
+    callback transport: x, mask, signal, labels, iteration and sweep counts -- on a flat map, on the contract law (ragged row blocks,
+    a level built by owner) and on a power-law map of thousands of genomes; and the exchanges are counted by kind."""
+    from bin3c_amd.dist import DistSession
+    from bin3c_amd.pipeline import make_context, run_hot_path
+    from bin3c_amd.synth import make_synth
+    ctx = make_context(0)
+    maps = [make_synth(40000, 1300000, 21, genome_law='sqrt'), make_synth(60000, 3000000, 4),
+            make_synth(90000, 2400000, 31, 'powerlaw', genomes=6000)]
+    if os.environ.get('B3C_DIRECT_C4'):
+        maps = []
+    total_d = total_c = 0
+    for sm in maps:
+        counts = ctx.upload(sm.indptr, sm.indices, sm.counts)
+        out = {}
+        for tr in ('callback', 'direct'):
+            os.environ['B3C_DIST_TRANSPORT'] = tr
+            sess = DistSession(ctx, sm.n)
+            assert sess.direct == (tr == 'direct'), sess.transport
+            res = run_hot_path(ctx, counts, sm.sites, sm.lengths, 1000, 5, max_iter=5000)
+            sess.check()
+            nd, nall = sess.n_exchanges_direct, sess.n_exchanges
+            sess.close()
+            out[tr] = (res, nd, nall)
+        os.environ.pop('B3C_DIST_TRANSPORT')
+        (rc, nd_c, na_c), (rd, nd_d, na_d) = out['callback'], out['direct']
+        assert nd_c == 0 and nd_d > 0.8 * na_d and na_d == na_c, (nd_c, nd_d, na_d, na_c)     # every all-gather went through the window
+        assert rd.kr_info.n_iter == rc.kr_info.n_iter and np.array_equal(rd.x, rc.x)
+        assert np.array_equal(rd.mask, rc.mask) and np.array_equal(rd.signal, rc.signal) and np.array_equal(rd.labels, rc.labels)
+        assert (rd.lv_info.n_sweeps, rd.lv_info.n_levels, rd.lv_info.modularity) == (rc.lv_info.n_sweeps, rc.lv_info.n_levels, rc.lv_info.modularity)
+        lab = torch.as_tensor(rd.labels.astype(np.int64))
+        ref = lab.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(lab, ref)
+        total_d += nd_d
+        total_c += na_d - nd_d
+        counts.free()
+    if os.environ.get('B3C_DIRECT_C4'):
+        # C4's workload (the C3 contract map) through the direct transport, against the single-rank run
+        from bin3c_amd.synth import CONFIGS, make_edges
+        n, e, seed, law = CONFIGS['C3']
+        lo, hi, c, diag, lengths, sites, genome = make_edges(n, e, seed, law, genome_law='survey')
+        counts, n_edges = ctx.coo_symmetrise(n, lo, hi, c, diag)
+        del lo, hi, c
+        single = run_hot_path(ctx, counts, sites, lengths, 1000, 5)
+        os.environ['B3C_DIST_TRANSPORT'] = 'direct'
+        sess = DistSession(ctx, n)
+        res = run_hot_path(ctx, counts, sites, lengths, 1000, 5)
+        sess.check()
+        total_d, total_c = sess.n_exchanges_direct, sess.n_exchanges - sess.n_exchanges_direct
+        sess.close()
+        os.environ.pop('B3C_DIST_TRANSPORT')
+        _agree(res, single, rank)
+        assert res.lv_info.levels_sharded == 1 and total_d > res.kr_info.n_iter
+        counts.free()
+    print('rank %d gpu-direct ok (%d exchanges by peer writes, %d by collectives)' % (rank, total_d, total_c))
+    ctx.close()
+
+
 def gpu_empty_mode(rank, world):
     """One rank's row block is masked out completely (all its contigs shorter than min_len): that rank still has to take part
     in every collective of the cluster stage (maximum, degrees, label gathers, bins) with an empty sub-map."""
@@ -363,6 +424,6 @@ if __name__ == '__main__':
     print('rank %d rendezvous done' % dist.get_rank(), flush=True)
     r, w = dist.get_rank(), dist.get_world_size()
     {'cpu': cpu_mode, 'gpu': gpu_mode, 'gpu-many': gpu_many_mode, 'gpu-empty': gpu_empty_mode, 'gpu-large': gpu_large_mode,
-     'gpu-c4': gpu_c4_mode}[sys.argv[1]](r, w)
+     'gpu-c4': gpu_c4_mode, 'gpu-direct': gpu_direct_mode}[sys.argv[1]](r, w)
     dist.barrier()
     dist.destroy_process_group()

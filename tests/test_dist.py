@@ -102,6 +102,20 @@ def test_c4_workload_through_the_sharded_code_two_ranks_one_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 3])
+def test_direct_transport_is_bitwise_the_collective_one(world):
+    """the all-gathers as peer writes into IPC-mapped windows (two / three processes sharing one GPU) against the callback transport"""
+    text = _launch('gpu-direct', 1200, world=world)
+    assert all('rank %d gpu-direct ok' % r in text for r in range(world))
+
+
+@pytest.mark.gpu
+def test_c4_workload_through_the_direct_transport_two_ranks_one_gpu():
+    text = _launch('gpu-direct', 1200, B3C_DIRECT_C4='1')
+    assert 'rank 0 gpu-direct ok' in text and 'rank 1 gpu-direct ok' in text
+
+
+@pytest.mark.gpu
 def test_a_rank_with_an_empty_block_takes_part_two_ranks_one_gpu():
     text = _launch('gpu-empty', 900)
     assert 'rank 0 gpu-empty ok' in text and 'rank 1 gpu-empty ok' in text
@@ -140,6 +154,15 @@ def test_bench_two_ranks_one_gpu(mode):
     assert 'one map over 2 GPUs by contig-row blocks' in d['config']['parallelism']
     if mode == 'auto':
         assert d['replicas']['value'] > 0 and d['replicas']['scaling'] == 'weak' and d['agrees_with_single_gpu'] is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_one_gpu_direct_transport():
+    """the sharded leg of bench.py with the all-gathers as peer writes (B3C_DIST_TRANSPORT=direct): counted by kind, same agreement"""
+    d = _bench_two_ranks('auto', B3C_DIST_TRANSPORT='direct')
+    k = d['exchanges_per_step_by_kind']
+    assert k['direct'] > 100 and k['direct'] + k['collective'] == d['exchanges_per_step'] and k['collective'] < 40, k
+    assert 'direct peer writes' in d['transport'] and d['agrees_with_single_gpu'] is True
 
 
 @pytest.mark.gpu
