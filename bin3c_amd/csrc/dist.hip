@@ -186,6 +186,8 @@ int b3c_dist_allgatherv(b3c_ctx *ctx, void *base, int esz, const int64_t *starts
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct WinItem { char *base; int64_t off, bytes; };     // this rank's range of a full vector: bytes [off, off + bytes) of base
+constexpr int WIN_MAXW = 16;                              // ranks whose ranges travel as kernel arguments (a node has 8 GPUs)
+struct WinRanges { int64_t a[WIN_MAXW + 1], b[WIN_MAXW + 1]; };
 
 constexpr unsigned long long WIN_TIMEOUT = 500000000ull;      // wall_clock64 ticks (100 MHz): five seconds
 
@@ -223,10 +225,10 @@ __global__ void __launch_bounds__(256) k_win_push(int world, int me, char *const
 }
 
 __global__ void __launch_bounds__(256) k_win_pull(int world, int me, char *__restrict__ local, int64_t slot_off, int64_t flag_off, int nitems,
-                                                  char *a_base, int a_esz, const int64_t *__restrict__ a_starts,
-                                                  char *b_base, int b_esz, const int64_t *__restrict__ b_starts, int64_t b_stage,
+                                                  char *a_base, int a_esz, char *b_base, int b_esz, WinRanges rg, int64_t b_stage,
                                                   unsigned long long seq)
 {
+    const int64_t *a_starts = rg.a, *b_starts = rg.b;
     if ((int)threadIdx.x < world && (int)threadIdx.x != me) {
         const unsigned long long *f = (const unsigned long long *)(local + flag_off) + threadIdx.x;
         const unsigned long long t0 = wall_clock64();
@@ -273,12 +275,10 @@ int win_allgather(b3c_ctx *ctx, int nitems, void *a_base, int a_esz, const int64
     const int64_t slot = (int64_t)(Wn.seq & 1ull);
     const int64_t slot_stride = Wn.slot_bytes + 8 * (int64_t)((W + 31) & ~31);
     const int64_t slot_off = slot * slot_stride, flag_off = slot_off + Wn.slot_bytes;
-    // the ranges in device memory for the pull kernel: a small pooled block per call (W + 1 offsets per item)
-    int64_t *st_dev = (int64_t *)ctx->alloc(sizeof(int64_t) * 2 * (size_t)(W + 1));
-    if (!st_dev) return ctx->fail(B3C_E_NOMEM, "direct exchange");
-    struct Hold { b3c_ctx *c; void *p; ~Hold() { c->release(p); } } hold{ctx, st_dev};
-    HIP_TRY(ctx, hipMemcpyAsync(st_dev, a_starts, sizeof(int64_t) * (size_t)(W + 1), hipMemcpyHostToDevice, ctx->stream));
-    if (nitems > 1) HIP_TRY(ctx, hipMemcpyAsync(st_dev + W + 1, b_starts, sizeof(int64_t) * (size_t)(W + 1), hipMemcpyHostToDevice, ctx->stream));
+    // (the ranges ride along as kernel arguments: nothing to upload, nothing to wait for)
+    WinRanges rg;
+    memset(&rg, 0, sizeof(rg));
+    for (int r = 0; r <= W; r++) { rg.a[r] = a_starts[r]; if (nitems > 1) rg.b[r] = b_starts[r]; }
     WinItem ia{(char *)a_base, a_starts[me] * a_esz, (a_starts[me + 1] - a_starts[me]) * a_esz};
     WinItem ib{nitems > 1 ? (char *)b_base : nullptr, nitems > 1 ? b_starts[me] * b_esz : 0, nitems > 1 ? (b_starts[me + 1] - b_starts[me]) * b_esz : 0};
     const int64_t most = std::max(ia.bytes, ib.bytes);
@@ -286,10 +286,9 @@ int win_allgather(b3c_ctx *ctx, int nitems, void *a_base, int a_esz, const int64
     hipLaunchKernelGGL(k_win_push, dim3(gp), dim3(256), 0, ctx->stream, W, me, (char *const *)Wn.peer_dev, slot_off, flag_off, ia, ib, b_stage, Wn.seq, Wn.ticket);
     const int64_t all = a_total + (nitems > 1 ? b_starts[W] * b_esz : 0);
     const int gq = (int)std::max<int64_t>(1, std::min<int64_t>(64, (all / 16 + 255) / 256));
-    hipLaunchKernelGGL(k_win_pull, dim3(gq), dim3(256), 0, ctx->stream, W, me, Wn.local, slot_off, flag_off, nitems, (char *)a_base, a_esz, st_dev,
-                       (char *)b_base, b_esz, st_dev + W + 1, b_stage, Wn.seq);
+    hipLaunchKernelGGL(k_win_pull, dim3(gq), dim3(256), 0, ctx->stream, W, me, Wn.local, slot_off, flag_off, nitems, (char *)a_base, a_esz,
+                       (char *)b_base, b_esz, rg, b_stage, Wn.seq);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (the pooled offsets; a per-context ring of them would drop this wait)
     return B3C_OK;
 }
 }  // namespace
@@ -320,6 +319,7 @@ extern "C" int b3c_dist_window_open(b3c_ctx *ctx, const void *handles)
     if (!ctx) return B3C_E_ARG;
     b3c_ctx::Window &Wn = ctx->win;
     if (!handles || !Wn.local || Wn.open) return ctx->fail(B3C_E_ARG, "b3c_dist_window_open: bad argument");
+    if (ctx->dist.world > WIN_MAXW) return ctx->fail(B3C_E_ARG, "b3c_dist_window_open: at most %d ranks", WIN_MAXW);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int W = ctx->dist.world, me = ctx->dist.rank;
     Wn.peer.assign(W, nullptr);
