@@ -2679,7 +2679,8 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
     // the CSR hub kernel instead of the dictionary form: 1.97 of 4.4 ms per SpMV.  Row-group lanes loop over long rows; what
     // the hub kernel is for are rows so long that one lane group would hold its tile up
     const int hub_floor = avg > 128 ? 2 * HUB_LEN : HUB_LEN;
-    const int hub_thr = std::max(hub_floor, (int)std::min<double>(16384.0, 16.0 * avg));
+    const int hub_thr = CFG.on("B3C_KR_HUB_LEN") ? (int)std::max<int64_t>(64, CFG.num("B3C_KR_HUB_LEN", 0))
+                                                   : std::max(hub_floor, (int)std::min<double>(16384.0, 16.0 * avg));
     const bool hub_kb = maxdeg > (unsigned long long)hub_thr && !CFG.on("B3C_KR_NO_HUB");
     const int64_t hub_cap = hub_kb ? a->nnz / hub_thr + 1 : 0;
     const int hub_len = hub_kb ? hub_thr : 0x7fffffff;
