@@ -542,10 +542,11 @@ constexpr int MEGA_CHUNK = 4 * MEGA_NT;    // entries one workgroup of the inser
 __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_insert(const NodeRec *__restrict__ list, int chunks, const int32_t *__restrict__ indices,
                                                              const int64_t *__restrict__ q, const int32_t *__restrict__ com,
                                                              const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
-                                                             u64 *__restrict__ gvals, u64 *__restrict__ own_acc)
+                                                             u64 *__restrict__ gvals, u64 *__restrict__ own_acc, const int64_t *__restrict__ cnt_dev = nullptr)
 {
     __shared__ long long red[MEGA_NT / 64];
     const int m = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    if (cnt_dev && m >= *cnt_dev) return;                            // (the list was thinned on the device: k_lv_prune)
     const NodeRec rec = list[m];
     if ((int64_t)ch * MEGA_CHUNK >= rec.deg) return;                 // (uniform per workgroup)
     const int32_t i = rec.node;
@@ -595,13 +596,14 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_eval_split(const NodeRec *_
                                                                  const int32_t *__restrict__ csize, int32_t *__restrict__ nxt,
                                                                  const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
                                                                  u64 *__restrict__ gvals, u64 *__restrict__ own_acc, MegaPart *__restrict__ part,
-                                                                 unsigned int *__restrict__ ticket)
+                                                                 unsigned int *__restrict__ ticket, const int64_t *__restrict__ cnt_dev = nullptr)
 {
     __shared__ long long red_hi[MEGA_NT / 64];
     __shared__ u64 red_lo[MEGA_NT / 64];
     __shared__ int32_t red_com[MEGA_NT / 64], red_have[MEGA_NT / 64];
     __shared__ int last;
     const int m = blockIdx.x / echunks, ch = blockIdx.x % echunks;
+    if (cnt_dev && m >= *cnt_dev) return;
     const NodeRec rec = list[m];
     const int lg = table_lg(rec.deg);
     const uint32_t size = 1u << lg;
@@ -830,7 +832,7 @@ constexpr int MEGA_LDS_LG = 13;            // table_lg(MEGA_CHUNK)
 __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_insert_lds(const NodeRec *__restrict__ list, int chunks, const int32_t *__restrict__ indices,
                                                                  const int64_t *__restrict__ q, const int32_t *__restrict__ com,
                                                                  const int64_t *__restrict__ goff, int32_t *__restrict__ gkeys,
-                                                                 u64 *__restrict__ gvals, u64 *__restrict__ own_acc)
+                                                                 u64 *__restrict__ gvals, u64 *__restrict__ own_acc, const int64_t *__restrict__ cnt_dev = nullptr)
 {
     constexpr int SLOTS = 1 << MEGA_LDS_LG;
     extern __shared__ __align__(16) unsigned char lv_wg_smem[];
@@ -838,6 +840,7 @@ __global__ void __launch_bounds__(MEGA_NT) k_lv_mega_insert_lds(const NodeRec *_
     int32_t *lkeys = (int32_t *)(lvals + SLOTS);
     long long *red = (long long *)(lkeys + SLOTS);
     const int m = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    if (cnt_dev && m >= *cnt_dev) return;                            // (the list was thinned on the device: k_lv_prune)
     const NodeRec rec = list[m];
     if ((int64_t)ch * MEGA_CHUNK >= rec.deg) return;                 // (uniform per workgroup)
     for (int t = threadIdx.x; t < SLOTS; t += MEGA_NT) { lkeys[t] = EMPTY; lvals[t] = 0; }
@@ -3007,9 +3010,9 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         HIP_TRY(ctx, hipMemsetAsync(mega_ticket.p, 0, sizeof(unsigned int) * (size_t)(max_mega + 1), s));
         if (!mega_own.p) return ctx->fail(B3C_E_NOMEM, "b3c_louvain: mega rows");
         HIP_TRY(ctx, hipMemsetAsync(mega_own.p, 0, sizeof(u64) * (size_t)(max_mega + 1), s));
-        DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1), plist_h(ctx, can_prune ? max_hlist + 1 : 1);
+        DevBuf<NodeRec> plist(ctx, can_prune ? max_list + 1 : 1), plist_h(ctx, can_prune ? max_hlist + 1 : 1), plist_m(ctx, can_prune ? max_mega + 1 : 1);
         DevBuf<unsigned long long> pcnt(ctx, LV_SEGS);    // [0] grouped nodes left after pruning, [1 .. 5] hubs left, by class
-        if (!plist.p || !plist_h.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
+        if (!plist.p || !plist_h.p || !plist_m.p || !pcnt.p) { free_graph(ctx, g); return ctx->fail(B3C_E_NOMEM, "b3c_louvain: pruned list"); }
         auto modularity = [&](double *out, bool full, u64 *moved) -> int {
             HIP_TRY(ctx, hipMemsetAsync(ctr.p + 3, 0, sizeof(u64) * 4, s));
             if (full) {
@@ -3145,15 +3148,26 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                 if (grouped && lend[r] > moff[r]) {       // mega rows: workgroups per node (side stream, beside the others)
                     const int64_t nm = lend[r] - moff[r];
                     const int chunks = (int)((maxdeg + MEGA_CHUNK - 1) / MEGA_CHUNK);
+                    // pruned like the other classes in the sweeps that track own[] (round 6: BASELINE's C5 has thousands of rows of
+                    // 10^4 .. 10^6 entries, most of them settled after the first sweeps, and inserting and evaluating their tables
+                    // in every sub-round was two thirds of its Louvain stage).  Row-sharded runs keep scanning them (see k_lv_prune)
+                    const NodeRec *mlist = nlist_p + moff[r];
+                    const int64_t *mcnt_dev = nullptr;
+                    if (incr && can_prune && !stamps) {
+                        hipLaunchKernelGGL(k_lv_prune, dim3(grid_for(nm, 4 * BLK, 8 * ctx->n_cu)), dim3(BLK), 0, ms, nm, mlist, m2, kdeg.p,
+                                           wnl.p, own.p, tot.p, com.p, nxt_p, plist_m.p, pcnt.p + (LV_SEGS - 1), stamp_p, tstamp_p);
+                        mlist = plist_m.p;
+                        mcnt_dev = (const int64_t *)(pcnt.p + (LV_SEGS - 1));
+                    }
                     // from the second sweep on the chunk's entries are summed per community in LDS before they reach the node's table
                     if (mega_lds && sweep > 1)
-                        hipLaunchKernelGGL(k_lv_mega_insert_lds, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), mega_lds_bytes, ms, nlist_p + moff[r], chunks, g.indices, g.q,
-                                           com.p, goff.p, gkeys.p, gvals.p, mega_own.p);
+                        hipLaunchKernelGGL(k_lv_mega_insert_lds, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), mega_lds_bytes, ms, mlist, chunks, g.indices, g.q,
+                                           com.p, goff.p, gkeys.p, gvals.p, mega_own.p, mcnt_dev);
                     else
-                        hipLaunchKernelGGL(k_lv_mega_insert, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], chunks, g.indices, g.q,
-                                           com.p, goff.p, gkeys.p, gvals.p, mega_own.p);
-                    hipLaunchKernelGGL(k_lv_mega_eval_split, dim3((unsigned)(nm * mega_echunks)), dim3(MEGA_NT), 0, ms, nlist_p + moff[r], mega_echunks, m2, kdeg.p,
-                                       tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p, mega_part.p, mega_ticket.p);
+                        hipLaunchKernelGGL(k_lv_mega_insert, dim3((unsigned)(nm * chunks)), dim3(MEGA_NT), 0, ms, mlist, chunks, g.indices, g.q,
+                                           com.p, goff.p, gkeys.p, gvals.p, mega_own.p, mcnt_dev);
+                    hipLaunchKernelGGL(k_lv_mega_eval_split, dim3((unsigned)(nm * mega_echunks)), dim3(MEGA_NT), 0, ms, mlist, mega_echunks, m2, kdeg.p,
+                                       tot.p, com.p, csize.p, nxt_p, goff.p, gkeys.p, gvals.p, mega_own.p, mega_part.p, mega_ticket.p, mcnt_dev);
                     if (ms != s && ms != hs) {
                         HIP_TRY(ctx, hipEventRecord(ctx->ev_join2, ms));
                         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join2, 0));
