@@ -282,8 +282,11 @@ def main():
     def traffic_key(w):
         """name of this workload's records in profiles/traffic.json: '<config>' for the contract workload, '<config>_variant' for
         the rank^-0.5 genome-size variant; none for the hard map and the power-law draws"""
-        if w.hard or w.law == 'powerlaw':
+        if w.hard:
             return '-'
+        if w.law == 'powerlaw':
+            # BASELINE's largest map to the letter of the contract generator (survey genome sizes, duplicate draws summed): 'C5'
+            return w.config if (w.synth == 'survey' and args.c5_counts == 'summed-draws') else '-'
         return w.config if w.synth == 'survey' else w.config + '_variant'
 
     def spmv_roofline(w, last, acc, share, sharded):
