@@ -188,8 +188,9 @@ def test_locality_order_shortcut_equals_the_full_gather(ctx):
         sm = make_synth(*args)
         maps.append((sm.indptr, sm.indices, sm.counts))
     rs = np.random.RandomState(2)
-    a = sp.random(40000, 40000, density=60.0 / 40000, random_state=rs, format='csr')
-    a.data[:] = 1.0
+    # (sixty random columns per row; scipy's sp.random draws WITHOUT replacement from all 1.6e9 cells: a minute of host time)
+    r_, c_ = np.repeat(np.arange(40000), 60), rs.randint(0, 40000, 40000 * 60)
+    a = sp.coo_matrix((np.ones(r_.shape[0]), (r_, c_)), shape=(40000, 40000)).tocsr()
     a = ((a + a.T) > 0).astype(np.uint32).tocsr()
     a.sort_indices()
     maps.append((a.indptr.astype(np.int64), a.indices.astype(np.int32), a.data.astype(np.uint32)))
