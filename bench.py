@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+L1_FILL_GATHERS_PER_S = 2.6e11   # random 4-byte gathers per second from an L2-resident array, chip-wide (profiles/r06_l1fill_probe.txt)
 
 
 def measured_traffic(key, kernel, algorithmic=None, field='hbm_bytes_per_launch'):
@@ -351,7 +352,13 @@ def main():
                 'traffic': traffic, 'frac_traffic': rate(traffic, ms) / HBM_PEAK_GBS if traffic else None,
                 'bytes_per_launch': b, 'avg_launch_ms': ms,
                 'frac_mean_incl_pruned': rate(mean_bytes, mean_ms) / HBM_PEAK_GBS, 'avg_launch_ms_all': mean_ms,
-                'launches_per_step': acc['move_n'] / max(1, acc.get('steps', 1))}
+                'launches_per_step': acc['move_n'] / max(1, acc.get('steps', 1)),
+                # what the scan is bound by: one 4-byte label gather per stored entry, nearly every one an L1 miss
+                # that fills a 128-byte line.  Ceiling: tools/probes/l1fill_probe.hip on this chip, random 4-byte gathers from an
+                # L2-resident array, the same under every cache policy (profiles/r06_l1fill_probe.txt)
+                'label_gathers': {'per_s': ((sub if sub else w.nnz * share) / nsub) / (first_ms * 1e-3) if use_first else None,
+                                  'ceiling_per_s': L1_FILL_GATHERS_PER_S,
+                                  'frac': ((sub if sub else w.nnz * share) / nsub) / (first_ms * 1e-3) / L1_FILL_GATHERS_PER_S if use_first else None}}
 
     def step_algorithmic(w, last, n_acc):
         """SURVEY 8(d)'s algorithmic bytes of the WHOLE step (what a CSR fp64 implementation of every stage would move), so that the
