@@ -708,13 +708,20 @@ __global__ void kr_hub_fill(int64_t r0, int64_t n, const int64_t *__restrict__ f
 // of HUB_SPLIT entries, one workgroup each (C5 on the contract generator: rows of 10^6 entries, each of which used to be ONE
 // workgroup's 2.5 ms of gathers while the kernel's other workgroups had long finished); kr_kb_hub_fin adds a row's pieces in piece
 // order and runs the epilogue.  Maps whose longest row fits one piece keep the single launch (pieces == nullptr).
+// Cache policy of the matrix streams (round 6).  A map whose SpMV streams more than the caches hold (C3: 0.8 GB of tail words per
+// launch against 256 MB of Infinity Cache and 4 MB of L2 per XCD) reads them with the NON-TEMPORAL bit: the words pass through
+// without pushing the operand vector out of the L2, 0.240 -> 0.227 ms per SpMV at C3 (nt, sc0 nt, sc1 nt, sc0 sc1 nt: the same).
+// A map that FITS (C2: 40 MB) must keep the default policy -- it stays cache-resident from one SpMV to the next and through the
+// compress that follows, and nt made C2's KR stage 5.6 -> 6.6 ms.  The policy is an instruction bit, hence the two loads under
+// a wave-uniform branch.
+constexpr int64_t KR_STREAM_NT_MIN = 192ll << 20;         // bytes one SpMV streams (b3c_kr_info.spmv_stream_bytes)
 constexpr int HUB_SPLIT = 16384;        // (B3C_KR_HUB_SPLIT: the tests cut shorter rows)
 
 struct HubPiece { int32_t row_idx, piece; };        // index into hub_rows, piece number inside the row
 
 template <typename VT>
 __device__ __forceinline__ double hub_dot(const int32_t *__restrict__ indices, const VT *__restrict__ a, const double *__restrict__ u,
-                                           int64_t s, int64_t len, double *lds)
+                                           int64_t s, int64_t len, double *lds, int stream_nt)
 {
     // four spans of 64 consecutive entries per wave and pass: index and value loads of all four in flight, then the four gathers
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -726,8 +733,8 @@ __device__ __forceinline__ double hub_dot(const int32_t *__restrict__ indices, c
         for (int q = 0; q < 4; q++) {
             const int64_t k = base + q * 64 + lane;
             const int64_t kk = k < len ? k : 0;
-            c[q] = indices[s + kk];
-            m[q] = a[s + kk];
+            c[q] = stream_nt ? __builtin_nontemporal_load(&indices[s + kk]) : indices[s + kk];       // (KR_STREAM_NT_MIN)
+            m[q] = stream_nt ? __builtin_nontemporal_load(&a[s + kk]) : a[s + kk];
         }
         double g[4];
 #pragma unroll
@@ -774,7 +781,7 @@ __global__ void __launch_bounds__(BLK) kr_kb_hub(const int64_t *__restrict__ hub
                                                   const double *__restrict__ x, const double *__restrict__ p,
                                                   double *__restrict__ v, double *__restrict__ rk, double *__restrict__ w,
                                                   double *__restrict__ part_out, const HubPiece *__restrict__ pieces,
-                                                  double *__restrict__ piece_sum, int hub_split)
+                                                  double *__restrict__ piece_sum, int hub_split, int stream_nt)
 {
     __shared__ double lds[BLK];
     const int32_t phase = sin->phase;
@@ -788,13 +795,13 @@ __global__ void __launch_bounds__(BLK) kr_kb_hub(const int64_t *__restrict__ hub
         const int64_t row = hub_rows[pc.row_idx];
         const int64_t s = indptr[row] + (int64_t)pc.piece * hub_split;
         const int64_t left = indptr[row + 1] - s;
-        const double d = hub_dot<VT>(indices, a, u, s, left < hub_split ? left : hub_split, lds);
+        const double d = hub_dot<VT>(indices, a, u, s, left < hub_split ? left : hub_split, lds, stream_nt);
         if (threadIdx.x == 0) piece_sum[blockIdx.x] = d;
         return;
     }
     const int64_t row = hub_rows[blockIdx.x];
     const int64_t s = indptr[row];
-    const double d = hub_dot<VT>(indices, a, u, s, indptr[row + 1] - s, lds);
+    const double d = hub_dot<VT>(indices, a, u, s, indptr[row + 1] - s, lds, stream_nt);
     if (threadIdx.x == 0) part_out[blockIdx.x] = hub_epilogue(phase == A_INNER, row, d, rs, dfix, x, p, v, rk, w);
 }
 
@@ -1462,7 +1469,7 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
                                                       int S, int rbits, uint32_t cmask, const unsigned long long *__restrict__ words, const double *__restrict__ u,
                                                       unsigned long long *__restrict__ yhi, int *__restrict__ ylo, int *__restrict__ tex,
                                                       const uint32_t *__restrict__ cw, const uint32_t *__restrict__ hdr,
-                                                      const unsigned long long *__restrict__ rwords, int64_t n_res, int st_shift, int pipe, int64_t ncols)
+                                                      const unsigned long long *__restrict__ rwords, int64_t n_res, int st_shift, int pipe, int64_t ncols, int stream_nt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long xt_lds[];
     unsigned long long *acc = xt_lds;                 // S 64-bit sums
@@ -1520,7 +1527,8 @@ __global__ void __launch_bounds__(XT_NT) kr_kb_tails(const KRState *__restrict__
             u32x4 wn, hn;
             auto fetch = [&](int st) {
                 const int blk = __builtin_amdgcn_readfirstlane(16 * st + wave);
-                wn = __builtin_amdgcn_raw_buffer_load_b128(rw, (uint32_t)(blk * 1024 + lane * 16), 0, 0);   // beyond the chunk's blocks: zeros
+                const uint32_t wo = (uint32_t)(blk * 1024 + lane * 16);                                       // beyond the chunk's blocks: zeros
+                wn = stream_nt ? __builtin_amdgcn_raw_buffer_load_b128(rw, wo, 0, 2) : __builtin_amdgcn_raw_buffer_load_b128(rw, wo, 0, 0);
                 int64_t gi = bs + blk;
                 gi = gi < nblk_all ? gi : nblk_all;
                 hn = *(const u32x4 *)(hdr + 4 * gi);                          // uniform: one scalar load of the four base columns
@@ -3133,6 +3141,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             info->spmv_stream_bytes = ent * (4 + vbytes) + nloc * 56 + n * 8;             // CSR: column + value per entry; per row indptr, x / p / v / 1/s / dfix, out; the operand vector once
         }
     }
+    const int stream_nt = info->spmv_stream_bytes > KR_STREAM_NT_MIN && !CFG.on("B3C_KR_NO_NT") ? 1 : 0;
     // an all-tails layout never built (or only sampled) the dictionary arrays: the dictionary kernel must not run on it
     if (xt_all && !(tile_split && tails_xt && n_tl_with == 0))
         return ctx->fail(B3C_E_HIP, "b3c_kr_balance: all-tails layout with dictionary tiles listed (%lld)", (long long)n_tl_with);
@@ -3227,7 +3236,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                     hipLaunchKernelGGL(kr_kb_tails, dim3((unsigned)(xt_super * xt_chunks)), dim3(XT_NT), xt_shmem, s, s0, pumax.p, GA, xt_lg_bound, xt_lo_bits, xt_chunks, n_tails,
                                        xt_tr ? (const int64_t *)a->indptr : (const int64_t *)xt_off.p, r0, r1, xt_S, xt_rbits, (uint32_t)((1u << xt_cbits) - 1u), xt_words.p, u.p, yhi.p, ylo.p, tex.p,
                                        xt_packed ? xt_cw.p : nullptr, xt_hdr.p, xt_res.p, xt_n_res, xt_st_shift,
-                                       n_tails < (1ll << 29) ? 1 : 0, n);    // (32-bit byte offsets inside a chunk of the packed stream)
+                                       n_tails < (1ll << 29) ? 1 : 0, n, stream_nt);    // (32-bit byte offsets inside a chunk of the packed stream)
                 // dictionary waves and tail waves side by side (512-thread workgroups)
                 const bool split = tile_split && tails_xt;      // dictionary tiles by list, the others by kr_kb_epi
                 if (split && n_tl_without)
@@ -3265,13 +3274,13 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
                 double *hps = (double *)hub_piece_sum.p;
                 if (a->kind == B3C_U32 && v16 && !n_big)           // (hub rows read the full 32-bit counts when some are large)
                     hipLaunchKernelGGL(kr_kb_hub<uint16_t>, dim3(hub_grid), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices, v16,
-                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out, hp, hps, hub_split);
+                                       rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out, hp, hps, hub_split, stream_nt);
                 else if (a->kind == B3C_U32)
                     hipLaunchKernelGGL(kr_kb_hub<uint32_t>, dim3(hub_grid), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out, hp, hps, hub_split);
+                                       (const uint32_t *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out, hp, hps, hub_split, stream_nt);
                 else
                     hipLaunchKernelGGL(kr_kb_hub<double>, dim3(hub_grid), dim3(BLK), 0, s, hub_rows.p, s0, a->indptr, a->indices,
-                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out, hp, hps, hub_split);
+                                       (const double *)a->data, rs, dfix.p, u.p, x.p, p.p, v.p, rk.p, w_kb, hub_out, hp, hps, hub_split, stream_nt);
                 if (n_hub_pieces)
                     hipLaunchKernelGGL(kr_kb_hub_fin, dim3((unsigned)((n_hub + BLK - 1) / BLK)), dim3(BLK), 0, s, n_hub, hub_rows.p, s0, (const int64_t *)hub_piece_first.p,
                                        (const double *)hub_piece_sum.p, rs, dfix.p, x.p, p.p, v.p, rk.p, w_kb, hub_out);

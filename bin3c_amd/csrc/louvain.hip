@@ -43,6 +43,17 @@ typedef unsigned long long u64;
 typedef int32_t i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef long long i64x2_u __attribute__((ext_vector_type(2), aligned(8)));
 typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));
+// The entry streams of a large level (ids, weights: 50-200x the labels and totals the gathers want to find in the L2) are loaded
+// with the non-temporal policy, so that they pass through without pushing those out -- under the same rule as the KR tail pass's
+// words (kr.hip, KR_STREAM_NT_MIN): only when the level does not fit the caches anyway (C3: the scan 31.8 -> 31.3 ms per step;
+// C2's level 0, 120 MB, stays resident between sub-rounds and keeps the default policy).  Measured on `k_lv_decide_g` only: the
+// same bit on the recount, tracking, workgroup and set-up kernels together cost 0.7 ms at C3.
+constexpr int64_t LV_STREAM_NT_MIN = 192ll << 20;        // bytes of a level's entries (12 per stored entry)
+template <class T>
+__device__ __forceinline__ T lv_stream(const T *p, int nt)
+{
+    return nt ? __builtin_nontemporal_load(p) : *p;
+}
 
 __host__ __device__ __forceinline__ uint32_t bucket_of(int64_t i, int n_sub)
 {
@@ -1050,7 +1061,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(LPR ==
     int64_t cnt_max, const int64_t *__restrict__ cnt_dev, const NodeRec *__restrict__ list, u64 m2, const int32_t *__restrict__ indices,
     const int64_t *__restrict__ q, const int64_t *__restrict__ kdeg, const int64_t *__restrict__ tot, const int32_t *__restrict__ com,
     const int32_t *__restrict__ csize, int32_t *__restrict__ nxt, int64_t *__restrict__ own_out, int32_t *__restrict__ stamp_out,
-    int32_t epoch, int xcd, int band_shift)
+    int32_t epoch, int xcd, int band_shift, int stream_nt)
 {
     constexpr int CAP = LPR * UN > 384 ? 1024 : 512;       // >= 1.25 * LPR * UN + 1
     constexpr int LG = LPR * UN > 384 ? 10 : 9;
@@ -1110,7 +1121,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(LPR ==
         const int eb = UN * sl < r.deg ? UN * sl : 0;
 #pragma unroll
         for (int v = 0; v < UN / 4; v++) {
-            const i32x4_u x = *(const i32x4_u *)(indices + r.start + eb + 4 * v);
+            const i32x4_u x = lv_stream((const i32x4_u *)(indices + r.start + eb + 4 * v), stream_nt);
 #pragma unroll
             for (int k = 0; k < 4; k++) jj[4 * v + k] = UN * sl + 4 * v + k < r.deg ? x[k] : r.node;
         }
@@ -1119,7 +1130,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(LPR ==
         const int eb = UN * sl < r.deg ? UN * sl : 0;
 #pragma unroll
         for (int v = 0; v < UN / 2; v++) {
-            const i64x2_u y = *(const i64x2_u *)(q + r.start + eb + 2 * v);
+            const i64x2_u y = lv_stream((const i64x2_u *)(q + r.start + eb + 2 * v), stream_nt);
 #pragma unroll
             for (int k = 0; k < 2; k++) qq[2 * v + k] = UN * sl + 2 * v + k < r.deg ? (u64)y[k] : 0;
         }
@@ -2977,6 +2988,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const bool mega_lds = use_wg;                          // mega-row chunks summed per community in LDS first (from the second sweep on)
         // band of the grouped scan's contender rule (k_lv_decide_g): (k_i >> band_shift) + 1, the tot * k / 2m of a community of about
         // 32 average nodes of this level.  Any value gives the same decisions; it only steers how often the exact fall-back runs
+        const int stream_nt = g.nnz * 12 > LV_STREAM_NT_MIN && !CFG.on("B3C_LV_NO_NT") ? 1 : 0;      // (lv_stream)
         int band_shift = 0;
         while ((2ll << band_shift) <= n) band_shift++;          // floor(log2 n)
         band_shift = std::max(0, band_shift - 5);
@@ -3115,7 +3127,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
     { const int g_ = LV_GRID_G(L);                                                                                       \
       hipLaunchKernelGGL((k_lv_decide_g<L, U>), dim3(g_), dim3(BLK), 0, s, cntr, cnt_dev, lst,                            \
                        m2, g.indices, g.q, kdeg.p, tot.p, com.p, csize.p, nxt_p, incr && stamps ? own.p : nullptr, stamp_p, epoch, \
-                       g_ >= 64 ? 1 : 0, band_shift); }
+                       g_ >= 64 ? 1 : 0, band_shift, stream_nt); }
                     if (sweep == 1 && r == 0 && !incr && !CFG.on("B3C_LV_NO_FIRST")) {
                         // every node is still alone: the table-free form (k_lv_first_g)
 #define LV_FIRST_G(L, U)                                                                                                 \
@@ -3212,7 +3224,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
                                 // the hub stream, instead of the wave-per-node kernel
                                 const int g_ = grid_for(w1, WPB, 16 * ctx->n_cu);
                                 hipLaunchKernelGGL((k_lv_decide_g<64, 8>), dim3(g_), dim3(BLK), 0, hs, w1, hcnt_dev, hubs, m2, g.indices, g.q, kdeg.p, tot.p,
-                                                   com.p, csize.p, nxt_p, (int64_t *)nullptr, (int32_t *)nullptr, epoch, 0, band_shift);
+                                                   com.p, csize.p, nxt_p, (int64_t *)nullptr, (int32_t *)nullptr, epoch, 0, band_shift, stream_nt);
                             } else if (k == 1 || !use_wg) {
                                 LV_DECIDE_CAP((int64_t)0, w1, hubs, hcnt_dev);
                             } else {
