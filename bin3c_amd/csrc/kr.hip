@@ -3141,7 +3141,7 @@ static int kr_balance_impl(b3c_ctx *ctx, const b3c_mat *a, const double *sites_i
             info->spmv_stream_bytes = ent * (4 + vbytes) + nloc * 56 + n * 8;             // CSR: column + value per entry; per row indptr, x / p / v / 1/s / dfix, out; the operand vector once
         }
     }
-    const int stream_nt = info->spmv_stream_bytes > KR_STREAM_NT_MIN && !CFG.on("B3C_KR_NO_NT") ? 1 : 0;
+    const int stream_nt = info->spmv_stream_bytes > CFG.num("B3C_KR_NT_MIN", KR_STREAM_NT_MIN) ? 1 : 0;      // (the tests force it with 0)
     // an all-tails layout never built (or only sampled) the dictionary arrays: the dictionary kernel must not run on it
     if (xt_all && !(tile_split && tails_xt && n_tl_with == 0))
         return ctx->fail(B3C_E_HIP, "b3c_kr_balance: all-tails layout with dictionary tiles listed (%lld)", (long long)n_tl_with);

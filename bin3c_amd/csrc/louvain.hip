@@ -2988,7 +2988,7 @@ extern "C" int b3c_louvain(b3c_ctx *ctx, const b3c_mat *a, double scl, int n_sub
         const bool mega_lds = use_wg;                          // mega-row chunks summed per community in LDS first (from the second sweep on)
         // band of the grouped scan's contender rule (k_lv_decide_g): (k_i >> band_shift) + 1, the tot * k / 2m of a community of about
         // 32 average nodes of this level.  Any value gives the same decisions; it only steers how often the exact fall-back runs
-        const int stream_nt = g.nnz * 12 > LV_STREAM_NT_MIN && !CFG.on("B3C_LV_NO_NT") ? 1 : 0;      // (lv_stream)
+        const int stream_nt = g.nnz * 12 > CFG.num("B3C_LV_NT_MIN", LV_STREAM_NT_MIN) ? 1 : 0;      // (lv_stream; the tests force it with 0)
         int band_shift = 0;
         while ((2ll << band_shift) <= n) band_shift++;          // floor(log2 n)
         band_shift = std::max(0, band_shift - 5);

@@ -12,10 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('seed,env', [(7, {}), (8, {}), (9, {'B3C_KR_TCD_XT': '1'}), (10, {'B3C_KR_NO_TCD': '1'})])
+@pytest.mark.parametrize('seed,env', [(7, {}), (8, {}), (9, {'B3C_KR_TCD_XT': '1'}), (10, {'B3C_KR_NO_TCD': '1'}),
+                                      (11, {'B3C_KR_TCD_XT': '1', 'B3C_KR_HUB_SPLIT': '256', 'B3C_KR_NT_MIN': '0', 'B3C_LV_NT_MIN': '0'})])
 def test_random_maps_against_the_oracle(seed, env):
     """env: the tail pass of the dictionary SpMV forced on for every map that takes the dictionary form (it is automatic only
-    beyond 2^19 contigs) / the CSR row kernels for all maps."""
+    beyond 2^19 contigs) / the CSR row kernels for all maps / the non-temporal stream policy of maps beyond the caches forced on
+    every map (tail words, hub rows in pieces, the Louvain scan's entries)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_parity.py'), '80', str(seed)],
                          env=dict(os.environ, PYTHONPATH=ROOT, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     text = out.stdout.decode()

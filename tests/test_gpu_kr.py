@@ -257,6 +257,26 @@ def test_long_hub_rows_run_as_pieces(ctx, oracle_lib, monkeypatch):
     fm.free()
 
 
+def test_stream_policy_is_a_cache_hint_only(ctx, monkeypatch):
+    """Round 6: a map whose SpMV streams more than the caches hold loads its tail words and hub rows non-temporally (KR_STREAM_NT_MIN).
+    Forced on a 30,000-contig power-law map (B3C_KR_NT_MIN=0) beside the default policy, on the tail-pass form with hub rows whole and
+    in pieces: the same iteration count and x BIT FOR BIT -- the bit changes where a line is kept, not what is read."""
+    from bin3c_amd.synth import make_synth
+    sm = make_synth(30000, 900000, 9, 'powerlaw')
+    cm = ctx.upload(sm.indptr, sm.indices, sm.counts)
+    for env in ({'B3C_KR_TCD_XT': '1'}, {'B3C_KR_TCD_XT': '1', 'B3C_KR_HUB_SPLIT': '512'}, {'B3C_KR_NO_TCD': '1', 'B3C_KR_HUB_SPLIT': '512'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _, x0, i0 = ctx.kr_balance_counts(cm, sm.sites)
+        monkeypatch.setenv('B3C_KR_NT_MIN', '0')
+        _, x1, i1 = ctx.kr_balance_counts(cm, sm.sites)
+        monkeypatch.delenv('B3C_KR_NT_MIN')
+        assert i0.n_iter == i1.n_iter and np.array_equal(x0, x1)
+        for k in env:
+            monkeypatch.delenv(k)
+    cm.free()
+
+
 def test_all_tails_rule_decided_on_a_sample_of_the_tiles(ctx, oracle_lib, monkeypatch):
     """From 256 tiles on, the all-tails rule is first applied to every 16th tile and the full dictionary pass is skipped when the
     sample already says "no dictionary kernel" (round 5; the dictionary arrays of the other tiles are then never written).  A

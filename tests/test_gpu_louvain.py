@@ -215,12 +215,14 @@ def test_rows_of_every_length_class(ctx, oracle_lib):
 
 
 @pytest.mark.parametrize('env', [{'B3C_LV_NO_FIRST': '1'}, {'B3C_LV_MEGA_DEG': '2048'}, {'B3C_LV_MEGA_DEG': '100000'},
-                                 {'B3C_LV_AGG_SORT': '1'}, {'B3C_LV_AGG_SORT': '1', 'B3C_LV_NO_AGG_HASH': '1'}, {'B3C_LV_NO_PRUNE': '1'}])
+                                 {'B3C_LV_AGG_SORT': '1'}, {'B3C_LV_AGG_SORT': '1', 'B3C_LV_NO_AGG_HASH': '1'}, {'B3C_LV_NO_PRUNE': '1'},
+                                 {'B3C_LV_NT_MIN': '0'}])
 def test_kernel_choices_do_not_show_in_the_result(ctx, oracle_lib, monkeypatch, env):
     """The per-level kernel choices that are still switchable (round 5 deleted the alternatives whose measurements DESIGN.md records as
     lost) -- the table-free first sub-round, the entry count from which a row gets workgroups and a table in global memory, aggregation
     by hashing (forced on every level here: B3C_LV_AGG_SORT=1 takes the many-communities branch) or by the pair sort, the exact
-    pruning of the scan -- are all exact integer arithmetic on the same schedule: switching any of them off or moving the threshold
+    pruning of the scan, the non-temporal policy of the scan's entry stream (automatic only for levels beyond the caches) -- are all
+    exact integer arithmetic on the same schedule: switching any of them off or moving the threshold
     leaves labels, sweep and level counts and the modularity bit for bit, and equal to the scalar schedule's.  The graph has 4500
     planted groups under 35 % noise (several levels, the later ones with thousands of nodes) and two stars of 12,000 and 3,000 entries
     (rows on either side of every threshold)."""
